@@ -1,0 +1,609 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU oracle for the BELLA overlap hot path.
+ *
+ * A plain-C restatement of the reference's algorithm (PASSIONLab/BELLA, paths relative to
+ * /root/reference).  It is the checker for the HIP path; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  The product (bella_amd/) never links or calls it.
+ *
+ * Parity status: PINNED.  tests/test_oracle.py checks this file against (a) golden .out files produced
+ * by the reference binary at OMP_NUM_THREADS=1 (tests/golden/, made by oracle/make_golden.py), (b) the
+ * reference's own code called in-process through oracle/_ref/libbella_ref.so (HashSpGEMM, xavierAlign)
+ * when that library is present, and (c) the xavier/demo.cpp known answer.
+ *
+ * Every function cites the reference file:line it restates.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#define EMPTY32 0xFFFFFFFFu
+
+/* ---------------------------------------------------------------------------------------------------
+ * Operand assembly
+ * ------------------------------------------------------------------------------------------------- */
+
+static uint32_t pow2_at_least(uint32_t minsz, uint64_t n) { /* CSC.cpp:322-326, overlap.hpp:230-234,291-295 */
+    uint64_t s = minsz;
+    while (s < n) s <<= 1;
+    return (uint32_t)s;
+}
+
+/* B = transpmat: CSC tuple constructor (src/CSC.cpp:422-479, needsort=false) followed by
+ * MergeDuplicates (src/CSC.cpp:301-420, issorted=false) with the "keep p1" lambda of
+ * src/main.cpp:477-480 (the LATER position of a duplicated k-mer wins, CSC.cpp:344).
+ * Tuples are (kmer, read, pos) in generation order.  colptr[nreads+1]; rowids/values sized ntuples.
+ * Returns nnz after the merge. */
+int64_t oracle_build_B(uint32_t nreads, uint64_t ntuples, const uint32_t* t_kmer, const uint32_t* t_read,
+                       const uint16_t* t_pos, uint32_t* colptr, uint32_t* rowids, uint16_t* values) {
+    uint32_t* cnt = (uint32_t*)calloc((size_t)nreads + 1, sizeof(uint32_t));
+    uint32_t* start = (uint32_t*)calloc((size_t)nreads + 1, sizeof(uint32_t));
+    uint32_t* r0 = (uint32_t*)malloc(sizeof(uint32_t) * (ntuples ? ntuples : 1));
+    uint16_t* v0 = (uint16_t*)malloc(sizeof(uint16_t) * (ntuples ? ntuples : 1));
+    for (uint64_t t = 0; t < ntuples; ++t) cnt[t_read[t]]++;                 /* CSC.cpp:433-437 */
+    for (uint32_t r = 0; r < nreads; ++r) start[r + 1] = start[r] + cnt[r];  /* CumulativeSum :441 */
+    memset(cnt, 0, sizeof(uint32_t) * nreads);
+    for (uint64_t t = 0; t < ntuples; ++t) {                                 /* CSC.cpp:466-472 (stable) */
+        uint32_t c = t_read[t];
+        r0[start[c] + cnt[c]] = t_kmer[t];
+        v0[start[c] + cnt[c]] = t_pos[t];
+        cnt[c]++;
+    }
+    uint64_t nnz = 0;
+    colptr[0] = 0;
+    uint32_t cap = 16;
+    uint32_t* hk = (uint32_t*)malloc(sizeof(uint32_t) * cap);
+    uint16_t* hv = (uint16_t*)malloc(sizeof(uint16_t) * cap);
+    for (uint32_t i = 0; i < nreads; ++i) {                                  /* CSC.cpp:316-375 */
+        uint32_t n = start[i + 1] - start[i];
+        uint32_t ht = pow2_at_least(16, n);
+        if (ht > cap) {
+            cap = ht;
+            hk = (uint32_t*)realloc(hk, sizeof(uint32_t) * cap);
+            hv = (uint16_t*)realloc(hv, sizeof(uint16_t) * cap);
+        }
+        for (uint32_t j = 0; j < ht; ++j) hk[j] = EMPTY32;
+        for (uint32_t j = start[i]; j < start[i + 1]; ++j) {
+            uint32_t key = r0[j];
+            uint32_t h = (key * 107u) & (ht - 1);
+            for (;;) {
+                if (hk[h] == key) { hv[h] = v0[j]; break; }       /* addop(values[j], old) -> values[j] */
+                if (hk[h] == EMPTY32) { hk[h] = key; hv[h] = v0[j]; break; }
+                h = (h + 1) & (ht - 1);
+            }
+        }
+        for (uint32_t j = 0; j < ht; ++j)                                    /* slot order, CSC.cpp:358-373 */
+            if (hk[j] != EMPTY32) { rowids[nnz] = hk[j]; values[nnz] = hv[j]; nnz++; }
+        colptr[i + 1] = (uint32_t)nnz;
+    }
+    free(hk); free(hv); free(cnt); free(start); free(r0); free(v0);
+    return (int64_t)nnz;
+}
+
+/* A = B.Transpose() (src/CSC.cpp:289-299 -> include/common/transpose.h:13-52).  With one thread the
+ * atomic counter hands out slots in row order, i.e. every k-mer column lists its reads ASCENDING. */
+void oracle_transpose(uint32_t nreads, uint32_t nkmers, const uint32_t* Bcolptr, const uint32_t* Browids,
+                      const uint16_t* Bvalues, uint32_t* Acolptr, uint32_t* Arowids, uint16_t* Avalues) {
+    uint64_t nnz = Bcolptr[nreads];
+    memset(Acolptr, 0, sizeof(uint32_t) * ((size_t)nkmers + 1));
+    for (uint64_t e = 0; e < nnz; ++e) Acolptr[Browids[e] + 1]++;
+    for (uint32_t c = 0; c < nkmers; ++c) Acolptr[c + 1] += Acolptr[c];
+    uint32_t* fill = (uint32_t*)calloc((size_t)nkmers + 1, sizeof(uint32_t));
+    for (uint32_t r = 0; r < nreads; ++r)
+        for (uint32_t e = Bcolptr[r]; e < Bcolptr[r + 1]; ++e) {
+            uint32_t c = Browids[e];
+            uint32_t loc = Acolptr[c] + fill[c]++;
+            Arowids[loc] = r;
+            Avalues[loc] = Bvalues[e];
+        }
+    free(fill);
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * The semiring value (include/common/common.h:119-183) and its operations (include/chain.hpp)
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct { uint16_t h, v; } opos_t;
+typedef struct { uint16_t overlap; uint32_t npos, cap; opos_t* pos; } obin_t;  /* support == npos always */
+typedef struct { uint16_t count; uint32_t nbins, cap; obin_t* bins; } oval_t;
+
+static void bin_push(obin_t* b, opos_t p) {
+    if (b->npos == b->cap) { b->cap = b->cap ? b->cap * 2 : 4; b->pos = (opos_t*)realloc(b->pos, sizeof(opos_t) * b->cap); }
+    b->pos[b->npos++] = p;
+}
+static void val_free(oval_t* v) {
+    for (uint32_t b = 0; b < v->nbins; ++b) free(v->bins[b].pos);
+    free(v->bins);
+    v->bins = NULL; v->nbins = v->cap = 0;
+}
+
+/* chain.hpp:35-44 checkstrand + :47-71 overlapop.  read1 = H (row key), read2 = V (column i).
+ * All the u16 truncations of the reference are kept. */
+static int o_overlapop(const char* read1, uint32_t len1, const char* read2, uint32_t len2, uint16_t begpH,
+                       uint16_t begpV, uint16_t k) {
+    int read1len = (int)len1, read2len = (int)len2;
+    int oriented = memcmp(read1 + begpH, read2 + begpV, k) == 0;              /* :35-44 */
+    if (!oriented) begpH = (uint16_t)(len1 - begpH - k);                      /* :57-60 */
+    uint16_t endpH = (uint16_t)(begpH + k), endpV = (uint16_t)(begpV + k);    /* :63-64 */
+    int margin1 = begpH < begpV ? begpH : begpV;                              /* :66 */
+    int m2a = read1len - endpH, m2b = read2len - endpV;
+    int margin2 = m2a < m2b ? m2a : m2b;                                      /* :67 */
+    return margin1 + margin2 + k;                                             /* :68 */
+}
+int oracle_overlapop(const char* read1, uint32_t len1, const char* read2, uint32_t len2, uint16_t begpH,
+                     uint16_t begpV, uint16_t k) {
+    return o_overlapop(read1, len1, read2, len2, begpH, begpV, k);
+}
+
+static int iabs(int x) { return x < 0 ? -x : x; }
+
+/* chain.hpp:74-86 multiop builds the singleton; chain.hpp:100-150 chainop is called as
+ * addop(result_new, slot_old) (overlap.hpp:326, main.cpp:514-524) and the NEW object survives.
+ * `S` is the accumulated value and is updated in place to the new value. */
+static void o_fold(oval_t* S, int first, opos_t q, uint16_t ovq, int binSize, int k) {
+    if (first) {                                                               /* multiop */
+        S->count = 1; S->nbins = 1; S->cap = 2;
+        S->bins = (obin_t*)calloc(S->cap, sizeof(obin_t));
+        S->bins[0].overlap = ovq;
+        bin_push(&S->bins[0], q);
+        return;
+    }
+    obin_t head; memset(&head, 0, sizeof(head));
+    head.overlap = ovq;
+    bin_push(&head, q);
+    uint16_t count = (uint16_t)(1 + S->count);                                /* :104 */
+    obin_t* nb = (obin_t*)calloc((size_t)S->nbins + 1, sizeof(obin_t));
+    uint32_t nn = 1;
+    uint32_t inserted = 0;
+    for (uint32_t i = 0; i < S->nbins; ++i) {                                 /* :109-135 (m1 has ONE bin) */
+        obin_t* b = &S->bins[i];
+        if (iabs((int)b->overlap - (int)ovq) < binSize) {                     /* :114 */
+            for (uint32_t x = 0; x < b->npos; ++x) {                          /* :116-126 */
+                int dh = iabs((int)q.h - (int)b->pos[x].h), dv = iabs((int)q.v - (int)b->pos[x].v);
+                if (dh > k && dv > k) { bin_push(&head, b->pos[x]); inserted++; }   /* :88-97,121 */
+            }
+            free(b->pos);
+        } else {
+            nb[nn++] = *b;                                                    /* orphan :131-134,144-149 */
+        }
+    }
+    count = (uint16_t)(count + inserted);                                     /* :140 */
+    nb[0] = head;
+    free(S->bins);
+    S->bins = nb; S->nbins = nn; S->cap = S->nbins; S->count = count;
+}
+
+/* ---- libstdc++ std::sort (bits/stl_algo.h: __sort -> __introsort_loop + __final_insertion_sort),
+ * restated for an array of u16 ids with comparator comp(a,b) = support[a] > support[b]
+ * (common.h:112-117 SortBy).  Needed because choose() (common.h:162-170) keeps only ids[0] and the
+ * sort is not stable once there are more than 16 bins (_S_threshold).                              */
+typedef struct { const uint32_t* sup; } cmp_t;
+static int cmp_gt(const cmp_t* c, uint16_t a, uint16_t b) { return c->sup[a] > c->sup[b]; }
+static void ss_swap(uint16_t* a, uint16_t* b) { uint16_t t = *a; *a = *b; *b = t; }
+static void ss_adjust_heap(uint16_t* first, long hole, long len, uint16_t value, const cmp_t* c) {
+    const long top = hole; long child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (cmp_gt(c, first[child], first[child - 1])) child--;
+        first[hole] = first[child]; hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1]; hole = child - 1;
+    }
+    long parent = (hole - 1) / 2;                                              /* __push_heap */
+    while (hole > top && cmp_gt(c, first[parent], value)) {
+        first[hole] = first[parent]; hole = parent; parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+static void ss_heap_sort(uint16_t* first, uint16_t* last, const cmp_t* c) {   /* __partial_sort(first,last,last) */
+    long len = last - first;
+    if (len >= 2) {                                                            /* __make_heap */
+        long parent = (len - 2) / 2;
+        for (;;) { uint16_t v = first[parent]; ss_adjust_heap(first, parent, len, v, c); if (parent == 0) break; parent--; }
+    }
+    /* __heap_select's loop over [middle,last) is empty; __sort_heap: */
+    while (last - first > 1) {
+        --last;
+        uint16_t v = *last; *last = *first;
+        ss_adjust_heap(first, 0, last - first, v, c);
+    }
+}
+static void ss_move_median_to_first(uint16_t* result, uint16_t* a, uint16_t* b, uint16_t* cc, const cmp_t* c) {
+    if (cmp_gt(c, *a, *b)) {
+        if (cmp_gt(c, *b, *cc)) ss_swap(result, b);
+        else if (cmp_gt(c, *a, *cc)) ss_swap(result, cc);
+        else ss_swap(result, a);
+    } else if (cmp_gt(c, *a, *cc)) ss_swap(result, a);
+    else if (cmp_gt(c, *b, *cc)) ss_swap(result, cc);
+    else ss_swap(result, b);
+}
+static uint16_t* ss_unguarded_partition(uint16_t* first, uint16_t* last, uint16_t* pivot, const cmp_t* c) {
+    for (;;) {
+        while (cmp_gt(c, *first, *pivot)) ++first;
+        --last;
+        while (cmp_gt(c, *pivot, *last)) --last;
+        if (!(first < last)) return first;
+        ss_swap(first, last);
+        ++first;
+    }
+}
+static void ss_introsort_loop(uint16_t* first, uint16_t* last, long depth, const cmp_t* c) {
+    while (last - first > 16) {
+        if (depth == 0) { ss_heap_sort(first, last, c); return; }
+        --depth;
+        uint16_t* mid = first + (last - first) / 2;
+        ss_move_median_to_first(first, first + 1, mid, last - 1, c);
+        uint16_t* cut = ss_unguarded_partition(first + 1, last, first, c);
+        ss_introsort_loop(cut, last, depth, c);
+        last = cut;
+    }
+}
+static void ss_unguarded_linear_insert(uint16_t* last, const cmp_t* c) {
+    uint16_t val = *last; uint16_t* next = last - 1;
+    while (cmp_gt(c, val, *next)) { *last = *next; last = next; --next; }
+    *last = val;
+}
+static void ss_insertion_sort(uint16_t* first, uint16_t* last, const cmp_t* c) {
+    if (first == last) return;
+    for (uint16_t* i = first + 1; i != last; ++i) {
+        if (cmp_gt(c, *i, *first)) { uint16_t v = *i; memmove(first + 1, first, (size_t)(i - first) * sizeof(uint16_t)); *first = v; }
+        else ss_unguarded_linear_insert(i, c);
+    }
+}
+static void std_sort_ids(uint16_t* first, uint16_t* last, const cmp_t* c) {
+    if (first == last) return;
+    long n = last - first, lg = 0;
+    while ((1L << (lg + 1)) <= n) lg++;                                        /* std::__lg */
+    ss_introsort_loop(first, last, lg * 2, c);
+    if (last - first > 16) {
+        ss_insertion_sort(first, first + 16, c);
+        for (uint16_t* i = first + 16; i != last; ++i) ss_unguarded_linear_insert(i, c);
+    } else ss_insertion_sort(first, last, c);
+}
+/* common.h:142-150 chain() / :162-170 choose(): index of the winning bin.  ids are u16 (iota wraps for
+ * more than 65536 bins, which cannot happen: bins <= products of a pair <= 65535 positions). */
+uint32_t oracle_choose_bin(const uint32_t* support, uint32_t nbins) {
+    if (nbins <= 1) return 0;
+    uint16_t* ids = (uint16_t*)malloc(sizeof(uint16_t) * nbins);
+    for (uint32_t i = 0; i < nbins; ++i) ids[i] = (uint16_t)i;
+    cmp_t c; c.sup = support;
+    std_sort_ids(ids, ids + nbins, &c);
+    uint32_t w = ids[0];
+    free(ids);
+    return w;
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * HashSpGEMM (include/overlap.hpp:650-789): estimateFLOP :157, estimateNNZ_Hash :205, LocalSpGEMM :281
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t rid;       /* row of C = the larger read id (H, "read1")           */
+    uint32_t cid;       /* column of C = read i (V, "read2")                     */
+    uint16_t count;     /* spmatType_::count                                     */
+    uint16_t seedH;     /* choose().first                                        */
+    uint16_t seedV;     /* choose().second                                       */
+    uint16_t nbins;     /* number of bins at the end (saturated at 65535)        */
+    uint16_t support;   /* chain(): support of the winning bin                   */
+    uint16_t binov;     /* overlap estimate stored in the winning bin            */
+    int32_t overlap;    /* overlapop(read[rid], read[cid], seedH, seedV) (:583)  */
+} oracle_pair;
+
+/* Phase 1: flops per column (estimateFLOP, lowtri) and nnz per column (estimateNNZ_Hash).
+ * colflop/colnnz have nreads entries. */
+void oracle_symbolic(uint32_t nreads, const uint32_t* Bcolptr, const uint32_t* Browids, const uint32_t* Acolptr,
+                     const uint32_t* Arowids, uint32_t* colflop, uint32_t* colnnz) {
+    uint32_t cap = 16;
+    uint32_t* tab = (uint32_t*)malloc(sizeof(uint32_t) * cap);
+    for (uint32_t i = 0; i < nreads; ++i) {
+        uint32_t f = 0;
+        for (uint32_t j = Bcolptr[i]; j < Bcolptr[i + 1]; ++j) {              /* overlap.hpp:177-198 */
+            uint32_t c = Browids[j];
+            for (uint32_t k = Acolptr[c]; k < Acolptr[c + 1]; ++k) if (i < Arowids[k]) ++f;
+        }
+        colflop[i] = f;
+        uint32_t ht = pow2_at_least(16, f);                                   /* :230-234 */
+        if (ht > cap) { cap = ht; tab = (uint32_t*)realloc(tab, sizeof(uint32_t) * cap); }
+        for (uint32_t j = 0; j < ht; ++j) tab[j] = EMPTY32;
+        uint32_t nz = 0;
+        for (uint32_t j = Bcolptr[i]; j < Bcolptr[i + 1]; ++j) {              /* :242-272 */
+            uint32_t c = Browids[j];
+            for (uint32_t k = Acolptr[c]; k < Acolptr[c + 1]; ++k) {
+                uint32_t key = Arowids[k];
+                if (i >= key) continue;
+                uint32_t h = (key * 107u) & (ht - 1);
+                for (;;) {
+                    if (tab[h] == key) break;
+                    if (tab[h] == EMPTY32) { tab[h] = key; nz++; break; }
+                    h = (h + 1) & (ht - 1);
+                }
+            }
+        }
+        colnnz[i] = nz;
+    }
+    free(tab);
+}
+
+/* Phase 2: LocalSpGEMM (overlap.hpp:281-363) + what RunPairWiseAlignments reads from each value
+ * (overlap.hpp:531-585: chain(), choose(), overlapop on the chosen seed).
+ * colptrC = exclusive scan of colnnz (nreads+1).  out has colptrC[nreads] records, column-major, slot
+ * order within a column -- exactly the order the reference writes lines in at one thread. */
+void oracle_numeric(uint32_t nreads, const uint32_t* Bcolptr, const uint32_t* Browids, const uint16_t* Bvalues,
+                    const uint32_t* Acolptr, const uint32_t* Arowids, const uint16_t* Avalues,
+                    const char* const* seqs, const uint32_t* lens, int k, int binSize, const uint32_t* colptrC,
+                    oracle_pair* out) {
+    uint32_t cap = 16;
+    uint32_t* hk = (uint32_t*)malloc(sizeof(uint32_t) * cap);
+    oval_t* hv = (oval_t*)calloc(cap, sizeof(oval_t));
+    for (uint32_t i = 0; i < nreads; ++i) {
+        uint32_t nnzc = colptrC[i + 1] - colptrC[i];
+        uint32_t ht = pow2_at_least(16, nnzc);                                /* :291-295 */
+        if (ht > cap) {
+            hk = (uint32_t*)realloc(hk, sizeof(uint32_t) * ht);
+            hv = (oval_t*)realloc(hv, sizeof(oval_t) * ht);
+            memset(hv + cap, 0, sizeof(oval_t) * (ht - cap));
+            cap = ht;
+        }
+        for (uint32_t j = 0; j < ht; ++j) hk[j] = EMPTY32;
+        for (uint32_t j = Bcolptr[i]; j < Bcolptr[i + 1]; ++j) {              /* :306 */
+            uint32_t c = Browids[j];
+            uint16_t posV = Bvalues[j];
+            for (uint32_t kk = Acolptr[c]; kk < Acolptr[c + 1]; ++kk) {       /* :310 */
+                uint32_t key = Arowids[kk];
+                if (i >= key) continue;                                       /* :315 */
+                uint16_t posH = Avalues[kk];
+                opos_t q; q.h = posH; q.v = posV;
+                uint16_t ovq = (uint16_t)o_overlapop(seqs[key], lens[key], seqs[i], lens[i], posH, posV, (uint16_t)k);
+                uint32_t h = (key * 107u) & (ht - 1);
+                for (;;) {
+                    if (hk[h] == key) { o_fold(&hv[h], 0, q, ovq, binSize, k); break; }       /* :324-328 */
+                    if (hk[h] == EMPTY32) { hk[h] = key; o_fold(&hv[h], 1, q, ovq, binSize, k); break; } /* :329-334 */
+                    h = (h + 1) & (ht - 1);
+                }
+            }
+        }
+        oracle_pair* o = out + colptrC[i];
+        uint32_t idx = 0;
+        for (uint32_t j = 0; j < ht; ++j) {                                   /* :343-361 slot order */
+            if (hk[j] == EMPTY32) continue;
+            oval_t* v = &hv[j];
+            uint32_t* sup = (uint32_t*)malloc(sizeof(uint32_t) * v->nbins);
+            for (uint32_t b = 0; b < v->nbins; ++b) sup[b] = (uint16_t)v->bins[b].npos;   /* support is u16 */
+            uint32_t w = oracle_choose_bin(sup, v->nbins);
+            oracle_pair p;
+            p.rid = hk[j]; p.cid = i; p.count = v->count;
+            p.seedH = v->bins[w].pos[0].h; p.seedV = v->bins[w].pos[0].v;
+            p.nbins = v->nbins > 65535 ? 65535 : (uint16_t)v->nbins;
+            p.support = (uint16_t)sup[w];
+            p.binov = v->bins[w].overlap;
+            p.overlap = o_overlapop(seqs[p.rid], lens[p.rid], seqs[i], lens[i], p.seedH, p.seedV, (uint16_t)k);
+            o[idx++] = p;
+            free(sup);
+            val_free(v);
+        }
+    }
+    free(hk); free(hv);
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * Xavier X-drop (xavier/xavier.h, xavier/simdutils.h) -- scalar restatement of the AVX2 int8 code
+ * ------------------------------------------------------------------------------------------------- */
+#define XW 32          /* VECTORWIDTH  simdutils.h:22 */
+#define XLW 31         /* LOGICALWIDTH simdutils.h:23 */
+#define XNINF (-128)   /* NINF         simdutils.h:48 */
+#define XMIDDLE 15     /* MIDDLE       simdutils.h:51 */
+#define XCUTOFF 102    /* CUTOFF       simdutils.h:53 */
+
+static int8_t adds8(int a, int b) { int s = a + b; return (int8_t)(s > 127 ? 127 : (s < -128 ? -128 : s)); }
+static int8_t subs8(int a, int b) { int s = a - b; return (int8_t)(s > 127 ? 127 : (s < -128 ? -128 : s)); }
+
+typedef struct {
+    const int8_t *qh, *qv;    /* padded: len+1 chars (incl. NUL) then 32 x NINF, simdutils.h:187-196 */
+    uint32_t hl, vl;          /* hlength = len+1, simdutils.h:175-176 */
+    int hoff, voff;
+    int8_t vqh[XW], vqv[XW], a1[XW], a2[XW], a3[XW];
+    int64_t best, curr, off, X;
+    int endH, endV;           /* state.seed end positions */
+    int xdrop;
+    int flagged;              /* the uninitialised-maxpos first iteration was hit */
+} xstate;
+
+static void x_step(xstate* s) {                                              /* xavier.h:111-129 / :193-211 */
+    int8_t a1f[XW], a2f[XW];
+    for (int e = 0; e < XW; ++e) {
+        int m = (s->vqh[e] == s->vqv[e]) ? 1 : -1;                           /* cmpeq + blendv */
+        a1f[e] = adds8(m, s->a1[e]);
+        int sh = (e == XW - 1) ? XNINF : s->a2[e + 1];                        /* shiftLeft simdutils.h:106-117 */
+        int mx = sh > s->a2[e] ? sh : s->a2[e];
+        a2f[e] = adds8(mx, -1);
+    }
+    for (int e = 0; e < XW; ++e) s->a3[e] = a1f[e] > a2f[e] ? a1f[e] : a2f[e];
+    s->a3[XLW] = XNINF;                                                      /* :128 */
+}
+static void x_move_right(xstate* s) {                                        /* simdutils.h:263-274 */
+    for (int e = 0; e < XW - 1; ++e) s->vqh[e] = s->vqh[e + 1];
+    s->vqh[XW - 1] = XNINF;
+    s->vqh[XLW - 1] = s->qh[s->hoff++];
+    for (int e = 0; e < XW - 1; ++e) s->a1[e] = s->a2[e + 1];
+    s->a1[XW - 1] = XNINF;
+    memcpy(s->a2, s->a3, XW);
+}
+static void x_move_down(xstate* s) {                                         /* simdutils.h:276-289 */
+    for (int e = XW - 1; e > 0; --e) s->vqv[e] = s->vqv[e - 1];
+    s->vqv[0] = s->qv[s->voff++];
+    memcpy(s->a1, s->a2, XW);
+    for (int e = XW - 1; e > 0; --e) s->a2[e] = s->a3[e - 1];
+    s->a2[0] = XNINF;
+}
+/* returns 1 if the X-drop fired (caller returns) */
+static int x_after_step(xstate* s, int8_t* adb_out) {
+    int8_t adb = s->a3[0];
+    for (int e = 1; e < XW; ++e) if (s->a3[e] > adb) adb = s->a3[e];          /* :134 max over VECTORWIDTH */
+    s->curr = adb + s->off;                                                  /* :135 */
+    if (s->curr < s->best - s->X) { s->xdrop = 1; return 1; }                 /* :137-150 */
+    if (adb > XCUTOFF) {                                                     /* :152-158 */
+        int8_t mn = s->a3[0];
+        for (int e = 1; e < XLW; ++e) if (s->a3[e] < mn) mn = s->a3[e];       /* min over LOGICALWIDTH */
+        for (int e = 0; e < XW; ++e) { s->a2[e] = subs8(s->a2[e], mn); s->a3[e] = subs8(s->a3[e], mn); }
+        s->off += mn;
+    }
+    if (s->curr > s->best) s->best = s->curr;                                 /* :161-162 */
+    *adb_out = adb;
+    return 0;
+}
+
+static void x_one_direction(xstate* s) {                                     /* xavier.h:257-274 */
+    /* ---- Phase 1, xavier.h:20-103 */
+    int DP[XLW + 2][XLW + 2];
+    DP[0][0] = 0;
+    for (int i = 1; i < XLW + 2; ++i) { DP[0][i] = -i; DP[i][0] = -i; }
+    int DPmax = 0;
+    for (int i = 1; i < XLW + 2; ++i)
+        for (int j = 1; j <= XLW + 2 - i; ++j) {
+            int oneF = DP[i - 1][j - 1] + ((s->qh[i - 1] == s->qv[j - 1]) ? 1 : -1);
+            int twoF = (DP[i - 1][j] > DP[i][j - 1] ? DP[i - 1][j] : DP[i][j - 1]) - 1;
+            DP[i][j] = oneF > twoF ? oneF : twoF;
+            if (DP[i][j] > DPmax) DPmax = DP[i][j];
+        }
+    for (int i = 0; i < XLW; ++i) { s->vqh[i] = s->qh[i + 1]; s->vqv[i] = s->qv[XLW - i]; }
+    s->vqh[XLW] = XNINF; s->vqv[XLW] = XNINF;
+    int adm = -128;
+    for (int i = 1; i < XLW + 1; ++i) {
+        int v1 = DP[i][XLW - i + 1], v2 = DP[i + 1][XLW - i + 1];
+        s->a1[i - 1] = (int8_t)v1; s->a2[i] = (int8_t)v2;
+        if (v1 > adm) adm = v1;
+    }
+    s->a1[XLW] = XNINF; s->a2[0] = XNINF;
+    for (int e = 0; e < XW; ++e) s->a3[e] = XNINF;
+    s->best = DPmax; s->curr = adm;
+    if (adm < DPmax - s->X) { s->xdrop = 1; s->endH = s->hoff; s->endV = s->voff; return; }   /* :91-99 */
+
+    /* ---- Phase 2, xavier.h:105-183 */
+    int maxpos = 0;          /* uninitialised in the reference (:165); policy: 0, and flag first-iteration use */
+    int first = 1;
+    while (s->hoff < (int)s->hl && s->voff < (int)s->vl) {
+        int8_t adb;
+        x_step(s);
+        if (x_after_step(s, &adb)) { s->endH = s->hoff; s->endV = s->voff; return; }          /* :141-149 */
+        int mx = 0, found = 0;
+        for (int e = 0; e < XW; ++e) if (s->a3[e] > mx) { maxpos = e; mx = s->a3[e]; found = 1; }  /* :165-173 */
+        if (first && !found) s->flagged = 1;
+        first = 0;
+        s->endH = s->hoff; s->endV = s->voff;                                 /* :175-176 */
+        if (maxpos > XMIDDLE) x_move_right(s); else x_move_down(s);           /* :178-181 */
+    }
+    /* ---- Phase 4, xavier.h:185-251 */
+    int dir = s->hoff >= (int)s->hl ? 1 : 0;                                  /* goDOWN=1, goRIGHT=0 */
+    for (int i = 0; i < XLW - 3; ++i) {
+        int8_t adb;
+        x_step(s);
+        if (x_after_step(s, &adb)) return;                                    /* :219-223 (end not updated) */
+        int next = dir ^ 1;
+        if (next == 0) x_move_right(s); else x_move_down(s);
+        dir = next;
+    }
+}
+
+static void x_run(const char* h, uint32_t hn, const char* v, uint32_t vn, int X, xstate* s, int8_t** bufs) {
+    memset(s, 0, sizeof(*s));
+    int8_t* qh = (int8_t*)malloc((size_t)hn + 1 + XW);
+    int8_t* qv = (int8_t*)malloc((size_t)vn + 1 + XW);
+    memcpy(qh, h, hn); qh[hn] = 0; memset(qh + hn + 1, XNINF, XW);            /* simdutils.h:191-196 */
+    memcpy(qv, v, vn); qv[vn] = 0; memset(qv + vn + 1, XNINF, XW);
+    s->qh = qh; s->qv = qv; s->hl = hn + 1; s->vl = vn + 1;
+    s->hoff = XLW; s->voff = XLW; s->X = X;
+    bufs[0] = qh; bufs[1] = qv;
+}
+
+typedef struct {
+    int32_t score;
+    int32_t begH, endH, begV, endV;
+    int32_t strand;      /* 0 = "n", 1 = "c" */
+    int32_t flagged;     /* an extension used the uninitialised maxpos (reference is ASLR-dependent there) */
+    int32_t steps;       /* anti-diagonal steps taken, both directions (work unit for GCUPS) */
+} oracle_aln;
+
+static char comp(char c) { switch (c) { case 'A': return 'T'; case 'T': return 'A'; case 'G': return 'C'; case 'C': return 'G'; } return 'N'; }
+
+/* xavier.h:276-374 XavierXDrop, XAVIER_EXTEND_BOTH branch (:325-373), on already-oriented strings. */
+void oracle_xavier_xdrop(const char* target, uint32_t tlen, const char* query, uint32_t qlen, int begH, int begV,
+                         int k, int X, oracle_aln* out) {
+    int bH = begH, bV = begV, eH = begH + k, eV = begV + k;
+    int64_t best1 = 0, best2 = 0;
+    int flagged = 0, steps = 0;
+    /* left: reversed prefixes INCLUDING the seed (:330-334) */
+    uint32_t tpn = (uint32_t)eH, qpn = (uint32_t)eV;
+    if (tpn < XW || qpn < XW) { bH = eH - (int)tpn; bV = eV - (int)qpn; }      /* :338-342 */
+    else {
+        char* tp = (char*)malloc(tpn); char* qp = (char*)malloc(qpn);
+        for (uint32_t i = 0; i < tpn; ++i) tp[i] = target[tpn - 1 - i];
+        for (uint32_t i = 0; i < qpn; ++i) qp[i] = query[qpn - 1 - i];
+        xstate s; int8_t* bufs[2];
+        x_run(tp, tpn, qp, qpn, X, &s, bufs);
+        x_one_direction(&s);
+        bH = eH - s.endH; bV = eV - s.endV;                                   /* :345-348 */
+        best1 = s.best; flagged |= s.flagged;
+        steps += (s.hoff - XLW) + (s.voff - XLW);
+        free(bufs[0]); free(bufs[1]); free(tp); free(qp);
+    }
+    /* right: suffixes AFTER the seed (:351-352) */
+    uint32_t tsn = tlen - (uint32_t)eH, qsn = qlen - (uint32_t)eV;
+    if (tsn < XW || qsn < XW) { bH = eH + (int)tsn; bV = eV + (int)qsn; }      /* :356-360 writes BEGIN (sic) */
+    else {
+        xstate s; int8_t* bufs[2];
+        x_run(target + eH, tsn, query + eV, qsn, X, &s, bufs);
+        x_one_direction(&s);
+        eH += s.endH; eV += s.endV;                                           /* :365-366 */
+        best2 = s.best; flagged |= s.flagged;
+        steps += (s.hoff - XLW) + (s.voff - XLW);
+        free(bufs[0]); free(bufs[1]);
+    }
+    out->score = (int32_t)(best1 + best2);                                    /* simdutils.h:333-337 */
+    out->begH = bH; out->endH = eH; out->begV = bV; out->endV = eV;
+    out->flagged = flagged; out->steps = steps;
+}
+
+/* include/align.hpp:152-202 xavierAlign: row = H read (rid), col = V read (cid). */
+void oracle_xavier_align(const char* row, uint32_t rowLen, const char* col, uint32_t colLen, int i, int j, int X,
+                         int k, oracle_aln* out) {
+    int rc = 1;                                                               /* :171-176 */
+    for (int t = 0; t < k; ++t) if (comp(row[i + k - 1 - t]) != col[j + t]) { rc = 0; break; }
+    if (rc) {
+        char* cpy = (char*)malloc(rowLen);
+        for (uint32_t t = 0; t < rowLen; ++t) cpy[t] = comp(row[rowLen - 1 - t]);     /* :178-179 */
+        oracle_xavier_xdrop(cpy, rowLen, col, colLen, (int)rowLen - i - k, j, k, X, out);  /* :181-185 */
+        out->strand = 1;
+        free(cpy);
+    } else {
+        oracle_xavier_xdrop(row, rowLen, col, colLen, i, j, k, X, out);       /* :191 */
+        out->strand = 0;
+    }
+}
+
+/* include/overlap.hpp:413-497 PostAlignDecision (fixedThreshold == -1): returns pass/fail and the u16
+ * overlap estimate `ov`.  ratiophi = slope(e) (align.hpp:72-80), delta = deltaChernoff. */
+int oracle_post_align(int score, int begV, int endV, int begH, int endH, uint32_t len1_H, uint32_t len2_V,
+                      double ratiophi, double delta, uint16_t* ov_out) {
+    uint16_t read1len = (uint16_t)len1_H, read2len = (uint16_t)len2_V;        /* :441-442 */
+    uint16_t overlapLenV = (uint16_t)(endV - begV), overlapLenH = (uint16_t)(endH - begH);   /* :444-445 */
+    uint16_t minLeft = (uint16_t)(begV < begH ? begV : begH);                 /* :447 */
+    int r2 = read2len - endV, r1 = read1len - endH;
+    uint16_t minRight = (uint16_t)(r2 < r1 ? r2 : r1);                        /* :448 */
+    uint16_t ov = (uint16_t)(minLeft + minRight + (overlapLenV + overlapLenH) / 2);   /* :449 */
+    float thr = (float)((1 - delta) * (ratiophi * (float)ov));                /* :456 */
+    *ov_out = ov;
+    return (float)score >= thr;                                               /* :457 */
+}
+
+/* overlap.hpp:149-154 toOriginalCoordinates (PAF, "-" strand) */
+void oracle_to_original(int* begpH, int* endpH, int lenH) {
+    unsigned int tmp = (unsigned int)*begpH;
+    *begpH = lenH - *endpH;
+    *endpH = lenH - (int)tmp;
+}
+
+double oracle_slope(double error) {                                          /* align.hpp:72-80 */
+    double p_mat = (1 - error) * (1 - error);   /* pow(1-error,2) */
+    double p_mis = 1 - p_mat;
+    return 1.0 * p_mat - 1.0 * p_mis;
+}

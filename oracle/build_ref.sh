@@ -1,0 +1,47 @@
+#!/usr/bin/env bash
+# TEST INFRASTRUCTURE ONLY -- builds the *reference itself* (PASSIONLab/BELLA, CPU path) from the
+# sources where they lie under /root/reference into oracle/_ref/.  Nothing is copied into the repo;
+# oracle/_ref/ is git-ignored (but travels to the GPU box with the snapshot, like our own .so files).
+#
+# Does NOT run the reference's build system (no `make -C libbloom`, no makefile-nersc): every
+# translation unit is compiled directly with gcc/g++, flags taken from makefile-nersc:18-61 and
+# libbloom/Makefile:24-47.  `-lbz2 -lz` are dropped (NO_GZIP is defined, kmercode/common.h:16) and the
+# `rmat` target is skipped (never linked into `bella`, makefile-nersc:60-61).
+#
+# Products:
+#   oracle/_ref/bella_ref        the reference CLI (src/main.cpp)            -> golden .out files
+#   oracle/_ref/bella_ref_dump   same with -DWRITEDATAMATRIX (bellaio.h:2-47)  -> readbykmers.mtx
+#   oracle/_ref/libbella_ref.so  oracle/ref_shim.cpp (ours) #including the reference headers:
+#                                C entry points around HashSpGEMM / xavierAlign for tests + cpu_baseline
+set -euo pipefail
+REF=${BELLA_REFERENCE:-/root/reference}
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/_ref"
+if [ ! -d "$REF/src" ]; then
+  echo "build_ref: $REF not present (GPU box?) -- using prebuilt oracle/_ref if any"; exit 0
+fi
+mkdir -p "$OUT/obj"
+O="$OUT/obj"
+INC="-I$REF/include/common/GTgraph/sprng2.0-lite/include -I$REF/loganGPU -I$REF/seqan"
+stamp="$O/.stamp"
+if [ -f "$stamp" ] && [ "$OUT/libbella_ref.so" -nt "$HERE/ref_shim.cpp" ] && [ -x "$OUT/bella_ref" ] \
+   && [ -x "$OUT/bella_ref_dump" ] && [ "${1:-}" != "--force" ]; then
+  echo "build_ref: up to date"; exit 0
+fi
+set -x
+g++ -O3 -I"$REF/libbloom" -I"$REF/libbloom/murmur2" -fPIC -c "$REF/libbloom/bloom64.cpp" -o "$O/bloom64.o"
+g++ -O3 -I"$REF/libbloom" -I"$REF/libbloom/murmur2" -fPIC -c "$REF/libbloom/murmur2/MurmurHash2.c" -o "$O/murmurhash2.o"
+gcc -O3 -fopenmp -fPIC -c -o "$O/Buffer.o" "$REF/kmercode/Buffer.c"
+gcc -O3 -fopenmp -fPIC -std=gnu99 -c -o "$O/fq_reader.o" "$REF/kmercode/fq_reader.c"
+gcc -O3 -fopenmp -fPIC -c -o "$O/hash_funcs.o" "$REF/kmercode/hash_funcs.c"
+g++ -std=c++11 -fpermissive -w -O3 -fPIC -I"$REF" -c "$REF/optlist/optlist.c" -o "$O/optlist.o"
+g++ -O3 -fopenmp -fPIC -std=c++11 -c -o "$O/Kmer.o" "$REF/kmercode/Kmer.cpp"
+OBJS="$O/hash_funcs.o $O/Kmer.o $O/Buffer.o $O/fq_reader.o $O/optlist.o $O/bloom64.o $O/murmurhash2.o"
+g++ -std=c++14 -w -O3 $INC -mavx2 -fopenmp -fpermissive -o "$OUT/bella_ref" $OBJS "$REF/src/main.cpp" -lpthread &
+g++ -std=c++14 -w -O3 $INC -mavx2 -fopenmp -fpermissive -DWRITEDATAMATRIX -o "$OUT/bella_ref_dump" $OBJS "$REF/src/main.cpp" -lpthread &
+g++ -std=c++14 -w -O3 $INC -I"$REF" -DBELLA_REF_ROOT="\"$REF\"" -mavx2 -fopenmp -fpermissive -fPIC -shared \
+    -o "$OUT/libbella_ref.so" "$HERE/ref_shim.cpp" $OBJS -lpthread &
+wait
+set +x
+touch "$stamp"
+ls -la "$OUT"

@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- regenerates tests/golden/ from the *reference binary*.
+
+Runs only in the build container (needs /root/reference and oracle/_ref/ built by
+oracle/build_ref.sh).  For every fixture set it writes a FASTQ, runs the reference
+(`bella_ref_dump` = src/main.cpp with -DWRITEDATAMATRIX, `bella_ref`) at OMP_NUM_THREADS=1
+(the only reproducible setting) and stores *data only*:
+
+  reads.fastq.gz   input
+  tuples.npz       (kmer, read, pos) from readbykmers.mtx (include/common/bellaio.h:2-47) -- pins k-mer ids
+  skip.out.gz      bella_ref --skip-alignment          (overlap.hpp:580-585, 6 columns)
+  align.out.gz     bella_ref (default, Xavier X-drop)  (overlap.hpp:472-473, 12 columns)
+  paf.out.gz       bella_ref --paf                     (overlap.hpp:476-489)
+  stdout.json      stdout protocol numbers (nkmer, nnzA, nnzC, outputted)
+  meta.json        flags used
+
+plus tests/golden/xavier_kat.json: XavierXDrop/xavierAlign known answers (xavier/demo.cpp inputs and
+hand-made edge cases) computed by the reference through oracle/_ref/libbella_ref.so.
+"""
+import ctypes
+import gzip
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bella_amd import synth  # noqa: E402
+
+REF = os.environ.get("BELLA_REFERENCE", "/root/reference")
+RB = os.path.join(ROOT, "oracle", "_ref")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def run_ref(binary, fastq, extra, cwd):
+    with open(os.path.join(cwd, "in.txt"), "w") as f:
+        f.write(fastq + "\n")  # list file must end in '\n' (kmercount.hpp:96)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run([os.path.join(RB, binary), "-f", "in.txt", "-o", "out"] + extra, cwd=cwd, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    # exit status is meaningless (teardown abort): judge by the final stdout line
+    out = p.stdout.decode(errors="replace")
+    with open(os.path.join(cwd, "out.out"), "rb") as f:
+        data = f.read()
+    return out, data
+
+
+def stdout_numbers(txt):
+    nums = [ln.strip() for ln in txt.splitlines() if re.fullmatch(r"[0-9.eE+-]+", ln.strip())]
+    return nums
+
+
+def make_set(name, rs, flags):
+    d = os.path.join(GOLD, name)
+    os.makedirs(d, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        fq = os.path.join(tmp, "reads.fastq")
+        synth.write_fastq(fq, rs)
+        so, align = run_ref("bella_ref_dump", fq, flags, tmp)
+        tup = synth.read_mtx_tuples(os.path.join(tmp, "readbykmers.mtx"))
+        # the reference emits tuples read by read at one thread; keep its order
+        np.savez_compressed(os.path.join(d, "tuples.npz"), kmer=tup.kmer, read=tup.read, pos=tup.pos,
+                            nkmers=np.int64(tup.nkmers))
+        so2, align2 = run_ref("bella_ref", fq, flags, tmp)
+        assert align2 == align, "reference not reproducible at 1 thread?"
+        so3, skip = run_ref("bella_ref", fq, flags + ["--skip-alignment"], tmp)
+        so4, paf = run_ref("bella_ref", fq, flags + ["--paf"], tmp)
+        with open(fq, "rb") as f, gzip.open(os.path.join(d, "reads.fastq.gz"), "wb", compresslevel=9) as g:
+            g.write(f.read())
+        for nm, data in (("align.out.gz", align), ("skip.out.gz", skip), ("paf.out.gz", paf)):
+            with gzip.open(os.path.join(d, nm), "wb", compresslevel=9) as g:
+                g.write(data)
+        with open(os.path.join(d, "stdout.json"), "w") as f:
+            json.dump({"align": stdout_numbers(so2), "skip": stdout_numbers(so3)}, f, indent=1)
+        with open(os.path.join(d, "meta.json"), "w") as f:
+            json.dump({"flags": flags, "nreads": rs.nreads, "threads": 1}, f, indent=1)
+    print(name, "reads", rs.nreads, "tuples", tup.kmer.shape[0], "nkmers", tup.nkmers, "align lines",
+          align.count(b"\n"), "skip lines", skip.count(b"\n"))
+
+
+def repeat_genome_reads(seed):
+    """reads from a genome with a duplicated 1.5 kb segment -> pairs with several overlap bins"""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=7000, dtype=np.uint8)
+    g[4000:5500] = g[500:2000]
+    rs = synth.make_reads(90, read_len=2200, err=0.12, seed=seed, genome_len=7000)
+    # make_reads draws its own genome; rebuild the reads from OUR genome with the same recipe
+    rng2 = np.random.default_rng(seed + 1)
+    seqs, names = [], []
+    for r in range(90):
+        L = 2200
+        st = int(rng2.integers(0, 7000 - L))
+        t = g[st:st + L].copy()
+        if rng2.integers(0, 2):
+            t = (3 - t)[::-1]
+        u = rng2.random(L)
+        out = []
+        for b, x in zip(t, u):
+            if x < 0.036:
+                continue
+            if x < 0.048:
+                b = (b + int(rng2.integers(1, 4))) & 3
+            out.append(int(b))
+            if 0.048 <= x < 0.12:
+                out.append(int(rng2.integers(0, 4)))
+        seqs.append(bytes(synth.BASES[np.asarray(out, dtype=np.uint8)]))
+        names.append("rep%d_%d" % (r, st))
+    return synth.readset_from_seqs(seqs, names)
+
+
+def xavier_kats():
+    lib = ctypes.CDLL(os.path.join(RB, "libbella_ref.so"))
+    lib.bella_ref_xavier_xdrop.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    lib.bella_ref_xavier_align.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p]
+    kats = []
+    # 1) the reference's own demo inputs (xavier/demo.cpp:108-121): sequences are data held by the demo
+    src = open(os.path.join(REF, "xavier", "demo.cpp")).read()
+    s1 = re.search(r'^\s*seq1 = "([ACGT]+)', src, re.M).group(1)
+    s2 = re.search(r'^\s*seq2 = "([ACGT]+)', src, re.M).group(1)
+    out = (ctypes.c_int * 6)()
+    lib.bella_ref_xavier_xdrop(s1.encode(), s2.encode(), 56, 1916, 17, 15, out)
+    kats.append({"kind": "xdrop", "name": "demo.cpp", "target": s1, "query": s2, "begH": 56, "begV": 1916, "k": 17,
+                 "x": 15, "expect": list(out)[:5], "exit_score": out[5]})
+    rng = np.random.default_rng(42)
+
+    def rnd(n):
+        return bytes(synth.BASES[rng.integers(0, 4, size=n, dtype=np.uint8)]).decode()
+
+    def mutate(s, e):
+        o = []
+        for ch in s:
+            u = rng.random()
+            if u < e * 0.3:
+                continue
+            if u < e * 0.4:
+                ch = "ACGT"[(("ACGT".index(ch)) + int(rng.integers(1, 4))) & 3]
+            o.append(ch)
+            if e * 0.4 <= u < e:
+                o.append("ACGT"[int(rng.integers(0, 4))])
+        return "".join(o)
+
+    def rc(s):
+        return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+    def add_align(name, row, col, i, j, x=7, k=17):
+        o = (ctypes.c_int * 5)()
+        st = ctypes.create_string_buffer(2)
+        lib.bella_ref_xavier_align(row.encode(), col.encode(), len(row), i, j, x, k, o, st)
+        kats.append({"kind": "align", "name": name, "row": row, "col": col, "i": i, "j": j, "k": k, "x": x,
+                     "expect": list(o), "strand": st.value.decode()[:1]})
+
+    base = rnd(3000)
+    seed = base[1500:1517]
+    # identical / noisy copies, both strands; seed positions vary to hit short-prefix / short-suffix paths
+    a = mutate(base[:1500], 0.15) + seed + mutate(base[1517:], 0.15)
+    b = mutate(base[:1500], 0.15) + seed + mutate(base[1517:], 0.15)
+    ia, ib = a.index(seed), b.index(seed)
+    add_align("noisy_n", a, b, ia, ib)
+    ra = rc(a)
+    add_align("noisy_c", ra, b, len(a) - ia - 17, ib)
+    add_align("identical_rebase", base, base, 1500, 1500)                # long exact match -> re-basing > CUTOFF
+    add_align("identical_x15", base, base, 700, 700, x=15)
+    add_align("short_prefix", a[ia - 10:], b[ib - 3:], 10, 3)            # prefix < 32 on both
+    add_align("short_prefix_one", a[ia - 10:], b, 10, ib)                 # prefix < 32 on H only
+    add_align("short_suffix", a[:ia + 17 + 9], b[:ib + 17 + 40], ia, ib)  # suffix < 32 on H (begin-instead-of-end quirk)
+    add_align("short_both", a[ia - 5:ia + 17 + 5], b[ib - 5:ib + 17 + 5], 5, 5)
+    add_align("exact_32_prefix", a[ia - 15:], b[ib - 15:], 15, 15)       # prefix length == 32 exactly
+    add_align("exact_31_prefix", a[ia - 14:], b[ib - 14:], 14, 14)
+    # unrelated sequences sharing only the seed: drifts, phase-4 exits, x-drop exits
+    for t in range(6):
+        u1, u2 = rnd(900 + 97 * t), rnd(1100 - 53 * t)
+        p1, p2 = 100 + 60 * t, 500 - 70 * t
+        u1 = u1[:p1] + seed + u1[p1 + 17:]
+        u2 = u2[:p2] + seed + u2[p2 + 17:]
+        add_align("junk%d" % t, u1, u2, p1, p2)
+        add_align("junk%d_x2" % t, u1, u2, p1, p2, x=2)
+    # unequal lengths -> one sequence ends first (phase 4), both directions
+    add_align("h_ends_first", a[ia - 200:ia + 217], b, 200, ib)
+    add_align("v_ends_first", a, b[ib - 150:ib + 167], ia, 150)
+    add_align("k15", a, b, ia, ib, k=15)
+    for e in (0.02, 0.08, 0.25, 0.4):
+        aa = mutate(base[:1500], e) + seed + mutate(base[1517:], e)
+        bb = mutate(base[:1500], e) + seed + mutate(base[1517:], e)
+        add_align("err%g" % e, aa, bb, aa.index(seed), bb.index(seed))
+    with open(os.path.join(GOLD, "xavier_kat.json"), "w") as f:
+        json.dump(kats, f, indent=0)
+    print("xavier KATs:", len(kats), "demo ->", kats[0]["expect"], kats[0]["exit_score"])
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    # the reference's own 3-read sanity input is a data file (sanitytests/reversecomptest.fastq)
+    rs = synth.read_fastq(os.path.join(REF, "sanitytests", "reversecomptest.fastq"))
+    make_set("sanity3", rs, [])
+    make_set("toy120", synth.make_reads(120, read_len=2000, err=0.15, seed=7), [])
+    make_set("toylen80", synth.make_reads(80, read_len=1800, err=0.15, seed=11, len_jitter=0.5, coverage=25.0), [])
+    make_set("toyhifi50", synth.make_reads(50, read_len=2500, err=0.005, seed=3, mix=(1 / 3, 1 / 3, 1 / 3), coverage=5.0),
+             ["-e", "0.005"])
+    make_set("toyrep90", repeat_genome_reads(5), ["-e", "0.12", "-u", "30"])
+    xavier_kats()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,222 @@
+"""TEST INFRASTRUCTURE: ctypes binding of oracle/bella_oracle.c (the CPU restatement) and, when present,
+of oracle/_ref/libbella_ref.so (the reference's own code).  Only tests/, smoke() and bench.py's
+cpu_baseline leg import this module; nothing under bella_amd/ does."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ODIR, "liboracle.so")
+REFLIB = os.path.join(ODIR, "_ref", "libbella_ref.so")
+
+PAIR_DT = np.dtype([("rid", "<u4"), ("cid", "<u4"), ("count", "<u2"), ("seedH", "<u2"), ("seedV", "<u2"),
+                    ("nbins", "<u2"), ("support", "<u2"), ("binov", "<u2"), ("overlap", "<i4")])
+ALN_DT = np.dtype([("score", "<i4"), ("begH", "<i4"), ("endH", "<i4"), ("begV", "<i4"), ("endV", "<i4"),
+                   ("strand", "<i4"), ("flagged", "<i4"), ("steps", "<i4")])
+
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+
+
+def build_oracle(force: bool = False) -> str:
+    src = os.path.join(ODIR, "bella_oracle.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-std=c99", "-shared", "-fPIC", "-o", LIB, src, "-lm"])
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build_oracle())
+        L = _lib
+        L.oracle_build_B.restype = C.c_int64
+        L.oracle_build_B.argtypes = [C.c_uint32, C.c_uint64, u32p, u32p, u16p, u32p, u32p, u16p]
+        L.oracle_transpose.argtypes = [C.c_uint32, C.c_uint32, u32p, u32p, u16p, u32p, u32p, u16p]
+        L.oracle_symbolic.argtypes = [C.c_uint32, u32p, u32p, u32p, u32p, u32p, u32p]
+        L.oracle_numeric.argtypes = [C.c_uint32, u32p, u32p, u16p, u32p, u32p, u16p, C.POINTER(C.c_char_p), u32p,
+                                     C.c_int, C.c_int, u32p, C.c_void_p]
+        L.oracle_xavier_align.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_void_p]
+        L.oracle_xavier_xdrop.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_void_p]
+        L.oracle_post_align.restype = C.c_int
+        L.oracle_post_align.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                        C.c_double, C.c_double, C.POINTER(C.c_uint16)]
+        L.oracle_slope.restype = C.c_double
+        L.oracle_slope.argtypes = [C.c_double]
+        L.oracle_choose_bin.restype = C.c_uint32
+        L.oracle_choose_bin.argtypes = [u32p, C.c_uint32]
+        L.oracle_overlapop.restype = C.c_int
+        L.oracle_overlapop.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint16, C.c_uint16, C.c_uint16]
+    return _lib
+
+
+def build_B(nreads, tk, tr, tp):
+    n = len(tk)
+    colptr = np.zeros(nreads + 1, np.uint32)
+    rowids = np.zeros(max(n, 1), np.uint32)
+    vals = np.zeros(max(n, 1), np.uint16)
+    nnz = lib().oracle_build_B(nreads, n, np.ascontiguousarray(tk, np.uint32), np.ascontiguousarray(tr, np.uint32),
+                               np.ascontiguousarray(tp, np.uint16), colptr, rowids, vals)
+    return colptr, rowids[:nnz].copy(), vals[:nnz].copy()
+
+
+def transpose(nreads, nkmers, Bc, Br, Bv):
+    nnz = len(Br)
+    Ac = np.zeros(nkmers + 1, np.uint32)
+    Ar = np.zeros(max(nnz, 1), np.uint32)
+    Av = np.zeros(max(nnz, 1), np.uint16)
+    lib().oracle_transpose(nreads, nkmers, Bc, _pad(Br, np.uint32), _pad(Bv, np.uint16), Ac, Ar, Av)
+    return Ac, Ar[:nnz].copy(), Av[:nnz].copy()
+
+
+def _pad(a, dt):
+    a = np.ascontiguousarray(a, dt)
+    return a if a.size else np.zeros(1, dt)
+
+
+def spgemm(seqs, nkmers, Bc, Br, Bv, k=17, bin_size=500):
+    """returns (colflop, colptrC, pairs[PAIR_DT]) in the reference's 1-thread output order"""
+    nreads = len(seqs)
+    Ac, Ar, Av = transpose(nreads, nkmers, Bc, Br, Bv)
+    flop = np.zeros(nreads, np.uint32)
+    nnzc = np.zeros(nreads, np.uint32)
+    lib().oracle_symbolic(nreads, Bc, _pad(Br, np.uint32), Ac, _pad(Ar, np.uint32), flop, nnzc)
+    colptrC = np.zeros(nreads + 1, np.uint32)
+    np.cumsum(nnzc, out=colptrC[1:])
+    pairs = np.zeros(int(colptrC[-1]), PAIR_DT)
+    arr = (C.c_char_p * nreads)(*[bytes(s) for s in seqs])
+    lens = np.asarray([len(s) for s in seqs], np.uint32)
+    out = pairs if pairs.size else np.zeros(1, PAIR_DT)
+    lib().oracle_numeric(nreads, Bc, _pad(Br, np.uint32), _pad(Bv, np.uint16), Ac, _pad(Ar, np.uint32),
+                         _pad(Av, np.uint16), arr, lens, k, bin_size, colptrC, out.ctypes.data)
+    return flop, colptrC, pairs
+
+
+def xavier_align(row: bytes, col: bytes, i: int, j: int, x: int = 7, k: int = 17):
+    out = np.zeros(1, ALN_DT)
+    lib().oracle_xavier_align(row, len(row), col, len(col), i, j, x, k, out.ctypes.data)
+    return out[0]
+
+
+def xavier_xdrop(target: bytes, query: bytes, begH: int, begV: int, k: int, x: int):
+    out = np.zeros(1, ALN_DT)
+    lib().oracle_xavier_xdrop(target, len(target), query, len(query), begH, begV, k, x, out.ctypes.data)
+    return out[0]
+
+
+def post_align(score, begV, endV, begH, endH, lenH, lenV, ratiophi, delta=0.1):
+    ov = C.c_uint16(0)
+    ok = lib().oracle_post_align(int(score), int(begV), int(endV), int(begH), int(endH), int(lenH), int(lenV),
+                                 float(ratiophi), float(delta), C.byref(ov))
+    return bool(ok), int(ov.value)
+
+
+def slope(e):
+    return lib().oracle_slope(float(e))
+
+
+# ---- output formatting (overlap.hpp:472-489, 580-585), independent of the product's writer ----------
+def skip_lines(names, lens, pairs) -> bytes:
+    out = []
+    for p in pairs:
+        out.append("%s\t%s\t%d\t%d\t%d\t%d\n" % (names[p["cid"]], names[p["rid"]], p["count"], p["overlap"],
+                                                 lens[p["cid"]] & 0xFFFF, lens[p["rid"]] & 0xFFFF))
+    return "".join(out).encode()
+
+
+def align_lines(names, seqs, pairs, x=7, k=17, err=0.15, delta=0.1, paf=False):
+    """returns (bytes, alignments[ALN_DT], passed mask)"""
+    phi = slope(err)
+    out = []
+    alns = np.zeros(len(pairs), ALN_DT)
+    passed = np.zeros(len(pairs), bool)
+    for n, p in enumerate(pairs):
+        rid, cid = int(p["rid"]), int(p["cid"])
+        a = xavier_align(seqs[rid], seqs[cid], int(p["seedH"]), int(p["seedV"]), x, k)
+        alns[n] = a
+        ok, ov = post_align(a["score"], a["begV"], a["endV"], a["begH"], a["endH"], len(seqs[rid]), len(seqs[cid]), phi, delta)
+        passed[n] = ok
+        if not ok:
+            continue
+        r1, r2 = len(seqs[rid]) & 0xFFFF, len(seqs[cid]) & 0xFFFF
+        st = "c" if a["strand"] else "n"
+        if not paf:
+            out.append("%s\t%s\t%d\t%d\t%d\t%s\t%d\t%d\t%d\t%d\t%d\t%d\n" % (
+                names[cid], names[rid], p["count"], a["score"], ov, st, a["begV"], a["endV"], r2, a["begH"], a["endH"], r1))
+        else:
+            bH, eH = int(a["begH"]), int(a["endH"])
+            if st == "c":
+                bH, eH = r1 - eH, r1 - int(np.uint32(bH))   # toOriginalCoordinates, overlap.hpp:149-154
+            out.append("%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%d\n" % (
+                names[cid], r2, a["begV"], a["endV"], "-" if st == "c" else "+", names[rid], r1, bH, eH, a["score"], ov, 255))
+    return "".join(out).encode(), alns, passed
+
+
+# ---- the reference itself, in-process (only where oracle/_ref was built) ---------------------------
+_ref = None
+
+
+def have_ref() -> bool:
+    return os.path.exists(REFLIB)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(REFLIB)
+        R = _ref
+        R.bella_ref_build_B.restype = C.c_int64
+        R.bella_ref_build_B.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, u32p, u32p, u16p, u32p, u32p, u16p]
+        R.bella_ref_transpose_B.restype = C.c_int64
+        R.bella_ref_transpose_B.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, u32p, u32p, u16p, u32p, u32p, u16p]
+        R.bella_ref_hashspgemm.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, u32p, u32p, u16p, C.POINTER(C.c_char_p),
+                                           C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_double, C.c_double, C.c_double, C.c_char_p, C.c_char_p, C.c_size_t,
+                                           C.c_char_p, C.c_size_t]
+        R.bella_ref_xavier_align.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(C.c_int), C.c_char_p]
+        R.bella_ref_slope.restype = C.c_double
+        R.bella_ref_slope.argtypes = [C.c_double]
+    return _ref
+
+
+def ref_build_B(nreads, nkmers, tk, tr, tp):
+    n = len(tk)
+    colptr = np.zeros(nreads + 1, np.uint32)
+    rowids = np.zeros(max(n, 1), np.uint32)
+    vals = np.zeros(max(n, 1), np.uint16)
+    nnz = ref().bella_ref_build_B(nreads, nkmers, n, _pad(tk, np.uint32), _pad(tr, np.uint32), _pad(tp, np.uint16),
+                                  colptr, rowids, vals)
+    return colptr, rowids[:nnz].copy(), vals[:nnz].copy()
+
+
+def ref_hashspgemm(seqs, names, nkmers, tk, tr, tp, outfile, k=17, bin_size=500, xdrop=7, skip=True, paf=False,
+                   err=0.15, delta=0.1, mem_mb=64000.0):
+    """runs the reference's HashSpGEMM on the tuples; returns (file bytes, stdout, stderr)"""
+    nreads = len(seqs)
+    sarr = (C.c_char_p * nreads)(*[bytes(s) for s in seqs])
+    narr = (C.c_char_p * nreads)(*[n.encode() for n in names])
+    so = C.create_string_buffer(1 << 16)
+    se = C.create_string_buffer(1 << 16)
+    ref().bella_ref_hashspgemm(nreads, nkmers, len(tk), _pad(tk, np.uint32), _pad(tr, np.uint32), _pad(tp, np.uint16),
+                               sarr, narr, k, bin_size, xdrop, int(skip), int(paf), err, delta, mem_mb,
+                               outfile.encode(), so, len(so), se, len(se))
+    data = open(outfile, "rb").read() if os.path.exists(outfile) else b""
+    return data, so.value.decode(), se.value.decode()
+
+
+def ref_xavier_align(row: bytes, col: bytes, i, j, x=7, k=17):
+    o = (C.c_int * 5)()
+    st = C.create_string_buffer(2)
+    ref().bella_ref_xavier_align(row, col, len(row), i, j, x, k, o, st)
+    return list(o), st.value.decode()[:1]

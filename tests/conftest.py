@@ -1,0 +1,56 @@
+import gzip
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+# the reference (oracle/_ref) is only reproducible at one OpenMP thread; libgomp reads this at load
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+GOLDEN_SETS = ["sanity3", "toy120", "toylen80", "toyhifi50", "toyrep90"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    def __init__(self, name):
+        from bella_amd import synth
+        d = os.path.join(GOLD, name)
+        self.name = name
+        self.rs = synth.read_fastq(os.path.join(d, "reads.fastq.gz"))
+        self.seqs = self.rs.seqs()
+        self.names = self.rs.names
+        z = np.load(os.path.join(d, "tuples.npz"))
+        self.tk, self.tr, self.tp = z["kmer"], z["read"], z["pos"]
+        self.nkmers = int(z["nkmers"])
+        self.meta = json.load(open(os.path.join(d, "meta.json")))
+        self.stdout = json.load(open(os.path.join(d, "stdout.json")))
+        self.out = {k: gzip.open(os.path.join(d, k + ".out.gz"), "rb").read() for k in ("skip", "align", "paf")}
+        fl = self.meta["flags"]
+        self.err = float(fl[fl.index("-e") + 1]) if "-e" in fl else 0.15
+        self.k = 17
+        self.xdrop = 7
+
+
+_cache = {}
+
+
+def load_golden(name):
+    if name not in _cache:
+        _cache[name] = Golden(name)
+    return _cache[name]
+
+
+@pytest.fixture(params=GOLDEN_SETS)
+def golden(request):
+    return load_golden(request.param)
