@@ -1,0 +1,71 @@
+"""ctypes loader for libbella_hip.so (the C ABI of include/bella_hip.h).
+
+There is no fallback: if the library is missing or no gfx950 device is present the product path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(HERE, "libbella_hip.so")
+
+PAIR_DT = np.dtype([("rid", "<u4"), ("cid", "<u4"), ("count", "<u2"), ("seedH", "<u2"), ("seedV", "<u2"), ("flags", "<u2")])
+EXT_DT = np.dtype([("nbins", "<u2"), ("support", "<u2"), ("binov", "<u2"), ("pad", "<u2")])
+ALN_DT = np.dtype([("score", "<i4"), ("begH", "<i4"), ("endH", "<i4"), ("begV", "<i4"), ("endV", "<i4"), ("ov", "<u2"),
+                   ("strand", "u1"), ("passed", "u1"), ("steps", "<u4"), ("flagged", "<u4")])
+SEED_DT = np.dtype([("rid", "<u4"), ("cid", "<u4"), ("seedH", "<u2"), ("seedV", "<u2")])
+assert PAIR_DT.itemsize == 16 and EXT_DT.itemsize == 8 and ALN_DT.itemsize == 32 and SEED_DT.itemsize == 12
+
+
+class Params(C.Structure):
+    _fields_ = [("kmer_size", C.c_uint16), ("bin_size", C.c_uint16), ("xdrop", C.c_uint16), ("skip_alignment", C.c_uint16),
+                ("error_rate", C.c_double), ("delta_chernoff", C.c_double)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("assemble_ms", C.c_float), ("symbolic_ms", C.c_float), ("spgemm_ms", C.c_float), ("compact_ms", C.c_float),
+                ("xdrop_ms", C.c_float), ("overlap_total_ms", C.c_float), ("spgemm_launches", C.c_uint32), ("pad", C.c_uint32)]
+
+
+# every symbol include/bella_hip.h declares: (name, restype, argtypes)
+vp = C.c_void_p
+SIGNATURES = [
+    ("bella_hip_abi_version", C.c_int, []),
+    ("bella_hip_device_count", C.c_int, []),
+    ("bella_hip_init", C.c_int, [C.c_int, C.POINTER(vp)]),
+    ("bella_hip_destroy", None, [vp]),
+    ("bella_hip_strerror", C.c_char_p, [C.c_int]),
+    ("bella_hip_last_error", C.c_char_p, [vp]),
+    ("bella_hip_set_reads", C.c_int, [vp, vp, vp, C.c_uint32]),
+    ("bella_hip_assemble_tuples", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint64, vp, vp, vp]),
+    ("bella_hip_set_B", C.c_int, [vp, C.c_uint16, C.c_uint32, vp, vp, vp]),
+    ("bella_hip_get_B", C.c_int, [vp, C.POINTER(C.c_uint64), vp, vp, vp]),
+    ("bella_hip_set_partition", C.c_int, [vp, C.c_uint32, C.c_uint32]),
+    ("bella_hip_overlap", C.c_int, [vp, C.POINTER(Params), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("bella_hip_get_pairs", C.c_int, [vp, vp, vp, vp]),
+    ("bella_hip_align_pairs", C.c_int, [vp, C.POINTER(Params), C.POINTER(C.c_uint64)]),
+    ("bella_hip_get_alignments", C.c_int, [vp, vp]),
+    ("bella_hip_xdrop_batch", C.c_int, [vp, vp, C.c_uint64, C.POINTER(Params), vp]),
+    ("bella_hip_get_timings", C.c_int, [vp, C.POINTER(Timings)]),
+    ("bella_hip_set_debug", C.c_int, [vp, C.c_uint32]),
+]
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise RuntimeError("libbella_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIBPATH)
+        for name, res, args in SIGNATURES:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

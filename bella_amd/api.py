@@ -1,0 +1,210 @@
+"""Host-side mirror of the reference's call surface for the overlap hot path, over the C ABI.
+
+`Engine` wraps one `bella_ctx` (one GPU).  `hash_spgemm(...)` is shaped like the reference's
+`HashSpGEMM(A, B, multop, addop, reads, getvaluetype, filename, bpars, ratiophi)`
+(include/overlap.hpp:650-652): operands + reads + BELLApars in, results delivered as the output file in
+BELLA / PAF format and the stdout protocol numbers."""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import sys
+
+import numpy as np
+
+from . import _lib
+from ._lib import ALN_DT, EXT_DT, PAIR_DT, SEED_DT, Params, Timings
+
+
+class BellaHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("bella_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+@dataclasses.dataclass
+class BellaPars:
+    """BELLApars (include/common/common.h:46-74): the fields of the hot path, reference defaults."""
+    kmerSize: int = 17
+    binSize: int = 500
+    xDrop: int = 7
+    skipAlignment: bool = False
+    outputPaf: bool = False
+    errorRate: float = 0.15
+    deltaChernoff: float = 0.10
+
+    def c(self) -> Params:
+        return Params(self.kmerSize, self.binSize, self.xDrop, int(self.skipAlignment), self.errorRate, self.deltaChernoff)
+
+
+def _p(a):
+    return a.ctypes.data if a is not None and a.size else None
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.bella_hip_init(device, C.byref(h))
+        if rc:
+            raise BellaHipError(rc, self.lib.bella_hip_strerror(rc).decode() + " (bella_hip_init; no CPU fallback exists)")
+        self.h = h
+        self.nreads = 0
+        self.lengths = None
+        self.names = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bella_hip_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc:
+            raise BellaHipError(rc, self.lib.bella_hip_last_error(self.h).decode() or self.lib.bella_hip_strerror(rc).decode())
+
+    # ---- reads (readVector_) ----
+    def set_reads(self, rs):
+        from .synth import BASES
+        asc = np.ascontiguousarray(BASES[rs.codes])
+        offs = np.ascontiguousarray(rs.offsets, dtype=np.uint64)
+        self._chk(self.lib.bella_hip_set_reads(self.h, _p(asc), offs.ctypes.data, rs.nreads))
+        self.nreads = rs.nreads
+        self.lengths = rs.lengths
+        self.names = rs.names
+
+    def set_reads_raw(self, ascii_bases: np.ndarray, offsets: np.ndarray, names=None):
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        asc = np.ascontiguousarray(ascii_bases, dtype=np.uint8)
+        self._chk(self.lib.bella_hip_set_reads(self.h, _p(asc), offs.ctypes.data, len(offs) - 1))
+        self.nreads = len(offs) - 1
+        self.lengths = np.diff(offs).astype(np.uint32)
+        self.names = names
+
+    # ---- operands ----
+    def assemble_tuples(self, k, nkmers, tk, tr, tp):
+        tk = np.ascontiguousarray(tk, np.uint32); tr = np.ascontiguousarray(tr, np.uint32); tp = np.ascontiguousarray(tp, np.uint16)
+        self._chk(self.lib.bella_hip_assemble_tuples(self.h, k, nkmers, len(tk), _p(tk), _p(tr), _p(tp)))
+
+    def set_B(self, k, nkmers, colptr, rowids, values):
+        colptr = np.ascontiguousarray(colptr, np.uint32); rowids = np.ascontiguousarray(rowids, np.uint32)
+        values = np.ascontiguousarray(values, np.uint16)
+        self._chk(self.lib.bella_hip_set_B(self.h, k, nkmers, colptr.ctypes.data, _p(rowids), _p(values)))
+
+    def get_B(self):
+        nnz = C.c_uint64(0)
+        self._chk(self.lib.bella_hip_get_B(self.h, C.byref(nnz), None, None, None))
+        colptr = np.zeros(self.nreads + 1, np.uint32)
+        rowids = np.zeros(max(nnz.value, 1), np.uint32)
+        values = np.zeros(max(nnz.value, 1), np.uint16)
+        self._chk(self.lib.bella_hip_get_B(self.h, C.byref(nnz), colptr.ctypes.data, rowids.ctypes.data, values.ctypes.data))
+        return colptr, rowids[:nnz.value], values[:nnz.value]
+
+    def set_partition(self, first, stride):
+        self._chk(self.lib.bella_hip_set_partition(self.h, first, stride))
+
+    def set_debug(self, flags):
+        self._chk(self.lib.bella_hip_set_debug(self.h, flags))
+
+    # ---- HashSpGEMM ----
+    def overlap(self, pars: BellaPars):
+        n, f = C.c_uint64(0), C.c_uint64(0)
+        cp = pars.c()
+        self._chk(self.lib.bella_hip_overlap(self.h, C.byref(cp), C.byref(n), C.byref(f)))
+        self.npairs, self.flops = n.value, f.value
+        return n.value, f.value
+
+    def get_pairs(self, ext=True):
+        pairs = np.zeros(self.npairs, PAIR_DT)
+        ex = np.zeros(self.npairs, EXT_DT) if ext else None
+        colptrC = np.zeros(self.nreads + 1, np.uint64)
+        self._chk(self.lib.bella_hip_get_pairs(self.h, _p(pairs), _p(ex) if ext else None, colptrC.ctypes.data))
+        return pairs, ex, colptrC
+
+    # ---- RunPairWiseAlignments ----
+    def align_pairs(self, pars: BellaPars):
+        n = C.c_uint64(0)
+        cp = pars.c()
+        self._chk(self.lib.bella_hip_align_pairs(self.h, C.byref(cp), C.byref(n)))
+        return n.value
+
+    def get_alignments(self):
+        out = np.zeros(self.npairs, ALN_DT)
+        if self.npairs:
+            self._chk(self.lib.bella_hip_get_alignments(self.h, out.ctypes.data))
+        return out
+
+    def xdrop_batch(self, seeds: np.ndarray, pars: BellaPars):
+        seeds = np.ascontiguousarray(seeds, SEED_DT)
+        out = np.zeros(len(seeds), ALN_DT)
+        cp = pars.c()
+        self._chk(self.lib.bella_hip_xdrop_batch(self.h, _p(seeds), len(seeds), C.byref(cp), _p(out)))
+        return out
+
+    def timings(self) -> Timings:
+        t = Timings()
+        self._chk(self.lib.bella_hip_get_timings(self.h, C.byref(t)))
+        return t
+
+
+# ---------------------------------------------------------------------------------------------------
+# output writers: overlap.hpp:472-473 (BELLA), :476-489 (PAF), :580-585 (--skip-alignment)
+# ---------------------------------------------------------------------------------------------------
+def overlap_of_seed(pairs, lengths, k):
+    """chain.hpp:47-71 overlapop on the chosen seed (int, NOT truncated to u16) from the pair flags."""
+    lenH = lengths[pairs["rid"]].astype(np.int64)
+    lenV = lengths[pairs["cid"]].astype(np.int64)
+    posH = pairs["seedH"].astype(np.int64)
+    posV = pairs["seedV"].astype(np.int64)
+    oriented = (pairs["flags"] & 1).astype(bool)
+    begH = np.where(oriented, posH, (lenH - posH - k) & 0xFFFF)
+    endH = (begH + k) & 0xFFFF
+    endV = (posV + k) & 0xFFFF
+    return np.minimum(begH, posV) + np.minimum(lenH - endH, lenV - endV) + k
+
+
+def format_skip(names, lengths, pairs, k) -> bytes:
+    ov = overlap_of_seed(pairs, lengths, k)
+    l16 = lengths & 0xFFFF
+    out = ["%s\t%s\t%d\t%d\t%d\t%d\n" % (names[c], names[r], cnt, o, l16[c], l16[r])
+           for r, c, cnt, o in zip(pairs["rid"].tolist(), pairs["cid"].tolist(), pairs["count"].tolist(), ov.tolist())]
+    return "".join(out).encode()
+
+
+def format_aligned(names, lengths, pairs, alns, paf=False) -> bytes:
+    l16 = (lengths & 0xFFFF).tolist()
+    out = []
+    for p, a in zip(pairs.tolist(), alns.tolist()):
+        rid, cid, count = p[0], p[1], p[2]
+        score, bH, eH, bV, eV, ov, strand, passed = a[:8]
+        if not passed:
+            continue
+        r1, r2 = l16[rid], l16[cid]
+        if not paf:
+            out.append("%s\t%s\t%d\t%d\t%d\t%s\t%d\t%d\t%d\t%d\t%d\t%d\n" % (
+                names[cid], names[rid], count, score, ov, "c" if strand else "n", bV, eV, r2, bH, eH, r1))
+        else:
+            if strand:
+                bH, eH = r1 - eH, r1 - bH          # toOriginalCoordinates, overlap.hpp:149-154
+            out.append("%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%d\n" % (
+                names[cid], r2, bV, eV, "-" if strand else "+", names[rid], r1, bH, eH, score, ov, 255))
+    return "".join(out).encode()
+
+
+def hash_spgemm(engine: Engine, pars: BellaPars, filename: str, stdout=sys.stdout):
+    """HashSpGEMM-shaped driver (include/overlap.hpp:650-789): the operands and reads are already in `engine`.
+    Writes `filename` and the stdout protocol lines nnz(C) (:686) and, when aligning, outputted (:771)."""
+    npairs, _ = engine.overlap(pars)
+    print(npairs, file=stdout)
+    pairs, _, _ = engine.get_pairs(ext=False)
+    if pars.skipAlignment:
+        data = format_skip(engine.names, engine.lengths, pairs, pars.kmerSize)
+    else:
+        outputted = engine.align_pairs(pars)
+        alns = engine.get_alignments()
+        data = format_aligned(engine.names, engine.lengths, pairs, alns, pars.outputPaf)
+        print(outputted, file=stdout)
+    with open(filename, "wb") as f:
+        f.write(data)
+    return npairs

@@ -1,0 +1,721 @@
+// bella_hip.hip -- libbella_hip.so: context, memory, launch sequencing and the C ABI (include/bella_hip.h).
+// gfx950 only.  No CPU execution path: every entry point either runs the HIP kernels or returns an error.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bella_hip.h"
+#include "assemble.hpp"
+#include "core.hpp"
+#include "spgemm.hpp"
+#include "util.hpp"
+#include "xdrop.hpp"
+
+using namespace bella;
+
+namespace {
+
+struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+constexpr uint32_t kNumTiers = 6;  // 5 LDS tiers + the global-workspace tier
+const uint32_t kTierCaps[kNumTiers] = {768, 1280, 2048, 3072, 4096, 65535};
+constexpr uint32_t kGlobalGrid = 512;
+constexpr uint32_t kAsmGrid = 1024;
+
+struct CastU64 {
+    __host__ __device__ uint64_t operator()(const uint32_t& v) const { return (uint64_t)v; }
+};
+
+}  // namespace
+
+struct bella_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    uint32_t debug = 0;
+
+    // reads
+    uint32_t nreads = 0;
+    uint64_t total_bases = 0;
+    Buf packed, roff;
+    // B (reference layout) and device layout
+    uint32_t nkmers = 0, kmer_size = 0;
+    uint64_t nnz = 0;
+    bool have_reads = false, have_matrix = false, have_pairs = false, have_alns = false;
+    Buf Bptr, Bk, Bpos, Bent, Aent;
+    uint32_t part_first = 0, part_stride = 1;
+    // assembly temporaries
+    Buf t_kmer, t_read, t_pos, tstart, Bk_tmp, Bpos_tmp, rowcnt, asm_ws;
+    Buf Brow, deg, minread, colstart, fill, ori, w, wscan, Atmp;
+    // overlap
+    uint64_t flops = 0, npairs = 0;
+    Buf flopsr, flopptr, nnzC, colptrC, tierflag, rowlists, tiercnt, tiercaps, tmp_pairs, tmp_ext, pairs, ext, sortscr, ws,
+        status, cubtmp;
+    // alignment
+    uint64_t nalns = 0;
+    Buf alns, seeds;
+    bella_timings tm{};
+    hipEvent_t ev[10]{};
+};
+
+namespace {
+
+int fail(bella_ctx* c, int code, const char* fmt, ...) {
+    char b[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(b, sizeof(b), fmt, ap);
+    va_end(ap);
+    if (c) c->err = b;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                                           \
+    do {                                                                                                          \
+        hipError_t e_ = (call);                                                                                   \
+        if (e_ != hipSuccess)                                                                                     \
+            return fail(c, BELLA_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define KCHK(c) HIPCHK(c, hipGetLastError())
+
+int ensure_bytes(bella_ctx* c, Buf& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return 0;
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t want = bytes + bytes / 16 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(c, BELLA_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return 0;
+}
+#define ENSURE(c, buf, bytes)                  \
+    do {                                       \
+        int r_ = ensure_bytes(c, buf, bytes);  \
+        if (r_) return r_;                     \
+    } while (0)
+
+void release(Buf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+template <class T>
+T* ptr(const Buf& b) { return (T*)b.p; }
+
+inline unsigned nblk(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
+
+int read_status(bella_ctx* c, uint32_t* out) {
+    HIPCHK(c, hipMemcpyAsync(out, c->status.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int status_to_error(bella_ctx* c, uint32_t st) {
+    if (st & 4u) return fail(c, BELLA_ERR_BAD_BASE, "reads must be upper-case ACGT only");
+    if (st & 8u) return fail(c, BELLA_ERR_TUPLE_ORDER, "tuples must be grouped by non-decreasing read id < nreads");
+    if (st & 16u) return fail(c, BELLA_ERR_READ_TOO_LONG, "a read has >= 65536 tuples");
+    if (st & 32u) return fail(c, BELLA_ERR_BAD_ARG, "k-mer id >= nkmers");
+    if (st & 64u) return fail(c, BELLA_ERR_BAD_ARG, "a k-mer occurs in more than 32767 reads");
+    if (st & 2u) return fail(c, BELLA_ERR_ROW_TOO_LARGE, "an output column has >= 65536 products");
+    return 0;
+}
+
+// exclusive scans (rocPRIM through hipCUB: plumbing, not a hot op)
+int scan_u32(bella_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
+    size_t tb = 0;
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, (int)n, c->stream));
+    ENSURE(c, c->cubtmp, tb);
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cubtmp.p, tb, in, out, (int)n, c->stream));
+    return 0;
+}
+int scan_u32_to_u64(bella_ctx* c, const uint32_t* in, uint64_t* out, uint64_t n) {
+    hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> it(in, CastU64());
+    size_t tb = 0;
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, out, (int)n, c->stream));
+    ENSURE(c, c->cubtmp, tb);
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cubtmp.p, tb, it, out, (int)n, c->stream));
+    return 0;
+}
+
+// B (Bptr/Bk/Bpos on device) -> Bent / Aent   (see assemble.hpp)
+int build_layout(bella_ctx* c) {
+    const uint64_t nnz = c->nnz;
+    const uint32_t nk = c->nkmers;
+    if (nnz >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "nnz(A) must be < 2^32 (KMERINDEX uint32, main.cpp:60)");
+    ENSURE(c, c->Brow, 4 * nnz);
+    ENSURE(c, c->deg, 4 * (size_t)nk);
+    ENSURE(c, c->minread, 4 * (size_t)nk);
+    ENSURE(c, c->colstart, 4 * (size_t)nk);
+    ENSURE(c, c->fill, 4 * (size_t)nk);
+    ENSURE(c, c->ori, nnz);
+    ENSURE(c, c->w, 4 * nnz);
+    ENSURE(c, c->wscan, 4 * nnz);
+    ENSURE(c, c->Atmp, 8 * nnz);
+    ENSURE(c, c->Bent, 8 * nnz);
+    ENSURE(c, c->Aent, 8 * nnz + 64);
+    HIPCHK(c, hipMemsetAsync(c->deg.p, 0, 4 * (size_t)nk, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->minread.p, 0xFF, 4 * (size_t)nk, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->fill.p, 0, 4 * (size_t)nk, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->colstart.p, 0, 4 * (size_t)nk, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
+    if (nnz) {
+        k_entry_rows<<<nblk(c->nreads, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), c->nreads, ptr<uint32_t>(c->Brow));
+        KCHK(c);
+        k_kmer_stats<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos), ptr<uint32_t>(c->Brow), nnz,
+                                                       ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), c->kmer_size, nk,
+                                                       ptr<uint32_t>(c->deg), ptr<uint32_t>(c->minread), ptr<uint8_t>(c->ori),
+                                                       ptr<uint32_t>(c->status));
+        KCHK(c);
+        k_first_weight<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bk), ptr<uint32_t>(c->Brow), nnz, ptr<uint32_t>(c->deg),
+                                                         ptr<uint32_t>(c->minread), ptr<uint32_t>(c->w));
+        KCHK(c);
+        int rc = scan_u32(c, ptr<uint32_t>(c->w), ptr<uint32_t>(c->wscan), nnz);
+        if (rc) return rc;
+        k_col_starts<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bk), ptr<uint32_t>(c->Brow), nnz, ptr<uint32_t>(c->minread),
+                                                       ptr<uint32_t>(c->wscan), ptr<uint32_t>(c->colstart));
+        KCHK(c);
+        k_fill_A<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bk), ptr<uint32_t>(c->Brow), nnz, ptr<uint32_t>(c->colstart),
+                                                   ptr<uint32_t>(c->fill), ptr<uint2>(c->Atmp));
+        KCHK(c);
+        k_finalize_cols<<<nblk(nk), 256, 0, c->stream>>>(nk, ptr<uint32_t>(c->deg), ptr<uint32_t>(c->colstart), ptr<uint2>(c->Atmp),
+                                                         ptr<uint16_t>(c->Bpos), ptr<uint8_t>(c->ori), ptr<uint64_t>(c->roff),
+                                                         ptr<uint2>(c->Aent), ptr<uint2>(c->Bent), ptr<uint32_t>(c->status));
+        KCHK(c);
+    }
+    uint32_t st = 0;
+    int rc = read_status(c, &st);
+    if (rc) return rc;
+    rc = status_to_error(c, st);
+    if (rc) return rc;
+    // assembly temporaries are large (tens of bytes per nonzero): give them back
+    release(c->Brow); release(c->deg); release(c->minread); release(c->colstart); release(c->fill); release(c->ori);
+    release(c->w); release(c->wscan); release(c->Atmp);
+    c->have_matrix = true;
+    c->have_pairs = c->have_alns = false;
+    return 0;
+}
+
+float ev_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms;
+}
+
+int check_params(bella_ctx* c, const bella_params* p) {
+    if (!p) return fail(c, BELLA_ERR_BAD_ARG, "params is NULL");
+    if (p->kmer_size != c->kmer_size)
+        return fail(c, BELLA_ERR_BAD_ARG, "params.kmer_size (%u) differs from the matrix's (%u)", p->kmer_size, c->kmer_size);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bella_hip_abi_version(void) { return BELLA_HIP_ABI_VERSION; }
+
+int bella_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* bella_hip_strerror(int code) {
+    switch (code) {
+        case BELLA_OK: return "ok";
+        case BELLA_ERR_NO_DEVICE: return "no gfx950 HIP device";
+        case BELLA_ERR_HIP: return "HIP runtime error";
+        case BELLA_ERR_BAD_ARG: return "bad argument";
+        case BELLA_ERR_BAD_BASE: return "read contains a character other than ACGT";
+        case BELLA_ERR_READ_TOO_LONG: return "read too long for 16-bit positions";
+        case BELLA_ERR_TUPLE_ORDER: return "tuples not grouped by read";
+        case BELLA_ERR_STATE: return "call order violated";
+        case BELLA_ERR_ROW_TOO_LARGE: return "output column too large";
+        case BELLA_ERR_BINS: return "more than 16 overlap bins";
+        case BELLA_ERR_NOMEM: return "out of device memory";
+    }
+    return "unknown error";
+}
+
+const char* bella_hip_last_error(const bella_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int bella_hip_init(int device, bella_ctx** out) {
+    if (!out) return BELLA_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return BELLA_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BELLA_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BELLA_ERR_NO_DEVICE;
+    bella_ctx* c = new bella_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return BELLA_ERR_HIP; }
+    for (auto& e : c->ev) (void)hipEventCreate(&e);
+    if (ensure_bytes(c, c->status, 64)) { delete c; return BELLA_ERR_NOMEM; }
+    (void)hipMemset(c->status.p, 0, 64);
+    *out = c;
+    return 0;
+}
+
+void bella_hip_destroy(bella_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Aent, &c->t_kmer, &c->t_read, &c->t_pos,
+                  &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->Brow, &c->deg, &c->minread, &c->colstart,
+                  &c->fill, &c->ori, &c->w, &c->wscan, &c->Atmp, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC, &c->tierflag,
+                  &c->rowlists, &c->tiercnt, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
+                  &c->status, &c->cubtmp, &c->alns, &c->seeds};
+    for (Buf* b : all) release(*b);
+    for (auto& e : c->ev) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bella_hip_set_debug(bella_ctx* c, uint32_t flags) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    c->debug = flags;
+    return 0;
+}
+
+int bella_hip_set_partition(bella_ctx* c, uint32_t first, uint32_t stride) {
+    if (!c || stride == 0 || first >= stride) return fail(c, BELLA_ERR_BAD_ARG, "partition needs 0 <= first < stride");
+    c->part_first = first;
+    c->part_stride = stride;
+    c->have_pairs = c->have_alns = false;
+    return 0;
+}
+
+int bella_hip_set_reads(bella_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads) {
+    if (!c || !offsets || (nreads && !bases)) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t total = offsets[nreads];
+    for (uint32_t r = 0; r < nreads; ++r) {
+        if (offsets[r + 1] < offsets[r]) return fail(c, BELLA_ERR_BAD_ARG, "offsets must be non-decreasing");
+        if (offsets[r + 1] - offsets[r] >= 65536ull)
+            return fail(c, BELLA_ERR_READ_TOO_LONG, "read %u has %llu bases; positions are 16 bit (common.h:122-126)", r,
+                        (unsigned long long)(offsets[r + 1] - offsets[r]));
+    }
+    const uint64_t nwords = (total + 15) / 16;
+    ENSURE(c, c->packed, 4 * (nwords + 4));
+    ENSURE(c, c->roff, 8 * ((size_t)nreads + 1));
+    Buf raw;
+    int rc = ensure_bytes(c, raw, total);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(raw.p, bases, total, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->roff.p, offsets, 8 * ((size_t)nreads + 1), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->packed.p, 0, 4 * (nwords + 4), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->status.p, 0, 4, c->stream);
+    if (e == hipSuccess && nwords) {
+        k_pack_reads<<<nblk(nwords), 256, 0, c->stream>>>(ptr<uint8_t>(raw), total, ptr<uint32_t>(c->packed), nwords,
+                                                          ptr<uint32_t>(c->status));
+        e = hipGetLastError();
+    }
+    uint32_t st = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&st, c->status.p, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    release(raw);
+    if (e != hipSuccess) return fail(c, BELLA_ERR_HIP, "set_reads: %s", hipGetErrorString(e));
+    rc = status_to_error(c, st);
+    if (rc) return rc;
+    c->nreads = nreads;
+    c->total_bases = total;
+    c->have_reads = true;
+    c->have_matrix = c->have_pairs = c->have_alns = false;
+    return 0;
+}
+
+int bella_hip_set_B(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, const uint32_t* colptr, const uint32_t* rowids,
+                    const uint16_t* values) {
+    if (!c || !colptr) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+    if (!c->have_reads) return fail(c, BELLA_ERR_STATE, "set_reads first");
+    if (kmer_size < 1 || kmer_size > 32) return fail(c, BELLA_ERR_BAD_ARG, "k must be in [1,32] (MAX_KMER_SIZEK, kmercode/common.h:13)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t nnz = colptr[c->nreads];
+    if (nnz && (!rowids || !values)) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    ENSURE(c, c->Bptr, 4 * ((size_t)c->nreads + 1));
+    ENSURE(c, c->Bk, 4 * nnz);
+    ENSURE(c, c->Bpos, 2 * nnz);
+    HIPCHK(c, hipMemcpyAsync(c->Bptr.p, colptr, 4 * ((size_t)c->nreads + 1), hipMemcpyHostToDevice, c->stream));
+    if (nnz) {
+        HIPCHK(c, hipMemcpyAsync(c->Bk.p, rowids, 4 * nnz, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->Bpos.p, values, 2 * nnz, hipMemcpyHostToDevice, c->stream));
+    }
+    c->nkmers = nkmers;
+    c->nnz = nnz;
+    c->kmer_size = kmer_size;
+    int rc = build_layout(c);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    c->tm.assemble_ms = ev_ms(c->ev[0], c->ev[1]);
+    return 0;
+}
+
+int bella_hip_assemble_tuples(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, uint64_t ntuples, const uint32_t* t_kmer,
+                              const uint32_t* t_read, const uint16_t* t_pos) {
+    if (!c || (ntuples && (!t_kmer || !t_read || !t_pos))) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+    if (!c->have_reads) return fail(c, BELLA_ERR_STATE, "set_reads first");
+    if (kmer_size < 1 || kmer_size > 32) return fail(c, BELLA_ERR_BAD_ARG, "k must be in [1,32]");
+    if (ntuples >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "tuple count must be < 2^32");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t nr = c->nreads;
+    ENSURE(c, c->t_kmer, 4 * ntuples);
+    ENSURE(c, c->t_read, 4 * ntuples);
+    ENSURE(c, c->t_pos, 2 * ntuples);
+    ENSURE(c, c->tstart, 8 * ((size_t)nr + 2));
+    ENSURE(c, c->Bk_tmp, 4 * ntuples);
+    ENSURE(c, c->Bpos_tmp, 2 * ntuples);
+    ENSURE(c, c->rowcnt, 4 * ((size_t)nr + 2));
+    ENSURE(c, c->Bptr, 4 * ((size_t)nr + 2));
+    const uint64_t ws_stride = (uint64_t)16 * 65536;
+    ENSURE(c, c->asm_ws, ws_stride * kAsmGrid);
+    if (ntuples) {
+        HIPCHK(c, hipMemcpyAsync(c->t_kmer.p, t_kmer, 4 * ntuples, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->t_read.p, t_read, 4 * ntuples, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->t_pos.p, t_pos, 2 * ntuples, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->rowcnt.p, 0, 4 * ((size_t)nr + 2), c->stream));
+    k_tuple_bounds<<<nblk(ntuples + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->t_read), ntuples, nr, ptr<uint64_t>(c->tstart),
+                                                             ptr<uint32_t>(c->status));
+    KCHK(c);
+    uint32_t st = 0;
+    int rc = read_status(c, &st);
+    if (rc) return rc;
+    rc = status_to_error(c, st);
+    if (rc) return rc;
+    AsmArgs a;
+    a.t_kmer = ptr<uint32_t>(c->t_kmer);
+    a.t_pos = ptr<uint16_t>(c->t_pos);
+    a.tstart = ptr<uint64_t>(c->tstart);
+    a.nreads = nr;
+    a.Bk_tmp = ptr<uint32_t>(c->Bk_tmp);
+    a.Bpos_tmp = ptr<uint16_t>(c->Bpos_tmp);
+    a.rowcnt = ptr<uint32_t>(c->rowcnt);
+    a.ws = ptr<uint8_t>(c->asm_ws);
+    a.ws_stride = ws_stride;
+    a.status = ptr<uint32_t>(c->status);
+    if (nr) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_asm_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAsmLdsBytes));
+        const unsigned grid = nr < kAsmGrid ? nr : kAsmGrid;
+        k_asm_rows<<<grid, kBlock, kAsmLdsBytes, c->stream>>>(a);
+        KCHK(c);
+    }
+    rc = scan_u32(c, ptr<uint32_t>(c->rowcnt), ptr<uint32_t>(c->Bptr), (uint64_t)nr + 1);
+    if (rc) return rc;
+    uint32_t nnz32 = 0;
+    HIPCHK(c, hipMemcpyAsync(&nnz32, ptr<uint32_t>(c->Bptr) + nr, 4, hipMemcpyDeviceToHost, c->stream));
+    rc = read_status(c, &st);
+    if (rc) return rc;
+    rc = status_to_error(c, st);
+    if (rc) return rc;
+    const uint64_t nnz = nnz32;
+    ENSURE(c, c->Bk, 4 * nnz);
+    ENSURE(c, c->Bpos, 2 * nnz);
+    if (nr) {
+        k_compact_B<<<nblk(nr, kWaves), kBlock, 0, c->stream>>>(ptr<uint64_t>(c->tstart), ptr<uint32_t>(c->Bptr), nr,
+                                                                ptr<uint32_t>(c->Bk_tmp), ptr<uint16_t>(c->Bpos_tmp),
+                                                                ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos));
+        KCHK(c);
+    }
+    c->nkmers = nkmers;
+    c->nnz = nnz;
+    c->kmer_size = kmer_size;
+    rc = build_layout(c);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    c->tm.assemble_ms = ev_ms(c->ev[0], c->ev[1]);
+    release(c->t_kmer); release(c->t_read); release(c->t_pos); release(c->Bk_tmp); release(c->Bpos_tmp); release(c->asm_ws);
+    return 0;
+}
+
+int bella_hip_get_B(bella_ctx* c, uint64_t* nnz, uint32_t* colptr, uint32_t* rowids, uint16_t* values) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    if (!c->have_matrix) return fail(c, BELLA_ERR_STATE, "no matrix");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (nnz) *nnz = c->nnz;
+    if (colptr) HIPCHK(c, hipMemcpyAsync(colptr, c->Bptr.p, 4 * ((size_t)c->nreads + 1), hipMemcpyDeviceToHost, c->stream));
+    if (rowids && c->nnz) HIPCHK(c, hipMemcpyAsync(rowids, c->Bk.p, 4 * c->nnz, hipMemcpyDeviceToHost, c->stream));
+    if (values && c->nnz) HIPCHK(c, hipMemcpyAsync(values, c->Bpos.p, 2 * c->nnz, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int run_spgemm(bella_ctx* c, const bella_params* p, bool with_sort_scratch, uint32_t* status_out) {
+    const uint32_t nr = c->nreads;
+    const bool force_global = (c->debug & 1u) != 0;
+    const bool want_ext = (c->debug & 2u) == 0;
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    ENSURE(c, c->flopsr, 4 * ((size_t)nr + 2));
+    ENSURE(c, c->flopptr, 8 * ((size_t)nr + 2));
+    ENSURE(c, c->nnzC, 4 * ((size_t)nr + 2));
+    ENSURE(c, c->colptrC, 8 * ((size_t)nr + 2));
+    ENSURE(c, c->tierflag, (size_t)kNumTiers * nr);
+    ENSURE(c, c->rowlists, 4 * (size_t)kNumTiers * nr);
+    ENSURE(c, c->tiercnt, 4 * kNumTiers);
+    ENSURE(c, c->tiercaps, 4 * kNumTiers);
+    uint32_t caps[kNumTiers];
+    for (uint32_t t = 0; t < kNumTiers; ++t) caps[t] = force_global && t + 1 < kNumTiers ? 0 : kTierCaps[t];
+    HIPCHK(c, hipMemcpyAsync(c->tiercaps.p, caps, sizeof(caps), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->flopsr.p, 0, 4 * ((size_t)nr + 2), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->nnzC.p, 0, 4 * ((size_t)nr + 2), c->stream));
+    k_row_flops<<<nblk(nr, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint2>(c->Bent), nr, c->part_first,
+                                                            c->part_stride, ptr<uint32_t>(c->flopsr));
+    KCHK(c);
+    int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->flopsr), ptr<uint64_t>(c->flopptr), (uint64_t)nr + 1);
+    if (rc) return rc;
+    k_tier_flags<<<nblk(nr), 256, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, ptr<uint32_t>(c->tiercaps), kNumTiers,
+                                                  ptr<uint8_t>(c->tierflag), ptr<uint32_t>(c->status));
+    KCHK(c);
+    for (uint32_t t = 0; t < kNumTiers; ++t) {
+        hipcub::CountingInputIterator<uint32_t> ids(0);
+        size_t tb = 0;
+        HIPCHK(c, hipcub::DeviceSelect::Flagged(nullptr, tb, ids, ptr<uint8_t>(c->tierflag) + (size_t)t * nr,
+                                                ptr<uint32_t>(c->rowlists) + (size_t)t * nr, ptr<uint32_t>(c->tiercnt) + t,
+                                                (int)nr, c->stream));
+        ENSURE(c, c->cubtmp, tb);
+        HIPCHK(c, hipcub::DeviceSelect::Flagged(c->cubtmp.p, tb, ids, ptr<uint8_t>(c->tierflag) + (size_t)t * nr,
+                                                ptr<uint32_t>(c->rowlists) + (size_t)t * nr, ptr<uint32_t>(c->tiercnt) + t,
+                                                (int)nr, c->stream));
+    }
+    uint32_t tcnt[kNumTiers];
+    uint64_t F = 0;
+    HIPCHK(c, hipMemcpyAsync(tcnt, c->tiercnt.p, sizeof(tcnt), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&F, ptr<uint64_t>(c->flopptr) + nr, 8, hipMemcpyDeviceToHost, c->stream));
+    uint32_t st = 0;
+    rc = read_status(c, &st);
+    if (rc) return rc;
+    rc = status_to_error(c, st);
+    if (rc) return rc;
+    c->flops = F;
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+
+    ENSURE(c, c->tmp_pairs, sizeof(bella_pair) * F);
+    if (want_ext) ENSURE(c, c->tmp_ext, sizeof(bella_pair_ext) * F);
+    if (with_sort_scratch) ENSURE(c, c->sortscr, 2 * F);
+    const uint64_t ws_stride = (row_mem_bytes(65535) + 255) & ~(size_t)255;
+    if (tcnt[kNumTiers - 1]) ENSURE(c, c->ws, ws_stride * kGlobalGrid);
+
+    SpgemmArgs a;
+    a.Bptr = ptr<uint32_t>(c->Bptr);
+    a.Bent = ptr<uint2>(c->Bent);
+    a.Aent = ptr<uint2>(c->Aent);
+    a.roff = ptr<uint64_t>(c->roff);
+    a.packed = ptr<uint32_t>(c->packed);
+    a.flopptr = ptr<uint64_t>(c->flopptr);
+    a.tmp_pairs = ptr<bella_pair>(c->tmp_pairs);
+    a.tmp_ext = want_ext ? ptr<bella_pair_ext>(c->tmp_ext) : nullptr;
+    a.nnzC = ptr<uint32_t>(c->nnzC);
+    a.sort_scratch = with_sort_scratch ? ptr<uint16_t>(c->sortscr) : nullptr;
+    a.status = ptr<uint32_t>(c->status);
+    a.ws = ptr<uint8_t>(c->ws);
+    a.ws_stride = ws_stride;
+    a.k = p->kmer_size;
+    a.binSize = p->bin_size;
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    uint32_t launches = 0;
+    for (uint32_t t = 0; t < kNumTiers; ++t) {
+        if (!tcnt[t]) continue;
+        a.rowlist = ptr<uint32_t>(c->rowlists) + (size_t)t * nr;
+        a.nrows = tcnt[t];
+        a.cap = kTierCaps[t];
+        if (t + 1 < kNumTiers) {
+            const size_t lds = row_mem_bytes(a.cap);
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_spgemm_rows_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_spgemm_rows_lds<<<tcnt[t], kBlock, lds, c->stream>>>(a);
+        } else {
+            const unsigned grid = tcnt[t] < kGlobalGrid ? tcnt[t] : kGlobalGrid;
+            k_spgemm_rows_global<<<grid, kBlock, 0, c->stream>>>(a);
+        }
+        KCHK(c);
+        launches++;
+    }
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    rc = scan_u32_to_u64(c, ptr<uint32_t>(c->nnzC), ptr<uint64_t>(c->colptrC), (uint64_t)nr + 1);
+    if (rc) return rc;
+    uint64_t P = 0;
+    HIPCHK(c, hipMemcpyAsync(&P, ptr<uint64_t>(c->colptrC) + nr, 8, hipMemcpyDeviceToHost, c->stream));
+    rc = read_status(c, &st);
+    if (rc) return rc;
+    *status_out = st;
+    c->npairs = P;
+    ENSURE(c, c->pairs, sizeof(bella_pair) * P);
+    if (want_ext) ENSURE(c, c->ext, sizeof(bella_pair_ext) * P);
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    if (nr) {
+        k_compact_pairs<<<nblk(nr, kWaves), kBlock, 0, c->stream>>>(ptr<uint64_t>(c->flopptr), ptr<uint64_t>(c->colptrC),
+                                                                    ptr<uint32_t>(c->nnzC), nr, ptr<bella_pair>(c->tmp_pairs),
+                                                                    want_ext ? ptr<bella_pair_ext>(c->tmp_ext) : nullptr,
+                                                                    ptr<bella_pair>(c->pairs),
+                                                                    want_ext ? ptr<bella_pair_ext>(c->ext) : nullptr);
+        KCHK(c);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[7]));
+    c->tm.symbolic_ms = ev_ms(c->ev[2], c->ev[3]);
+    c->tm.spgemm_ms = ev_ms(c->ev[4], c->ev[5]);
+    c->tm.compact_ms = ev_ms(c->ev[6], c->ev[7]);
+    c->tm.overlap_total_ms = ev_ms(c->ev[2], c->ev[7]);
+    c->tm.spgemm_launches = launches;
+    return 0;
+}
+
+int bella_hip_overlap(bella_ctx* c, const bella_params* p, uint64_t* npairs, uint64_t* flops) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    if (!c->have_matrix) return fail(c, BELLA_ERR_STATE, "set_B / assemble_tuples first");
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t st = 0;
+    rc = run_spgemm(c, p, c->sortscr.p != nullptr, &st);
+    if (rc) return rc;
+    if ((st & 1u) && c->sortscr.p == nullptr) {
+        // a pair ended with more than 16 bins: choose() needs libstdc++'s introsort order; rerun with scratch
+        rc = run_spgemm(c, p, true, &st);
+        if (rc) return rc;
+    }
+    c->have_pairs = true;
+    c->have_alns = false;
+    if (npairs) *npairs = c->npairs;
+    if (flops) *flops = c->flops;
+    return 0;
+}
+
+int bella_hip_get_pairs(bella_ctx* c, bella_pair* pairs, bella_pair_ext* ext, uint64_t* colptrC) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    if (!c->have_pairs) return fail(c, BELLA_ERR_STATE, "overlap first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (pairs && c->npairs)
+        HIPCHK(c, hipMemcpyAsync(pairs, c->pairs.p, sizeof(bella_pair) * c->npairs, hipMemcpyDeviceToHost, c->stream));
+    if (ext && c->npairs) {
+        if (c->debug & 2u) return fail(c, BELLA_ERR_STATE, "pair_ext output disabled by debug flag");
+        HIPCHK(c, hipMemcpyAsync(ext, c->ext.p, sizeof(bella_pair_ext) * c->npairs, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (colptrC)
+        HIPCHK(c, hipMemcpyAsync(colptrC, c->colptrC.p, 8 * ((size_t)c->nreads + 1), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_seeds, const bella_pair* d_pairs, uint64_t n,
+                     bella_aln* d_out) {
+    XdropArgs a;
+    a.seeds = d_seeds;
+    a.pairs = d_pairs;
+    a.n = n;
+    a.packed = ptr<uint32_t>(c->packed);
+    a.roff = ptr<uint64_t>(c->roff);
+    a.k = p->kmer_size;
+    a.xdrop = p->xdrop;
+    a.out = d_out;
+    // ratiophi = slope(e) (align.hpp:72-80), computed in double on the host exactly as main.cpp:323 does
+    const double p_mat = pow(1 - p->error_rate, 2), p_mis = 1 - p_mat;
+    a.ratiophi = 1.0 * p_mat - 1.0 * p_mis;
+    a.delta = p->delta_chernoff;
+    HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
+    if (n) {
+        k_xdrop<<<nblk(n, kXdropPairsPerBlock), kXdropBlock, 0, c->stream>>>(a);
+        KCHK(c);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[9]));
+    c->tm.xdrop_ms = ev_ms(c->ev[8], c->ev[9]);
+    return 0;
+}
+
+int bella_hip_align_pairs(bella_ctx* c, const bella_params* p, uint64_t* npassed) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    if (!c->have_pairs) return fail(c, BELLA_ERR_STATE, "overlap first");
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    ENSURE(c, c->alns, sizeof(bella_aln) * c->npairs);
+    rc = run_xdrop(c, p, nullptr, ptr<bella_pair>(c->pairs), c->npairs, ptr<bella_aln>(c->alns));
+    if (rc) return rc;
+    c->nalns = c->npairs;
+    c->have_alns = true;
+    if (npassed) {
+        // small reduction on the host side of the ABI would need a copy; count on device instead
+        ENSURE(c, c->cubtmp, 64);
+        HIPCHK(c, hipMemsetAsync(c->status.p, 0, 16, c->stream));
+        if (c->nalns) {
+            k_count_passed<<<nblk(c->nalns), 256, 0, c->stream>>>(ptr<bella_aln>(c->alns), c->nalns,
+                                                                  (unsigned long long*)(ptr<uint32_t>(c->status) + 2));
+            KCHK(c);
+        }
+        unsigned long long cnt = 0;
+        HIPCHK(c, hipMemcpyAsync(&cnt, ptr<uint32_t>(c->status) + 2, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *npassed = cnt;
+    }
+    return 0;
+}
+
+int bella_hip_get_alignments(bella_ctx* c, bella_aln* out) {
+    if (!c || !out) return BELLA_ERR_BAD_ARG;
+    if (!c->have_alns) return fail(c, BELLA_ERR_STATE, "align_pairs first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->nalns) HIPCHK(c, hipMemcpyAsync(out, c->alns.p, sizeof(bella_aln) * c->nalns, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bella_hip_xdrop_batch(bella_ctx* c, const bella_seed* seeds, uint64_t n, const bella_params* p, bella_aln* out) {
+    if (!c || !p || (n && (!seeds || !out))) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+    if (!c->have_reads) return fail(c, BELLA_ERR_STATE, "set_reads first");
+    if (p->kmer_size < 1 || p->kmer_size > 32) return fail(c, BELLA_ERR_BAD_ARG, "k must be in [1,32]");
+    HIPCHK(c, hipSetDevice(c->device));
+    // validate on the host: the kernel trusts seeds
+    std::vector<uint64_t> off((size_t)c->nreads + 1);
+    HIPCHK(c, hipMemcpy(off.data(), c->roff.p, 8 * ((size_t)c->nreads + 1), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) {
+        const bella_seed& s = seeds[i];
+        if (s.rid >= c->nreads || s.cid >= c->nreads) return fail(c, BELLA_ERR_BAD_ARG, "seed %llu: read id out of range", (unsigned long long)i);
+        const uint64_t lh = off[s.rid + 1] - off[s.rid], lv = off[s.cid + 1] - off[s.cid];
+        if ((uint64_t)s.seedH + p->kmer_size > lh || (uint64_t)s.seedV + p->kmer_size > lv)
+            return fail(c, BELLA_ERR_BAD_ARG, "seed %llu: k-mer past the end of a read", (unsigned long long)i);
+    }
+    Buf dalns;
+    ENSURE(c, c->seeds, sizeof(bella_seed) * n);
+    int rc = ensure_bytes(c, dalns, sizeof(bella_aln) * n);
+    if (rc) return rc;
+    hipError_t e = hipSuccess;
+    if (n) e = hipMemcpyAsync(c->seeds.p, seeds, sizeof(bella_seed) * n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        rc = run_xdrop(c, p, ptr<bella_seed>(c->seeds), nullptr, n, ptr<bella_aln>(dalns));
+        if (rc == 0 && n) e = hipMemcpyAsync(out, dalns.p, sizeof(bella_aln) * n, hipMemcpyDeviceToHost, c->stream);
+        if (rc == 0 && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    release(dalns);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(c, BELLA_ERR_HIP, "xdrop_batch: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int bella_hip_get_timings(bella_ctx* c, bella_timings* t) {
+    if (!c || !t) return BELLA_ERR_BAD_ARG;
+    *t = c->tm;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+/*
+ * bella_hip.h -- C ABI of the MI355X-native BELLA overlap engine (libbella_hip.so).
+ *
+ * The reference (PASSIONLab/BELLA) has no FFI layer: its boundary for this path is two header-level
+ * C++ call sites.  Each entry point below names the reference interface it replaces (paths relative
+ * to the reference tree).  INTEGRATION.md shows the shim a BELLA maintainer adds so that
+ * src/main.cpp:498-525 calls these instead of include/overlap.hpp's HashSpGEMM.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 or a negative BELLA_ERR_*;
+ * no exceptions or exit() cross the ABI; inputs are borrowed for the duration of the call; results
+ * live in the context (device memory) until overwritten or destroyed and are copied out by the
+ * bella_hip_get_* calls into caller-owned buffers.  One host thread per context.
+ * The library never falls back to a CPU implementation: without a gfx950 device
+ * bella_hip_init returns BELLA_ERR_NO_DEVICE.
+ */
+#ifndef BELLA_HIP_H
+#define BELLA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BELLA_HIP_ABI_VERSION 1
+
+enum {
+    BELLA_OK = 0,
+    BELLA_ERR_NO_DEVICE = -1,     /* no HIP device / not gfx950                                         */
+    BELLA_ERR_HIP = -2,           /* a HIP runtime call failed (bella_hip_last_error has the text)       */
+    BELLA_ERR_BAD_ARG = -3,
+    BELLA_ERR_BAD_BASE = -4,      /* read contains a character other than ACGT (align.hpp:40-55 asserts) */
+    BELLA_ERR_READ_TOO_LONG = -5, /* read >= 65,536 bases: u16 positions (common.h:122-126)             */
+    BELLA_ERR_TUPLE_ORDER = -6,   /* tuples not grouped by non-decreasing read id                       */
+    BELLA_ERR_STATE = -7,         /* call order: reads -> matrix -> overlap -> align                    */
+    BELLA_ERR_ROW_TOO_LARGE = -8, /* an output row has >= 65,536 products (wide path not built yet)     */
+    BELLA_ERR_BINS = -9,          /* a pair ended with > 16 overlap bins: std::sort tie order path      */
+    BELLA_ERR_NOMEM = -10
+};
+
+typedef struct bella_ctx bella_ctx;
+
+/* BELLApars (include/common/common.h:46-74), the fields the hot path reads. */
+typedef struct {
+    uint16_t kmer_size;       /* -k, kmerSize      (<= 32)                       */
+    uint16_t bin_size;        /* -b, binSize       (chain.hpp:114)               */
+    uint16_t xdrop;           /* -x, xDrop         (align.hpp:152)               */
+    uint16_t skip_alignment;  /* --skip-alignment  (overlap.hpp:542,577)         */
+    double error_rate;        /* -e : ratiophi = slope(e) (align.hpp:72-80)      */
+    double delta_chernoff;    /* --score-deviation (overlap.hpp:456)             */
+} bella_params;
+
+/* One nonzero of C = A*A^T after the semiring fold, i.e. what RunPairWiseAlignments
+ * (overlap.hpp:531-585) reads from a spmatType_ (common.h:119-183): count, and choose()'s seed.
+ * Order of the array = the reference's 1-thread output order: column (cid) ascending, hash-slot
+ * order inside a column (overlap.hpp:343-361). */
+typedef struct {
+    uint32_t rid;     /* row of C: the larger read id; "read1"/H in chain.hpp            */
+    uint32_t cid;     /* column of C: read i; "read2"/V                                   */
+    uint16_t count;   /* spmatType_::count (u16 wrap kept)                                */
+    uint16_t seedH;   /* choose().first  : seed k-mer position on read rid               */
+    uint16_t seedV;   /* choose().second : seed k-mer position on read cid               */
+    uint16_t flags;   /* bit0: seed k-mers identical (checkstrand true, chain.hpp:35-44)
+                         bit1: revcomp(seedH)==seedV (strand "c", align.hpp:171)          */
+} bella_pair;
+
+/* Diagnostics of the final semiring value (tests compare them with the oracle). */
+typedef struct {
+    uint16_t nbins;    /* pos.size() at the end                                           */
+    uint16_t support;  /* chain(): support of the winning bin (common.h:142-150)          */
+    uint16_t binov;    /* overlap[] of the winning bin                                    */
+    uint16_t pad;
+} bella_pair_ext;
+
+/* xavierResult (common.h:83-87) + what PostAlignDecision (overlap.hpp:413-497) derives from it. */
+typedef struct {
+    int32_t score;            /* best1 + best2 (simdutils.h:333-337)                      */
+    int32_t begH, endH;       /* SeedX positions on (possibly reverse-complemented) read rid */
+    int32_t begV, endV;       /* on read cid                                              */
+    uint16_t ov;              /* overlap estimate `ov` (overlap.hpp:449)                   */
+    uint8_t strand;           /* 0 = "n", 1 = "c"                                          */
+    uint8_t passed;           /* (float)score >= (1-delta)*phi*ov (overlap.hpp:456-460)    */
+    uint32_t steps;           /* anti-diagonal steps taken (both directions): GCUPS = 31*steps */
+    uint32_t flagged;         /* 1 if an extension began with no positive lane: the reference reads an
+                                 uninitialised `maxpos` there (xavier.h:165); we use 0 */
+} bella_aln;
+
+/* Explicit seed for the batched xavierAlign (the alignLogan-shaped entry, align.hpp:210-211). */
+typedef struct {
+    uint32_t rid, cid;        /* reads previously given to bella_hip_set_reads             */
+    uint16_t seedH, seedV;
+} bella_seed;
+
+typedef struct {
+    float assemble_ms;        /* tuples/B -> device CSR layout (all assembly kernels)      */
+    float symbolic_ms;        /* per-row flops + tiering (estimateFLOP, overlap.hpp:157)   */
+    float spgemm_ms;          /* the fused symbolic+numeric row kernels (overlap.hpp:205,281) */
+    float compact_ms;         /* pair compaction to the dense output                        */
+    float xdrop_ms;           /* X-drop kernel                                              */
+    float overlap_total_ms;   /* bella_hip_overlap, stream time start to end                */
+    uint32_t spgemm_launches;
+    uint32_t pad;
+} bella_timings;
+
+/* ---- lifecycle ---------------------------------------------------------------------------------- */
+int bella_hip_abi_version(void);
+int bella_hip_device_count(void);
+int bella_hip_init(int device, bella_ctx** out);
+void bella_hip_destroy(bella_ctx* ctx);
+const char* bella_hip_strerror(int code);
+const char* bella_hip_last_error(const bella_ctx* ctx);
+
+/* ---- reads: readVector_ (common.h:98-109) -------------------------------------------------------- */
+/* `bases` = all reads concatenated, upper-case ASCII ACGT; offsets has nreads+1 entries. */
+int bella_hip_set_reads(bella_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads);
+
+/* ---- operands ------------------------------------------------------------------------------------ */
+/* From the (kmer, read, pos) tuple list: replaces the CSC tuple constructor + MergeDuplicates +
+ * Transpose of src/main.cpp:476-489 (src/CSC.cpp:422-479,301-420; include/common/transpose.h:13).
+ * Tuples must be grouped by non-decreasing read id, in generation order inside a read.
+ * kmer_size = Kmer::set_k (main.cpp:183): needed here because the strand test of multiop
+ * (chain.hpp:35-44) is precomputed as one orientation bit per nonzero. */
+int bella_hip_assemble_tuples(bella_ctx* ctx, uint16_t kmer_size, uint32_t nkmers, uint64_t ntuples,
+                              const uint32_t* t_kmer, const uint32_t* t_read, const uint16_t* t_pos);
+/* From the reference's own B = transpmat CSC arrays (the HashSpGEMM boundary, overlap.hpp:650):
+ * colptr[nreads+1], rowids = k-mer ids in MergeDuplicates slot order, values = positions.
+ * A = spmat is derived on device (ascending read ids per k-mer = the reference's 1-thread Transpose). */
+int bella_hip_set_B(bella_ctx* ctx, uint16_t kmer_size, uint32_t nkmers, const uint32_t* colptr,
+                    const uint32_t* rowids, const uint16_t* values);
+/* Copies B back in the reference's layout (tests: compare with CSC.cpp's result). Any pointer may be NULL. */
+int bella_hip_get_B(bella_ctx* ctx, uint64_t* nnz, uint32_t* colptr, uint32_t* rowids, uint16_t* values);
+
+/* Multi-GPU (one context per GPU/process): this context computes output columns i with
+ * i % stride == first.  Default (0,1) = all columns.  Every rank holds the full operands. */
+int bella_hip_set_partition(bella_ctx* ctx, uint32_t first, uint32_t stride);
+
+/* ---- HashSpGEMM (overlap.hpp:650-789): estimateFLOP + estimateNNZ_Hash + LocalSpGEMM ---------------- */
+int bella_hip_overlap(bella_ctx* ctx, const bella_params* p, uint64_t* npairs, uint64_t* flops);
+/* pairs[npairs]; ext (nullable) [npairs]; colptrC (nullable) [nreads+1] */
+int bella_hip_get_pairs(bella_ctx* ctx, bella_pair* pairs, bella_pair_ext* ext, uint64_t* colptrC);
+
+/* ---- RunPairWiseAlignments (overlap.hpp:499-645): xavierAlign + PostAlignDecision on every pair ----- */
+int bella_hip_align_pairs(bella_ctx* ctx, const bella_params* p, uint64_t* npassed);
+int bella_hip_get_alignments(bella_ctx* ctx, bella_aln* out);
+/* xavierAlign (align.hpp:152) on explicit seeds; out[n] index-aligned with seeds[n]. */
+int bella_hip_xdrop_batch(bella_ctx* ctx, const bella_seed* seeds, uint64_t n, const bella_params* p,
+                          bella_aln* out);
+
+/* ---- measurement --------------------------------------------------------------------------------- */
+int bella_hip_get_timings(bella_ctx* ctx, bella_timings* t);
+/* 0 = default; bit0 = force the global-memory row path (tests); bit1 = no pair_ext output */
+int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BELLA_HIP_H */

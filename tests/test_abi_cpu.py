@@ -1,0 +1,80 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds/loads, exports every symbol include/bella_hip.h
+declares, and fails loudly without a GPU (no compute calls here)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from bella_amd import _lib, api, synth
+from conftest import ROOT, load_golden
+import _oracle as O
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "bella_hip.h")).read()
+    declared = set(re.findall(r"\b(bella_hip_[a-z_A-Z0-9]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == {s[0] for s in _lib.SIGNATURES}
+    assert lib.bella_hip_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert _lib.PAIR_DT.itemsize == 16 and _lib.EXT_DT.itemsize == 8 and _lib.ALN_DT.itemsize == 32 and _lib.SEED_DT.itemsize == 12
+    import ctypes
+    assert ctypes.sizeof(_lib.Params) == 24 and ctypes.sizeof(_lib.Timings) == 32
+
+
+def test_no_cpu_fallback_without_gpu():
+    lib = _lib.load()
+    if lib.bella_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.BellaHipError) as e:
+        api.Engine(0)
+    assert e.value.code == -1
+
+
+def test_product_never_imports_the_oracle():
+    for dp, _, files in os.walk(os.path.join(ROOT, "bella_amd")):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "_oracle" not in txt and "liboracle" not in txt and "bella_ref" not in txt, f
+
+
+def test_host_writers_against_golden(golden):
+    """the product's output formatting (api.format_*) fed with ORACLE results reproduces the golden files"""
+    g = golden
+    Bc, Br, Bv = O.build_B(g.rs.nreads, g.tk, g.tr, g.tp)
+    _, _, op = O.spgemm(g.seqs, g.nkmers, Bc, Br, Bv, g.k)
+    pairs = np.zeros(len(op), _lib.PAIR_DT)
+    for f in ("rid", "cid", "count", "seedH", "seedV"):
+        pairs[f] = op[f]
+    for n, p in enumerate(op):
+        a, b = g.seqs[p["rid"]], g.seqs[p["cid"]]
+        pairs["flags"][n] = int(a[p["seedH"]:p["seedH"] + g.k] == b[p["seedV"]:p["seedV"] + g.k])
+    assert api.format_skip(g.names, g.rs.lengths, pairs, g.k) == g.out["skip"]
+    txt, oal, passed = O.align_lines(g.names, g.seqs, op, g.xdrop, g.k, g.err)
+    alns = np.zeros(len(op), _lib.ALN_DT)
+    phi = O.slope(g.err)
+    for n, (p, a) in enumerate(zip(op, oal)):
+        ok, ov = O.post_align(a["score"], a["begV"], a["endV"], a["begH"], a["endH"], len(g.seqs[p["rid"]]), len(g.seqs[p["cid"]]), phi)
+        alns[n] = (a["score"], a["begH"], a["endH"], a["begV"], a["endV"], ov, a["strand"], ok, a["steps"], a["flagged"])
+    assert api.format_aligned(g.names, g.rs.lengths, pairs, alns) == txt
+    ptxt, _, _ = O.align_lines(g.names, g.seqs, op, g.xdrop, g.k, g.err, paf=True)
+    assert api.format_aligned(g.names, g.rs.lengths, pairs, alns, paf=True) == ptxt
+
+
+def test_synth_dictionary_matches_reference_counts():
+    """count_and_tuples (caller-side numpy) gives the reference's reliable-k-mer COUNT and tuple multiset on a
+    golden set (ids differ: the reference's are cuckoo-table order)."""
+    g = load_golden("toy120")
+    t = synth.count_and_tuples(g.rs, 17, 2, 8)
+    assert t.nkmers == g.nkmers and len(t.kmer) == len(g.tk)
+    assert np.array_equal(t.read, g.tr) and np.array_equal(t.pos, g.tp)
+    # same partition of tuples into k-mer classes
+    a = np.unique(np.stack([t.kmer, g.tk]), axis=1)
+    assert a.shape[1] == g.nkmers

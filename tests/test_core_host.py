@@ -1,0 +1,213 @@
+"""CPU tests of the per-lane functions the kernels inline (bella_amd/csrc/core.hpp, xdrop.hpp), compiled as
+host C++ by tests/harness/core_harness.cpp and compared with the oracle on the golden sets.  This is a
+unit-test harness: the product library has no CPU path."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from bella_amd import packing, synth
+from conftest import ROOT, load_golden
+
+HSRC = os.path.join(ROOT, "tests", "harness", "core_harness.cpp")
+HLIB = os.path.join(ROOT, "tests", "harness", "libcore_harness.so")
+
+ALN_DT = np.dtype([("score", "<i4"), ("begH", "<i4"), ("endH", "<i4"), ("begV", "<i4"), ("endV", "<i4"), ("ov", "<u2"),
+                   ("strand", "u1"), ("passed", "u1"), ("steps", "<u4"), ("flagged", "<u4")])
+
+
+@pytest.fixture(scope="module")
+def H():
+    deps = [HSRC] + [os.path.join(ROOT, "bella_amd", "csrc", f) for f in ("core.hpp", "xdrop.hpp")]
+    if not os.path.exists(HLIB) or any(os.path.getmtime(d) > os.path.getmtime(HLIB) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", HLIB, HSRC])
+    h = C.CDLL(HLIB)
+    h.h_choose.restype = C.c_uint32
+    h.h_choose.argtypes = [C.c_void_p, C.c_uint32]
+    h.h_overlap_estimate.restype = C.c_int
+    h.h_xdrop_pair.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                               C.c_int, C.c_double, C.c_double, C.c_void_p]
+    h.h_kmer_words.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    h.h_fold_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
+    return h
+
+
+def products_by_pair(g, Bc, Br, Bv):
+    """per output pair (cid, rid): products in the reference's order as (posH, posV, ov)"""
+    nreads = g.rs.nreads
+    Ac, Ar, Av = O.transpose(nreads, g.nkmers, Bc, Br, Bv)
+    lens = g.rs.lengths
+    out = {}
+    for i in range(nreads):
+        for j in range(Bc[i], Bc[i + 1]):
+            km, posV = Br[j], int(Bv[j])
+            for x in range(Ac[km], Ac[km + 1]):
+                key = int(Ar[x])
+                if key <= i:
+                    continue
+                posH = int(Av[x])
+                ov = O.lib().oracle_overlapop(g.seqs[key], int(lens[key]), g.seqs[i], int(lens[i]), posH, posV, g.k) & 0xFFFF
+                out.setdefault((i, key), []).append((posH, posV, ov))
+    return out
+
+
+@pytest.mark.parametrize("name", ["sanity3", "toy120", "toyhifi50", "toyrep90"])
+def test_fold_pair_matches_oracle(H, name):
+    g = load_golden(name)
+    Bc, Br, Bv = O.build_B(g.rs.nreads, g.tk, g.tr, g.tp)
+    _, _, pairs = O.spgemm(g.seqs, g.nkmers, Bc, Br, Bv, g.k)
+    prods = products_by_pair(g, Bc, Br, Bv)
+    assert len(prods) == len(pairs)
+    out = np.zeros(7, np.uint32)
+    multi = 0
+    for p in pairs:
+        lst = prods[(int(p["cid"]), int(p["rid"]))]
+        hv = np.asarray([a | (b << 16) for a, b, _ in lst], np.uint32)
+        ov = np.asarray([c for _, _, c in lst], np.uint16)
+        for shuffle in (0, 12345):
+            H.h_fold_pair(hv.ctypes.data, ov.ctypes.data, len(lst), g.k, 500, 1, shuffle, out.ctypes.data)
+            assert (int(out[0]), int(out[4]), int(out[5])) == (int(p["count"]), int(p["seedH"]), int(p["seedV"])), (p, shuffle)
+            assert (int(out[1]), int(out[2]), int(out[3])) == (int(p["nbins"]), int(p["support"]), int(p["binov"]))
+        multi += int(p["nbins"]) > 1
+    if name == "toyrep90":
+        assert multi > 0          # the repeat genome must exercise multi-bin states
+
+
+def test_fold_many_bins_random(H):
+    """adversarial lists: overlaps far apart -> many bins (> 16: std::sort path), then merges"""
+    rng = np.random.default_rng(5)
+    out = np.zeros(7, np.uint32)
+    import ctypes
+    for trial in range(300):
+        m = int(rng.integers(2, 120))
+        ovs = (rng.integers(0, 40, size=m) * int(rng.integers(100, 900))).astype(np.uint16)
+        ph = rng.integers(0, 3000, size=m).astype(np.uint32)
+        pv = rng.integers(0, 3000, size=m).astype(np.uint32)
+        hv = (ph | (pv << 16)).astype(np.uint32)
+        # python model of A.3 with libstdc++-equal choose via the oracle
+        count, bins = 1, [[int(ovs[0]), [(int(ph[0]), int(pv[0]))]]]
+        for t in range(1, m):
+            q, oq = (int(ph[t]), int(pv[t])), int(ovs[t])
+            ins, orphans = [], []
+            for b in bins:
+                if abs(b[0] - oq) < 500:
+                    ins += [x for x in b[1] if abs(x[0] - q[0]) > 17 and abs(x[1] - q[1]) > 17]
+                else:
+                    orphans.append(b)
+            count = (count + 1 + len(ins)) & 0xFFFF
+            bins = [[oq, [q] + ins]] + orphans
+        sup = np.asarray([len(b[1]) for b in bins], np.uint32)
+        w = O.lib().oracle_choose_bin(sup, len(sup))
+        H.h_fold_pair(hv.ctypes.data, ovs.ctypes.data, m, 17, 500, 1, trial, out.ctypes.data)
+        assert int(out[0]) == count and int(out[1]) == len(bins)
+        assert (int(out[2]), int(out[3]), int(out[4]), int(out[5])) == (len(bins[w][1]), bins[w][0], bins[w][1][0][0], bins[w][1][0][1]), trial
+
+
+def test_id_sorter_matches_oracle_restatement(H):
+    rng = np.random.default_rng(1)
+    for trial in range(500):
+        n = int(rng.integers(1, 600))
+        s = rng.integers(1, int(rng.integers(2, 7)), size=n).astype(np.uint32)
+        assert H.h_choose(s.ctypes.data, n) == O.lib().oracle_choose_bin(s, n)
+
+
+def test_kmer_words(H):
+    rs = synth.make_reads(5, read_len=300, seed=9)
+    pk = packing.pack_codes(rs.codes)
+    for k in (15, 17, 31, 32):
+        fw, rc, rid, pos, valid = synth.kmer_words(rs, k)
+        out = np.zeros(3, np.uint64)
+        for gidx in list(range(0, 40)) + [100, 333, 777, len(fw) - 1]:
+            H.h_kmer_words(pk.ctypes.data, gidx, k, out.ctypes.data)
+            assert int(out[1]) == int(fw[gidx]) and int(out[2]) == int(rc[gidx]), (k, gidx)
+
+
+def test_overlap_estimate_matches_oracle(H):
+    rng = np.random.default_rng(2)
+    a = bytes(synth.BASES[rng.integers(0, 4, 900, dtype=np.uint8)])
+    for trial in range(2000):
+        l1, l2 = int(rng.integers(40, 900)), int(rng.integers(40, 900))
+        p1, p2 = int(rng.integers(0, l1 - 17)), int(rng.integers(0, l2 - 17))
+        r1 = a[:l1]
+        # plant the same / a different k-mer to drive checkstrand both ways
+        same = bool(rng.integers(0, 2))
+        r2 = bytearray(a[100:100 + l2] if l2 <= 800 else a[:l2])
+        if same:
+            r2[p2:p2 + 17] = r1[p1:p1 + 17]
+        r2 = bytes(r2)
+        oriented = r1[p1:p1 + 17] == r2[p2:p2 + 17]
+        exp = O.lib().oracle_overlapop(r1, l1, r2, len(r2), p1, p2, 17)
+        assert H.h_overlap_estimate(p1, p2, l1, len(r2), int(oriented), 17) == exp
+
+
+def _xdrop_pairs(H, g, pairs, limit=None):
+    pk = packing.pack_codes(g.rs.codes)
+    offs = g.rs.offsets
+    phi = O.slope(g.err)
+    out = np.zeros(1, ALN_DT)
+    bad = []
+    nflag = 0
+    for n, p in enumerate(pairs[:limit]):
+        rid, cid = int(p["rid"]), int(p["cid"])
+        H.h_xdrop_pair(pk.ctypes.data, int(offs[rid]), len(g.seqs[rid]), int(offs[cid]), len(g.seqs[cid]), int(p["seedH"]),
+                       int(p["seedV"]), g.k, g.xdrop, phi, 0.1, out.ctypes.data)
+        a = O.xavier_align(g.seqs[rid], g.seqs[cid], int(p["seedH"]), int(p["seedV"]), g.xdrop, g.k)
+        ok, ov = O.post_align(a["score"], a["begV"], a["endV"], a["begH"], a["endH"], len(g.seqs[rid]), len(g.seqs[cid]), phi)
+        got = out[0]
+        exp = (int(a["score"]), int(a["begH"]), int(a["endH"]), int(a["begV"]), int(a["endV"]), ov, int(a["strand"]), int(ok),
+               int(a["flagged"]), int(a["steps"]))
+        have = (int(got["score"]), int(got["begH"]), int(got["endH"]), int(got["begV"]), int(got["endV"]), int(got["ov"]),
+                int(got["strand"]), int(got["passed"]), int(got["flagged"]), int(got["steps"]))
+        nflag += int(a["flagged"])
+        if exp != have:
+            bad.append((n, exp, have))
+    return bad, nflag
+
+
+@pytest.mark.parametrize("name", ["sanity3", "toy120", "toylen80", "toyhifi50"])
+def test_xdrop_lane_function_matches_oracle(H, name):
+    g = load_golden(name)
+    Bc, Br, Bv = O.build_B(g.rs.nreads, g.tk, g.tr, g.tp)
+    _, _, pairs = O.spgemm(g.seqs, g.nkmers, Bc, Br, Bv, g.k)
+    bad, nflag = _xdrop_pairs(H, g, pairs, limit=1200)
+    assert not bad, bad[:3]
+
+
+def test_ordered_insertion_fixed_point_equals_sequential():
+    """The atomicMin displacement scheme (spgemm.hpp phase O / assemble.hpp) under random interleavings."""
+    rng = np.random.default_rng(3)
+    EMPTY = 0xFFFFFFFF
+    for trial in range(300):
+        d = int(rng.integers(1, 200))
+        ht = 16
+        while ht < d:
+            ht <<= 1
+        keys = rng.choice(1 << 20, size=d, replace=False).astype(np.uint64)
+        prio = rng.permutation(d)                     # first-occurrence order
+        # sequential reference: insert in prio order, linear probing
+        seq = [EMPTY] * ht
+        for s in np.argsort(prio):
+            h = int(keys[s] * 107) & (ht - 1)
+            while seq[h] != EMPTY:
+                h = (h + 1) & (ht - 1)
+            seq[h] = int(s)
+        # concurrent: every key is an agent (item, h); a random agent takes one atomicMin step at a time
+        T2 = [EMPTY] * ht
+        agents = [[(int(prio[s]) << 16) | s, int(keys[s] * 107) & (ht - 1)] for s in range(d)]
+        live = list(range(d))
+        while live:
+            ai = int(rng.integers(0, len(live)))
+            ag = agents[live[ai]]
+            old = T2[ag[1]]
+            T2[ag[1]] = min(old, ag[0])
+            if old == EMPTY:
+                live.pop(ai)
+                continue
+            if old > ag[0]:
+                ag[0] = old
+            ag[1] = (ag[1] + 1) & (ht - 1)
+        got = [EMPTY if x == EMPTY else (x & 0xFFFF) for x in T2]
+        assert got == seq, trial

@@ -1,0 +1,239 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI, against the oracle
+(tests/_oracle.py -> oracle/bella_oracle.c) on the same inputs and against the reference's golden outputs."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from bella_amd import BellaPars, Engine, api, synth
+from bella_amd.api import BellaHipError
+from conftest import GOLD, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def oracle_pairs(rs, seqs, nkmers, tk, tr, tp, k=17):
+    Bc, Br, Bv = O.build_B(rs.nreads, tk, tr, tp)
+    flop, colptrC, pairs = O.spgemm(seqs, nkmers, Bc, Br, Bv, k)
+    return (Bc, Br, Bv), flop, colptrC, pairs
+
+
+def check_pairs(got, ext, exp, lengths, k):
+    assert len(got) == len(exp)
+    for f in ("rid", "cid", "count", "seedH", "seedV"):
+        assert np.array_equal(got[f], exp[f]), f
+    if ext is not None:
+        for f in ("nbins", "support", "binov"):
+            assert np.array_equal(ext[f], exp[f]), f
+    assert np.array_equal(api.overlap_of_seed(got, lengths, k), exp["overlap"].astype(np.int64))
+
+
+def test_assembly_matches_reference_layout(eng, golden):
+    g = golden
+    eng.set_reads(g.rs)
+    eng.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
+    got = eng.get_B()
+    exp = O.build_B(g.rs.nreads, g.tk, g.tr, g.tp)
+    for a, b in zip(got, exp):
+        assert np.array_equal(a, b)           # colptr, k-mer ids in MergeDuplicates slot order, positions
+
+
+@pytest.mark.parametrize("debug", [0, 1])
+def test_spgemm_pairs_bit_exact(eng, golden, debug):
+    g = golden
+    eng.set_debug(debug)                       # 1 = force the global-workspace row path
+    try:
+        eng.set_reads(g.rs)
+        eng.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
+        n, flops = eng.overlap(BellaPars(skipAlignment=True))
+        pairs, ext, colptrC = eng.get_pairs()
+        _, flop, ecol, exp = oracle_pairs(g.rs, g.seqs, g.nkmers, g.tk, g.tr, g.tp, g.k)
+        assert flops == int(flop.sum()) and n == len(exp)
+        assert np.array_equal(colptrC, ecol.astype(np.uint64))
+        check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
+    finally:
+        eng.set_debug(0)
+
+
+def test_set_B_boundary_equals_tuple_assembly(eng, golden):
+    """HashSpGEMM boundary: the reference's own B arrays in, same result."""
+    g = golden
+    Bc, Br, Bv = O.build_B(g.rs.nreads, g.tk, g.tr, g.tp)
+    eng.set_reads(g.rs)
+    eng.set_B(g.k, g.nkmers, Bc, Br, Bv)
+    eng.overlap(BellaPars(skipAlignment=True))
+    pairs, ext, _ = eng.get_pairs()
+    _, _, _, exp = oracle_pairs(g.rs, g.seqs, g.nkmers, g.tk, g.tr, g.tp, g.k)
+    check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
+
+
+def test_golden_files_byte_identical(eng, golden, tmp_path):
+    g = golden
+    eng.set_reads(g.rs)
+    eng.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
+    import io
+    so = io.StringIO()
+    f = str(tmp_path / "o.out")
+    api.hash_spgemm(eng, BellaPars(skipAlignment=True, errorRate=g.err), f, stdout=so)
+    assert open(f, "rb").read() == g.out["skip"]
+    assert so.getvalue().split()[0] == g.stdout["skip"][2]           # nnz(C), overlap.hpp:686
+    for key, paf in (("align", False), ("paf", True)):
+        so = io.StringIO()
+        api.hash_spgemm(eng, BellaPars(errorRate=g.err, outputPaf=paf), f, stdout=so)
+        got = open(f, "rb").read()
+        if got != g.out[key]:
+            # only alignments that hit the reference's uninitialised maxpos may differ
+            pairs, _, _ = eng.get_pairs(ext=False)
+            alns = eng.get_alignments()
+            fl = {(g.names[p["cid"]], g.names[p["rid"]]) for p, a in zip(pairs, alns) if a["flagged"]}
+            col = (0, 5) if paf else (0, 1)
+            bad = [l for l in set(got.split(b"\n")) ^ set(g.out[key].split(b"\n"))
+                   if l and (l.decode().split("\t")[col[0]], l.decode().split("\t")[col[1]]) not in fl]
+            assert not bad, bad[:4]
+        else:
+            assert so.getvalue().split()[1] == g.stdout["align"][3]   # outputted, overlap.hpp:771
+
+
+def test_alignments_match_oracle_fieldwise(eng, golden):
+    g = golden
+    eng.set_reads(g.rs)
+    eng.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
+    pars = BellaPars(errorRate=g.err)
+    eng.overlap(pars)
+    npass = eng.align_pairs(pars)
+    pairs, _, _ = eng.get_pairs(ext=False)
+    alns = eng.get_alignments()
+    assert npass == int(alns["passed"].sum())
+    phi = O.slope(g.err)
+    for p, a in list(zip(pairs, alns))[:1500]:
+        rid, cid = int(p["rid"]), int(p["cid"])
+        e = O.xavier_align(g.seqs[rid], g.seqs[cid], int(p["seedH"]), int(p["seedV"]), g.xdrop, g.k)
+        ok, ov = O.post_align(e["score"], e["begV"], e["endV"], e["begH"], e["endH"], len(g.seqs[rid]), len(g.seqs[cid]), phi)
+        exp = (int(e["score"]), int(e["begH"]), int(e["endH"]), int(e["begV"]), int(e["endV"]), ov, int(e["strand"]), int(ok),
+               int(e["steps"]), int(e["flagged"]))
+        got = (int(a["score"]), int(a["begH"]), int(a["endH"]), int(a["begV"]), int(a["endV"]), int(a["ov"]), int(a["strand"]),
+               int(a["passed"]), int(a["steps"]), int(a["flagged"]))
+        assert got == exp, (rid, cid)
+
+
+def test_xavier_known_answers_on_gpu(eng):
+    kats = json.load(open(os.path.join(GOLD, "xavier_kat.json")))
+    seqs, seeds, exps = [], [], []
+    for kat in kats:
+        if kat["kind"] == "xdrop":
+            row, col, i, j = kat["target"], kat["query"], kat["begH"], kat["begV"]
+        else:
+            row, col, i, j = kat["row"], kat["col"], kat["i"], kat["j"]
+        seqs += [row.encode(), col.encode()]
+        seeds.append((len(seqs) - 2, len(seqs) - 1, i, j, kat["k"], kat["x"]))
+        exps.append(kat)
+    rs = synth.readset_from_seqs(seqs)
+    eng.set_reads(rs)
+    for (rid, cid, i, j, k, x), kat in zip(seeds, exps):
+        sd = np.zeros(1, api.SEED_DT)
+        sd[0] = (rid, cid, i, j)
+        a = eng.xdrop_batch(sd, BellaPars(kmerSize=k, xDrop=x))[0]
+        if a["flagged"]:
+            continue
+        got = [int(a["score"]), int(a["begH"]), int(a["endH"]), int(a["begV"]), int(a["endV"])]
+        assert got == kat["expect"], kat["name"]
+        if kat["kind"] == "align":
+            assert ("c" if a["strand"] else "n") == kat["strand"]
+
+
+def test_partition_union_equals_whole(eng):
+    g = load_golden("toy120")
+    eng.set_reads(g.rs)
+    eng.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
+    eng.set_partition(0, 1)
+    eng.overlap(BellaPars())
+    whole, _, _ = eng.get_pairs(ext=False)
+    parts = []
+    try:
+        for r in range(3):
+            eng.set_partition(r, 3)
+            eng.overlap(BellaPars())
+            p, _, _ = eng.get_pairs(ext=False)
+            assert (p["cid"] % 3 == r).all()
+            parts.append(p)
+    finally:
+        eng.set_partition(0, 1)
+    merged = np.concatenate(parts)
+    order = np.argsort(merged["cid"], kind="stable")      # columns ascending, slot order kept inside a column
+    assert np.array_equal(merged[order], whole)
+
+
+def test_medium_synthetic_vs_oracle(eng):
+    """2,000 reads x 6 kb (SpGEMM) -- bigger hash tables, LDS tiers and the ordering emulation under load"""
+    rs = synth.make_reads(2000, read_len=6000, err=0.15, seed=21)
+    t = synth.count_and_tuples(rs, 17, 2, 8)
+    seqs = rs.seqs()
+    eng.set_reads(rs)
+    eng.assemble_tuples(17, t.nkmers, t.kmer, t.read, t.pos)
+    got = eng.get_B()
+    (Bc, Br, Bv), flop, ecol, exp = oracle_pairs(rs, seqs, t.nkmers, t.kmer, t.read, t.pos)
+    for a, b in zip(got, (Bc, Br, Bv)):
+        assert np.array_equal(a, b)
+    n, flops = eng.overlap(BellaPars())
+    assert n == len(exp) and flops == int(flop.sum())
+    pairs, ext, _ = eng.get_pairs()
+    check_pairs(pairs, ext, exp, rs.lengths, 17)
+    # idempotence: a second pass over the same resident operands gives the same bytes
+    eng.overlap(BellaPars())
+    again, _, _ = eng.get_pairs()
+    assert again.tobytes() == pairs.tobytes()
+    # X-drop on a sample of the pairs
+    eng.align_pairs(BellaPars())
+    alns = eng.get_alignments()
+    phi = O.slope(0.15)
+    idx = np.random.default_rng(0).choice(len(pairs), size=300, replace=False)
+    for n_ in idx:
+        p, a = pairs[n_], alns[n_]
+        rid, cid = int(p["rid"]), int(p["cid"])
+        e = O.xavier_align(seqs[rid], seqs[cid], int(p["seedH"]), int(p["seedV"]), 7, 17)
+        ok, ov = O.post_align(e["score"], e["begV"], e["endV"], e["begH"], e["endH"], len(seqs[rid]), len(seqs[cid]), phi)
+        assert (int(a["score"]), int(a["begH"]), int(a["endH"]), int(a["begV"]), int(a["endV"]), int(a["ov"]), int(a["passed"])) == \
+               (int(e["score"]), int(e["begH"]), int(e["endH"]), int(e["begV"]), int(e["endV"]), ov, int(ok))
+
+
+def test_edge_cases(eng):
+    # empty matrix, reads without tuples, a single pair
+    rs = synth.readset_from_seqs([b"ACGT" * 20, b"TTTT" * 30, b"ACGT" * 20])
+    eng.set_reads(rs)
+    eng.assemble_tuples(17, 5, np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint16))
+    assert eng.overlap(BellaPars()) == (0, 0)
+    eng.assemble_tuples(17, 5, np.array([3, 3], np.uint32), np.array([0, 2], np.uint32), np.array([0, 4], np.uint16))
+    assert eng.overlap(BellaPars())[0] == 1
+    p, _, _ = eng.get_pairs()
+    assert (int(p["rid"][0]), int(p["cid"][0]), int(p["count"][0]), int(p["seedH"][0]), int(p["seedV"][0])) == (2, 0, 1, 4, 0)
+    # duplicated k-mer inside a read: LAST position wins, slot decided by FIRST occurrence (CSC.cpp:344)
+    tk = np.array([7, 9, 7, 9, 7], np.uint32); tr = np.array([0, 0, 0, 2, 2], np.uint32); tp = np.array([0, 4, 8, 4, 12], np.uint16)
+    eng.assemble_tuples(17, 10, tk, tr, tp)
+    exp = O.build_B(3, tk, tr, tp)
+    for a, b in zip(eng.get_B(), exp):
+        assert np.array_equal(a, b)
+
+
+def test_errors_are_loud(eng):
+    with pytest.raises(BellaHipError) as e:
+        eng.set_reads_raw(np.frombuffer(b"ACGTNACGT", np.uint8), np.array([0, 9], np.uint64))
+    assert e.value.code == -4
+    with pytest.raises(BellaHipError) as e:
+        eng.set_reads_raw(np.frombuffer(b"A" * 70000, np.uint8), np.array([0, 70000], np.uint64))
+    assert e.value.code == -5
+    rs = synth.readset_from_seqs([b"ACGT" * 20, b"ACGT" * 20])
+    eng.set_reads(rs)
+    with pytest.raises(BellaHipError) as e:
+        eng.assemble_tuples(17, 5, np.array([1, 1], np.uint32), np.array([1, 0], np.uint32), np.array([0, 0], np.uint16))
+    assert e.value.code == -6
+    with pytest.raises(BellaHipError):
+        eng.overlap(BellaPars())              # no matrix after the failed assembly
