@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void k_spgemm_rows_global(SpgemmArgs a) {
     for (uint32_t x = blockIdx.x; x < a.nrows; x += gridDim.x) {
         const uint32_t i = a.rowlist[x];
         const uint32_t f = (uint32_t)(a.flopptr[i + 1] - a.flopptr[i]);
-        const RowMem m = carve(ws, f);
+        const RowMem m = carve(ws, f < 16u ? 16u : f);   // T2 (>= 16 slots) overlays 2*cap words
         process_row(a, i, m);
         __syncthreads();
     }
