@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -532,6 +533,12 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, bool with_sort_scratc
     a.ws_stride = ws_stride;
     a.k = p->kmer_size;
     a.binSize = p->bin_size;
+    a.phase = nullptr;
+    const bool phase_timers = getenv("BELLA_HIP_PHASE_TIMERS") != nullptr;
+    if (phase_timers) {
+        HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 4, 0, 32, c->stream));
+        a.phase = (unsigned long long*)(ptr<uint32_t>(c->status) + 4);
+    }
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     uint32_t launches = 0;
     for (uint32_t t = 0; t < kNumTiers; ++t) {
@@ -577,6 +584,13 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, bool with_sort_scratc
     c->tm.compact_ms = ev_ms(c->ev[6], c->ev[7]);
     c->tm.overlap_total_ms = ev_ms(c->ev[2], c->ev[7]);
     c->tm.spgemm_launches = launches;
+    if (phase_timers) {
+        unsigned long long ph[4];
+        HIPCHK(c, hipMemcpy(ph, ptr<uint32_t>(c->status) + 4, 32, hipMemcpyDeviceToHost));
+        const double tot = (double)(ph[0] + ph[1] + ph[2] + ph[3]) + 1e-9;
+        fprintf(stderr, "[bella_hip] row-kernel phase cycles (sum over workgroups): expand %.1f%% order %.1f%% scatter %.1f%% fold %.1f%% ; total %.3g cycles, kernels %.3f ms\n",
+                100.0 * ph[0] / tot, 100.0 * ph[1] / tot, 100.0 * ph[2] / tot, 100.0 * ph[3] / tot, tot, c->tm.spgemm_ms);
+    }
     return 0;
 }
 

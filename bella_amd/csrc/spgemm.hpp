@@ -52,6 +52,7 @@ struct SpgemmArgs {
     uint32_t cap;
     int k;
     int binSize;
+    unsigned long long* phase;   // optional per-phase cycle counters (development aid, BELLA_HIP_PHASE_TIMERS=1)
 };
 
 constexpr uint32_t kRowScratchBytes = 64;                    // block scan scratch + counters
@@ -98,6 +99,9 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
     for (uint32_t s = tid; s < H1; s += kBlock) { m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0; }
     if (tid == 0) *s_d = 0;
     __syncthreads();
+    long long tc = 0;
+    if (a.phase && tid == 0) tc = clock64();
+#define BELLA_PHASE(n) if (a.phase && tid == 0) { const long long t2 = clock64(); atomicAdd(a.phase + (n), (unsigned long long)(t2 - tc)); tc = t2; }
 
     // ---- X: expand products in reference order, group keys --------------------------------------------
     uint32_t running = 0;
@@ -133,6 +137,7 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
     const uint32_t F = running;
     __syncthreads();
     const uint32_t d = *s_d;
+    BELLA_PHASE(0)
 
     // ---- O: the reference's slot order (overlap.hpp:289-361) -----------------------------------------
     const uint32_t ht = pow2_at_least(16u, d);
@@ -175,6 +180,7 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
+    BELLA_PHASE(1)
 
     // ---- S: scatter products into per-pair lists -----------------------------------------------------
     for (uint32_t p = tid; p < F; p += kBlock) {
@@ -186,6 +192,7 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
         m.S_pov[slot] = (p << 16) | (gov & 0xFFFFu);
     }
     __syncthreads();
+    BELLA_PHASE(2)
 
     // ---- F/W: fold each pair, write its record -------------------------------------------------------
     const uint64_t obase = a.flopptr[i];
@@ -220,6 +227,8 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     if (tid == 0) a.nnzC[i] = d;
+    if (a.phase) { __syncthreads(); BELLA_PHASE(3) }
+#undef BELLA_PHASE
 }
 
 // LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap)

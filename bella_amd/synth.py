@@ -157,10 +157,51 @@ class Tuples:
     nkmers: int
 
 
-def count_and_tuples(rs: ReadSet, k: int = 17, lower: int = 2, upper: int = 8) -> Tuples:
+def _count_and_tuples_torch(rs: ReadSet, k: int, lower: int, upper: int, device: str) -> Tuples:
+    """same result as the numpy path, with the sort/unique of the k-mer words done by torch on the GPU
+    (input preparation for benchmarks -- not part of the overlap hot path)"""
+    import torch
+    dev = torch.device(device)
+    n = rs.codes.shape[0]
+    m = max(0, n - k + 1)
+    c = torch.from_numpy(rs.codes).to(dev).to(torch.int64)
+    fw = torch.zeros(m, dtype=torch.int64, device=dev)
+    rc = torch.zeros(m, dtype=torch.int64, device=dev)
+    for t in range(k):
+        sl = c[t:t + m]
+        fw = (fw << 2) | sl
+        rc = rc | ((3 - sl) << (2 * t))
+    canon = torch.minimum(fw, rc)
+    del fw, rc, c
+    lens = torch.from_numpy(np.diff(rs.offsets)).to(dev)
+    offs = torch.from_numpy(rs.offsets).to(dev)
+    rid = torch.repeat_interleave(torch.arange(rs.nreads, device=dev), lens)[:m]
+    pos = torch.arange(m, device=dev) - offs[rid]
+    valid = pos <= (lens[rid] - k)
+    canon, rid, pos = canon[valid], rid[valid], pos[valid]
+    uniq, cnt = torch.unique(canon, return_counts=True)
+    rel = uniq[(cnt >= lower) & (cnt <= upper)]
+    del uniq, cnt
+    idx = torch.searchsorted(rel, canon)
+    idx[idx >= rel.shape[0]] = 0
+    hit = rel[idx] == canon
+    out = Tuples(idx[hit].to(torch.int32).cpu().numpy().astype(np.uint32), rid[hit].to(torch.int32).cpu().numpy().astype(np.uint32),
+                 pos[hit].to(torch.int32).cpu().numpy().astype(np.uint16), int(rel.shape[0]))
+    torch.cuda.empty_cache()
+    return out
+
+
+def count_and_tuples(rs: ReadSet, k: int = 17, lower: int = 2, upper: int = 8, device: str | None = None) -> Tuples:
     """kmercount.hpp:467-677 (SplitCount, exact 1-thread semantics) + main.cpp:391-416."""
     if int(np.diff(rs.offsets).max(initial=0)) >= 65536:
         raise ValueError("reads must be shorter than 65,536 bases (u16 positions, common.h:122-126)")
+    if device is not None and k <= 31:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                return _count_and_tuples_torch(rs, k, lower, upper, device)
+        except ImportError:
+            pass
     fw, rc, rid, pos, valid = kmer_words(rs, k)
     canon = np.minimum(fw, rc)[valid]
     rid = rid[valid]

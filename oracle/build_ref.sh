@@ -11,6 +11,7 @@
 # Products:
 #   oracle/_ref/bella_ref        the reference CLI (src/main.cpp)            -> golden .out files
 #   oracle/_ref/bella_ref_dump   same with -DWRITEDATAMATRIX (bellaio.h:2-47)  -> readbykmers.mtx
+#   oracle/_ref/libbella_dropin.so  oracle/dropin_shim.cpp: reference headers + bella_amd/host/bella_hip_shim.hpp (drop-in proof)
 #   oracle/_ref/libbella_ref.so  oracle/ref_shim.cpp (ours) #including the reference headers:
 #                                C entry points around HashSpGEMM / xavierAlign for tests + cpu_baseline
 set -euo pipefail
@@ -24,8 +25,10 @@ mkdir -p "$OUT/obj"
 O="$OUT/obj"
 INC="-I$REF/include/common/GTgraph/sprng2.0-lite/include -I$REF/loganGPU -I$REF/seqan"
 stamp="$O/.stamp"
+ROOTDIR="$(cd "$HERE/.." && pwd)"
 if [ -f "$stamp" ] && [ "$OUT/libbella_ref.so" -nt "$HERE/ref_shim.cpp" ] && [ -x "$OUT/bella_ref" ] \
-   && [ -x "$OUT/bella_ref_dump" ] && [ "${1:-}" != "--force" ]; then
+   && [ -x "$OUT/bella_ref_dump" ] && [ "$OUT/libbella_dropin.so" -nt "$HERE/dropin_shim.cpp" ] \
+   && [ "$OUT/libbella_dropin.so" -nt "$ROOTDIR/bella_amd/host/bella_hip_shim.hpp" ] && [ "${1:-}" != "--force" ]; then
   echo "build_ref: up to date"; exit 0
 fi
 set -x
@@ -41,6 +44,13 @@ g++ -std=c++14 -w -O3 $INC -mavx2 -fopenmp -fpermissive -o "$OUT/bella_ref" $OBJ
 g++ -std=c++14 -w -O3 $INC -mavx2 -fopenmp -fpermissive -DWRITEDATAMATRIX -o "$OUT/bella_ref_dump" $OBJS "$REF/src/main.cpp" -lpthread &
 g++ -std=c++14 -w -O3 $INC -I"$REF" -DBELLA_REF_ROOT="\"$REF\"" -mavx2 -fopenmp -fpermissive -fPIC -shared \
     -o "$OUT/libbella_ref.so" "$HERE/ref_shim.cpp" $OBJS -lpthread &
+# the drop-in proof: reference headers + the product's shim header, linked against libbella_hip.so (built first by
+# __graft_entry__.build(); located at run time through $ORIGIN)
+if [ -f "$ROOTDIR/bella_amd/libbella_hip.so" ]; then
+g++ -std=c++14 -w -O2 $INC -I"$REF" -I"$ROOTDIR/include" -I"$ROOTDIR/bella_amd/host" -mavx2 -fopenmp -fpermissive -fPIC -shared \
+    -o "$OUT/libbella_dropin.so" "$HERE/dropin_shim.cpp" $OBJS -L"$ROOTDIR/bella_amd" -lbella_hip \
+    -Wl,-rpath,'$ORIGIN/../../bella_amd' -lpthread &
+fi
 wait
 set +x
 touch "$stamp"

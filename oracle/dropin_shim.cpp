@@ -1,0 +1,106 @@
+// TEST INFRASTRUCTURE ONLY.  Proves the drop-in claim of INTEGRATION.md: this translation unit includes the REFERENCE's
+// headers exactly as src/main.cpp:32-55 does, then bella_amd/host/bella_hip_shim.hpp, and makes the reference's own call
+// (main.cpp:476-525, same lambdas).  Overload resolution must pick the shim's HashSpGEMM, i.e. the work runs in
+// libbella_hip.so on the GPU.  Built by oracle/build_ref.sh into oracle/_ref/libbella_dropin.so (needs /root/reference).
+#include <iostream>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <istream>
+#include <vector>
+#include <string>
+#include <algorithm>
+#include <utility>
+#include <array>
+#include <typeinfo>
+#include <tuple>
+#include <queue>
+#include <memory>
+#include <stack>
+#include <functional>
+#include <cstring>
+#include <math.h>
+#include <cassert>
+#include <ios>
+#include <chrono>
+#include <thread>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <map>
+#include <unordered_map>
+#include <sstream>
+#include <omp.h>
+
+#include "include/cxxopts.hpp"
+#include "libcuckoo/cuckoohash_map.hh"
+#include "include/kmercount.hpp"
+#include "include/chain.hpp"
+#include "include/common/bellaio.h"
+#include "include/minimizer.hpp"
+#include "include/syncmer.hpp"
+#include "kmercode/hash_funcs.h"
+#include "kmercode/Kmer.hpp"
+#include "kmercode/Buffer.h"
+#include "kmercode/common.h"
+#include "kmercode/fq_reader.h"
+#include "kmercode/ParallelFASTQ.h"
+#include "kmercode/bound.hpp"
+#include "include/common/utility.h"
+#include "include/common/CSC.h"
+#include "include/common/CSR.h"
+#include "include/common/common.h"
+#include "include/common/IO.h"
+#include "include/overlap.hpp"
+#include "include/align.hpp"
+// ---- the one line a BELLA maintainer adds to src/main.cpp (after its line 55) ----
+#include "bella_hip_shim.hpp"
+
+typedef uint32_t KIDX;
+
+extern "C" int bella_dropin_hashspgemm(uint32_t nreads, uint32_t nkmers, uint64_t ntuples, const uint32_t* t_kmer,
+                                       const uint32_t* t_read, const uint16_t* t_pos, const char* const* seqs,
+                                       const char* const* names, int kmerSize, int binSize, int xDrop, int skipAlignment,
+                                       int outputPaf, double errorRate, double deltaChernoff, const char* outfile,
+                                       char* stdout_log, size_t stdout_cap) {
+    std::stringstream sc;
+    std::streambuf* oc = std::cout.rdbuf(sc.rdbuf());
+    BELLApars bpars;
+    bpars.kmerSize = kmerSize; bpars.binSize = binSize; bpars.xDrop = xDrop;
+    bpars.skipAlignment = skipAlignment != 0; bpars.outputPaf = outputPaf != 0;
+    bpars.errorRate = errorRate; bpars.deltaChernoff = deltaChernoff;
+    bpars.totalMemory = 400000.0; bpars.userDefMem = true;
+    double ratiophi = slope(bpars.errorRate);
+    readVector_ reads(nreads);
+    for (uint32_t r = 0; r < nreads; ++r) { reads[r].nametag = names[r]; reads[r].seq = seqs[r]; reads[r].readid = r; }
+    std::vector<std::tuple<KIDX, KIDX, unsigned short>> transtuples(ntuples);
+    for (uint64_t i = 0; i < ntuples; ++i) transtuples[i] = std::make_tuple(t_kmer[i], t_read[i], t_pos[i]);
+    std::cout << nkmers << std::endl;
+    CSC<KIDX, unsigned short> transpmat(transtuples, nkmers, nreads, [](unsigned short& p1, unsigned short& p2) { return p1; }, false);
+    CSC<KIDX, unsigned short> spmat = transpmat.Transpose();
+    std::string of(outfile);
+    remove(of.c_str());
+    std::vector<char> ofc(of.begin(), of.end());
+    ofc.push_back(0);
+    spmatPtr_ getvaluetype(std::make_shared<spmatType_>());
+    HashSpGEMM(                                                   // verbatim call shape of src/main.cpp:498-525
+        spmat, transpmat,
+        [&bpars, &reads](const unsigned short int& begpH, const unsigned short int& begpV, const unsigned int& id1,
+                         const unsigned int& id2) {
+            spmatPtr_ value(std::make_shared<spmatType_>());
+            std::string& read1 = reads[id1].seq;
+            std::string& read2 = reads[id2].seq;
+            multiop(value, read1, read2, begpH, begpV, bpars.kmerSize);
+            return value;
+        },
+        [&bpars, &reads](spmatPtr_& m1, spmatPtr_& m2, const unsigned int& id1, const unsigned int& id2) {
+            std::string& readname1 = reads[id1].nametag;
+            std::string& readname2 = reads[id2].nametag;
+            chainop(m1, m2, bpars, readname1, readname2);
+            return m1;
+        },
+        reads, getvaluetype, ofc.data(), bpars, ratiophi);
+    std::cout.rdbuf(oc);
+    std::string s = sc.str();
+    if (stdout_log && stdout_cap) { size_t n = std::min(stdout_cap - 1, s.size()); memcpy(stdout_log, s.data(), n); stdout_log[n] = 0; }
+    return 0;
+}

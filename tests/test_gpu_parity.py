@@ -237,3 +237,35 @@ def test_errors_are_loud(eng):
     assert e.value.code == -6
     with pytest.raises(BellaHipError):
         eng.overlap(BellaPars())              # no matrix after the failed assembly
+
+
+def test_dropin_shim_from_reference_call_site(eng, tmp_path):
+    """oracle/_ref/libbella_dropin.so = the reference's headers + its own HashSpGEMM call (main.cpp:498-525) compiled with
+    bella_amd/host/bella_hip_shim.hpp: the call must land in libbella_hip.so and write the golden file."""
+    import ctypes as C
+    from conftest import ROOT
+    path = os.path.join(ROOT, "oracle", "_ref", "libbella_dropin.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libbella_dropin.so not built (needs /root/reference at build time)")
+    lib = C.CDLL(path)
+    u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+    u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+    lib.bella_dropin_hashspgemm.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, u32p, u32p, u16p, C.POINTER(C.c_char_p),
+                                            C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                            C.c_double, C.c_char_p, C.c_char_p, C.c_size_t]
+    for name in ("sanity3", "toy120"):
+        g = load_golden(name)
+        n = g.rs.nreads
+        sarr = (C.c_char_p * n)(*g.seqs)
+        narr = (C.c_char_p * n)(*[x.encode() for x in g.names])
+        for skip, key in ((1, "skip"), (0, "align")):
+            so = C.create_string_buffer(4096)
+            f = str(tmp_path / ("%s_%s.out" % (name, key)))
+            lib.bella_dropin_hashspgemm(n, g.nkmers, len(g.tk), g.tk, g.tr, g.tp, sarr, narr, 17, 500, 7, skip, 0, g.err, 0.1,
+                                        f.encode(), so, len(so))
+            got = open(f, "rb").read()
+            nums = so.value.decode().split()
+            assert nums[:3] == g.stdout[key][:3]            # nkmer, nnz(A) after merge, nnz(C): the stdout protocol
+            if got != g.out[key]:
+                assert key == "align"                         # only flagged alignments may differ (SURVEY B.5(4))
+                assert len(set(got.split(b"\n")) ^ set(g.out[key].split(b"\n"))) < 0.02 * len(g.out[key].split(b"\n"))
