@@ -25,8 +25,8 @@ class Params(C.Structure):
 
 
 class Timings(C.Structure):
-    _fields_ = [("assemble_ms", C.c_float), ("symbolic_ms", C.c_float), ("spgemm_ms", C.c_float), ("compact_ms", C.c_float),
-                ("xdrop_ms", C.c_float), ("overlap_total_ms", C.c_float), ("spgemm_launches", C.c_uint32), ("pad", C.c_uint32)]
+    _fields_ = [("assemble_ms", C.c_float), ("symbolic_ms", C.c_float), ("spgemm_ms", C.c_float), ("fold_ms", C.c_float),
+                ("compact_ms", C.c_float), ("xdrop_ms", C.c_float), ("overlap_total_ms", C.c_float), ("spgemm_launches", C.c_uint32)]
 
 
 # every symbol include/bella_hip.h declares: (name, restype, argtypes)

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void k_entry_rows(const uint32_t* Bptr, uin
 }
 
 // per entry: degree histogram, smallest read of the k-mer, orientation bit (occurrence is not the canonical
-// form: Kmer::rep() = min(kmer, twin), kmercode/Kmer.cpp:314-317; palindromes get 0)
+// form: Kmer::rep() = min(kmer, twin), kmercode/Kmer.cpp:314-317; palindromes get 0) and palindrome bit
 __global__ void k_kmer_stats(const uint32_t* Bk, const uint16_t* Bpos, const uint32_t* Brow, uint64_t nnz,
                              const uint32_t* packed, const uint64_t* roff, uint32_t k, uint32_t nkmers, uint32_t* deg,
                              uint32_t* minread, uint8_t* ori, uint32_t* status) {
@@ -164,7 +164,8 @@ __global__ void k_kmer_stats(const uint32_t* Bk, const uint16_t* Bpos, const uin
     const uint32_t km = Bk[e], r = Brow[e];
     if (km >= nkmers) { atomicOr(status, 32u); return; }
     const uint64_t le = kmer_le(packed, roff[r] + Bpos[e], k);
-    ori[e] = kmer_fw_from_le(le, k) > kmer_rc_from_le(le, k) ? 1 : 0;
+    const uint64_t fw = kmer_fw_from_le(le, k), rc = kmer_rc_from_le(le, k);
+    ori[e] = (uint8_t)((fw > rc ? 1u : 0u) | (fw == rc ? 2u : 0u));   // bit0: not the canonical form, bit1: palindrome
     atomicAdd(&deg[km], 1u);
     atomicMin(&minread[km], r);
 }
@@ -204,7 +205,7 @@ __global__ void k_finalize_cols(uint32_t nkmers, const uint32_t* deg, const uint
     if (km >= nkmers) return;
     const uint32_t dg = deg[km];
     if (dg == 0) return;
-    if (dg > 32767u) { atomicOr(status, 64u); return; }
+    if (dg > 16383u) { atomicOr(status, 64u); return; }
     const uint32_t cs = colstart[km];
     for (uint32_t x = 1; x < dg; ++x) {
         const uint2 v = Atmp[cs + x];
@@ -215,10 +216,10 @@ __global__ void k_finalize_cols(uint32_t nkmers, const uint32_t* deg, const uint
     for (uint32_t x = 0; x < dg; ++x) {
         const uint2 v = Atmp[cs + x];
         const uint32_t r = v.x, e = v.y;
-        const uint32_t o = ori[e], pos = Bpos[e];
+        const uint32_t o = ori[e] & 1u, pal = (ori[e] >> 1) & 1u, pos = Bpos[e];
         const uint32_t len = (uint32_t)(roff[r + 1] - roff[r]);
         Aent[cs + x] = make_uint2(r | (o << 31), pos | (len << 16));
-        Bent[e] = make_uint2(cs + x + 1, pos | ((dg - 1 - x) << 16) | (o << 31));
+        Bent[e] = make_uint2(cs + x + 1, pos | ((dg - 1 - x) << 16) | (pal << 30) | (o << 31));
     }
 }
 

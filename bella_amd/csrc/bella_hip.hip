@@ -30,6 +30,7 @@ struct Buf {
 constexpr uint32_t kNumTiers = 6;  // 5 LDS tiers + the global-workspace tier
 const uint32_t kTierCaps[kNumTiers] = {768, 1280, 2048, 3072, 4096, 65535};
 constexpr uint32_t kGlobalGrid = 512;
+constexpr uint32_t kFoldGrid = 512;       // persistent k_fold workgroups (2 per CU at 72 KB LDS)
 constexpr uint32_t kAsmGrid = 1024;
 
 struct CastU64 {
@@ -60,7 +61,8 @@ struct bella_ctx {
     // overlap
     uint64_t flops = 0, npairs = 0;
     Buf flopsr, flopptr, nnzC, colptrC, tierflag, rowlists, tiercnt, tiercaps, tmp_pairs, tmp_ext, pairs, ext, sortscr, ws,
-        status, cubtmp;
+        status, cubtmp, plist_hv, plist_ov, desc, overflow, ctl;
+    uint32_t n_overflow = 0;
     // alignment
     uint64_t nalns = 0;
     Buf alns, seeds;
@@ -281,7 +283,7 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->Brow, &c->deg, &c->minread, &c->colstart,
                   &c->fill, &c->ori, &c->w, &c->wscan, &c->Atmp, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC, &c->tierflag,
                   &c->rowlists, &c->tiercnt, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
-                  &c->status, &c->cubtmp, &c->alns, &c->seeds};
+                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->plist_ov, &c->desc, &c->overflow, &c->ctl};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
@@ -461,7 +463,7 @@ int bella_hip_get_B(bella_ctx* c, uint64_t* nnz, uint32_t* colptr, uint32_t* row
     return 0;
 }
 
-static int run_spgemm(bella_ctx* c, const bella_params* p, bool with_sort_scratch, uint32_t* status_out) {
+static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out) {
     const uint32_t nr = c->nreads;
     const bool force_global = (c->debug & 1u) != 0;
     const bool want_ext = (c->debug & 2u) == 0;
@@ -474,10 +476,12 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, bool with_sort_scratc
     ENSURE(c, c->rowlists, 4 * (size_t)kNumTiers * nr);
     ENSURE(c, c->tiercnt, 4 * kNumTiers);
     ENSURE(c, c->tiercaps, 4 * kNumTiers);
+    ENSURE(c, c->ctl, 4 * kCtlWords + 8 * kNumBuckets + 64);
     uint32_t caps[kNumTiers];
     for (uint32_t t = 0; t < kNumTiers; ++t) caps[t] = force_global && t + 1 < kNumTiers ? 0 : kTierCaps[t];
     HIPCHK(c, hipMemcpyAsync(c->tiercaps.p, caps, sizeof(caps), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * kCtlWords, c->stream));
     HIPCHK(c, hipMemsetAsync(c->flopsr.p, 0, 4 * ((size_t)nr + 2), c->stream));
     HIPCHK(c, hipMemsetAsync(c->nnzC.p, 0, 4 * ((size_t)nr + 2), c->stream));
     k_row_flops<<<nblk(nr, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint2>(c->Bent), nr, c->part_first,
@@ -511,9 +515,19 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, bool with_sort_scratc
     c->flops = F;
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
 
+    // bucket b (2^b <= products of a pair < 2^(b+1)) can hold at most F >> b descriptors
+    uint64_t bbase[kNumBuckets];
+    uint64_t ndesc = 0;
+    for (uint32_t b = 0; b < kNumBuckets; ++b) { bbase[b] = ndesc; ndesc += b ? (F >> b) + 64 : 0; }
     ENSURE(c, c->tmp_pairs, sizeof(bella_pair) * F);
     if (want_ext) ENSURE(c, c->tmp_ext, sizeof(bella_pair_ext) * F);
-    if (with_sort_scratch) ENSURE(c, c->sortscr, 2 * F);
+    ENSURE(c, c->plist_hv, 4 * F);
+    ENSURE(c, c->plist_ov, 4 * F);
+    ENSURE(c, c->desc, 16 * ndesc);
+    ENSURE(c, c->overflow, 16 * ((F >> 1) + 64));
+    ENSURE(c, c->sortscr, 2 * F);
+    uint64_t* d_bbase = (uint64_t*)(ptr<uint32_t>(c->ctl) + kCtlWords);
+    HIPCHK(c, hipMemcpyAsync(d_bbase, bbase, sizeof(bbase), hipMemcpyHostToDevice, c->stream));
     const uint64_t ws_stride = (row_mem_bytes(65535) + 255) & ~(size_t)255;
     if (tcnt[kNumTiers - 1]) ENSURE(c, c->ws, ws_stride * kGlobalGrid);
 
@@ -527,8 +541,11 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, bool with_sort_scratc
     a.tmp_pairs = ptr<bella_pair>(c->tmp_pairs);
     a.tmp_ext = want_ext ? ptr<bella_pair_ext>(c->tmp_ext) : nullptr;
     a.nnzC = ptr<uint32_t>(c->nnzC);
-    a.sort_scratch = with_sort_scratch ? ptr<uint16_t>(c->sortscr) : nullptr;
-    a.status = ptr<uint32_t>(c->status);
+    a.plist_hv = ptr<uint32_t>(c->plist_hv);
+    a.plist_ov = ptr<uint32_t>(c->plist_ov);
+    a.desc = ptr<uint4>(c->desc);
+    a.bucket_base = d_bbase;
+    a.ctl = ptr<uint32_t>(c->ctl);
     a.ws = ptr<uint8_t>(c->ws);
     a.ws_stride = ws_stride;
     a.k = p->kmer_size;
@@ -536,7 +553,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, bool with_sort_scratc
     a.phase = nullptr;
     const bool phase_timers = getenv("BELLA_HIP_PHASE_TIMERS") != nullptr;
     if (phase_timers) {
-        HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 4, 0, 32, c->stream));
+        HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 4, 0, 40, c->stream));
         a.phase = (unsigned long long*)(ptr<uint32_t>(c->status) + 4);
     }
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
@@ -558,13 +575,38 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, bool with_sort_scratc
         launches++;
     }
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    FoldArgs fa;
+    fa.desc = a.desc;
+    fa.bucket_base = d_bbase;
+    fa.ctl = a.ctl;
+    fa.overflow = ptr<uint4>(c->overflow);
+    fa.flopptr = a.flopptr;
+    fa.plist_hv = a.plist_hv;
+    fa.plist_ov = a.plist_ov;
+    fa.roff = a.roff;
+    fa.packed = a.packed;
+    fa.tmp_pairs = a.tmp_pairs;
+    fa.tmp_ext = a.tmp_ext;
+    fa.sort_scratch = ptr<uint16_t>(c->sortscr);
+    fa.k = a.k;
+    fa.binSize = a.binSize;
+    if (F) {
+        k_fold<<<kFoldGrid, 64 * kFoldWavesPerBlock, 0, c->stream>>>(fa);
+        KCHK(c);
+        k_fold_overflow<<<256, 64, 0, c->stream>>>(fa);
+        KCHK(c);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
     rc = scan_u32_to_u64(c, ptr<uint32_t>(c->nnzC), ptr<uint64_t>(c->colptrC), (uint64_t)nr + 1);
     if (rc) return rc;
     uint64_t P = 0;
+    uint32_t ctl_host[kCtlWords];
     HIPCHK(c, hipMemcpyAsync(&P, ptr<uint64_t>(c->colptrC) + nr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ctl_host, c->ctl.p, sizeof(ctl_host), hipMemcpyDeviceToHost, c->stream));
     rc = read_status(c, &st);
     if (rc) return rc;
-    *status_out = st;
+    *status_out = ctl_host[kCtlStatus];
+    c->n_overflow = ctl_host[kCtlOverflow];
     c->npairs = P;
     ENSURE(c, c->pairs, sizeof(bella_pair) * P);
     if (want_ext) ENSURE(c, c->ext, sizeof(bella_pair_ext) * P);
@@ -581,15 +623,18 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, bool with_sort_scratc
     HIPCHK(c, hipEventSynchronize(c->ev[7]));
     c->tm.symbolic_ms = ev_ms(c->ev[2], c->ev[3]);
     c->tm.spgemm_ms = ev_ms(c->ev[4], c->ev[5]);
+    c->tm.fold_ms = ev_ms(c->ev[5], c->ev[8]);
     c->tm.compact_ms = ev_ms(c->ev[6], c->ev[7]);
     c->tm.overlap_total_ms = ev_ms(c->ev[2], c->ev[7]);
     c->tm.spgemm_launches = launches;
     if (phase_timers) {
-        unsigned long long ph[4];
-        HIPCHK(c, hipMemcpy(ph, ptr<uint32_t>(c->status) + 4, 32, hipMemcpyDeviceToHost));
-        const double tot = (double)(ph[0] + ph[1] + ph[2] + ph[3]) + 1e-9;
-        fprintf(stderr, "[bella_hip] row-kernel phase cycles (sum over workgroups): expand %.1f%% order %.1f%% scatter %.1f%% fold %.1f%% ; total %.3g cycles, kernels %.3f ms\n",
-                100.0 * ph[0] / tot, 100.0 * ph[1] / tot, 100.0 * ph[2] / tot, 100.0 * ph[3] / tot, tot, c->tm.spgemm_ms);
+        unsigned long long ph[5];
+        HIPCHK(c, hipMemcpy(ph, ptr<uint32_t>(c->status) + 4, 40, hipMemcpyDeviceToHost));
+        const double tot = (double)(ph[0] + ph[1] + ph[2] + ph[3] + ph[4]) + 1e-9;
+        fprintf(stderr, "[bella_hip] row-kernel phase cycles: expand %.1f%% order %.1f%% scatter %.1f%% rank/emit %.1f%% describe %.1f%% ; "
+                        "rows %.3f ms, fold %.3f ms (overflow pairs %u), symbolic %.3f ms, compact %.3f ms\n",
+                100.0 * ph[0] / tot, 100.0 * ph[1] / tot, 100.0 * ph[2] / tot, 100.0 * ph[3] / tot, 100.0 * ph[4] / tot,
+                c->tm.spgemm_ms, c->tm.fold_ms, c->n_overflow, c->tm.symbolic_ms, c->tm.compact_ms);
     }
     return 0;
 }
@@ -601,13 +646,9 @@ int bella_hip_overlap(bella_ctx* c, const bella_params* p, uint64_t* npairs, uin
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t st = 0;
-    rc = run_spgemm(c, p, c->sortscr.p != nullptr, &st);
+    rc = run_spgemm(c, p, &st);
     if (rc) return rc;
-    if ((st & 1u) && c->sortscr.p == nullptr) {
-        // a pair ended with more than 16 bins: choose() needs libstdc++'s introsort order; rerun with scratch
-        rc = run_spgemm(c, p, true, &st);
-        if (rc) return rc;
-    }
+    if (st & 1u) return fail(c, BELLA_ERR_BINS, "internal: > 16 bins without sort scratch");
     c->have_pairs = true;
     c->have_alns = false;
     if (npairs) *npairs = c->npairs;

@@ -150,7 +150,7 @@ struct IdSorter {
         long lg = 0;
         while ((1L << (lg + 1)) <= n) lg++;
         // __introsort_loop with an explicit stack (the recursion is on the right part, bits/stl_algo.h)
-        long stf[64], stl[64], std_[64];
+        int stf[40], stl[40], std_[40];      // depth <= 2*lg(65536) = 32 pending right parts
         int sp = 0;
         long first = 0, last = n, depth = 2 * lg;
         for (;;) {
@@ -160,7 +160,7 @@ struct IdSorter {
                 long mid = first + (last - first) / 2;
                 median_to_first(first, first + 1, mid, last - 1);
                 long cut = partition(first + 1, last, first);
-                stf[sp] = cut; stl[sp] = last; std_[sp] = depth; sp++;   // recurse on [cut,last) FIRST
+                stf[sp] = (int)cut; stl[sp] = (int)last; std_[sp] = (int)depth; sp++;   // recurse on [cut,last) FIRST
                 last = cut;
             }
             // the reference recursion order is right part first, then the loop continues on the left; the
@@ -194,14 +194,25 @@ struct FoldResult {
     uint32_t many_bins;  // nb > 16 (std::sort tie path used)
 };
 
-template <class PtrP, class PtrB>
-BELLA_HD void fold_pair(PtrP P, PtrB Bm, uint32_t m, int k, int binSize, uint16_t* sort_scratch, FoldResult& out) {
+// fold_core: state arrays (P, Bm) + a product source.  prod(t, q, ovq) delivers product t; it is called once per t, in
+// order, BEFORE anything at index >= t of the state arrays is written, so the in-place use (state and products in the
+// same arrays) stays valid.  capP / capB bound the state (lane-private LDS in k_fold): returns false on overflow
+// (nothing useful in `out`), true otherwise.
+template <class PtrP, class PtrB, class ProdFn>
+BELLA_HD bool fold_core(PtrP P, PtrB Bm, uint32_t m, ProdFn prod, uint32_t capP, uint32_t capB, int k, int binSize,
+                        uint16_t* sort_scratch, FoldResult& out) {
     uint32_t nb = 1, np = 1;
     uint32_t count = 1;
-    Bm[0] = (Bm[0] & 0xFFFFu) | (1u << 16);                                   // multiop: one bin, support 1
+    {
+        uint32_t q0, ov0;
+        prod(0u, q0, ov0);
+        P[0] = q0;
+        Bm[0] = (ov0 & 0xFFFFu) | (1u << 16);                                  // multiop: one bin, support 1
+    }
     for (uint32_t t = 1; t < m; ++t) {
-        const uint32_t q = P[t];
-        const uint32_t ovq = Bm[t] & 0xFFFFu;
+        uint32_t q, ovq;
+        prod(t, q, ovq);
+        ovq &= 0xFFFFu;
         const int qh = (int)(q & 0xFFFFu), qv = (int)(q >> 16);
         uint32_t r = 0, w = 0, bw = 0, ins = 0;
         for (uint32_t b = 0; b < nb; ++b) {                                   // chainop, chain.hpp:109-135
@@ -230,6 +241,7 @@ BELLA_HD void fold_pair(PtrP P, PtrB Bm, uint32_t m, int k, int binSize, uint16_
             }
             r += bn;
         }
+        if (w >= capP || bw >= capB) return false;
         P[w++] = q;                                                            // the new k-mer heads the bin
         Bm[bw++] = ovq | ((ins + 1) << 16);
         nb = bw; np = w;
@@ -261,6 +273,14 @@ BELLA_HD void fold_pair(PtrP P, PtrB Bm, uint32_t m, int k, int binSize, uint16_
     out.binov = (uint16_t)(Bm[wm] & 0xFFFFu);
     out.seed = P[end - 1];
     (void)np;
+    return true;
+}
+
+// in-place form: products and state share (P, Bm)
+template <class PtrP, class PtrB>
+BELLA_HD void fold_pair(PtrP P, PtrB Bm, uint32_t m, int k, int binSize, uint16_t* sort_scratch, FoldResult& out) {
+    auto prod = [&](uint32_t t, uint32_t& q, uint32_t& ovq) { q = P[t]; ovq = Bm[t] & 0xFFFFu; };
+    (void)fold_core(P, Bm, m, prod, 0xFFFFFFFFu, 0xFFFFFFFFu, k, binSize, sort_scratch, out);
 }
 
 // order a pair's (P, Bm) entries by the product index stored in Bm's upper half (scatter order fix-up)

@@ -1,30 +1,36 @@
 // spgemm.hpp -- C = A*A^T (strict lower triangle) under BELLA's position-binning semiring, gfx950.
 //
 // Replaces estimateFLOP (include/overlap.hpp:157-202), estimateNNZ_Hash (:205-276) and LocalSpGEMM
-// (:281-363) with multiop/chainop (include/chain.hpp:74-150) of the reference.  One workgroup
-// (4 wavefronts) owns one output column i (= read i) and runs five bulk-synchronous phases over LDS
-// (or over a global workspace for columns whose product list does not fit the LDS tiers):
+// (:281-363) with multiop/chainop (include/chain.hpp:74-150) of the reference.  Two kernels:
 //
-//   X  expand   stream the column's B' entries (8 B each, coalesced); every entry carries a direct
-//               pointer to the suffix "reads > i" of its k-mer's list in A' (8 B entries, contiguous),
-//               so there is no column-pointer indirection.  Products are written to LDS in the
-//               reference's order (B slot order, then ascending read id) together with their u16
-//               overlap estimate, and their key (row id) is inserted into a grouping hash table T1.
-//   O  order    emulate the reference's per-column open-addressing table (size 2^n >= max(16,nnz),
-//               hash key*107, linear probe) to obtain its SLOT ORDER: keys are inserted in parallel with
-//               atomicMin on (first-product-index, key): an entry with an earlier first occurrence
-//               displaces a later one, which resumes probing -- the fixed point is exactly the layout
-//               sequential insertion produces.  A scan over the table gives every key its output rank.
-//   S  scatter  counting-sort the products by key into contiguous per-pair lists (rank order).
-//   F  fold     one lane per pair: restore product order inside the list, then fold it in place with
-//               core.hpp's fold_pair (order-dependent semiring) and choose() the seed.
-//   W  write    16-byte pair records at a per-column temporary offset (exclusive scan of flops);
-//               k_compact_pairs packs them once nnz(C) per column is known.
+// k_spgemm_rows_*  one workgroup (4 wavefronts) per output column i (= read i), bulk-synchronous phases in LDS
+//                  (or in a global workspace for columns whose product list does not fit the LDS tiers):
+//   X  expand   stream the column's B' entries (8 B each, coalesced); every entry carries a direct pointer to the
+//               suffix "reads > i" of its k-mer's list in A' (8 B entries, contiguous): no column-pointer
+//               indirection.  Products land in LDS in the reference's order (B slot order, then ascending read
+//               id) with their u16 overlap estimate; their key (row id) goes into a grouping hash table T1.
+//   O  order    emulate the reference's per-column open-addressing table (size 2^n >= max(16,nnz), hash key*107,
+//               linear probe) to obtain its SLOT ORDER: keys are inserted in parallel with atomicMin on
+//               (first-product-index, key): an entry with an earlier first occurrence displaces a later one,
+//               which resumes probing -- the fixed point is exactly the layout sequential insertion produces.
+//               A scan over the table gives every key its output rank and its list start.
+//   S  scatter  product indices into per-pair lists (unordered inside a list).
+//   R  rank     every product finds its rank inside its pair's list (= product order) and is written to the
+//               pair's list in HBM; single-product pairs (92 % at 100k reads) are finished here: 16-byte record
+//               straight to the output.
+//   D  describe multi-product pairs are appended to a bucket list by floor(log2(#products)).
+//
+// k_fold           persistent wavefronts pull 64 pair descriptors of ONE bucket at a time (similar work per lane),
+//               one lane per pair; the lane streams its product list from HBM and folds it under the
+//               order-dependent semiring (core.hpp: fold_core) with the state (positions + bins) in
+//               lane-interleaved LDS (element e of lane l at word e*64+l: bank = lane, conflict-free at any
+//               per-lane index).  A pair whose state outgrows the LDS budget goes to k_fold_overflow, which
+//               folds in place in HBM (same function), including the libstdc++-exact std::sort for > 16 bins.
 //
 // Data layout in HBM (built by assemble.hpp):
-//   Bent[e] = { a_ptr, posV | cnt << 16 | ori << 31 }   e in B' order (column i, MergeDuplicates slot order)
-//   Aent[x] = { read | ori << 31, posH | readlen << 16 } k-mer lists, ascending read id, stored in order of
-//                                                          first appearance in B' (streaming for the owner row)
+//   Bent[e] = { a_ptr, posV | cnt << 16 (14 bit) | pal << 30 | ori << 31 }  e in B' order (MergeDuplicates slot order)
+//   Aent[x] = { read | ori << 31, posH | readlen << 16 }  k-mer lists, ascending read id, stored in order of first
+//                                                          appearance in B' (streaming for the owner row)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/bella_hip.h"
@@ -32,6 +38,15 @@
 #include "util.hpp"
 
 namespace bella {
+
+constexpr uint32_t kNumBuckets = 16;      // bucket b holds pairs with 2^b <= #products < 2^(b+1), b = 1..15
+// control block (u32 words) zeroed before every pass
+constexpr uint32_t kCtlBucketCnt = 0;     // [16]
+constexpr uint32_t kCtlWork = 16;         // k_fold chunk counter
+constexpr uint32_t kCtlOverflow = 17;     // overflow list length
+constexpr uint32_t kCtlWork2 = 18;        // k_fold_overflow counter
+constexpr uint32_t kCtlStatus = 19;       // bit0: a pair ended with > 16 bins and no scratch was given
+constexpr uint32_t kCtlWords = 32;
 
 struct SpgemmArgs {
     const uint32_t* rowlist;
@@ -41,12 +56,15 @@ struct SpgemmArgs {
     const uint2* Aent;
     const uint64_t* roff;
     const uint32_t* packed;
-    const uint64_t* flopptr;
+    const uint64_t* flopptr;     // exclusive scan of per-column products: temporary output / list offsets
     bella_pair* tmp_pairs;
     bella_pair_ext* tmp_ext;
     uint32_t* nnzC;
-    uint16_t* sort_scratch;
-    uint32_t* status;
+    uint32_t* plist_hv;          // [F] per-pair product lists (posH | posV << 16), product order
+    uint32_t* plist_ov;          // [F] overlap estimate (low 16 bits)
+    uint4* desc;                 // bucketed pair descriptors {cid, key, start | m << 16, rank}
+    const uint64_t* bucket_base; // [16] start of each bucket inside desc
+    uint32_t* ctl;
     uint8_t* ws;
     uint64_t ws_stride;
     uint32_t cap;
@@ -55,19 +73,19 @@ struct SpgemmArgs {
     unsigned long long* phase;   // optional per-phase cycle counters (development aid, BELLA_HIP_PHASE_TIMERS=1)
 };
 
-constexpr uint32_t kRowScratchBytes = 64;                    // block scan scratch + counters
-__host__ __device__ inline size_t row_mem_bytes(uint32_t cap) { return kRowScratchBytes + (size_t)30 * cap; }
+constexpr uint32_t kRowScratchBytes = 256;                   // block scan scratch, counters, bucket histogram
+__host__ __device__ inline size_t row_mem_bytes(uint32_t cap) { return kRowScratchBytes + (size_t)32 * cap; }
 
 struct RowMem {
-    uint32_t* scr;      // 16 words
+    uint32_t* scr;      // 64 words: [0..7] scan, [8] distinct keys, [16..31] bucket counts, [32..47] bucket bases
     uint32_t* A_hv;     // [cap]  posH | posV << 16, product order
     uint32_t* A_gov;    // [cap]  T1 slot << 16 | overlap estimate
-    uint32_t* S_hv;     // [cap]  grouped by pair           (phase O: T2 overlays S_hv..S_pov, 2*cap words)
-    uint32_t* S_pov;    // [cap]  product index << 16 | overlap estimate ; fold: bin metadata
     uint32_t* T1key;    // [cap]
     uint32_t* T1first;  // [cap]  first product index ; after phase O: list start | rank << 16
     uint32_t* T1cnt;    // [cap]  products | scatter cursor << 16
+    uint32_t* T2;       // [2*cap] slot-order table ; after phase O reused: S_p (u16 [cap]) product index lists
     uint16_t* G;        // [cap]  rank -> T1 slot
+    uint8_t* A_fl;      // [cap]  bit0 oriented (checkstrand), bit1 palindromic k-mer
     uint32_t cap;
 };
 
@@ -77,12 +95,12 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap) {
     uint32_t* w = (uint32_t*)(base + kRowScratchBytes);
     m.A_hv = w;            w += cap;
     m.A_gov = w;           w += cap;
-    m.S_hv = w;            w += cap;
-    m.S_pov = w;           w += cap;
     m.T1key = w;           w += cap;
     m.T1first = w;         w += cap;
     m.T1cnt = w;           w += cap;
-    m.G = (uint16_t*)w;
+    m.T2 = w;              w += 2 * cap;
+    m.G = (uint16_t*)w;    w += (cap + 1) / 2;
+    m.A_fl = (uint8_t*)w;
     m.cap = cap;
     return m;
 }
@@ -91,6 +109,8 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
     const uint32_t tid = threadIdx.x;
     const uint32_t H1 = m.cap;
     uint32_t* s_d = m.scr + 8;
+    uint32_t* bcount = m.scr + 16;
+    uint32_t* bbase = m.scr + 32;
     const uint32_t b0 = a.Bptr[i];
     const uint32_t n = a.Bptr[i + 1] - b0;
     const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
@@ -98,6 +118,7 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
 
     for (uint32_t s = tid; s < H1; s += kBlock) { m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0; }
     if (tid == 0) *s_d = 0;
+    if (tid < 16) bcount[tid] = 0;
     __syncthreads();
     long long tc = 0;
     if (a.phase && tid == 0) tc = clock64();
@@ -109,15 +130,16 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
         const uint32_t j = base + tid;
         uint2 be = make_uint2(0u, 0u);
         if (j < n) be = a.Bent[b0 + j];
-        const uint32_t cnt = (be.y >> 16) & 0x7FFFu;
+        const uint32_t cnt = (be.y >> 16) & 0x3FFFu;
         uint32_t tot;
         const uint32_t off = running + block_excl_scan(cnt, m.scr, &tot);
-        const uint32_t oriB = be.y >> 31, posV = be.y & 0xFFFFu;
+        const uint32_t oriB = be.y >> 31, pal = (be.y >> 30) & 1u, posV = be.y & 0xFFFFu;
         for (uint32_t t = 0; t < cnt; ++t) {
             const uint2 ae = a.Aent[(uint64_t)be.x + t];
             const uint32_t key = ae.x & 0x7FFFFFFFu;
             const uint32_t posH = ae.y & 0xFFFFu, lenH = ae.y >> 16;
-            const uint32_t ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, (ae.x >> 31) == oriB, k) & 0xFFFFu;
+            const bool oriented = (ae.x >> 31) == oriB;
+            const uint32_t ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, k) & 0xFFFFu;
             const uint32_t p = off + t;
             uint32_t h = hash_range(key, H1);
             uint32_t old;
@@ -131,6 +153,7 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
             atomicAdd(&m.T1cnt[h], 1u);
             m.A_hv[p] = posH | (posV << 16);
             m.A_gov[p] = (h << 16) | ov;
+            m.A_fl[p] = (uint8_t)((oriented ? 1u : 0u) | (pal << 1));
         }
         running += tot;
     }
@@ -141,7 +164,7 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
 
     // ---- O: the reference's slot order (overlap.hpp:289-361) -----------------------------------------
     const uint32_t ht = pow2_at_least(16u, d);
-    uint32_t* T2 = m.S_hv;
+    uint32_t* T2 = m.T2;
     for (uint32_t s = tid; s < ht; s += kBlock) T2[s] = kEmpty;
     __syncthreads();
     for (uint32_t s = tid; s < H1; s += kBlock) {
@@ -182,52 +205,67 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
     __syncthreads();
     BELLA_PHASE(1)
 
-    // ---- S: scatter products into per-pair lists -----------------------------------------------------
+    // ---- S: product indices into per-pair lists (T2 is dead: its memory becomes S_p) -------------------
+    uint16_t* S_p = (uint16_t*)m.T2;
     for (uint32_t p = tid; p < F; p += kBlock) {
-        const uint32_t gov = m.A_gov[p];
-        const uint32_t g = gov >> 16;
+        const uint32_t g = m.A_gov[p] >> 16;
         const uint32_t old = atomicAdd(&m.T1cnt[g], 0x10000u);
-        const uint32_t slot = (m.T1first[g] & 0xFFFFu) + (old >> 16);
-        m.S_hv[slot] = m.A_hv[p];
-        m.S_pov[slot] = (p << 16) | (gov & 0xFFFFu);
+        S_p[(m.T1first[g] & 0xFFFFu) + (old >> 16)] = (uint16_t)p;
     }
     __syncthreads();
     BELLA_PHASE(2)
 
-    // ---- F/W: fold each pair, write its record -------------------------------------------------------
+    // ---- R: rank inside the pair's list = product order; emit -------------------------------------------
     const uint64_t obase = a.flopptr[i];
-    const uint64_t goffV = a.roff[i];
-    for (uint32_t r = tid; r < d; r += kBlock) {
-        const uint32_t g = m.G[r];
-        const uint32_t key = m.T1key[g];
-        const uint32_t st = m.T1first[g] & 0xFFFFu;
+    for (uint32_t p = tid; p < F; p += kBlock) {
+        const uint32_t gov = m.A_gov[p];
+        const uint32_t g = gov >> 16;
+        const uint32_t fr = m.T1first[g];
+        const uint32_t st = fr & 0xFFFFu;
         const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
-        uint32_t* P = m.S_hv + st;
-        uint32_t* Bm = m.S_pov + st;
-        FoldResult fr;
-        if (mm == 1) {
-            fr.count = 1; fr.nbins = 1; fr.support = 1; fr.binov = (uint16_t)(Bm[0] & 0xFFFFu); fr.seed = P[0]; fr.many_bins = 0;
+        if (mm == 1) {                                    // multiop only: count 1, one bin, seed = this k-mer
+            const uint32_t hv = m.A_hv[p];
+            const uint32_t fl = m.A_fl[p];
+            bella_pair pr;
+            pr.rid = m.T1key[g]; pr.cid = i; pr.count = 1; pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
+            pr.flags = (uint16_t)((fl & 1u) | ((((fl & 1u) ^ 1u) | (fl >> 1)) << 1));   // bit1: revcomp(seedH)==seedV
+            a.tmp_pairs[obase + (fr >> 16)] = pr;
+            if (a.tmp_ext) {
+                bella_pair_ext ex;
+                ex.nbins = 1; ex.support = 1; ex.binov = (uint16_t)(gov & 0xFFFFu); ex.pad = 0;
+                a.tmp_ext[obase + (fr >> 16)] = ex;
+            }
         } else {
-            sort_products_by_index(P, Bm, mm);
-            fold_pair(P, Bm, mm, a.k, a.binSize, a.sort_scratch ? a.sort_scratch + obase + st : (uint16_t*)nullptr, fr);
-        }
-        if (fr.many_bins) atomicOr(a.status, 1u);
-        const uint32_t seedH = fr.seed & 0xFFFFu, seedV = fr.seed >> 16;
-        const uint64_t leH = kmer_le(a.packed, a.roff[key] + seedH, k);
-        const uint64_t leV = kmer_le(a.packed, goffV + seedV, k);
-        const uint32_t flags = (leH == leV ? 1u : 0u) | (kmer_rc_from_le(leH, k) == kmer_fw_from_le(leV, k) ? 2u : 0u);
-        bella_pair pr;
-        pr.rid = key; pr.cid = i; pr.count = fr.count; pr.seedH = (uint16_t)seedH; pr.seedV = (uint16_t)seedV;
-        pr.flags = (uint16_t)flags;
-        a.tmp_pairs[obase + r] = pr;
-        if (a.tmp_ext) {
-            bella_pair_ext ex;
-            ex.nbins = fr.nbins; ex.support = fr.support; ex.binov = fr.binov; ex.pad = 0;
-            a.tmp_ext[obase + r] = ex;
+            uint32_t rk = 0;
+            for (uint32_t x = 0; x < mm; ++x) rk += (S_p[st + x] < p);
+            a.plist_hv[obase + st + rk] = m.A_hv[p];
+            a.plist_ov[obase + st + rk] = gov & 0xFFFFu;
         }
     }
+    BELLA_PHASE(3)
+
+    // ---- D: descriptors of multi-product pairs, bucketed by floor(log2(m)) -----------------------------
+    for (uint32_t r = tid; r < d; r += kBlock) {
+        const uint32_t mm = m.T1cnt[m.G[r]] & 0xFFFFu;
+        if (mm >= 2) atomicAdd(&bcount[31 - __clz(mm)], 1u);
+    }
+    __syncthreads();
+    if (tid < kNumBuckets) {
+        const uint32_t c = bcount[tid];
+        bbase[tid] = c ? atomicAdd(&a.ctl[kCtlBucketCnt + tid], c) : 0u;
+        bcount[tid] = 0;
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < d; r += kBlock) {
+        const uint32_t g = m.G[r];
+        const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
+        if (mm < 2) continue;
+        const uint32_t b = 31 - __clz(mm);
+        const uint32_t loc = atomicAdd(&bcount[b], 1u);
+        a.desc[a.bucket_base[b] + bbase[b] + loc] = make_uint4(i, m.T1key[g], (m.T1first[g] & 0xFFFFu) | (mm << 16), r);
+    }
     if (tid == 0) a.nnzC[i] = d;
-    if (a.phase) { __syncthreads(); BELLA_PHASE(3) }
+    if (a.phase) { __syncthreads(); BELLA_PHASE(4) }
 #undef BELLA_PHASE
 }
 
@@ -245,9 +283,111 @@ __global__ __launch_bounds__(kBlock) void k_spgemm_rows_global(SpgemmArgs a) {
     for (uint32_t x = blockIdx.x; x < a.nrows; x += gridDim.x) {
         const uint32_t i = a.rowlist[x];
         const uint32_t f = (uint32_t)(a.flopptr[i + 1] - a.flopptr[i]);
-        const RowMem m = carve(ws, f < 16u ? 16u : f);   // T2 (>= 16 slots) overlays 2*cap words
+        const RowMem m = carve(ws, f < 16u ? 16u : f);   // T2 needs >= 16 slots
         process_row(a, i, m);
         __syncthreads();
+    }
+}
+
+// ---- the fold ---------------------------------------------------------------------------------------------------
+struct FoldArgs {
+    const uint4* desc;
+    const uint64_t* bucket_base;
+    uint32_t* ctl;
+    uint4* overflow;             // descriptors of pairs whose state outgrew the LDS budget
+    const uint64_t* flopptr;
+    uint32_t* plist_hv;
+    uint32_t* plist_ov;
+    const uint64_t* roff;
+    const uint32_t* packed;
+    bella_pair* tmp_pairs;
+    bella_pair_ext* tmp_ext;
+    uint16_t* sort_scratch;      // [F] (k_fold_overflow only)
+    int k;
+    int binSize;
+};
+
+constexpr uint32_t kFoldCapP = 64;   // positions of one pair's state held in LDS
+constexpr uint32_t kFoldCapB = 8;    // bins
+constexpr uint32_t kFoldWaveWords = (kFoldCapP + kFoldCapB) * 64;
+constexpr uint32_t kFoldWavesPerBlock = 4;
+
+struct LanePtr {                     // element e of this lane: word e*64 of the wave's region (bank = lane)
+    uint32_t* base;
+    __device__ __forceinline__ uint32_t& operator[](uint32_t e) const { return base[e * 64u]; }
+};
+
+__device__ __forceinline__ void write_pair(const FoldArgs& a, const uint4 ds, const FoldResult& fr) {
+    const uint32_t cid = ds.x, key = ds.y;
+    const uint32_t k = (uint32_t)a.k;
+    const uint32_t seedH = fr.seed & 0xFFFFu, seedV = fr.seed >> 16;
+    const uint64_t leH = kmer_le(a.packed, a.roff[key] + seedH, k);
+    const uint64_t leV = kmer_le(a.packed, a.roff[cid] + seedV, k);
+    const uint32_t flags = (leH == leV ? 1u : 0u) | (kmer_rc_from_le(leH, k) == kmer_fw_from_le(leV, k) ? 2u : 0u);
+    const uint64_t o = a.flopptr[cid] + ds.w;
+    bella_pair pr;
+    pr.rid = key; pr.cid = cid; pr.count = fr.count; pr.seedH = (uint16_t)seedH; pr.seedV = (uint16_t)seedV;
+    pr.flags = (uint16_t)flags;
+    a.tmp_pairs[o] = pr;
+    if (a.tmp_ext) {
+        bella_pair_ext ex;
+        ex.nbins = fr.nbins; ex.support = fr.support; ex.binov = fr.binov; ex.pad = 0;
+        a.tmp_ext[o] = ex;
+    }
+}
+
+__global__ __launch_bounds__(64 * kFoldWavesPerBlock) void k_fold(FoldArgs a) {
+    __shared__ uint32_t lds[kFoldWaveWords * kFoldWavesPerBlock];
+    const uint32_t lane = lane_id();
+    uint32_t* wl = lds + wave_id() * kFoldWaveWords + lane;
+    const LanePtr P{wl}, Bm{wl + kFoldCapP * 64u};
+    // chunk table: heaviest bucket first
+    uint32_t cnt_b = 0, nch_b = 0;
+    if (lane < kNumBuckets) { cnt_b = a.ctl[kCtlBucketCnt + lane]; nch_b = (cnt_b + 63u) / 64u; }
+    uint32_t total = 0;
+#pragma unroll
+    for (int b = 0; b < (int)kNumBuckets; ++b) total += __shfl(nch_b, b, 64);
+    for (;;) {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(&a.ctl[kCtlWork], 1u);
+        c = __shfl(c, 0, 64);
+        if (c >= total) break;
+        int bsel = 0;
+        uint32_t rem = c;
+        for (int b = (int)kNumBuckets - 1; b >= 1; --b) {
+            const uint32_t nb = __shfl(nch_b, b, 64);
+            if (rem < nb) { bsel = b; break; }
+            rem -= nb;
+        }
+        const uint32_t cntsel = __shfl(cnt_b, bsel, 64);
+        const uint32_t idx = rem * 64u + lane;
+        if (idx >= cntsel) continue;
+        const uint4 ds = a.desc[a.bucket_base[bsel] + idx];
+        const uint32_t mm = ds.z >> 16;
+        const uint64_t lo = a.flopptr[ds.x] + (ds.z & 0xFFFFu);
+        const uint32_t* hv = a.plist_hv + lo;
+        const uint32_t* ov = a.plist_ov + lo;
+        auto prod = [&](uint32_t t, uint32_t& q, uint32_t& o) { q = hv[t]; o = ov[t]; };
+        FoldResult fr;
+        const bool ok = fold_core(P, Bm, mm, prod, kFoldCapP, kFoldCapB, a.k, a.binSize, (uint16_t*)nullptr, fr);
+        if (ok) write_pair(a, ds, fr);
+        else a.overflow[atomicAdd(&a.ctl[kCtlOverflow], 1u)] = ds;
+    }
+}
+
+// rare: states larger than the LDS budget (or > 8 bins).  In place in HBM on the pair's own list.
+__global__ __launch_bounds__(64) void k_fold_overflow(FoldArgs a) {
+    const uint32_t n = a.ctl[kCtlOverflow];
+    for (;;) {
+        const uint32_t idx = atomicAdd(&a.ctl[kCtlWork2], 1u);
+        if (idx >= n) break;
+        const uint4 ds = a.overflow[idx];
+        const uint32_t mm = ds.z >> 16;
+        const uint64_t lo = a.flopptr[ds.x] + (ds.z & 0xFFFFu);
+        FoldResult fr;
+        fold_pair(a.plist_hv + lo, a.plist_ov + lo, mm, a.k, a.binSize, a.sort_scratch ? a.sort_scratch + lo : (uint16_t*)nullptr, fr);
+        if (fr.many_bins) atomicOr(&a.ctl[kCtlStatus], 1u);
+        write_pair(a, ds, fr);
     }
 }
 
@@ -260,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, cons
     uint32_t s = 0;
     if (i % stride == first) {
         const uint32_t b0 = Bptr[i], b1 = Bptr[i + 1];
-        for (uint32_t e = b0 + lane_id(); e < b1; e += 64) s += (Bent[e].y >> 16) & 0x7FFFu;
+        for (uint32_t e = b0 + lane_id(); e < b1; e += 64) s += (Bent[e].y >> 16) & 0x3FFFu;
     }
 #pragma unroll
     for (int dlt = 32; dlt > 0; dlt >>= 1) s += __shfl_xor(s, dlt, 64);

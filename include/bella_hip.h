@@ -29,7 +29,7 @@ enum {
     BELLA_OK = 0,
     BELLA_ERR_NO_DEVICE = -1,     /* no HIP device / not gfx950                                         */
     BELLA_ERR_HIP = -2,           /* a HIP runtime call failed (bella_hip_last_error has the text)       */
-    BELLA_ERR_BAD_ARG = -3,
+    BELLA_ERR_BAD_ARG = -3,       /* incl. a k-mer present in more than 16,383 reads                     */
     BELLA_ERR_BAD_BASE = -4,      /* read contains a character other than ACGT (align.hpp:40-55 asserts) */
     BELLA_ERR_READ_TOO_LONG = -5, /* read >= 65,536 bases: u16 positions (common.h:122-126)             */
     BELLA_ERR_TUPLE_ORDER = -6,   /* tuples not grouped by non-decreasing read id                       */
@@ -95,12 +95,12 @@ typedef struct {
 typedef struct {
     float assemble_ms;        /* tuples/B -> device CSR layout (all assembly kernels)      */
     float symbolic_ms;        /* per-row flops + tiering (estimateFLOP, overlap.hpp:157)   */
-    float spgemm_ms;          /* the fused symbolic+numeric row kernels (overlap.hpp:205,281) */
+    float spgemm_ms;          /* row kernels: symbolic + expansion + slot order (overlap.hpp:205,281) */
+    float fold_ms;            /* semiring fold kernels (chain.hpp:74-150)                    */
     float compact_ms;         /* pair compaction to the dense output                        */
     float xdrop_ms;           /* X-drop kernel                                              */
     float overlap_total_ms;   /* bella_hip_overlap, stream time start to end                */
-    uint32_t spgemm_launches;
-    uint32_t pad;
+    uint32_t spgemm_launches; /* row-kernel launches (one per non-empty LDS tier)            */
 } bella_timings;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */
