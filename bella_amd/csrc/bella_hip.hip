@@ -61,13 +61,15 @@ struct bella_ctx {
     // overlap
     uint64_t flops = 0, npairs = 0;
     Buf flopsr, flopptr, nnzC, colptrC, tierflag, rowlists, tiercnt, tiercaps, tmp_pairs, tmp_ext, pairs, ext, sortscr, ws,
-        status, cubtmp, plist_hv, plist_ov, desc, overflow, ctl;
+        status, cubtmp, plist_hv, plist_ov, desc, overflow, ctl, dbg;
     uint32_t n_overflow = 0;
     // alignment
     uint64_t nalns = 0;
     Buf alns, seeds;
     bella_timings tm{};
     hipEvent_t ev[10]{};
+    hipStream_t side[kNumTiers + 1]{};   // independent tier launches / fold instances run concurrently
+    hipEvent_t fork = nullptr, join[kNumTiers + 1]{};
 };
 
 namespace {
@@ -269,6 +271,9 @@ int bella_hip_init(int device, bella_ctx** out) {
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return BELLA_ERR_HIP; }
     for (auto& e : c->ev) (void)hipEventCreate(&e);
+    for (auto& st : c->side) (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    (void)hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+    for (auto& e : c->join) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     if (ensure_bytes(c, c->status, 64)) { delete c; return BELLA_ERR_NOMEM; }
     (void)hipMemset(c->status.p, 0, 64);
     *out = c;
@@ -283,9 +288,12 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->Brow, &c->deg, &c->minread, &c->colstart,
                   &c->fill, &c->ori, &c->w, &c->wscan, &c->Atmp, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC, &c->tierflag,
                   &c->rowlists, &c->tiercnt, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
-                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->plist_ov, &c->desc, &c->overflow, &c->ctl};
+                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->plist_ov, &c->desc, &c->overflow, &c->ctl, &c->dbg};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
+    for (auto& st : c->side) (void)hipStreamDestroy(st);
+    (void)hipEventDestroy(c->fork);
+    for (auto& e : c->join) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -521,8 +529,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     for (uint32_t b = 0; b < kNumBuckets; ++b) { bbase[b] = ndesc; ndesc += b ? (F >> b) + 64 : 0; }
     ENSURE(c, c->tmp_pairs, sizeof(bella_pair) * F);
     if (want_ext) ENSURE(c, c->tmp_ext, sizeof(bella_pair_ext) * F);
-    ENSURE(c, c->plist_hv, 4 * F);
-    ENSURE(c, c->plist_ov, 4 * F);
+    ENSURE(c, c->plist_hv, 8 * F);
     ENSURE(c, c->desc, 16 * ndesc);
     ENSURE(c, c->overflow, 16 * ((F >> 1) + 64));
     ENSURE(c, c->sortscr, 2 * F);
@@ -541,8 +548,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     a.tmp_pairs = ptr<bella_pair>(c->tmp_pairs);
     a.tmp_ext = want_ext ? ptr<bella_pair_ext>(c->tmp_ext) : nullptr;
     a.nnzC = ptr<uint32_t>(c->nnzC);
-    a.plist_hv = ptr<uint32_t>(c->plist_hv);
-    a.plist_ov = ptr<uint32_t>(c->plist_ov);
+    a.plist = ptr<uint2>(c->plist_hv);
     a.desc = ptr<uint4>(c->desc);
     a.bucket_base = d_bbase;
     a.ctl = ptr<uint32_t>(c->ctl);
@@ -558,20 +564,27 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     }
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     uint32_t launches = 0;
-    for (uint32_t t = 0; t < kNumTiers; ++t) {
+    // the tiers are independent launches of the same kernel with different LDS budgets: fork them onto side streams
+    // (largest columns first) so that their tails overlap, then join
+    HIPCHK(c, hipEventRecord(c->fork, c->stream));
+    for (int t = (int)kNumTiers - 1; t >= 0; --t) {
         if (!tcnt[t]) continue;
+        hipStream_t sst = c->side[t];
+        HIPCHK(c, hipStreamWaitEvent(sst, c->fork, 0));
         a.rowlist = ptr<uint32_t>(c->rowlists) + (size_t)t * nr;
         a.nrows = tcnt[t];
         a.cap = kTierCaps[t];
-        if (t + 1 < kNumTiers) {
+        if (t + 1 < (int)kNumTiers) {
             const size_t lds = row_mem_bytes(a.cap);
             HIPCHK(c, hipFuncSetAttribute((const void*)k_spgemm_rows_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_spgemm_rows_lds<<<tcnt[t], kBlock, lds, c->stream>>>(a);
+            k_spgemm_rows_lds<<<tcnt[t], kRowBlock, lds, sst>>>(a);
         } else {
             const unsigned grid = tcnt[t] < kGlobalGrid ? tcnt[t] : kGlobalGrid;
-            k_spgemm_rows_global<<<grid, kBlock, 0, c->stream>>>(a);
+            k_spgemm_rows_global<<<grid, kRowBlock, 0, sst>>>(a);
         }
         KCHK(c);
+        HIPCHK(c, hipEventRecord(c->join[t], sst));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[t], 0));
         launches++;
     }
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
@@ -581,8 +594,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     fa.ctl = a.ctl;
     fa.overflow = ptr<uint4>(c->overflow);
     fa.flopptr = a.flopptr;
-    fa.plist_hv = a.plist_hv;
-    fa.plist_ov = a.plist_ov;
+    fa.plist = a.plist;
     fa.roff = a.roff;
     fa.packed = a.packed;
     fa.tmp_pairs = a.tmp_pairs;
@@ -590,9 +602,22 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     fa.sort_scratch = ptr<uint16_t>(c->sortscr);
     fa.k = a.k;
     fa.binSize = a.binSize;
+    fa.dbg = nullptr;
+    if (phase_timers) {
+        ENSURE(c, c->dbg, 8 * 48);
+        HIPCHK(c, hipMemsetAsync(c->dbg.p, 0, 8 * 48, c->stream));
+        fa.dbg = ptr<unsigned long long>(c->dbg);
+    }
     if (F) {
-        k_fold<<<kFoldGrid, 64 * kFoldWavesPerBlock, 0, c->stream>>>(fa);
+        // heavy pairs on the main stream, light pairs concurrently on a side stream
+        HIPCHK(c, hipEventRecord(c->fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side[kNumTiers], c->fork, 0));
+        k_fold<64, kFoldLightMaxBucket + 1, 15, kCtlWork><<<kFoldGrid, 64 * kFoldWavesPerBlock, 0, c->stream>>>(fa);
         KCHK(c);
+        k_fold<32, 1, kFoldLightMaxBucket, kCtlWorkLight><<<2 * kFoldGrid, 64 * kFoldWavesPerBlock, 0, c->side[kNumTiers]>>>(fa);
+        KCHK(c);
+        HIPCHK(c, hipEventRecord(c->join[kNumTiers], c->side[kNumTiers]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[kNumTiers], 0));
         k_fold_overflow<<<256, 64, 0, c->stream>>>(fa);
         KCHK(c);
     }
@@ -635,6 +660,11 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
                         "rows %.3f ms, fold %.3f ms (overflow pairs %u), symbolic %.3f ms, compact %.3f ms\n",
                 100.0 * ph[0] / tot, 100.0 * ph[1] / tot, 100.0 * ph[2] / tot, 100.0 * ph[3] / tot, 100.0 * ph[4] / tot,
                 c->tm.spgemm_ms, c->tm.fold_ms, c->n_overflow, c->tm.symbolic_ms, c->tm.compact_ms);
+        unsigned long long dbg[48];
+        HIPCHK(c, hipMemcpy(dbg, c->dbg.p, sizeof(dbg), hipMemcpyDeviceToHost));
+        for (int b = 1; b < 16; ++b)
+            if (dbg[b * 3 + 2]) fprintf(stderr, "[bella_hip]   fold bucket %2d: chunks %7llu  mean wave cycles/chunk %9.0f  max %9llu\n", b, dbg[b * 3 + 2],
+                                        (double)dbg[b * 3] / dbg[b * 3 + 2], dbg[b * 3 + 1]);
     }
     return 0;
 }

@@ -194,6 +194,20 @@ struct FoldResult {
     uint32_t many_bins;  // nb > 16 (std::sort tie path used)
 };
 
+// 1 iff |posH - qH| > k and |posV - qV| > k for two packed (posH | posV << 16) positions (chain.hpp:88-97)
+BELLA_HD uint32_t far_apart(uint32_t pp, uint32_t q, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 a = __builtin_bit_cast(us2, pp), b = __builtin_bit_cast(us2, q);
+    const us2 d = __builtin_elementwise_max(a, b) - __builtin_elementwise_min(a, b);       // v_pk_max/min/sub_u16
+    const us2 k1 = {(unsigned short)(k + 1), (unsigned short)(k + 1)};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(d, k1)) == __builtin_bit_cast(uint32_t, k1) ? 1u : 0u;
+#else
+    const int dh = iabs_((int)(pp & 0xFFFFu) - (int)(q & 0xFFFFu)), dv = iabs_((int)(pp >> 16) - (int)(q >> 16));
+    return (dh > k && dv > k) ? 1u : 0u;
+#endif
+}
+
 // fold_core: state arrays (P, Bm) + a product source.  prod(t, q, ovq) delivers product t; it is called once per t, in
 // order, BEFORE anything at index >= t of the state arrays is written, so the in-place use (state and products in the
 // same arrays) stays valid.  capP / capB bound the state (lane-private LDS in k_fold): returns false on overflow
@@ -213,7 +227,6 @@ BELLA_HD bool fold_core(PtrP P, PtrB Bm, uint32_t m, ProdFn prod, uint32_t capP,
         uint32_t q, ovq;
         prod(t, q, ovq);
         ovq &= 0xFFFFu;
-        const int qh = (int)(q & 0xFFFFu), qv = (int)(q >> 16);
         uint32_t r = 0, w = 0, bw = 0, ins = 0;
         for (uint32_t b = 0; b < nb; ++b) {                                   // chainop, chain.hpp:109-135
             const uint32_t meta = Bm[b];
@@ -233,10 +246,23 @@ BELLA_HD bool fold_core(PtrP P, PtrB Bm, uint32_t m, ProdFn prod, uint32_t capP,
                 w += bn;
                 Bm[bw++] = meta;
             } else {                                                          // dissolved into the new head bin
-                for (uint32_t x = 0; x < bn; ++x) {
+                // :88-97,121: a position survives iff BOTH coordinates are strictly more than k away from the new one.
+                // Branch-free compaction: every position is written at the cursor, the cursor advances only when it is
+                // kept (w <= r+x, so nothing unread is clobbered).  Four independent reads per round.
+                uint32_t x = 0;
+                for (; x + 4 <= bn; x += 4) {
+                    const uint32_t p0 = P[r + x], p1 = P[r + x + 1], p2 = P[r + x + 2], p3 = P[r + x + 3];
+                    const uint32_t k0 = far_apart(p0, q, k), k1 = far_apart(p1, q, k), k2 = far_apart(p2, q, k), k3 = far_apart(p3, q, k);
+                    P[w] = p0; w += k0;
+                    P[w] = p1; w += k1;
+                    P[w] = p2; w += k2;
+                    P[w] = p3; w += k3;
+                    ins += k0 + k1 + k2 + k3;
+                }
+                for (; x < bn; ++x) {
                     const uint32_t pp = P[r + x];
-                    const int dh = iabs_((int)(pp & 0xFFFFu) - qh), dv = iabs_((int)(pp >> 16) - qv);
-                    if (dh > k && dv > k) { P[w++] = pp; ins++; }             // :88-97,121 both strictly > k
+                    const uint32_t kk = far_apart(pp, q, k);
+                    P[w] = pp; w += kk; ins += kk;
                 }
             }
             r += bn;

@@ -39,13 +39,20 @@
 
 namespace bella {
 
+constexpr uint32_t kScatterChunk = 64;                    // phase S appends one wavefront of products at a time
+#ifndef BELLA_ROW_BLOCK
+#define BELLA_ROW_BLOCK 512
+#endif
+constexpr int kRowBlock = BELLA_ROW_BLOCK;                // threads per output column in the row kernels
+constexpr int kRowWaves = kRowBlock / 64;
 constexpr uint32_t kNumBuckets = 16;      // bucket b holds pairs with 2^b <= #products < 2^(b+1), b = 1..15
 // control block (u32 words) zeroed before every pass
 constexpr uint32_t kCtlBucketCnt = 0;     // [16]
 constexpr uint32_t kCtlWork = 16;         // k_fold chunk counter
 constexpr uint32_t kCtlOverflow = 17;     // overflow list length
 constexpr uint32_t kCtlWork2 = 18;        // k_fold_overflow counter
-constexpr uint32_t kCtlStatus = 19;       // bit0: a pair ended with > 16 bins and no scratch was given
+constexpr uint32_t kCtlStatus = 19;
+constexpr uint32_t kCtlWorkLight = 20;    // chunk counter of the light k_fold instance       // bit0: a pair ended with > 16 bins and no scratch was given
 constexpr uint32_t kCtlWords = 32;
 
 struct SpgemmArgs {
@@ -60,8 +67,7 @@ struct SpgemmArgs {
     bella_pair* tmp_pairs;
     bella_pair_ext* tmp_ext;
     uint32_t* nnzC;
-    uint32_t* plist_hv;          // [F] per-pair product lists (posH | posV << 16), product order
-    uint32_t* plist_ov;          // [F] overlap estimate (low 16 bits)
+    uint2* plist;                // [F] per-pair product lists {posH | posV << 16, overlap estimate}, product order
     uint4* desc;                 // bucketed pair descriptors {cid, key, start | m << 16, rank}
     const uint64_t* bucket_base; // [16] start of each bucket inside desc
     uint32_t* ctl;
@@ -77,7 +83,7 @@ constexpr uint32_t kRowScratchBytes = 256;                   // block scan scrat
 __host__ __device__ inline size_t row_mem_bytes(uint32_t cap) { return kRowScratchBytes + (size_t)32 * cap; }
 
 struct RowMem {
-    uint32_t* scr;      // 64 words: [0..7] scan, [8] distinct keys, [16..31] bucket counts, [32..47] bucket bases
+    uint32_t* scr;      // 64 words: [0..15] scan, [16..31] bucket counts, [32..47] bucket bases, [48] distinct keys
     uint32_t* A_hv;     // [cap]  posH | posV << 16, product order
     uint32_t* A_gov;    // [cap]  T1 slot << 16 | overlap estimate
     uint32_t* T1key;    // [cap]
@@ -108,7 +114,7 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap) {
 __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t i, const RowMem& m) {
     const uint32_t tid = threadIdx.x;
     const uint32_t H1 = m.cap;
-    uint32_t* s_d = m.scr + 8;
+    uint32_t* s_d = m.scr + 48;
     uint32_t* bcount = m.scr + 16;
     uint32_t* bbase = m.scr + 32;
     const uint32_t b0 = a.Bptr[i];
@@ -116,7 +122,7 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
     const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
     const uint32_t k = (uint32_t)a.k;
 
-    for (uint32_t s = tid; s < H1; s += kBlock) { m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0; }
+    for (uint32_t s = tid; s < H1; s += kRowBlock) { m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0; }
     if (tid == 0) *s_d = 0;
     if (tid < 16) bcount[tid] = 0;
     __syncthreads();
@@ -125,22 +131,53 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
 #define BELLA_PHASE(n) if (a.phase && tid == 0) { const long long t2 = clock64(); atomicAdd(a.phase + (n), (unsigned long long)(t2 - tc)); tc = t2; }
 
     // ---- X: expand products in reference order, group keys --------------------------------------------
+    // X1/X2: each thread owns a CONTIGUOUS run of B' entries (so one block scan orders all products); it only records,
+    // per product, where its A' entry lives and the B' side word -- LDS writes, no dependent global loads.
+    constexpr uint32_t RMAX = 8;
     uint32_t running = 0;
-    for (uint32_t base = 0; base < n; base += kBlock) {
-        const uint32_t j = base + tid;
-        uint2 be = make_uint2(0u, 0u);
-        if (j < n) be = a.Bent[b0 + j];
-        const uint32_t cnt = (be.y >> 16) & 0x3FFFu;
+    for (uint32_t jb = 0; jb < n; jb += RMAX * kRowBlock) {
+        const uint32_t nn = n - jb < RMAX * kRowBlock ? n - jb : RMAX * kRowBlock;
+        const uint32_t R = (nn + kRowBlock - 1) / kRowBlock;
+        const uint32_t j0 = tid * R;
+        uint2 be[RMAX];
+        uint32_t csum = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < RMAX; ++u) {
+            be[u] = make_uint2(0u, 0u);
+            if (u < R && j0 + u < nn) be[u] = a.Bent[b0 + jb + j0 + u];
+            csum += (be[u].y >> 16) & 0x3FFFu;
+        }
         uint32_t tot;
-        const uint32_t off = running + block_excl_scan(cnt, m.scr, &tot);
-        const uint32_t oriB = be.y >> 31, pal = (be.y >> 30) & 1u, posV = be.y & 0xFFFFu;
-        for (uint32_t t = 0; t < cnt; ++t) {
-            const uint2 ae = a.Aent[(uint64_t)be.x + t];
-            const uint32_t key = ae.x & 0x7FFFFFFFu;
-            const uint32_t posH = ae.y & 0xFFFFu, lenH = ae.y >> 16;
-            const bool oriented = (ae.x >> 31) == oriB;
+        uint32_t p = running + block_excl_scan<kRowWaves>(csum, m.scr, &tot);
+#pragma unroll
+        for (uint32_t u = 0; u < RMAX; ++u) {
+            const uint32_t cnt = (be[u].y >> 16) & 0x3FFFu;
+            for (uint32_t t = 0; t < cnt; ++t) { m.A_hv[p] = be[u].x + t; m.A_gov[p] = be[u].y; ++p; }
+        }
+        running += tot;
+    }
+    const uint32_t F = running;
+    __syncthreads();
+    // X3: product-parallel gather of the A' entries (balanced: every lane has work; four independent loads in flight)
+    for (uint32_t base = 0; base < F; base += 4 * kRowBlock) {
+        uint2 ae[4];
+        uint32_t bw[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t p = base + u * kRowBlock + tid;
+            ae[u] = make_uint2(0u, 0u);
+            bw[u] = 0;
+            if (p < F) { ae[u] = a.Aent[m.A_hv[p]]; bw[u] = m.A_gov[p]; }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t p = base + u * kRowBlock + tid;
+            if (p >= F) continue;
+            const uint32_t key = ae[u].x & 0x7FFFFFFFu;
+            const uint32_t posH = ae[u].y & 0xFFFFu, lenH = ae[u].y >> 16;
+            const uint32_t posV = bw[u] & 0xFFFFu, pal = (bw[u] >> 30) & 1u;
+            const bool oriented = (ae[u].x >> 31) == (bw[u] >> 31);
             const uint32_t ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, k) & 0xFFFFu;
-            const uint32_t p = off + t;
             uint32_t h = hash_range(key, H1);
             uint32_t old;
             for (;;) {
@@ -155,9 +192,7 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
             m.A_gov[p] = (h << 16) | ov;
             m.A_fl[p] = (uint8_t)((oriented ? 1u : 0u) | (pal << 1));
         }
-        running += tot;
     }
-    const uint32_t F = running;
     __syncthreads();
     const uint32_t d = *s_d;
     BELLA_PHASE(0)
@@ -165,9 +200,9 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
     // ---- O: the reference's slot order (overlap.hpp:289-361) -----------------------------------------
     const uint32_t ht = pow2_at_least(16u, d);
     uint32_t* T2 = m.T2;
-    for (uint32_t s = tid; s < ht; s += kBlock) T2[s] = kEmpty;
+    for (uint32_t s = tid; s < ht; s += kRowBlock) T2[s] = kEmpty;
     __syncthreads();
-    for (uint32_t s = tid; s < H1; s += kBlock) {
+    for (uint32_t s = tid; s < H1; s += kRowBlock) {
         const uint32_t key = m.T1key[s];
         if (key == kEmpty) continue;
         uint32_t item = (m.T1first[s] << 16) | s;
@@ -181,7 +216,7 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
     }
     __syncthreads();
     {
-        const uint32_t c = (ht + kBlock - 1) / kBlock;
+        const uint32_t c = (ht + kRowBlock - 1) / kRowBlock;
         const uint32_t lo = tid * c;
         const uint32_t hi = lo + c < ht ? lo + c : ht;
         uint32_t occ = 0, csum = 0;
@@ -190,7 +225,7 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
             if (it != kEmpty) { occ++; csum += m.T1cnt[it & 0xFFFFu] & 0xFFFFu; }
         }
         uint32_t tot;
-        const uint32_t ex = block_excl_scan((occ << 16) | csum, m.scr, &tot);
+        const uint32_t ex = block_excl_scan<kRowWaves>((occ << 16) | csum, m.scr, &tot);
         uint32_t rank = ex >> 16, st = ex & 0xFFFFu;
         for (uint32_t s = lo; s < hi; ++s) {
             const uint32_t it = T2[s];
@@ -205,19 +240,46 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
     __syncthreads();
     BELLA_PHASE(1)
 
-    // ---- S: product indices into per-pair lists (T2 is dead: its memory becomes S_p) -------------------
+    // ---- S: product indices into per-pair lists.  Wavefront 0 appends 64 products at a time in product order (LDS
+    // atomics of one wavefront execute in program order), so a list is ordered ACROSS 64-product chunks and only
+    // chunk-mates can be swapped; phase R repairs that.  The other wavefronts meanwhile build the bucket histogram of
+    // the multi-product pairs.  (T2 is dead: its memory becomes S_p.) -----------------------------------------------
     uint16_t* S_p = (uint16_t*)m.T2;
-    for (uint32_t p = tid; p < F; p += kBlock) {
-        const uint32_t g = m.A_gov[p] >> 16;
-        const uint32_t old = atomicAdd(&m.T1cnt[g], 0x10000u);
-        S_p[(m.T1first[g] & 0xFFFFu) + (old >> 16)] = (uint16_t)p;
+    if (wave_id() == 0) {
+        for (uint32_t base = 0; base < F; base += 4 * kScatterChunk) {
+            uint32_t g[4], old[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t p = base + u * kScatterChunk + tid;
+                g[u] = p < F ? (m.A_gov[p] >> 16) : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) old[u] = g[u] != 0xFFFFFFFFu ? atomicAdd(&m.T1cnt[g[u]], 0x10000u) : 0u;
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+                if (g[u] != 0xFFFFFFFFu) S_p[(m.T1first[g[u]] & 0xFFFFu) + (old[u] >> 16)] = (uint16_t)(base + u * kScatterChunk + tid);
+        }
+    } else {
+        for (uint32_t r = tid - 64; r < d; r += kRowBlock - 64) {
+            const uint32_t mm = m.T1cnt[m.G[r]] & 0xFFFFu;
+            if (mm >= 2) atomicAdd(&bcount[31 - __clz(mm)], 1u);
+        }
     }
     __syncthreads();
+    // reservation in the global bucket lists: issued now, the returned bases are only needed in phase D, so the
+    // device-scope atomics' latency hides under phase R
+    uint32_t my_bbase = 0;
+    if (tid < kNumBuckets) {
+        const uint32_t c = bcount[tid];
+        if (c) my_bbase = atomicAdd(&a.ctl[kCtlBucketCnt + tid], c);
+    }
     BELLA_PHASE(2)
 
-    // ---- R: rank inside the pair's list = product order; emit -------------------------------------------
+    // ---- R: list-position-parallel.  Inside a list only the members of one 256-product chunk can be out of order:
+    // rank = position corrected by the chunk-mates on the wrong side. ------------------------------------------------
     const uint64_t obase = a.flopptr[i];
-    for (uint32_t p = tid; p < F; p += kBlock) {
+    for (uint32_t x = tid; x < F; x += kRowBlock) {
+        const uint32_t p = S_p[x];
         const uint32_t gov = m.A_gov[p];
         const uint32_t g = gov >> 16;
         const uint32_t fr = m.T1first[g];
@@ -236,27 +298,28 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
                 a.tmp_ext[obase + (fr >> 16)] = ex;
             }
         } else {
-            uint32_t rk = 0;
-            for (uint32_t x = 0; x < mm; ++x) rk += (S_p[st + x] < p);
-            a.plist_hv[obase + st + rk] = m.A_hv[p];
-            a.plist_ov[obase + st + rk] = gov & 0xFFFFu;
+            const uint32_t ch = p / kScatterChunk;
+            uint32_t rk = x - st;
+            for (uint32_t y = x; y > st; --y) {           // chunk-mates on the left that belong after p
+                const uint32_t o = S_p[y - 1];
+                if (o / kScatterChunk != ch) break;
+                rk -= (o > p);
+            }
+            for (uint32_t y = x + 1; y < st + mm; ++y) {  // chunk-mates on the right that belong before p
+                const uint32_t o = S_p[y];
+                if (o / kScatterChunk != ch) break;
+                rk += (o < p);
+            }
+            a.plist[obase + st + rk] = make_uint2(m.A_hv[p], gov & 0xFFFFu);
         }
     }
     BELLA_PHASE(3)
 
     // ---- D: descriptors of multi-product pairs, bucketed by floor(log2(m)) -----------------------------
-    for (uint32_t r = tid; r < d; r += kBlock) {
-        const uint32_t mm = m.T1cnt[m.G[r]] & 0xFFFFu;
-        if (mm >= 2) atomicAdd(&bcount[31 - __clz(mm)], 1u);
-    }
     __syncthreads();
-    if (tid < kNumBuckets) {
-        const uint32_t c = bcount[tid];
-        bbase[tid] = c ? atomicAdd(&a.ctl[kCtlBucketCnt + tid], c) : 0u;
-        bcount[tid] = 0;
-    }
+    if (tid < kNumBuckets) { bbase[tid] = my_bbase; bcount[tid] = 0; }
     __syncthreads();
-    for (uint32_t r = tid; r < d; r += kBlock) {
+    for (uint32_t r = tid; r < d; r += kRowBlock) {
         const uint32_t g = m.G[r];
         const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
         if (mm < 2) continue;
@@ -270,7 +333,7 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
 }
 
 // LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap)
-__global__ __launch_bounds__(kBlock) void k_spgemm_rows_lds(SpgemmArgs a) {
+__global__ __launch_bounds__(kRowBlock) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t i = a.rowlist[blockIdx.x];
     const RowMem m = carve(smem, a.cap);
@@ -278,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_spgemm_rows_lds(SpgemmArgs a) {
 }
 
 // Global-workspace path: columns with cap < products < 65536; persistent workgroups, one workspace each.
-__global__ __launch_bounds__(kBlock) void k_spgemm_rows_global(SpgemmArgs a) {
+__global__ __launch_bounds__(kRowBlock) void k_spgemm_rows_global(SpgemmArgs a) {
     uint8_t* ws = a.ws + (uint64_t)blockIdx.x * a.ws_stride;
     for (uint32_t x = blockIdx.x; x < a.nrows; x += gridDim.x) {
         const uint32_t i = a.rowlist[x];
@@ -296,25 +359,52 @@ struct FoldArgs {
     uint32_t* ctl;
     uint4* overflow;             // descriptors of pairs whose state outgrew the LDS budget
     const uint64_t* flopptr;
-    uint32_t* plist_hv;
-    uint32_t* plist_ov;
+    uint2* plist;
     const uint64_t* roff;
     const uint32_t* packed;
     bella_pair* tmp_pairs;
     bella_pair_ext* tmp_ext;
     uint16_t* sort_scratch;      // [F] (k_fold_overflow only)
+    unsigned long long* dbg;     // optional [16][3]: per bucket sum / max cycles per chunk, chunks (development aid)
     int k;
     int binSize;
 };
 
-constexpr uint32_t kFoldCapP = 64;   // positions of one pair's state held in LDS
-constexpr uint32_t kFoldCapB = 8;    // bins
-constexpr uint32_t kFoldWaveWords = (kFoldCapP + kFoldCapB) * 64;
+constexpr uint32_t kFoldCapB = 8;    // bins of one pair's state held in LDS
 constexpr uint32_t kFoldWavesPerBlock = 4;
+constexpr uint32_t kFoldLightMaxBucket = 4;   // pairs with < 32 products: state fits 32 positions by construction
 
 struct LanePtr {                     // element e of this lane: word e*64 of the wave's region (bank = lane)
     uint32_t* base;
     __device__ __forceinline__ uint32_t& operator[](uint32_t e) const { return base[e * 64u]; }
+};
+
+// The lane's product list streamed from HBM through a double register buffer: batch t/8+1 is in flight while batch t/8
+// is folded, so the fold never waits on a single dependent load.
+struct ProductStream {
+    const uint2* base;
+    uint32_t m;
+    uint2 cur[8], nxt[8];
+    __device__ __forceinline__ void fill(uint2 (&dst)[8], uint32_t t0) {
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) dst[u] = (t0 + u < m) ? base[t0 + u] : make_uint2(0u, 0u);
+    }
+    __device__ __forceinline__ void operator()(uint32_t t, uint32_t& q, uint32_t& o) {
+        if ((t & 7u) == 0) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) cur[u] = nxt[u];
+            fill(nxt, t + 8);
+        }
+        uint2 v = cur[0];
+#pragma unroll
+        for (uint32_t u = 1; u < 8; ++u) if ((t & 7u) == u) v = cur[u];
+        q = v.x; o = v.y;
+    }
+};
+
+struct Stride2Ptr {                  // word e of an interleaved {x,y} list: base[2e]
+    uint32_t* base;
+    __device__ __forceinline__ uint32_t& operator[](uint32_t e) const { return base[2u * e]; }
 };
 
 __device__ __forceinline__ void write_pair(const FoldArgs& a, const uint4 ds, const FoldResult& fr) {
@@ -336,40 +426,56 @@ __device__ __forceinline__ void write_pair(const FoldArgs& a, const uint4 ds, co
     }
 }
 
+// CAPP = positions of one pair's state held in LDS; the instance serves buckets BMIN..BMAX (work counter WORK)
+template <uint32_t CAPP, int BMIN, int BMAX, uint32_t WORK>
 __global__ __launch_bounds__(64 * kFoldWavesPerBlock) void k_fold(FoldArgs a) {
-    __shared__ uint32_t lds[kFoldWaveWords * kFoldWavesPerBlock];
+    constexpr uint32_t kWaveWords = (CAPP + kFoldCapB) * 64;
+    __shared__ uint32_t lds[kWaveWords * kFoldWavesPerBlock];
     const uint32_t lane = lane_id();
-    uint32_t* wl = lds + wave_id() * kFoldWaveWords + lane;
-    const LanePtr P{wl}, Bm{wl + kFoldCapP * 64u};
+    uint32_t* wl = lds + wave_id() * kWaveWords + lane;
+    const LanePtr P{wl}, Bm{wl + CAPP * 64u};
     // chunk table: heaviest bucket first
     uint32_t cnt_b = 0, nch_b = 0;
-    if (lane < kNumBuckets) { cnt_b = a.ctl[kCtlBucketCnt + lane]; nch_b = (cnt_b + 63u) / 64u; }
+    if ((int)lane >= BMIN && (int)lane <= BMAX) { cnt_b = a.ctl[kCtlBucketCnt + lane]; nch_b = (cnt_b + 63u) / 64u; }
     uint32_t total = 0;
 #pragma unroll
     for (int b = 0; b < (int)kNumBuckets; ++b) total += __shfl(nch_b, b, 64);
+    long long tprev = 0;
+    int bprev = -1;
     for (;;) {
+        if (a.dbg) {                 // wave-level chunk time: all lanes are converged here
+            const long long tn = clock64();
+            if (bprev >= 0 && lane == 0) {
+                const unsigned long long dt = (unsigned long long)(tn - tprev);
+                atomicAdd(a.dbg + bprev * 3 + 0, dt);
+                atomicMax(a.dbg + bprev * 3 + 1, dt);
+                atomicAdd(a.dbg + bprev * 3 + 2, 1ull);
+            }
+            tprev = tn;
+        }
         uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(&a.ctl[kCtlWork], 1u);
+        if (lane == 0) c = atomicAdd(&a.ctl[WORK], 1u);
         c = __shfl(c, 0, 64);
         if (c >= total) break;
-        int bsel = 0;
+        int bsel = BMIN;
         uint32_t rem = c;
-        for (int b = (int)kNumBuckets - 1; b >= 1; --b) {
+        for (int b = BMAX; b >= BMIN; --b) {
             const uint32_t nb = __shfl(nch_b, b, 64);
             if (rem < nb) { bsel = b; break; }
             rem -= nb;
         }
+        bprev = bsel;
         const uint32_t cntsel = __shfl(cnt_b, bsel, 64);
         const uint32_t idx = rem * 64u + lane;
         if (idx >= cntsel) continue;
         const uint4 ds = a.desc[a.bucket_base[bsel] + idx];
         const uint32_t mm = ds.z >> 16;
-        const uint64_t lo = a.flopptr[ds.x] + (ds.z & 0xFFFFu);
-        const uint32_t* hv = a.plist_hv + lo;
-        const uint32_t* ov = a.plist_ov + lo;
-        auto prod = [&](uint32_t t, uint32_t& q, uint32_t& o) { q = hv[t]; o = ov[t]; };
+        ProductStream prod;
+        prod.base = a.plist + a.flopptr[ds.x] + (ds.z & 0xFFFFu);
+        prod.m = mm;
+        prod.fill(prod.nxt, 0);
         FoldResult fr;
-        const bool ok = fold_core(P, Bm, mm, prod, kFoldCapP, kFoldCapB, a.k, a.binSize, (uint16_t*)nullptr, fr);
+        const bool ok = fold_core(P, Bm, mm, prod, CAPP, kFoldCapB, a.k, a.binSize, (uint16_t*)nullptr, fr);
         if (ok) write_pair(a, ds, fr);
         else a.overflow[atomicAdd(&a.ctl[kCtlOverflow], 1u)] = ds;
     }
@@ -384,8 +490,9 @@ __global__ __launch_bounds__(64) void k_fold_overflow(FoldArgs a) {
         const uint4 ds = a.overflow[idx];
         const uint32_t mm = ds.z >> 16;
         const uint64_t lo = a.flopptr[ds.x] + (ds.z & 0xFFFFu);
+        uint32_t* w = (uint32_t*)(a.plist + lo);
         FoldResult fr;
-        fold_pair(a.plist_hv + lo, a.plist_ov + lo, mm, a.k, a.binSize, a.sort_scratch ? a.sort_scratch + lo : (uint16_t*)nullptr, fr);
+        fold_pair(Stride2Ptr{w}, Stride2Ptr{w + 1}, mm, a.k, a.binSize, a.sort_scratch ? a.sort_scratch + lo : (uint16_t*)nullptr, fr);
         if (fr.many_bins) atomicOr(&a.ctl[kCtlStatus], 1u);
         write_pair(a, ds, fr);
     }

@@ -21,14 +21,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 }
 
 // Exclusive scan over the 256 threads of a block; *total receives the block sum.
-// `scr` must hold kWaves+1 u32 in LDS.  Contains two barriers; safe to call back to back.
+// `scr` must hold NW u32 in LDS (NW = wavefronts per block).  Contains two barriers; safe to call back to back.
+template <int NW = kWaves>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* scr, uint32_t* total) {
     const uint32_t inc = wave_incl_scan(v);
     if (lane_id() == 63) scr[wave_id()] = inc;
     __syncthreads();
     uint32_t base = 0, sum = 0;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
+    for (int w = 0; w < NW; ++w) {
         const uint32_t s = scr[w];
         if (w < (int)wave_id()) base += s;
         sum += s;
