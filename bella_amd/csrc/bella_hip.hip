@@ -29,7 +29,7 @@ struct Buf {
 
 constexpr uint32_t kNumTiers = 6;  // 5 LDS tiers + the global-workspace tier
 const uint32_t kTierCaps[kNumTiers] = {768, 1280, 2048, 3072, 4096, 65535};
-constexpr uint32_t kGlobalGrid = 512;
+constexpr uint32_t kGlobalGrid = 256;
 constexpr uint32_t kFoldGrid = 512;       // persistent k_fold workgroups (2 per CU at 72 KB LDS)
 constexpr uint32_t kAsmGrid = 1024;
 
@@ -61,7 +61,8 @@ struct bella_ctx {
     // overlap
     uint64_t flops = 0, npairs = 0;
     Buf flopsr, flopptr, nnzC, colptrC, tierflag, rowlists, tiercnt, tiercaps, tmp_pairs, tmp_ext, pairs, ext, sortscr, ws,
-        status, cubtmp, plist_hv, plist_ov, desc, overflow, ctl, dbg;
+        status, cubtmp, plist_hv, plist_ov, desc, overflow, ctl, dbg, retry;
+    uint32_t n_retry = 0;
     uint32_t n_overflow = 0;
     // alignment
     uint64_t nalns = 0;
@@ -288,7 +289,7 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->Brow, &c->deg, &c->minread, &c->colstart,
                   &c->fill, &c->ori, &c->w, &c->wscan, &c->Atmp, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC, &c->tierflag,
                   &c->rowlists, &c->tiercnt, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
-                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->plist_ov, &c->desc, &c->overflow, &c->ctl, &c->dbg};
+                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->plist_ov, &c->desc, &c->overflow, &c->ctl, &c->dbg, &c->retry};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& st : c->side) (void)hipStreamDestroy(st);
@@ -535,8 +536,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     ENSURE(c, c->sortscr, 2 * F);
     uint64_t* d_bbase = (uint64_t*)(ptr<uint32_t>(c->ctl) + kCtlWords);
     HIPCHK(c, hipMemcpyAsync(d_bbase, bbase, sizeof(bbase), hipMemcpyHostToDevice, c->stream));
-    const uint64_t ws_stride = (row_mem_bytes(65535) + 255) & ~(size_t)255;
-    if (tcnt[kNumTiers - 1]) ENSURE(c, c->ws, ws_stride * kGlobalGrid);
+    const uint64_t ws_stride = (row_mem_bytes(65535, 65535) + 255) & ~(size_t)255;
+    ENSURE(c, c->ws, ws_stride * kGlobalGrid);
+    ENSURE(c, c->retry, 4 * ((size_t)nr + 1));
 
     SpgemmArgs a;
     a.Bptr = ptr<uint32_t>(c->Bptr);
@@ -552,6 +554,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     a.desc = ptr<uint4>(c->desc);
     a.bucket_base = d_bbase;
     a.ctl = ptr<uint32_t>(c->ctl);
+    a.retry = ptr<uint32_t>(c->retry);
+    a.nrows_dev = nullptr;
     a.ws = ptr<uint8_t>(c->ws);
     a.ws_stride = ws_stride;
     a.k = p->kmer_size;
@@ -575,7 +579,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         a.nrows = tcnt[t];
         a.cap = kTierCaps[t];
         if (t + 1 < (int)kNumTiers) {
-            const size_t lds = row_mem_bytes(a.cap);
+            const size_t lds = row_mem_bytes(a.cap, a.cap / 2);
             HIPCHK(c, hipFuncSetAttribute((const void*)k_spgemm_rows_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             k_spgemm_rows_lds<<<tcnt[t], kRowBlock, lds, sst>>>(a);
         } else {
@@ -587,6 +591,12 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[t], 0));
         launches++;
     }
+    // columns whose pair count overflowed an LDS tier's key table (list and count produced on the device)
+    a.rowlist = ptr<uint32_t>(c->retry);
+    a.nrows = 0;
+    a.nrows_dev = ptr<uint32_t>(c->ctl) + kCtlRetry;
+    k_spgemm_rows_global<<<kGlobalGrid, kRowBlock, 0, c->stream>>>(a);
+    KCHK(c);
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     FoldArgs fa;
     fa.desc = a.desc;
@@ -632,6 +642,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     if (rc) return rc;
     *status_out = ctl_host[kCtlStatus];
     c->n_overflow = ctl_host[kCtlOverflow];
+    c->n_retry = ctl_host[kCtlRetry];
     c->npairs = P;
     ENSURE(c, c->pairs, sizeof(bella_pair) * P);
     if (want_ext) ENSURE(c, c->ext, sizeof(bella_pair_ext) * P);
@@ -657,9 +668,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         HIPCHK(c, hipMemcpy(ph, ptr<uint32_t>(c->status) + 4, 40, hipMemcpyDeviceToHost));
         const double tot = (double)(ph[0] + ph[1] + ph[2] + ph[3] + ph[4]) + 1e-9;
         fprintf(stderr, "[bella_hip] row-kernel phase cycles: expand %.1f%% order %.1f%% scatter %.1f%% rank/emit %.1f%% describe %.1f%% ; "
-                        "rows %.3f ms, fold %.3f ms (overflow pairs %u), symbolic %.3f ms, compact %.3f ms\n",
+                        "rows %.3f ms (retried columns %u), fold %.3f ms (overflow pairs %u), symbolic %.3f ms, compact %.3f ms\n",
                 100.0 * ph[0] / tot, 100.0 * ph[1] / tot, 100.0 * ph[2] / tot, 100.0 * ph[3] / tot, 100.0 * ph[4] / tot,
-                c->tm.spgemm_ms, c->tm.fold_ms, c->n_overflow, c->tm.symbolic_ms, c->tm.compact_ms);
+                c->tm.spgemm_ms, c->n_retry, c->tm.fold_ms, c->n_overflow, c->tm.symbolic_ms, c->tm.compact_ms);
         unsigned long long dbg[48];
         HIPCHK(c, hipMemcpy(dbg, c->dbg.p, sizeof(dbg), hipMemcpyDeviceToHost));
         for (int b = 1; b < 16; ++b)

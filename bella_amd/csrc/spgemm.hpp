@@ -52,7 +52,8 @@ constexpr uint32_t kCtlWork = 16;         // k_fold chunk counter
 constexpr uint32_t kCtlOverflow = 17;     // overflow list length
 constexpr uint32_t kCtlWork2 = 18;        // k_fold_overflow counter
 constexpr uint32_t kCtlStatus = 19;
-constexpr uint32_t kCtlWorkLight = 20;    // chunk counter of the light k_fold instance       // bit0: a pair ended with > 16 bins and no scratch was given
+constexpr uint32_t kCtlWorkLight = 20;    // chunk counter of the light k_fold instance
+constexpr uint32_t kCtlRetry = 21;        // columns whose key table overflowed in an LDS tier (rerun on the global path)       // bit0: a pair ended with > 16 bins and no scratch was given
 constexpr uint32_t kCtlWords = 32;
 
 struct SpgemmArgs {
@@ -71,6 +72,8 @@ struct SpgemmArgs {
     uint4* desc;                 // bucketed pair descriptors {cid, key, start | m << 16, rank}
     const uint64_t* bucket_base; // [16] start of each bucket inside desc
     uint32_t* ctl;
+    uint32_t* retry;             // [nreads] columns to rerun on the global path
+    const uint32_t* nrows_dev;   // if set, the row count of this launch lives on the device
     uint8_t* ws;
     uint64_t ws_stride;
     uint32_t cap;
@@ -80,41 +83,48 @@ struct SpgemmArgs {
 };
 
 constexpr uint32_t kRowScratchBytes = 256;                   // block scan scratch, counters, bucket histogram
-__host__ __device__ inline size_t row_mem_bytes(uint32_t cap) { return kRowScratchBytes + (size_t)32 * cap; }
+// cap = products held, dcap = distinct keys (pairs) held.  LDS tiers budget dcap = cap/2: a column with more pairs than
+// that (never seen on PacBio-like sets: pairs/products is 0.03 at 10k reads, 0.28 at 100k) is rerun on the global path.
+__host__ __device__ inline size_t row_mem_bytes(uint32_t cap, uint32_t dcap) {
+    return kRowScratchBytes + (size_t)8 * cap + (size_t)20 * dcap + 2 * (size_t)((dcap + 1) & ~1u) + ((cap + 3) & ~3u);
+}
 
 struct RowMem {
     uint32_t* scr;      // 64 words: [0..15] scan, [16..31] bucket counts, [32..47] bucket bases, [48] distinct keys
     uint32_t* A_hv;     // [cap]  posH | posV << 16, product order
     uint32_t* A_gov;    // [cap]  T1 slot << 16 | overlap estimate
-    uint32_t* T1key;    // [cap]
-    uint32_t* T1first;  // [cap]  first product index ; after phase O: list start | rank << 16
-    uint32_t* T1cnt;    // [cap]  products | scatter cursor << 16
-    uint32_t* T2;       // [2*cap] slot-order table ; after phase O reused: S_p (u16 [cap]) product index lists
-    uint16_t* G;        // [cap]  rank -> T1 slot
+    uint32_t* T1key;    // [dcap]
+    uint32_t* T1first;  // [dcap]  first product index ; after phase O: list start | rank << 16
+    uint32_t* T1cnt;    // [dcap]  products | scatter cursor << 16
+    uint32_t* T2;       // [2*dcap] slot-order table ; after phase O reused: S_p (u16 [cap]) product index lists (dcap >= cap/4)
+    uint16_t* G;        // [dcap]  rank -> T1 slot
     uint8_t* A_fl;      // [cap]  bit0 oriented (checkstrand), bit1 palindromic k-mer
-    uint32_t cap;
+    uint32_t cap, dcap;
 };
 
-__device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap) {
+__device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dcap) {
     RowMem m;
     m.scr = (uint32_t*)base;
     uint32_t* w = (uint32_t*)(base + kRowScratchBytes);
     m.A_hv = w;            w += cap;
     m.A_gov = w;           w += cap;
-    m.T1key = w;           w += cap;
-    m.T1first = w;         w += cap;
-    m.T1cnt = w;           w += cap;
-    m.T2 = w;              w += 2 * cap;
-    m.G = (uint16_t*)w;    w += (cap + 1) / 2;
+    m.T1key = w;           w += dcap;
+    m.T1first = w;         w += dcap;
+    m.T1cnt = w;           w += dcap;
+    m.T2 = w;              w += 2 * dcap;
+    m.G = (uint16_t*)w;    w += (dcap + 1) / 2;
     m.A_fl = (uint8_t*)w;
     m.cap = cap;
+    m.dcap = dcap;
     return m;
 }
 
-__device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t i, const RowMem& m) {
+// returns false if the key table overflowed (no global side effect happened yet; the caller queues the column again)
+__device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t i, const RowMem& m) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t H1 = m.cap;
+    const uint32_t H1 = m.dcap;
     uint32_t* s_d = m.scr + 48;
+    uint32_t* s_fail = m.scr + 49;
     uint32_t* bcount = m.scr + 16;
     uint32_t* bbase = m.scr + 32;
     const uint32_t b0 = a.Bptr[i];
@@ -123,7 +133,7 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
     const uint32_t k = (uint32_t)a.k;
 
     for (uint32_t s = tid; s < H1; s += kRowBlock) { m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0; }
-    if (tid == 0) *s_d = 0;
+    if (tid == 0) { *s_d = 0; *s_fail = 0; }
     if (tid < 16) bcount[tid] = 0;
     __syncthreads();
     long long tc = 0;
@@ -179,12 +189,14 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
             const bool oriented = (ae[u].x >> 31) == (bw[u] >> 31);
             const uint32_t ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, k) & 0xFFFFu;
             uint32_t h = hash_range(key, H1);
-            uint32_t old;
-            for (;;) {
+            uint32_t old = 0;
+            uint32_t probes = 0;
+            for (; probes < H1; ++probes) {
                 old = atomicCAS(&m.T1key[h], kEmpty, key);
                 if (old == kEmpty || old == key) break;
                 h = (h + 1 == H1) ? 0 : h + 1;
             }
+            if (probes == H1) { *s_fail = 1; continue; }     // more pairs than this tier's key table holds
             if (old == kEmpty) atomicAdd(s_d, 1u);
             atomicMin(&m.T1first[h], p);
             atomicAdd(&m.T1cnt[h], 1u);
@@ -194,6 +206,7 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
+    if (*s_fail) return false;
     const uint32_t d = *s_d;
     BELLA_PHASE(0)
 
@@ -330,24 +343,28 @@ __device__ __forceinline__ void process_row(const SpgemmArgs& a, const uint32_t 
     if (tid == 0) a.nnzC[i] = d;
     if (a.phase) { __syncthreads(); BELLA_PHASE(4) }
 #undef BELLA_PHASE
+    return true;
 }
 
-// LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap)
+// LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap, cap/2)
 __global__ __launch_bounds__(kRowBlock) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t i = a.rowlist[blockIdx.x];
-    const RowMem m = carve(smem, a.cap);
-    process_row(a, i, m);
+    const RowMem m = carve(smem, a.cap, a.cap / 2);
+    if (!process_row(a, i, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
 }
 
-// Global-workspace path: columns with cap < products < 65536; persistent workgroups, one workspace each.
+// Global-workspace path: columns with more products than the largest LDS tier (< 65536), and -- second launch, list and
+// length produced on the device -- columns whose key table overflowed in an LDS tier.  Persistent workgroups.
 __global__ __launch_bounds__(kRowBlock) void k_spgemm_rows_global(SpgemmArgs a) {
     uint8_t* ws = a.ws + (uint64_t)blockIdx.x * a.ws_stride;
-    for (uint32_t x = blockIdx.x; x < a.nrows; x += gridDim.x) {
+    const uint32_t nrows = a.nrows_dev ? *a.nrows_dev : a.nrows;
+    for (uint32_t x = blockIdx.x; x < nrows; x += gridDim.x) {
         const uint32_t i = a.rowlist[x];
-        const uint32_t f = (uint32_t)(a.flopptr[i + 1] - a.flopptr[i]);
-        const RowMem m = carve(ws, f < 16u ? 16u : f);   // T2 needs >= 16 slots
-        process_row(a, i, m);
+        uint32_t f = (uint32_t)(a.flopptr[i + 1] - a.flopptr[i]);
+        if (f < 16u) f = 16u;                             // T2 needs >= 16 slots
+        const RowMem m = carve(ws, f, f);
+        (void)process_row(a, i, m);
         __syncthreads();
     }
 }

@@ -269,3 +269,55 @@ def test_dropin_shim_from_reference_call_site(eng, tmp_path):
             if got != g.out[key]:
                 assert key == "align"                         # only flagged alignments may differ
                 assert len(set(got.split(b"\n")) ^ set(g.out[key].split(b"\n"))) < 0.02 * len(g.out[key].split(b"\n"))
+
+
+def _run_constructed(eng, lens, per_read, nkmers, k=17, seed=0):
+    """reads of random bases with the given lengths; per_read[r] = [(kmer, pos), ...] in position order"""
+    rng = np.random.default_rng(seed)
+    arrs = [synth.BASES[rng.integers(0, 4, size=L, dtype=np.uint8)].copy() for L in lens]
+    kseq = {}
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    tk, tr, tp = [], [], []
+    for r, lst in enumerate(per_read):
+        for km, pos in lst:
+            if km not in kseq:
+                kseq[km] = synth.BASES[rng.integers(0, 4, size=k, dtype=np.uint8)].copy()
+            w = kseq[km]
+            if rng.integers(0, 2):                      # plant the k-mer or its reverse complement (same canonical k-mer)
+                w = np.asarray([comp[int(c)] for c in w[::-1]], np.uint8)
+            arrs[r][pos:pos + k] = w
+            tk.append(km); tr.append(r); tp.append(pos)
+    seqs = [bytes(a) for a in arrs]
+    rs = synth.readset_from_seqs(seqs)
+    tk, tr, tp = np.asarray(tk, np.uint32), np.asarray(tr, np.uint32), np.asarray(tp, np.uint16)
+    eng.set_reads(rs)
+    eng.assemble_tuples(k, nkmers, tk, tr, tp)
+    n, flops = eng.overlap(BellaPars(kmerSize=k))
+    pairs, ext, colptrC = eng.get_pairs()
+    _, flop, ecol, exp = oracle_pairs(rs, seqs, nkmers, tk, tr, tp, k)
+    assert n == len(exp) and flops == int(flop.sum())
+    check_pairs(pairs, ext, exp, rs.lengths, k)
+    return exp
+
+
+def test_key_table_overflow_is_retried_on_global_path(eng):
+    """a column with as many pairs as products (500 > cap/2 of its LDS tier): rerun on the global path"""
+    n = 501
+    per_read = [[(j, 30 * j) for j in range(500)]] + [[(j, 5)] for j in range(500)]
+    exp = _run_constructed(eng, [16000] + [100] * 500, per_read, 500)
+    assert len(exp) == 500 and (exp["count"] == 1).all()
+
+
+def test_many_bins_overflow_path_and_std_sort_order(eng):
+    """one pair whose products all land in different overlap bins (40 bins > 8 held in LDS, > 16 => libstdc++ introsort
+    tie order), plus a pair with a long single-bin state (> 64 positions): both go through k_fold_overflow"""
+    a = [(t, 600 * t + 200) for t in range(40)]                  # read 0: k-mers 0..39, far apart
+    b = [(t, 100 + 0 * t) for t in range(1)]                     # placeholder, replaced below
+    # read 1 holds the same 40 k-mers all near its start -> overlap estimates 600 apart -> 40 orphan bins
+    b = sorted([(t, 100 + 19 * t) for t in range(40)], key=lambda x: x[1])
+    # reads 2,3: 120 shared k-mers, positions 40 apart on both (never within k of each other) -> one bin, 120 positions
+    c = [(100 + t, 50 + 40 * t) for t in range(120)]
+    d = [(100 + t, 60 + 40 * t) for t in range(120)]
+    exp = _run_constructed(eng, [30000, 30000, 6000, 6000], [a, b, c, d], 300)
+    by = {(int(p["rid"]), int(p["cid"])): p for p in exp}
+    assert by[(1, 0)]["nbins"] > 16 and by[(3, 2)]["support"] > 64
