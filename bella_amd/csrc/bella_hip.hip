@@ -498,20 +498,10 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     KCHK(c);
     int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->flopsr), ptr<uint64_t>(c->flopptr), (uint64_t)nr + 1);
     if (rc) return rc;
-    k_tier_flags<<<nblk(nr), 256, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, ptr<uint32_t>(c->tiercaps), kNumTiers,
-                                                  ptr<uint8_t>(c->tierflag), ptr<uint32_t>(c->status));
+    HIPCHK(c, hipMemsetAsync(c->tiercnt.p, 0, 4 * kNumTiers, c->stream));
+    k_tier_lists<<<nblk(nr), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, ptr<uint32_t>(c->tiercaps), kNumTiers,
+                                                  ptr<uint32_t>(c->rowlists), ptr<uint32_t>(c->tiercnt), ptr<uint32_t>(c->status));
     KCHK(c);
-    for (uint32_t t = 0; t < kNumTiers; ++t) {
-        hipcub::CountingInputIterator<uint32_t> ids(0);
-        size_t tb = 0;
-        HIPCHK(c, hipcub::DeviceSelect::Flagged(nullptr, tb, ids, ptr<uint8_t>(c->tierflag) + (size_t)t * nr,
-                                                ptr<uint32_t>(c->rowlists) + (size_t)t * nr, ptr<uint32_t>(c->tiercnt) + t,
-                                                (int)nr, c->stream));
-        ENSURE(c, c->cubtmp, tb);
-        HIPCHK(c, hipcub::DeviceSelect::Flagged(c->cubtmp.p, tb, ids, ptr<uint8_t>(c->tierflag) + (size_t)t * nr,
-                                                ptr<uint32_t>(c->rowlists) + (size_t)t * nr, ptr<uint32_t>(c->tiercnt) + t,
-                                                (int)nr, c->stream));
-    }
     uint32_t tcnt[kNumTiers];
     uint64_t F = 0;
     HIPCHK(c, hipMemcpyAsync(tcnt, c->tiercnt.p, sizeof(tcnt), hipMemcpyDeviceToHost, c->stream));
@@ -622,10 +612,15 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         // heavy pairs on the main stream, light pairs concurrently on a side stream
         HIPCHK(c, hipEventRecord(c->fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side[kNumTiers], c->fork, 0));
-        k_fold<64, kFoldLightMaxBucket + 1, 15, kCtlWork><<<kFoldGrid, 64 * kFoldWavesPerBlock, 0, c->stream>>>(fa);
+        HIPCHK(c, hipStreamWaitEvent(c->side[0], c->fork, 0));
+        k_fold_coop<7, 15, kCtlWork><<<kFoldGrid / 4, 64 * kFoldWavesPerBlock, 0, c->stream>>>(fa);
+        KCHK(c);
+        k_fold<64, 5, 6, kCtlWorkMid><<<kFoldGrid, 64 * kFoldWavesPerBlock, 0, c->side[0]>>>(fa);
         KCHK(c);
         k_fold<32, 1, kFoldLightMaxBucket, kCtlWorkLight><<<2 * kFoldGrid, 64 * kFoldWavesPerBlock, 0, c->side[kNumTiers]>>>(fa);
         KCHK(c);
+        HIPCHK(c, hipEventRecord(c->join[0], c->side[0]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[0], 0));
         HIPCHK(c, hipEventRecord(c->join[kNumTiers], c->side[kNumTiers]));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[kNumTiers], 0));
         k_fold_overflow<<<256, 64, 0, c->stream>>>(fa);

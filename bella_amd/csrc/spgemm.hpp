@@ -53,6 +53,7 @@ constexpr uint32_t kCtlOverflow = 17;     // overflow list length
 constexpr uint32_t kCtlWork2 = 18;        // k_fold_overflow counter
 constexpr uint32_t kCtlStatus = 19;
 constexpr uint32_t kCtlWorkLight = 20;    // chunk counter of the light k_fold instance
+constexpr uint32_t kCtlWorkMid = 22;      // chunk counter of the mid k_fold instance
 constexpr uint32_t kCtlRetry = 21;        // columns whose key table overflowed in an LDS tier (rerun on the global path)       // bit0: a pair ended with > 16 bins and no scratch was given
 constexpr uint32_t kCtlWords = 32;
 
@@ -498,6 +499,149 @@ __global__ __launch_bounds__(64 * kFoldWavesPerBlock) void k_fold(FoldArgs a) {
     }
 }
 
+// Cooperative fold for pairs with many products: 8 lanes own one pair (8 pairs per wavefront).  Per product the 8 lanes
+// scan the whole state in parallel (position idx = 8*slot + lane), classify every position as orphan (its bin is far from
+// the new overlap estimate: survives, chain.hpp:131-149) or kept/dropped (its bin is dissolved into the new head bin,
+// chain.hpp:114-126), and compact with group ballots + popcounts: new state = orphans, then kept, then the new k-mer --
+// exactly fold_core's layout.  A step costs ~100 instructions whatever the state size, so the heaviest pair of a
+// column no longer decides the kernel's tail.  Same overflow rule as k_fold.
+constexpr uint32_t kCoopLanes = 8;
+constexpr uint32_t kCoopCapP = 64;
+constexpr uint32_t kCoopCapB = 8;
+constexpr uint32_t kCoopSlots = kCoopCapP / kCoopLanes;
+
+template <int BMIN, int BMAX, uint32_t WORK>
+__global__ __launch_bounds__(64 * kFoldWavesPerBlock) void k_fold_coop(FoldArgs a) {
+    constexpr uint32_t GPW = 64 / kCoopLanes;                       // pairs per wavefront
+    constexpr uint32_t GW = kCoopCapP + kCoopCapB;                  // LDS words per pair
+    __shared__ uint32_t lds[GW * GPW * kFoldWavesPerBlock];
+    const uint32_t lane = lane_id();
+    const uint32_t grp = lane / kCoopLanes, j = lane % kCoopLanes;
+    uint32_t* P = lds + (wave_id() * GPW + grp) * GW;
+    uint32_t* Bm = P + kCoopCapP;
+    const uint32_t ltmask = (1u << j) - 1u;
+    uint32_t cnt_b = 0, nch_b = 0;
+    if ((int)lane >= BMIN && (int)lane <= BMAX) { cnt_b = a.ctl[kCtlBucketCnt + lane]; nch_b = (cnt_b + GPW - 1) / GPW; }
+    uint32_t total = 0;
+#pragma unroll
+    for (int b = 0; b < (int)kNumBuckets; ++b) total += __shfl(nch_b, b, 64);
+    for (;;) {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(&a.ctl[WORK], 1u);
+        c = __shfl(c, 0, 64);
+        if (c >= total) break;
+        int bsel = BMIN;
+        uint32_t rem = c;
+        for (int b = BMAX; b >= BMIN; --b) {
+            const uint32_t nb_ = __shfl(nch_b, b, 64);
+            if (rem < nb_) { bsel = b; break; }
+            rem -= nb_;
+        }
+        const uint32_t cntsel = __shfl(cnt_b, bsel, 64);
+        const uint32_t idx = rem * GPW + grp;
+        const bool valid = idx < cntsel;
+        uint4 ds = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) ds = a.desc[a.bucket_base[bsel] + idx];
+        const uint32_t mm = ds.z >> 16;
+        const uint2* base = a.plist + (valid ? a.flopptr[ds.x] + (ds.z & 0xFFFFu) : 0ull);
+        uint32_t np = 1, nb = 1, count = 1;
+        bool ovf = false;
+        uint2 nxt = make_uint2(0u, 0u);
+        if (valid) {
+            const uint2 p0 = base[0];
+            if (j == 0) { P[0] = p0.x; Bm[0] = (p0.y & 0xFFFFu) | (1u << 16); }
+            if (mm > 1) nxt = base[1];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t t = 1; t < mm && !ovf; ++t) {
+            const uint32_t q = nxt.x, ovq = nxt.y & 0xFFFFu;
+            if (t + 1 < mm) nxt = base[t + 1];
+            // bins: which are dissolved, and where each one ends in the position array
+            uint32_t closemask = 0, ce[kCoopCapB];
+            const bool onebin = __all(nb == 1u);                      // wave-uniform fast path (99 % of the pairs)
+            if (onebin) {
+                if (iabs_((int)(Bm[0] & 0xFFFFu) - (int)ovq) < a.binSize) closemask = 1u;
+            } else {
+                uint32_t run = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < kCoopCapB; ++b) {
+                    ce[b] = 0xFFFFFFFFu;
+                    if (b < nb) {
+                        const uint32_t meta = Bm[b];
+                        run += meta >> 16;
+                        ce[b] = run;
+                        if (iabs_((int)(meta & 0xFFFFu) - (int)ovq) < a.binSize) closemask |= 1u << b;
+                    }
+                }
+            }
+            uint32_t reg[kCoopSlots], dst[kCoopSlots];
+            uint32_t norph = 0, nkept = 0;
+#pragma unroll
+            for (uint32_t s = 0; s < kCoopSlots; ++s) {
+                const uint32_t ix = s * kCoopLanes + j;
+                const bool act = ix < np;
+                dst[s] = 0xFFFFFFFFu;
+                reg[s] = 0;
+                if (__ballot(act) == 0ull) continue;                  // no pair of this wavefront has a position in this slot
+                const uint32_t v = act ? P[ix] : 0u;
+                reg[s] = v;
+                uint32_t binid = 0;
+                if (!onebin) {
+#pragma unroll
+                    for (uint32_t b = 0; b < kCoopCapB; ++b) binid += (ix >= ce[b]);
+                }
+                const bool isclose = (closemask >> binid) & 1u;
+                const bool orph = act && !isclose;
+                const bool kept = act && isclose && far_apart(v, q, a.k) != 0u;
+                const uint32_t mo = (uint32_t)(__ballot(orph) >> (grp * kCoopLanes)) & 0xFFu;
+                const uint32_t mk = (uint32_t)(__ballot(kept) >> (grp * kCoopLanes)) & 0xFFu;
+                // destination: orphans keep their order in front; kept ones follow (offset by the orphan total, added below)
+                dst[s] = orph ? (norph + __popc(mo & ltmask)) : (kept ? (0x80000000u | (nkept + __popc(mk & ltmask))) : 0xFFFFFFFFu);
+                norph += __popc(mo);
+                nkept += __popc(mk);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t newnp = norph + nkept + 1;
+            const uint32_t newnb = __popc(~closemask & ((1u << nb) - 1u)) + 1;
+            if (newnp > kCoopCapP || newnb > kCoopCapB) { ovf = true; break; }
+#pragma unroll
+            for (uint32_t s = 0; s < kCoopSlots; ++s) {
+                const uint32_t dd = dst[s];
+                if (dd != 0xFFFFFFFFu) P[(dd & 0x80000000u) ? norph + (dd & 0x7FFFFFFFu) : dd] = reg[s];
+            }
+            if (j == 0) {
+                P[newnp - 1] = q;
+                uint32_t bw = 0;
+                for (uint32_t b = 0; b < nb; ++b)
+                    if (!((closemask >> b) & 1u)) { const uint32_t mt = Bm[b]; Bm[bw++] = mt; }
+                Bm[bw] = ovq | ((nkept + 1) << 16);
+            }
+            __builtin_amdgcn_wave_barrier();
+            np = newnp; nb = newnb;
+            count = (count + 1 + nkept) & 0xFFFFu;
+        }
+        if (valid) {
+            if (ovf) {
+                if (j == 0) a.overflow[atomicAdd(&a.ctl[kCtlOverflow], 1u)] = ds;
+            } else if (j == 0) {
+                uint32_t win = 0, best = 0;
+                for (uint32_t l = 0; l < nb; ++l) {                    // <= 8 bins: std::sort is an insertion sort => first maximum
+                    const uint32_t sp = Bm[nb - 1 - l] >> 16;
+                    if (l == 0 || sp > best) { best = sp; win = l; }
+                }
+                const uint32_t wm = nb - 1 - win;
+                uint32_t end = 0;
+                for (uint32_t b = 0; b <= wm; ++b) end += Bm[b] >> 16;
+                FoldResult fr;
+                fr.count = (uint16_t)count; fr.nbins = (uint16_t)nb; fr.support = (uint16_t)(Bm[wm] >> 16);
+                fr.binov = (uint16_t)(Bm[wm] & 0xFFFFu); fr.seed = P[end - 1]; fr.many_bins = 0;
+                write_pair(a, ds, fr);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // rare: states larger than the LDS budget (or > 8 bins).  In place in HBM on the pair's own list.
 __global__ __launch_bounds__(64) void k_fold_overflow(FoldArgs a) {
     const uint32_t n = a.ctl[kCtlOverflow];
@@ -531,19 +675,26 @@ __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, cons
     if (lane_id() == 0) flops[i] = s;
 }
 
-// tier flags: flag[t*nreads + i] = 1 iff column i belongs to tier t (caps ascending; last tier = global path)
-__global__ void k_tier_flags(const uint32_t* flops, uint32_t nreads, const uint32_t* caps, uint32_t ntiers,
-                             uint8_t* flag, uint32_t* status) {
+// tier lists: column i with f products goes to the first tier whose cap >= f (caps ascending; last tier = global path).
+// One atomic per wavefront and tier; the order inside a list only affects scheduling.
+__global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, uint32_t nreads, const uint32_t* caps, uint32_t ntiers,
+                                                       uint32_t* lists, uint32_t* counts, uint32_t* status) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nreads) return;
-    const uint32_t f = flops[i];
+    const uint32_t f = i < nreads ? flops[i] : 0u;
     uint32_t tier = 0xFFFFFFFFu;
     if (f > 0) {
         for (uint32_t t = 0; t < ntiers; ++t)
             if (f <= caps[t]) { tier = t; break; }
         if (tier == 0xFFFFFFFFu) atomicOr(status, 2u);     // >= 65536 products: wide path missing
     }
-    for (uint32_t t = 0; t < ntiers; ++t) flag[(uint64_t)t * nreads + i] = (tier == t);
+    for (uint32_t t = 0; t < ntiers; ++t) {
+        const unsigned long long mask = __ballot(tier == t);
+        if (mask == 0) continue;
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(&counts[t], (uint32_t)__popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (tier == t) lists[(uint64_t)t * nreads + base + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull))] = i;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_compact_pairs(const uint64_t* flopptr, const uint64_t* colptrC,
