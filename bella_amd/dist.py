@@ -1,0 +1,46 @@
+"""Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in CPU tests).
+
+Output columns of C = A*A^T are independent: rank r computes the columns i with i % world == r
+(`Engine.set_partition`) -- cyclic, because the strictly-lower-triangular work of column i falls with i.  The timed step has
+no collective; gathering the per-rank pair records to rank 0 (16 B per pair) is the only exchange after it."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def partition(rank: int, world: int):
+    """(first, stride) for Engine.set_partition"""
+    return rank % world, world
+
+
+def merge_in_reference_order(parts):
+    """Per-rank pair arrays (each: its columns ascending, slot order inside a column) -> the reference's 1-thread order."""
+    merged = np.concatenate(parts) if len(parts) else np.zeros(0)
+    order = np.argsort(merged["cid"], kind="stable")
+    return merged[order]
+
+
+def gather_pairs(pairs_local: np.ndarray, device=None, group=None):
+    """all ranks call; returns the merged array on rank 0 (None elsewhere).  Records travel as raw bytes, padded to the
+    longest rank so that one all_gather over xGMI (or gloo in tests) carries them."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    n = torch.tensor([pairs_local.nbytes], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    mx = int(max(int(s.item()) for s in sizes))
+    buf = torch.zeros(max(mx, 1), dtype=torch.uint8, device=dev)
+    if pairs_local.nbytes:
+        buf[: pairs_local.nbytes] = torch.from_numpy(pairs_local.view(np.uint8).reshape(-1).copy()).to(dev)
+    outs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)
+    if rank != 0:
+        return None
+    parts = []
+    for o, s in zip(outs, sizes):
+        nb = int(s.item())
+        parts.append(np.frombuffer(o[:nb].cpu().numpy().tobytes(), dtype=pairs_local.dtype))
+    return merge_in_reference_order(parts)
