@@ -17,6 +17,7 @@
 #include "spgemm.hpp"
 #include "util.hpp"
 #include "xdrop.hpp"
+#include "xdrop_packed.hpp"
 
 using namespace bella;
 
@@ -324,14 +325,14 @@ int bella_hip_set_reads(bella_ctx* c, const uint8_t* bases, const uint64_t* offs
                         (unsigned long long)(offsets[r + 1] - offsets[r]));
     }
     const uint64_t nwords = (total + 15) / 16;
-    ENSURE(c, c->packed, 4 * (nwords + 4));
+    ENSURE(c, c->packed, 4 * (nwords + 16));
     ENSURE(c, c->roff, 8 * ((size_t)nreads + 1));
     Buf raw;
     int rc = ensure_bytes(c, raw, total);
     if (rc) return rc;
     hipError_t e = hipMemcpyAsync(raw.p, bases, total, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->roff.p, offsets, 8 * ((size_t)nreads + 1), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->packed.p, 0, 4 * (nwords + 4), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->packed.p, 0, 4 * (nwords + 16), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->status.p, 0, 4, c->stream);
     if (e == hipSuccess && nwords) {
         k_pack_reads<<<nblk(nwords), 256, 0, c->stream>>>(ptr<uint8_t>(raw), total, ptr<uint32_t>(c->packed), nwords,
@@ -725,7 +726,8 @@ static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_se
     a.delta = p->delta_chernoff;
     HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
     if (n) {
-        k_xdrop<<<nblk(n, kXdropPairsPerBlock), kXdropBlock, 0, c->stream>>>(a);
+        if (getenv("BELLA_HIP_XDROP_SCALAR")) k_xdrop<<<nblk(n, kXdropPairsPerBlock), kXdropBlock, 0, c->stream>>>(a);
+        else k_xdrop_packed<<<nblk(n, kXdropPairsPerBlock), kXdropBlock, 0, c->stream>>>(a);
         KCHK(c);
     }
     HIPCHK(c, hipEventRecord(c->ev[9], c->stream));

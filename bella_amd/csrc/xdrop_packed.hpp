@@ -1,0 +1,297 @@
+// xdrop_packed.hpp -- the production X-drop lane function (device only): same semantics as xdrop.hpp's
+// xavier_one_direction (which stays as the readable, host-testable statement of xavier/xavier.h:20-251), restructured for
+// gfx950 issue efficiency:
+//   * two band cells per VGPR as packed i16 (v_pk_add/max/min_i16, v_alignbit for the one-cell shifts): the five 32-cell
+//     vectors take 80 VGPRs instead of 160, so several wavefronts fit a SIMD;
+//   * moveRight / moveDown (simdutils.h:263-289) are per-lane selects, not branches: a wavefront whose lanes disagree does
+//     not execute both variants;
+//   * sequences come from a 64-base register window per stream, topped up at wave-uniform checkpoints (every 16 steps, all
+//     lanes at once, the next block prefetched one period ahead): no lane ever makes the wavefront wait on its own reload.
+// int8 saturation is emulated exactly: every add is followed by the clamp the AVX2 instruction applies (simdutils.h:26-27).
+#pragma once
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#include "xdrop.hpp"
+
+namespace bella {
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ s2 mk2(int a, int b) { s2 r; r.x = (short)a; r.y = (short)b; return r; }
+__device__ __forceinline__ s2 splat2(int a) { return mk2(a, a); }
+__device__ __forceinline__ uint32_t u32_of(s2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s2 s2_of(uint32_t v) { return __builtin_bit_cast(s2, v); }
+__device__ __forceinline__ s2 pmax(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s2 pmin(s2 a, s2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s2 sat8p(s2 v) { return pmin(pmax(v, splat2(-128)), splat2(127)); }
+// cells (e+1, e+2) from words holding (e, e+1) and (e+2, e+3)
+__device__ __forceinline__ s2 shl_cell(s2 cur, s2 next) { return s2_of(__builtin_amdgcn_alignbit(u32_of(next), u32_of(cur), 16)); }
+// cells (e-1, e) from words holding (e-2, e-1) and (e, e+1)
+__device__ __forceinline__ s2 shr_cell(s2 prev, s2 cur) { return s2_of(__builtin_amdgcn_alignbit(u32_of(cur), u32_of(prev), 16)); }
+
+__device__ __forceinline__ uint32_t rev2_32(uint32_t x) {      // reverse the order of the 16 two-bit groups
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(x);
+}
+
+// One sequence as the extension reads it (element t = base g0 + dir*t, complemented if comp), through a register window.
+struct SeqWin {
+    const uint32_t* packed;
+    int64_t g0;
+    int32_t dir;
+    uint32_t comp;       // 0 or 0xFFFFFFFF (complement = bitwise not of the 2-bit codes)
+    uint32_t len;
+    uint32_t wp;         // stream index of the first base in the window
+    uint64_t x0, x1;     // bases [wp, wp+32), [wp+32, wp+64), base i at bits 2(i%32)
+    uint32_t nw;         // prefetched block [wp+64, wp+80)
+
+    // 16 consecutive stream elements starting at t0, element j at bits 2j
+    __device__ __forceinline__ uint32_t block16(uint32_t t0) const {
+        const int64_t g = dir > 0 ? g0 + (int64_t)t0 : g0 - (int64_t)t0 - 15;
+        uint32_t v;
+        if (g >= 0) {
+            const uint64_t w = (uint64_t)g >> 4;
+            const uint32_t sh = (uint32_t)(g & 15) * 2;
+            const uint32_t a = packed[w], b = packed[w + 1];
+            v = sh ? ((a >> sh) | (b << (32 - sh))) : a;
+        } else {                                                   // a reversed stream running off the front of the array:
+            v = g > -16 ? packed[0] << (uint32_t)(-2 * g) : 0u;    // the missing positions are past the stream's end (masked)
+        }
+        if (dir < 0) v = rev2_32(v);
+        return v ^ comp;
+    }
+    __device__ __forceinline__ void init(uint32_t t0) {
+        wp = t0;
+        x0 = (uint64_t)block16(t0) | ((uint64_t)block16(t0 + 16) << 32);
+        x1 = (uint64_t)block16(t0 + 32) | ((uint64_t)block16(t0 + 48) << 32);
+        nw = block16(t0 + 64);
+    }
+    // wave-uniform checkpoint (every 16 steps): t = next element this lane will read
+    __device__ __forceinline__ void checkpoint(uint32_t t) {
+        if (t - wp >= 16u) {
+            x0 = (x0 >> 32) | (x1 << 32);
+            x1 = (x1 >> 32) | ((uint64_t)nw << 32);
+            wp += 16;
+            nw = block16(wp + 64);
+        }
+    }
+    __device__ __forceinline__ int code(uint32_t t) const {
+        if (t >= len) return t == len ? kCodeNul : kCodePad;
+        const uint32_t off = t - wp;
+        const uint64_t x = off < 32u ? x0 : x1;
+        return (int)((x >> ((off & 31u) * 2u)) & 3ull);
+    }
+};
+
+// xavier.h:257-274 on packed state.  h (len >= 32) and v (len >= 32) as SeqAcc geometry; dp = lane-strided LDS scratch.
+__device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, const SeqAcc& Vacc, const int X, int8_t* dp,
+                                                            const int dps, XRes& r) {
+    SeqWin H, V;
+    H.packed = Hacc.packed; H.g0 = Hacc.g0; H.dir = Hacc.dir; H.comp = Hacc.comp ? 0xFFFFFFFFu : 0u; H.len = Hacc.len;
+    V.packed = Vacc.packed; V.g0 = Vacc.g0; V.dir = Vacc.dir; V.comp = Vacc.comp ? 0xFFFFFFFFu : 0u; V.len = Vacc.len;
+    const int hl = (int)H.len + 1, vl = (int)V.len + 1;
+    // ---- Phase 1 (xavier.h:20-103): scalar DP on the 33x33 upper-left triangle (once per extension)
+    const uint64_t hp = (uint64_t)H.block16(0) | ((uint64_t)H.block16(16) << 32);
+    const uint64_t vp = (uint64_t)V.block16(0) | ((uint64_t)V.block16(16) << 32);
+    int8_t* prev = dp;
+    int8_t* cur = dp + 34 * dps;
+    int8_t* ex1 = dp + 68 * dps;
+    int8_t* ex2 = dp + 100 * dps;
+    for (int j = 0; j < 34; ++j) prev[j * dps] = (int8_t)(-j);
+    int DPmax = 0;
+    for (int i = 1; i < kXLW + 2; ++i) {
+        cur[0] = (int8_t)(-i);
+        const int hc = (int)((hp >> (2 * (i - 1))) & 3);
+        int left = -i;
+        for (int j = 1; j <= kXLW + 2 - i; ++j) {
+            const int vc = (int)((vp >> (2 * (j - 1))) & 3);
+            const int oneF = (int)prev[(j - 1) * dps] + (hc == vc ? 1 : -1);
+            const int twoF = imax_((int)prev[j * dps], left) - 1;
+            const int val = imax_(oneF, twoF);
+            cur[j * dps] = (int8_t)val;
+            left = val;
+            DPmax = imax_(DPmax, val);
+        }
+        if (i <= kXLW) ex1[(i - 1) * dps] = cur[(kXLW + 1 - i) * dps];
+        if (i >= 2) ex2[(i - 1) * dps] = cur[(kXLW + 2 - i) * dps];
+        int8_t* tmp = prev; prev = cur; cur = tmp;
+    }
+    s2 a1[16], a2[16], a3[16], qh[16], qv[16];
+    int adm = -128;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e0 = 2 * i, e1 = 2 * i + 1;
+        const int a1x = (int)ex1[e0 * dps], a1y = e1 < kXLW ? (int)ex1[e1 * dps] : kXNinf;
+        const int a2x = e0 >= 1 ? (int)ex2[e0 * dps] : kXNinf, a2y = (int)ex2[e1 * dps];
+        a1[i] = mk2(a1x, a1y);
+        a2[i] = mk2(a2x, a2y);
+        a3[i] = splat2(kXNinf);
+        adm = imax_(adm, a1x);
+        if (e1 < kXLW) adm = imax_(adm, a1y);
+        // vqueryh[e] = queryh[e+1], vqueryv[e] = queryv[31-e] for e < 31; cell 31 = a marker that equals itself
+        const int hx = (int)((hp >> (2 * (e0 + 1))) & 3), hy = e1 < kXLW ? (int)((hp >> (2 * ((e1 + 1) & 31))) & 3) : 7;
+        const int vx = (int)((vp >> (2 * (kXLW - e0))) & 3), vy = e1 < kXLW ? (int)((vp >> (2 * (kXLW - e1))) & 3) : 7;
+        qh[i] = mk2(hx, hy);
+        qv[i] = mk2(vx, vy);
+    }
+    int best = DPmax, off = 0;
+    int hoff = kXLW, voff = kXLW;
+    r.flagged = 0;
+    if (adm < DPmax - X) { r.best = best; r.endH = hoff; r.endV = voff; r.steps = 0; return; }
+
+    H.init((uint32_t)kXLW);
+    V.init((uint32_t)kXLW);
+    const s2 one = splat2(1), mone = splat2(-1), ninf = splat2(kXNinf), k32 = splat2(32);
+
+#define BELLA_PSTEP()                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                 \
+        const s2 xr = s2_of(u32_of(qh[i]) ^ u32_of(qv[i]));                       /* 0 iff the bases match (codes < 8) */ \
+        const s2 mt = pmax(xr * splat2(-2) + one, mone);                          /* +1 match, -1 mismatch */            \
+        const s2 a1f = sat8p(a1[i] + mt);                                                                             \
+        const s2 shv = shl_cell(a2[i], i < 15 ? a2[i < 15 ? i + 1 : 15] : ninf);  /* shiftLeft(antiDiag2) */            \
+        const s2 a2f = pmax(pmax(shv, a2[i]) + mone, ninf);                                                         \
+        a3[i] = pmax(a1f, a2f);                                                                                       \
+    }                                                                                                                 \
+    a3[15].y = (short)kXNinf;
+
+#define BELLA_PKEY(keyout)                                                                                           \
+    {                                                                                                                 \
+        s2 kk = a3[0] * k32 + mk2(31, 30);                                                                            \
+        _Pragma("unroll") for (int i = 1; i < 16; ++i) kk = pmax(kk, a3[i] * k32 + mk2(31 - 2 * i, 30 - 2 * i));      \
+        keyout = imax_((int)kk.x, (int)kk.y);                                                                         \
+    }
+
+#define BELLA_PREBASE()                                                                                              \
+    {                                                                                                                 \
+        s2 mn2 = a3[0];                                                                                               \
+        _Pragma("unroll") for (int i = 1; i < 15; ++i) mn2 = pmin(mn2, a3[i]);                                        \
+        int mn = imin_(imin_((int)mn2.x, (int)mn2.y), (int)a3[15].x);            /* cells 0..30 (LOGICALWIDTH) */      \
+        const s2 mnv = splat2(mn);                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) { a2[i] = sat8p(a2[i] - mnv); a3[i] = sat8p(a3[i] - mnv); }    \
+        off += mn;                                                                                                    \
+    }
+
+// moveRight (simdutils.h:263-274) if `right`, else moveDown (:276-289), as selects
+#define BELLA_PMOVE(right, c)                                                                                        \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                              \
+            const s2 a2l = shl_cell(a2[i], i < 15 ? a2[i < 15 ? i + 1 : 15] : ninf);      /* shiftLeft(antiDiag2) */   \
+            a1[i] = (right) ? a2l : a2[i];                                                                            \
+        }                                                                                                             \
+        _Pragma("unroll") for (int i = 15; i >= 0; --i) {                                                             \
+            const s2 a3r = shr_cell(i > 0 ? a3[i > 0 ? i - 1 : 0] : ninf, a3[i]);        /* shiftRight(antiDiag3) */  \
+            a2[i] = (right) ? a3[i] : a3r;                                                                            \
+        }                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                              \
+            s2 l = shl_cell(qh[i], i < 15 ? qh[i < 15 ? i + 1 : 15] : splat2(7));                                      \
+            if (i == 15) l = mk2((c), 7);                                  /* cell 30 <- new base, cell 31 marker */  \
+            qh[i] = (right) ? l : qh[i];                                                                              \
+        }                                                                                                             \
+        _Pragma("unroll") for (int i = 15; i >= 0; --i) {                                                             \
+            s2 rr = shr_cell(i > 0 ? qv[i > 0 ? i - 1 : 0] : splat2(0), qv[i]);                                        \
+            if (i == 0) rr = mk2((c), (int)qv[0].x);                      /* cell 0 <- new base */                    \
+            qv[i] = (right) ? qv[i] : rr;                                                                             \
+        }                                                                                                             \
+    }
+
+    // ---- Phase 2 (xavier.h:105-183)
+    int maxpos = 0;
+    int endH = hoff, endV = voff;
+    bool first = true;
+    uint32_t tick = 0;
+    while (hoff < hl && voff < vl) {
+        if ((tick & 15u) == 0u) { H.checkpoint((uint32_t)hoff); V.checkpoint((uint32_t)voff); }
+        ++tick;
+        BELLA_PSTEP()
+        int key;
+        BELLA_PKEY(key)
+        const int adb = key >> 5;
+        const int curr = adb + off;
+        if (curr < best - X) {
+            r.best = best; r.endH = hoff; r.endV = voff; r.steps = (hoff - kXLW) + (voff - kXLW);
+            return;
+        }
+        if (adb > kXCutoff) {
+            BELLA_PREBASE()
+            BELLA_PKEY(key)
+        }
+        if (curr > best) best = curr;
+        if ((key >> 5) > 0) maxpos = 31 - (key & 31);
+        else if (first) r.flagged = 1;
+        first = false;
+        endH = hoff; endV = voff;
+        const bool right = maxpos > kXMiddle;
+        const int c = right ? H.code((uint32_t)hoff) : V.code((uint32_t)voff);
+        hoff += right ? 1 : 0;
+        voff += right ? 0 : 1;
+        BELLA_PMOVE(right, c)
+    }
+    // ---- Phase 4 (xavier.h:185-251)
+    int dir = hoff >= hl ? 1 : 0;
+    H.checkpoint((uint32_t)hoff); V.checkpoint((uint32_t)voff);      // 28 more steps: at most 14 per stream, inside the window
+    for (int it = 0; it < kXLW - 3; ++it) {
+        BELLA_PSTEP()
+        int key;
+        BELLA_PKEY(key)
+        const int adb = key >> 5;
+        const int curr = adb + off;
+        if (curr < best - X) break;
+        if (adb > kXCutoff) { BELLA_PREBASE() }
+        if (curr > best) best = curr;
+        const int next = dir ^ 1;
+        const bool right = next == 0;
+        const int c = right ? H.code((uint32_t)hoff) : V.code((uint32_t)voff);
+        hoff += right ? 1 : 0;
+        voff += right ? 0 : 1;
+        BELLA_PMOVE(right, c)
+        dir = next;
+    }
+    r.best = best; r.endH = endH; r.endV = endV; r.steps = (hoff - kXLW) + (voff - kXLW);
+#undef BELLA_PSTEP
+#undef BELLA_PKEY
+#undef BELLA_PREBASE
+#undef BELLA_PMOVE
+}
+
+__global__ __launch_bounds__(kXdropBlock) void k_xdrop_packed(XdropArgs a) {
+    __shared__ int8_t dp[132 * kXdropBlock];
+    const uint64_t p = (uint64_t)blockIdx.x * kXdropPairsPerBlock + (threadIdx.x >> 1);
+    const int which = threadIdx.x & 1;
+    const bool valid = p < a.n;
+    uint32_t rid = 0, cid = 0, seedH = 0, seedV = 0;
+    if (valid) {
+        if (a.seeds) { const bella_seed s = a.seeds[p]; rid = s.rid; cid = s.cid; seedH = s.seedH; seedV = s.seedV; }
+        else { const bella_pair s = a.pairs[p]; rid = s.rid; cid = s.cid; seedH = s.seedH; seedV = s.seedV; }
+    }
+    PairGeom g;
+    XRes res;
+    res.best = 0; res.endH = 0; res.endV = 0; res.flagged = 0; res.steps = 0;
+    bool ran = false;
+    if (valid) {
+        const uint64_t goffH = a.roff[rid], goffV = a.roff[cid];
+        make_geom(a.packed, goffH, (uint32_t)(a.roff[rid + 1] - goffH), goffV, (uint32_t)(a.roff[cid + 1] - goffV), seedH, seedV,
+                  a.k, g);
+        SeqAcc H, V;
+        make_accessors(a.packed, goffH, goffV, g, which, H, V);
+        if (H.len >= (uint32_t)kXW && V.len >= (uint32_t)kXW) {
+            ran = true;
+            xavier_one_direction_packed(H, V, a.xdrop, dp + threadIdx.x, kXdropBlock, res);
+        }
+    }
+    XRes o;
+    o.best = __shfl_down(res.best, 1, 64);
+    o.endH = __shfl_down(res.endH, 1, 64);
+    o.endV = __shfl_down(res.endV, 1, 64);
+    o.flagged = __shfl_down(res.flagged, 1, 64);
+    o.steps = __shfl_down(res.steps, 1, 64);
+    const int oran = __shfl_down((int)ran, 1, 64);
+    if (valid && which == 0) {
+        bella_aln out;
+        finish_pair(g, ran, res, oran != 0, o, a.ratiophi, a.delta, out);
+        a.out[p] = out;
+    }
+}
+
+}  // namespace bella
+#endif

@@ -84,10 +84,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("BELLA_BENCH_BACKEND", "nccl")       # "gloo" only to exercise the N>1 path on a 1-GPU box
+    local = local % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
     n_gpus = world
     assert a.gpus == n_gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
 
@@ -135,7 +140,8 @@ def main():
         launches += tm.spgemm_launches
     sync()
     elapsed = time.perf_counter() - ts
-    tt = torch.tensor([elapsed, float(npairs), float(flops), kern_ms], dtype=torch.float64, device="cuda:%d" % local)
+    tt = torch.tensor([elapsed, float(npairs), float(flops), kern_ms], dtype=torch.float64,
+                      device=("cuda:%d" % local) if backend == "nccl" else "cpu")
     if world > 1:
         mx = tt.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -162,8 +168,6 @@ def main():
             % (len(al), npass, xms, t_al * 1e3, len(al) / (xms * 1e-3), steps_tot / (xms * 1e-3), 31 * steps_tot / (xms * 1e-3) / 1e9,
                int(al["flagged"].sum())))
 
-    nnzA = int(eng.get_B()[0][-1]) if False else None
-    nnz = int(np.uint64(0))
     colptr, _, _ = eng.get_B()
     nnz = int(colptr[-1])
     ms_per_step = elapsed * 1e3 / a.steps

@@ -1,0 +1,30 @@
+#!/usr/bin/env bash
+# HBM traffic of the SpGEMM kernels from the PMC counters (MI355X_MICROARCH.md "HBM"): FETCH_SIZE and WRITE_SIZE in SEPARATE
+# passes, each with --kernel-trace only.  Run on the GPU box:  bash tools/collect_traffic.sh  (writes gpurun_out/traffic/)
+set -euo pipefail
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/traffic
+mkdir -p "$OUT"
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -o t -- python "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/bench_$C.json" 2> "$OUT/bench_$C.err" || true
+done
+python - <<PY
+import csv, collections, json, glob
+out = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob("$OUT/%s/*counter_collection.csv" % c)
+    if not f: continue
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] != c: continue
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
+    out[c] = {k: {"sum_kb": v[0], "dispatches": v[1]} for k, v in agg.items() if "bella::" in k}
+json.dump(out, open("$OUT/traffic_raw.json", "w"), indent=1)
+steps = 5
+def tot(c, pred):
+    return sum(v["sum_kb"] for k, v in out.get(c, {}).items() if pred(k)) * 1024 / steps
+sp = lambda k: "k_spgemm_rows" in k or "k_fold" in k
+print("per step (5 dispatch groups): FETCH raw %.1f MB, WRITE raw %.1f MB (spgemm rows + fold kernels)" % (tot("FETCH_SIZE", sp) / 1e6, tot("WRITE_SIZE", sp) / 1e6))
+PY
