@@ -67,7 +67,7 @@ struct bella_ctx {
     uint32_t n_overflow = 0;
     // alignment
     uint64_t nalns = 0;
-    Buf alns, seeds;
+    Buf alns, seeds, xest, xest2, xids, xorder, xres;
     bella_timings tm{};
     hipEvent_t ev[10]{};
     hipStream_t side[kNumTiers + 1]{};   // independent tier launches / fold instances run concurrently
@@ -290,7 +290,7 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->Brow, &c->deg, &c->minread, &c->colstart,
                   &c->fill, &c->ori, &c->w, &c->wscan, &c->Atmp, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC, &c->tierflag,
                   &c->rowlists, &c->tiercnt, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
-                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->plist_ov, &c->desc, &c->overflow, &c->ctl, &c->dbg, &c->retry};
+                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->plist_ov, &c->desc, &c->overflow, &c->ctl, &c->dbg, &c->retry, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& st : c->side) (void)hipStreamDestroy(st);
@@ -726,9 +726,41 @@ static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_se
     a.delta = p->delta_chernoff;
     HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
     if (n) {
-        if (getenv("BELLA_HIP_XDROP_SCALAR")) k_xdrop<<<nblk(n, kXdropPairsPerBlock), kXdropBlock, 0, c->stream>>>(a);
-        else k_xdrop_packed<<<nblk(n, kXdropPairsPerBlock), kXdropBlock, 0, c->stream>>>(a);
-        KCHK(c);
+        if (getenv("BELLA_HIP_XDROP_SCALAR")) {
+            k_xdrop<<<nblk(n, kXdropPairsPerBlock), kXdropBlock, 0, c->stream>>>(a);
+            KCHK(c);
+        } else if (getenv("BELLA_HIP_XDROP_UNSORTED")) {
+            k_xdrop_packed<<<nblk(n, kXdropPairsPerBlock), kXdropBlock, 0, c->stream>>>(a);
+            KCHK(c);
+        } else {
+            // plan -> sort extensions by their step bound (longest first) -> run -> combine
+            const uint64_t ne = 2 * n;
+            ENSURE(c, c->xest, 4 * ne);
+            ENSURE(c, c->xest2, 4 * ne);
+            ENSURE(c, c->xids, 4 * ne);
+            ENSURE(c, c->xorder, 4 * ne);
+            ENSURE(c, c->xres, 16 * ne);
+            XdropSortedArgs sa;
+            sa.a = a;
+            sa.est = ptr<uint32_t>(c->xest);
+            sa.ids = ptr<uint32_t>(c->xids);
+            sa.order = ptr<uint32_t>(c->xorder);
+            sa.res = ptr<int4>(c->xres);
+            k_xdrop_plan<<<nblk(ne), 256, 0, c->stream>>>(sa);
+            KCHK(c);
+            size_t tb = 0;
+            HIPCHK(c, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, ptr<uint32_t>(c->xest), ptr<uint32_t>(c->xest2),
+                                                                  ptr<uint32_t>(c->xids), ptr<uint32_t>(c->xorder), (int)ne, 0, 18,
+                                                                  c->stream));
+            ENSURE(c, c->cubtmp, tb);
+            HIPCHK(c, hipcub::DeviceRadixSort::SortPairsDescending(c->cubtmp.p, tb, ptr<uint32_t>(c->xest), ptr<uint32_t>(c->xest2),
+                                                                  ptr<uint32_t>(c->xids), ptr<uint32_t>(c->xorder), (int)ne, 0, 18,
+                                                                  c->stream));
+            k_xdrop_sorted<<<nblk(ne, kXdropBlock), kXdropBlock, 0, c->stream>>>(sa);
+            KCHK(c);
+            k_xdrop_finish<<<nblk(n), 256, 0, c->stream>>>(sa);
+            KCHK(c);
+        }
     }
     HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev[9]));

@@ -293,5 +293,80 @@ __global__ __launch_bounds__(kXdropBlock) void k_xdrop_packed(XdropArgs a) {
     }
 }
 
+// ---- length-sorted scheduling ---------------------------------------------------------------------------------------
+// The extensions of a batch differ a lot in length (seed position, read lengths, junk pairs): with pair order a wavefront
+// runs until its longest lane ends.  Plan -> sort by an upper bound of the steps (descending: longest first) -> run in
+// that order -> combine left/right per pair.
+struct XdropSortedArgs {
+    XdropArgs a;
+    uint32_t* est;          // [2n] upper bound on anti-diagonal steps of extension e = 2*pair + which
+    uint32_t* ids;          // [2n] extension ids (iota before the sort, order after)
+    const uint32_t* order;  // [2n] sorted extension ids
+    int4* res;              // [2n] {best, endH, endV, flagged | ran << 1 | steps << 2}
+};
+
+__device__ __forceinline__ void xdrop_load_pair(const XdropArgs& a, uint64_t p, uint32_t& rid, uint32_t& cid, uint32_t& seedH,
+                                                uint32_t& seedV) {
+    if (a.seeds) { const bella_seed s = a.seeds[p]; rid = s.rid; cid = s.cid; seedH = s.seedH; seedV = s.seedV; }
+    else { const bella_pair s = a.pairs[p]; rid = s.rid; cid = s.cid; seedH = s.seedH; seedV = s.seedV; }
+}
+
+__global__ void k_xdrop_plan(XdropSortedArgs sa) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * sa.a.n) return;
+    uint32_t rid, cid, seedH, seedV;
+    xdrop_load_pair(sa.a, e >> 1, rid, cid, seedH, seedV);
+    const uint64_t goffH = sa.a.roff[rid], goffV = sa.a.roff[cid];
+    PairGeom g;
+    make_geom(sa.a.packed, goffH, (uint32_t)(sa.a.roff[rid + 1] - goffH), goffV, (uint32_t)(sa.a.roff[cid + 1] - goffV), seedH, seedV,
+              sa.a.k, g);
+    SeqAcc H, V;
+    make_accessors(sa.a.packed, goffH, goffV, g, (int)(e & 1), H, V);
+    const bool run = H.len >= (uint32_t)kXW && V.len >= (uint32_t)kXW;
+    sa.est[e] = run ? H.len + V.len : 0u;      // Phase 2 ends when either sequence is exhausted: at most lenH + lenV moves
+    sa.ids[e] = (uint32_t)e;
+}
+
+__global__ __launch_bounds__(kXdropBlock) void k_xdrop_sorted(XdropSortedArgs sa) {
+    __shared__ int8_t dp[132 * kXdropBlock];
+    const XdropArgs& a = sa.a;
+    const uint64_t t = (uint64_t)blockIdx.x * kXdropBlock + threadIdx.x;
+    if (t >= 2 * a.n) return;
+    const uint32_t e = sa.order[t];
+    uint32_t rid, cid, seedH, seedV;
+    xdrop_load_pair(a, e >> 1, rid, cid, seedH, seedV);
+    const uint64_t goffH = a.roff[rid], goffV = a.roff[cid];
+    PairGeom g;
+    make_geom(a.packed, goffH, (uint32_t)(a.roff[rid + 1] - goffH), goffV, (uint32_t)(a.roff[cid + 1] - goffV), seedH, seedV, a.k, g);
+    SeqAcc H, V;
+    make_accessors(a.packed, goffH, goffV, g, (int)(e & 1), H, V);
+    XRes res;
+    res.best = 0; res.endH = 0; res.endV = 0; res.flagged = 0; res.steps = 0;
+    bool ran = false;
+    if (H.len >= (uint32_t)kXW && V.len >= (uint32_t)kXW) {
+        ran = true;
+        xavier_one_direction_packed(H, V, a.xdrop, dp + threadIdx.x, kXdropBlock, res);
+    }
+    sa.res[e] = make_int4(res.best, res.endH, res.endV, (res.flagged & 1) | (ran ? 2 : 0) | (res.steps << 2));
+}
+
+__global__ void k_xdrop_finish(XdropSortedArgs sa) {
+    const XdropArgs& a = sa.a;
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    uint32_t rid, cid, seedH, seedV;
+    xdrop_load_pair(a, p, rid, cid, seedH, seedV);
+    const uint64_t goffH = a.roff[rid], goffV = a.roff[cid];
+    PairGeom g;
+    make_geom(a.packed, goffH, (uint32_t)(a.roff[rid + 1] - goffH), goffV, (uint32_t)(a.roff[cid + 1] - goffV), seedH, seedV, a.k, g);
+    const int4 l = sa.res[2 * p], r = sa.res[2 * p + 1];
+    XRes L, R;
+    L.best = l.x; L.endH = l.y; L.endV = l.z; L.flagged = l.w & 1; L.steps = l.w >> 2;
+    R.best = r.x; R.endH = r.y; R.endV = r.z; R.flagged = r.w & 1; R.steps = r.w >> 2;
+    bella_aln out;
+    finish_pair(g, (l.w & 2) != 0, L, (r.w & 2) != 0, R, a.ratiophi, a.delta, out);
+    a.out[p] = out;
+}
+
 }  // namespace bella
 #endif
