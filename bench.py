@@ -191,6 +191,15 @@ def main():
                                "compaction": comp_ms / a.steps},
         "assemble_ms": asm_ms,
     }
+    # HBM traffic of the same kernels from the PMC counters (tools/collect_traffic.sh, separate FETCH_SIZE / WRITE_SIZE passes,
+    # gfx950 FETCH_SIZE x2 correction calibrated on our own stream): a profiling run, so read from the committed summary
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+        if n_gpus == 1 and nreads == 10000 and abs(tr["algorithmic_bytes"] - alg_bytes) < 1e-3 * alg_bytes:
+            out["roofline"]["traffic"] = tr["hbm_bytes_corrected"]
+            out["roofline"]["traffic_source"] = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per step)"
+    except Exception:
+        pass
     if n_gpus == 1 and not a.no_cpu_baseline:
         try:
             import tempfile
