@@ -41,6 +41,10 @@ SIGNATURES = [
     ("bella_hip_set_reads", C.c_int, [vp, vp, vp, C.c_uint32]),
     ("bella_hip_assemble_tuples", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint64, vp, vp, vp]),
     ("bella_hip_set_B", C.c_int, [vp, C.c_uint16, C.c_uint32, vp, vp, vp]),
+    ("bella_hip_assemble_panel", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp]),
+    ("bella_hip_panel_device_ptrs", C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(vp),
+                                               C.POINTER(vp), C.POINTER(vp)]),
+    ("bella_hip_set_B_device", C.c_int, [vp, C.c_uint16, C.c_uint32, vp, vp, vp, C.c_uint64]),
     ("bella_hip_get_B", C.c_int, [vp, C.POINTER(C.c_uint64), vp, vp, vp]),
     ("bella_hip_set_partition", C.c_int, [vp, C.c_uint32, C.c_uint32]),
     ("bella_hip_overlap", C.c_int, [vp, C.POINTER(Params), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -92,6 +92,37 @@ class Engine:
         values = np.ascontiguousarray(values, np.uint16)
         self._chk(self.lib.bella_hip_set_B(self.h, k, nkmers, colptr.ctypes.data, _p(rowids), _p(values)))
 
+    # ---- multi-GPU assembly: row-block panels ----
+    def assemble_panel(self, k, nkmers, first_read, nreads_panel, tk, tr, tp):
+        tk = np.ascontiguousarray(tk, np.uint32); tr = np.ascontiguousarray(tr, np.uint32); tp = np.ascontiguousarray(tp, np.uint16)
+        self._chk(self.lib.bella_hip_assemble_panel(self.h, k, nkmers, first_read, nreads_panel, len(tk), _p(tk), _p(tr), _p(tp)))
+
+    def panel_tensors(self, device_index=0):
+        """(rowcnt int32[rows], rowids int32[nnz], values int16[nnz]) torch tensors ALIASING the library's device buffers
+        (valid until the next assembly call) -- what goes into the all-gather."""
+        import torch
+        first, rows, nnz = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+        pc, pr, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self.lib.bella_hip_panel_device_ptrs(self.h, C.byref(first), C.byref(rows), C.byref(nnz), C.byref(pc), C.byref(pr),
+                                                       C.byref(pv)))
+
+        class _Alias:
+            def __init__(self, ptr, n, typestr):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+        dev = torch.device("cuda", device_index)
+
+        def t(ptr, n, typestr, dt):
+            return torch.as_tensor(_Alias(ptr, n, typestr), device=dev) if n else torch.zeros(0, dtype=dt, device=dev)
+        return (t(pc.value, rows.value, "<i4", torch.int32), t(pr.value, nnz.value, "<i4", torch.int32),
+                t(pv.value, nnz.value, "<i2", torch.int16))
+
+    def set_B_device(self, k, nkmers, colptr_t, rowids_t, values_t):
+        """full B from torch device tensors (int32 colptr[nreads+1], int32 rowids, int16 values)"""
+        nnz = int(rowids_t.numel())
+        self._chk(self.lib.bella_hip_set_B_device(self.h, k, nkmers, colptr_t.data_ptr(), rowids_t.data_ptr() if nnz else None,
+                                                  values_t.data_ptr() if nnz else None, nnz))
+
     def get_B(self):
         nnz = C.c_uint64(0)
         self._chk(self.lib.bella_hip_get_B(self.h, C.byref(nnz), None, None, None))

@@ -38,12 +38,14 @@ __global__ void k_pack_reads(const uint8_t* bases, uint64_t total, uint32_t* pac
 }
 
 // tstart[r] = first tuple of read r (tuples grouped by non-decreasing read id); tstart[nreads] = ntuples
-__global__ void k_tuple_bounds(const uint32_t* t_read, uint64_t ntuples, uint32_t nreads, uint64_t* tstart, uint32_t* status) {
+// (reads are numbered from `first`: a panel of the matrix holds the rows first .. first+nreads-1)
+__global__ void k_tuple_bounds(const uint32_t* t_read, uint64_t ntuples, uint32_t first, uint32_t nreads, uint64_t* tstart,
+                               uint32_t* status) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t > ntuples) return;
-    const int64_t prev = t == 0 ? -1 : (int64_t)t_read[t - 1];
-    const int64_t cur = t == ntuples ? (int64_t)nreads : (int64_t)t_read[t];
-    if (cur < prev || (t < ntuples && cur >= (int64_t)nreads)) { atomicOr(status, 8u); return; }
+    const int64_t prev = t == 0 ? -1 : (int64_t)t_read[t - 1] - (int64_t)first;
+    const int64_t cur = t == ntuples ? (int64_t)nreads : (int64_t)t_read[t] - (int64_t)first;
+    if (cur < prev || prev < -1 || (t < ntuples && cur >= (int64_t)nreads)) { atomicOr(status, 8u); return; }
     for (int64_t r = prev + 1; r <= cur; ++r) tstart[r] = t;
 }
 

@@ -56,6 +56,9 @@ struct bella_ctx {
     bool have_reads = false, have_matrix = false, have_pairs = false, have_alns = false;
     Buf Bptr, Bk, Bpos, Bent, Aent;
     uint32_t part_first = 0, part_stride = 1;
+    bool have_panel = false;
+    uint32_t panel_first = 0, panel_rows = 0;
+    uint64_t panel_nnz = 0;
     // assembly temporaries
     Buf t_kmer, t_read, t_pos, tstart, Bk_tmp, Bpos_tmp, rowcnt, asm_ws;
     Buf Brow, deg, minread, colstart, fill, ori, w, wscan, Atmp;
@@ -381,14 +384,9 @@ int bella_hip_set_B(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, const uin
     return 0;
 }
 
-int bella_hip_assemble_tuples(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, uint64_t ntuples, const uint32_t* t_kmer,
-                              const uint32_t* t_read, const uint16_t* t_pos) {
-    if (!c || (ntuples && (!t_kmer || !t_read || !t_pos))) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
-    if (!c->have_reads) return fail(c, BELLA_ERR_STATE, "set_reads first");
-    if (kmer_size < 1 || kmer_size > 32) return fail(c, BELLA_ERR_BAD_ARG, "k must be in [1,32]");
-    if (ntuples >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "tuple count must be < 2^32");
-    HIPCHK(c, hipSetDevice(c->device));
-    const uint32_t nr = c->nreads;
+// tuples of the reads first .. first+nr-1 -> their rows of B (CSR: c->Bptr local offsets, c->Bk, c->Bpos), on device
+static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint64_t ntuples, const uint32_t* t_kmer,
+                                const uint32_t* t_read, const uint16_t* t_pos, uint64_t* nnz_out) {
     ENSURE(c, c->t_kmer, 4 * ntuples);
     ENSURE(c, c->t_read, 4 * ntuples);
     ENSURE(c, c->t_pos, 2 * ntuples);
@@ -407,7 +405,7 @@ int bella_hip_assemble_tuples(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers,
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->rowcnt.p, 0, 4 * ((size_t)nr + 2), c->stream));
-    k_tuple_bounds<<<nblk(ntuples + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->t_read), ntuples, nr, ptr<uint64_t>(c->tstart),
+    k_tuple_bounds<<<nblk(ntuples + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->t_read), ntuples, first, nr, ptr<uint64_t>(c->tstart),
                                                              ptr<uint32_t>(c->status));
     KCHK(c);
     uint32_t st = 0;
@@ -449,6 +447,22 @@ int bella_hip_assemble_tuples(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers,
                                                                 ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos));
         KCHK(c);
     }
+    *nnz_out = nnz;
+    return 0;
+}
+
+int bella_hip_assemble_tuples(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, uint64_t ntuples, const uint32_t* t_kmer,
+                              const uint32_t* t_read, const uint16_t* t_pos) {
+    if (!c || (ntuples && (!t_kmer || !t_read || !t_pos))) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+    if (!c->have_reads) return fail(c, BELLA_ERR_STATE, "set_reads first");
+    if (kmer_size < 1 || kmer_size > 32) return fail(c, BELLA_ERR_BAD_ARG, "k must be in [1,32]");
+    if (ntuples >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "tuple count must be < 2^32");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->have_matrix = c->have_pairs = c->have_alns = false;
+    c->have_panel = false;
+    uint64_t nnz = 0;
+    int rc = assemble_rows_device(c, 0, c->nreads, ntuples, t_kmer, t_read, t_pos, &nnz);
+    if (rc) return rc;
     c->nkmers = nkmers;
     c->nnz = nnz;
     c->kmer_size = kmer_size;
@@ -458,6 +472,78 @@ int bella_hip_assemble_tuples(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers,
     HIPCHK(c, hipEventSynchronize(c->ev[1]));
     c->tm.assemble_ms = ev_ms(c->ev[0], c->ev[1]);
     release(c->t_kmer); release(c->t_read); release(c->t_pos); release(c->Bk_tmp); release(c->Bpos_tmp); release(c->asm_ws);
+    return 0;
+}
+
+int bella_hip_assemble_panel(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, uint32_t first_read, uint32_t nreads_panel,
+                             uint64_t ntuples, const uint32_t* t_kmer, const uint32_t* t_read, const uint16_t* t_pos) {
+    if (!c || (ntuples && (!t_kmer || !t_read || !t_pos))) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+    if (!c->have_reads) return fail(c, BELLA_ERR_STATE, "set_reads first");
+    if (kmer_size < 1 || kmer_size > 32) return fail(c, BELLA_ERR_BAD_ARG, "k must be in [1,32]");
+    if ((uint64_t)first_read + nreads_panel > c->nreads) return fail(c, BELLA_ERR_BAD_ARG, "panel exceeds the read set");
+    if (ntuples >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "tuple count must be < 2^32");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->have_matrix = c->have_pairs = c->have_alns = false;
+    c->have_panel = false;
+    uint64_t nnz = 0;
+    int rc = assemble_rows_device(c, first_read, nreads_panel, ntuples, t_kmer, t_read, t_pos, &nnz);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    c->tm.assemble_ms = ev_ms(c->ev[0], c->ev[1]);
+    release(c->t_kmer); release(c->t_read); release(c->t_pos); release(c->Bk_tmp); release(c->Bpos_tmp); release(c->asm_ws);
+    c->nkmers = nkmers;
+    c->kmer_size = kmer_size;
+    c->panel_first = first_read;
+    c->panel_rows = nreads_panel;
+    c->panel_nnz = nnz;
+    c->have_panel = true;
+    return 0;
+}
+
+int bella_hip_panel_device_ptrs(bella_ctx* c, uint32_t* first_read, uint32_t* nreads_panel, uint64_t* nnz, const void** d_rowcnt,
+                                const void** d_rowids, const void** d_values) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    if (!c->have_panel) return fail(c, BELLA_ERR_STATE, "assemble_panel first");
+    if (first_read) *first_read = c->panel_first;
+    if (nreads_panel) *nreads_panel = c->panel_rows;
+    if (nnz) *nnz = c->panel_nnz;
+    if (d_rowcnt) *d_rowcnt = c->rowcnt.p;
+    if (d_rowids) *d_rowids = c->Bk.p;
+    if (d_values) *d_values = c->Bpos.p;
+    return 0;
+}
+
+int bella_hip_set_B_device(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, const uint32_t* d_colptr, const uint32_t* d_rowids,
+                           const uint16_t* d_values, uint64_t nnz) {
+    if (!c || !d_colptr || (nnz && (!d_rowids || !d_values))) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+    if (!c->have_reads) return fail(c, BELLA_ERR_STATE, "set_reads first");
+    if (kmer_size < 1 || kmer_size > 32) return fail(c, BELLA_ERR_BAD_ARG, "k must be in [1,32]");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->have_matrix = c->have_pairs = c->have_alns = false;
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    // the sources may alias our own panel buffers: stage through fresh allocations
+    Buf nBptr, nBk, nBpos;
+    int rc = ensure_bytes(c, nBptr, 4 * ((size_t)c->nreads + 2));
+    if (!rc) rc = ensure_bytes(c, nBk, 4 * nnz);
+    if (!rc) rc = ensure_bytes(c, nBpos, 2 * nnz);
+    if (rc) { release(nBptr); release(nBk); release(nBpos); return rc; }
+    hipError_t e = hipMemcpyAsync(nBptr.p, d_colptr, 4 * ((size_t)c->nreads + 1), hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess && nnz) e = hipMemcpyAsync(nBk.p, d_rowids, 4 * nnz, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess && nnz) e = hipMemcpyAsync(nBpos.p, d_values, 2 * nnz, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { release(nBptr); release(nBk); release(nBpos); return fail(c, BELLA_ERR_HIP, "set_B_device: %s", hipGetErrorString(e)); }
+    release(c->Bptr); release(c->Bk); release(c->Bpos);
+    c->Bptr = nBptr; c->Bk = nBk; c->Bpos = nBpos;
+    c->have_panel = false;
+    c->nkmers = nkmers;
+    c->nnz = nnz;
+    c->kmer_size = kmer_size;
+    rc = build_layout(c);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    c->tm.assemble_ms = ev_ms(c->ev[0], c->ev[1]);
     return 0;
 }
 

@@ -44,3 +44,44 @@ def gather_pairs(pairs_local: np.ndarray, device=None, group=None):
         nb = int(s.item())
         parts.append(np.frombuffer(o[:nb].cpu().numpy().tobytes(), dtype=pairs_local.dtype))
     return merge_in_reference_order(parts)
+
+
+def block_range(rank: int, world: int, nreads: int):
+    """contiguous read block owned by `rank` for ASSEMBLY (the compute partition is cyclic, see partition())"""
+    lo = (nreads * rank) // world
+    hi = (nreads * (rank + 1)) // world
+    return lo, hi - lo
+
+
+def allgather_panels(rowcnt, rowids, values, group=None):
+    """The one exchange of the multi-GPU path: every rank contributes the rows of B of its read block (torch tensors on the
+    rank's GPU -- RCCL over xGMI -- or on the CPU with gloo in tests) and receives the whole matrix:
+    returns (colptr int32[nreads+1], rowids int32[nnz], values int16[nnz]) on the same device."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = rowcnt.device
+    sizes = torch.tensor([rowcnt.numel(), rowids.numel()], dtype=torch.int64, device=dev)
+    allsz = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(allsz, sizes, group=group)
+    allsz = [(int(s[0].item()), int(s[1].item())) for s in allsz]
+    mr = max(1, max(a for a, _ in allsz))
+    mn = max(1, max(b for _, b in allsz))
+
+    def gather(x, pad_to, dtype):
+        buf = torch.zeros(pad_to, dtype=dtype, device=dev)
+        buf[: x.numel()] = x
+        raw = buf.view(torch.uint8)                      # bytes: every backend moves them (gloo has no int16)
+        outs = [torch.zeros_like(raw) for _ in range(world)]
+        dist.all_gather(outs, raw, group=group)
+        return [o.view(dtype) for o in outs]
+
+    g_cnt = gather(rowcnt, mr, torch.int32)
+    g_ids = gather(rowids, mn, torch.int32)
+    g_val = gather(values, mn, torch.int16)
+    cnt = torch.cat([g[:a] for g, (a, _) in zip(g_cnt, allsz)])
+    ids = torch.cat([g[:b] for g, (_, b) in zip(g_ids, allsz)])
+    val = torch.cat([g[:b] for g, (_, b) in zip(g_val, allsz)])
+    colptr = torch.zeros(cnt.numel() + 1, dtype=torch.int32, device=dev)
+    colptr[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+    return colptr, ids, val

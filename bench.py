@@ -106,9 +106,32 @@ def main():
         log("[bench] reads %d (%.1f s), reliable k-mers %d, tuples %d (%.1f s)" % (nreads, t1 - t0, tup.nkmers, len(tup.kmer), t2 - t1))
 
     eng = Engine(local)
-    eng.set_reads(rs)
-    eng.assemble_tuples(17, tup.nkmers, tup.kmer, tup.read, tup.pos)
-    asm_ms = eng.timings().assemble_ms
+    eng.set_reads(rs)                                   # reads are replicated (2 bit/base)
+    xchg_ms = None
+    if world == 1:
+        eng.assemble_tuples(17, tup.nkmers, tup.kmer, tup.read, tup.pos)
+        asm_ms = eng.timings().assemble_ms
+    else:
+        # row-block panels: each rank assembles the rows of B of ITS reads, one all-gather (RCCL over xGMI) gives every rank
+        # the whole matrix, which goes back into the library through device pointers
+        from bella_amd import dist as bd
+        lo, npanel = bd.block_range(rank, world, nreads)
+        sel = (tup.read >= lo) & (tup.read < lo + npanel)
+        eng.assemble_panel(17, tup.nkmers, lo, npanel, tup.kmer[sel], tup.read[sel], tup.pos[sel])
+        asm_ms = eng.timings().assemble_ms
+        pc, pr, pv = eng.panel_tensors(local)
+        if backend != "nccl":
+            pc, pr, pv = pc.cpu(), pr.cpu(), pv.cpu()
+        torch.cuda.synchronize()
+        dist.barrier()
+        tx = time.perf_counter()
+        colptr_t, ids_t, val_t = bd.allgather_panels(pc, pr, pv)
+        torch.cuda.synchronize()
+        xchg_ms = (time.perf_counter() - tx) * 1e3
+        dev = torch.device("cuda", local)
+        eng.set_B_device(17, tup.nkmers, colptr_t.to(dev), ids_t.to(dev), val_t.to(dev))
+        asm_ms += eng.timings().assemble_ms
+        del colptr_t, ids_t, val_t
     eng.set_partition(rank, n_gpus)
     eng.set_debug(2)                 # diagnostics array (pair_ext) off in the timed path
     pars = BellaPars(skipAlignment=True)
@@ -189,7 +212,7 @@ def main():
                      "launches_per_step": launches / a.steps, "algorithmic_bytes_per_step": alg_bytes},
         "phases_ms_per_step": {"symbolic+tiering": sym_ms / a.steps, "row_kernels": rows_ms / a.steps, "fold_kernels": fold_ms / a.steps,
                                "compaction": comp_ms / a.steps},
-        "assemble_ms": asm_ms,
+        "assemble_ms": asm_ms, "panel_allgather_ms": xchg_ms,
     }
     # HBM traffic of the same kernels from the PMC counters (tools/collect_traffic.sh, separate FETCH_SIZE / WRITE_SIZE passes,
     # gfx950 FETCH_SIZE x2 correction calibrated on our own stream): a profiling run, so read from the committed summary

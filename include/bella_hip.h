@@ -128,6 +128,17 @@ int bella_hip_assemble_tuples(bella_ctx* ctx, uint16_t kmer_size, uint32_t nkmer
  * A = spmat is derived on device (ascending read ids per k-mer = the reference's 1-thread Transpose). */
 int bella_hip_set_B(bella_ctx* ctx, uint16_t kmer_size, uint32_t nkmers, const uint32_t* colptr,
                     const uint32_t* rowids, const uint16_t* values);
+/* Multi-GPU assembly: rank r builds only the rows of B of ITS reads (a row-block panel) from their tuples (global read ids,
+ * same rules as above); the panels' device arrays are exchanged with one all-gather (RCCL over xGMI, done by the caller:
+ * bella_amd/dist.py) and the full matrix comes back through bella_hip_set_B_device.  Rows = per-read entry counts (u32),
+ * rowids = k-mer ids in MergeDuplicates slot order (u32), values = positions (u16). */
+int bella_hip_assemble_panel(bella_ctx* ctx, uint16_t kmer_size, uint32_t nkmers, uint32_t first_read, uint32_t nreads_panel,
+                             uint64_t ntuples, const uint32_t* t_kmer, const uint32_t* t_read, const uint16_t* t_pos);
+int bella_hip_panel_device_ptrs(bella_ctx* ctx, uint32_t* first_read, uint32_t* nreads_panel, uint64_t* nnz,
+                                const void** d_rowcnt, const void** d_rowids, const void** d_values);
+/* As bella_hip_set_B, from DEVICE pointers (colptr[nreads+1], rowids[nnz], values[nnz]); copied, the caller keeps ownership. */
+int bella_hip_set_B_device(bella_ctx* ctx, uint16_t kmer_size, uint32_t nkmers, const uint32_t* d_colptr, const uint32_t* d_rowids,
+                           const uint16_t* d_values, uint64_t nnz);
 /* Copies B back in the reference's layout (tests: compare with CSC.cpp's result). Any pointer may be NULL. */
 int bella_hip_get_B(bella_ctx* ctx, uint64_t* nnz, uint32_t* colptr, uint32_t* rowids, uint16_t* values);
 

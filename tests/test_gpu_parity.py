@@ -321,3 +321,29 @@ def test_many_bins_overflow_path_and_std_sort_order(eng):
     exp = _run_constructed(eng, [30000, 30000, 6000, 6000], [a, b, c, d], 300)
     by = {(int(p["rid"]), int(p["cid"])): p for p in exp}
     assert by[(1, 0)]["nbins"] > 16 and by[(3, 2)]["support"] > 64
+
+
+def test_panel_assembly_and_device_set_B(eng):
+    """multi-GPU assembly path on one GPU: two row-block panels assembled separately, concatenated on the device (what the
+    all-gather does), handed back through bella_hip_set_B_device -> same B and same pairs as the one-shot assembly"""
+    import torch
+    from bella_amd import dist as bd
+    g = load_golden("toylen80")
+    eng.set_reads(g.rs)
+    parts = []
+    for r in range(2):
+        lo, n = bd.block_range(r, 2, g.rs.nreads)
+        sel = (g.tr >= lo) & (g.tr < lo + n)
+        eng.assemble_panel(g.k, g.nkmers, lo, n, g.tk[sel], g.tr[sel], g.tp[sel])
+        parts.append([t.clone() for t in eng.panel_tensors(0)])
+    cnt = torch.cat([p[0] for p in parts]); ids = torch.cat([p[1] for p in parts]); val = torch.cat([p[2] for p in parts])
+    colptr = torch.zeros(cnt.numel() + 1, dtype=torch.int32, device=cnt.device)
+    colptr[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+    eng.set_B_device(g.k, g.nkmers, colptr, ids, val)
+    exp = O.build_B(g.rs.nreads, g.tk, g.tr, g.tp)
+    for a, b in zip(eng.get_B(), exp):
+        assert np.array_equal(a, b)
+    eng.overlap(BellaPars())
+    pairs, ext, _ = eng.get_pairs()
+    _, _, _, ep = oracle_pairs(g.rs, g.seqs, g.nkmers, g.tk, g.tr, g.tp, g.k)
+    check_pairs(pairs, ext, ep, g.rs.lengths, g.k)

@@ -43,6 +43,16 @@ def _worker(rank, world, port, q):
         ok = merged.tobytes() == whole.tobytes() and len(merged) > 1000
     else:
         ok = merged is None
+    # the panel exchange: every rank assembles the rows of B of its read block (oracle stands in for k_asm_rows) and
+    # all-gathers; every rank must end up with the reference's whole B
+    import torch
+    lo, n = bd.block_range(rank, world, g.rs.nreads)
+    sel = (g.tr >= lo) & (g.tr < lo + n)
+    pc, pr, pv = O.build_B(n, g.tk[sel], (g.tr[sel] - lo).astype(np.uint32), g.tp[sel])
+    colptr, ids, val = bd.allgather_panels(torch.from_numpy(np.diff(pc.astype(np.int64)).astype(np.int32)),
+                                           torch.from_numpy(pr.astype(np.int32)), torch.from_numpy(pv.astype(np.int16)))
+    ok = ok and np.array_equal(colptr.numpy().astype(np.uint32), Bc) and np.array_equal(ids.numpy().astype(np.uint32), Br) \
+        and np.array_equal(val.numpy().astype(np.uint16), Bv)
     q.put((rank, bool(ok), len(mine)))
     dist.barrier()
     dist.destroy_process_group()
