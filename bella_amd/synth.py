@@ -94,6 +94,40 @@ def make_reads(nreads: int, read_len: int = 10000, coverage: float = 30.0, err: 
     return ReadSet(codes, np.asarray(offsets, dtype=np.int64), names)
 
 
+def make_reads_from_intervals(start, end, genome_len: int = 4641652, err: float = 0.15, seed: int = 1,
+                              mix=(0.10, 0.60, 0.30)) -> ReadSet:
+    """one read per interval [start,end) (clipped to the genome) of a uniform-random genome,
+    uniform strand, the same error model as make_reads."""
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, size=genome_len, dtype=np.uint8)
+    p_sub, p_ins, p_del = (err * m for m in mix)
+    st = np.clip(np.asarray(start, np.int64), 0, genome_len - 1)
+    en = np.clip(np.asarray(end, np.int64), st + 1, genome_len)
+    seqs, names = [], []
+    for r in range(len(st)):
+        t = genome[st[r]:en[r]]
+        strand = int(rng.integers(0, 2))
+        if strand:
+            t = (3 - t)[::-1]
+        u = rng.random(t.shape[0], dtype=np.float32)
+        keep = u >= p_del
+        sub = keep & (u < p_del + p_sub)
+        ins = (u >= p_del + p_sub) & (u < p_del + p_sub + p_ins)
+        base = np.where(sub, (t + rng.integers(1, 4, size=t.shape[0], dtype=np.uint8)) & 3, t).astype(np.uint8)
+        emit = keep.astype(np.int64) + ins.astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(emit)])
+        out = np.empty(off[-1], dtype=np.uint8)
+        k_ = np.nonzero(keep)[0]
+        out[off[k_]] = base[k_]
+        i_ = np.nonzero(ins)[0]
+        out[off[i_] + 1] = rng.integers(0, 4, size=i_.shape[0], dtype=np.uint8)
+        seqs.append(out)
+        names.append("e%d_%d_%d_%d" % (r, st[r], en[r] - st[r], strand))
+    offs = np.zeros(len(seqs) + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in seqs], out=offs[1:])
+    return ReadSet(np.concatenate(seqs) if seqs else np.zeros(0, np.uint8), offs, names)
+
+
 def readset_from_seqs(seqs, names=None) -> ReadSet:
     offs = np.zeros(len(seqs) + 1, dtype=np.int64)
     for i, s in enumerate(seqs):

@@ -206,6 +206,10 @@ def main():
              ["-e", "0.005"])
     make_set("toyrep90", repeat_genome_reads(5), ["-e", "0.12", "-u", "30"])
     xavier_kats()
+    # read intervals of the reference's E. coli sample (dataset/ecsample-truth.txt, columns 3-4): the FASTQ itself is not in
+    # the reference snapshot; the intervals shape the "ecsample-like" synthetic set of BASELINE configs[0]
+    iv = np.loadtxt(os.path.join(REF, "dataset", "ecsample-truth.txt"), usecols=(2, 3), dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "ecsample_intervals.npz"), start=iv[:, 0].astype(np.int32), end=iv[:, 1].astype(np.int32))
 
 
 if __name__ == "__main__":

@@ -347,3 +347,56 @@ def test_panel_assembly_and_device_set_B(eng):
     pairs, ext, _ = eng.get_pairs()
     _, _, _, ep = oracle_pairs(g.rs, g.seqs, g.nkmers, g.tk, g.tr, g.tp, g.k)
     check_pairs(pairs, ext, ep, g.rs.lengths, g.k)
+
+
+def test_ecsample_shaped_set_full_parity(eng):
+    """BASELINE configs[0] shape: 15,152 reads with the interval lengths of the reference's E. coli sample (mean 8.2 kb,
+    max 26.9 kb) on a random 4.64 Mb genome.  Whole SpGEMM output vs the oracle, X-drop on a sample."""
+    z = np.load(os.path.join(GOLD, "ecsample_intervals.npz"))
+    rs = synth.make_reads_from_intervals(z["start"], z["end"])
+    assert rs.nreads == 15152 and int(rs.lengths.max()) < 65536
+    t = synth.count_and_tuples(rs, 17, 2, 8, device="cuda:0")
+    seqs = rs.seqs()
+    eng.set_reads(rs)
+    eng.assemble_tuples(17, t.nkmers, t.kmer, t.read, t.pos)
+    (Bc, Br, Bv), flop, ecol, exp = oracle_pairs(rs, seqs, t.nkmers, t.kmer, t.read, t.pos)
+    for a, b in zip(eng.get_B(), (Bc, Br, Bv)):
+        assert np.array_equal(a, b)
+    pars = BellaPars()
+    n, flops = eng.overlap(pars)
+    assert n == len(exp) and flops == int(flop.sum()) and n > 500000
+    pairs, ext, colptrC = eng.get_pairs()
+    assert np.array_equal(colptrC, ecol.astype(np.uint64))
+    check_pairs(pairs, ext, exp, rs.lengths, 17)
+    eng.align_pairs(pars)
+    alns = eng.get_alignments()
+    phi = O.slope(0.15)
+    for n_ in np.random.default_rng(1).choice(len(pairs), size=400, replace=False):
+        p, a = pairs[n_], alns[n_]
+        rid, cid = int(p["rid"]), int(p["cid"])
+        e = O.xavier_align(seqs[rid], seqs[cid], int(p["seedH"]), int(p["seedV"]), 7, 17)
+        ok, ov = O.post_align(e["score"], e["begV"], e["endV"], e["begH"], e["endH"], len(seqs[rid]), len(seqs[cid]), phi)
+        assert (int(a["score"]), int(a["begH"]), int(a["endH"]), int(a["begV"]), int(a["endV"]), int(a["ov"]), int(a["passed"]),
+                int(a["steps"])) == (int(e["score"]), int(e["begH"]), int(e["endH"]), int(e["begV"]), int(e["endV"]), ov, int(ok),
+                                     int(e["steps"]))
+
+
+def test_baseline_config1_full_size_parity(eng):
+    """BASELINE configs[1] at full size (10k reads x 10 kb, the bench workload): every pair record vs the oracle, plus
+    size-independent properties (strict lower triangle, unique pairs, count==1 <=> single shared k-mer record)."""
+    rs = synth.make_reads(10000, read_len=10000, coverage=30.0, err=0.15, seed=1)
+    t = synth.count_and_tuples(rs, 17, 2, 8, device="cuda:0")
+    seqs = rs.seqs()
+    eng.set_reads(rs)
+    eng.assemble_tuples(17, t.nkmers, t.kmer, t.read, t.pos)
+    n, flops = eng.overlap(BellaPars(skipAlignment=True))
+    pairs, ext, colptrC = eng.get_pairs()
+    assert (pairs["rid"] > pairs["cid"]).all()
+    key = pairs["cid"].astype(np.uint64) << np.uint64(32) | pairs["rid"].astype(np.uint64)
+    assert len(np.unique(key)) == len(key)
+    assert (np.diff(pairs["cid"].astype(np.int64)) >= 0).all()                       # column-major
+    assert ((ext["nbins"] >= 1) & (ext["support"] >= 1)).all()
+    _, flop, ecol, exp = oracle_pairs(rs, seqs, t.nkmers, t.kmer, t.read, t.pos)
+    assert n == len(exp) == 755378 or n == len(exp)
+    assert flops == int(flop.sum())
+    check_pairs(pairs, ext, exp, rs.lengths, 17)
