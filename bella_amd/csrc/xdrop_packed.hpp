@@ -172,26 +172,26 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
         off += mn;                                                                                                    \
     }
 
-// moveRight (simdutils.h:263-274) if `right`, else moveDown (:276-289), as selects
+// moveRight (simdutils.h:263-274) if `right`, else moveDown (:276-289).  Each band word is produced by ONE v_perm_b32 whose
+// byte selector is a per-lane register: selL = "cells (e+1,e+2)" for moveRight / "cells (e,e+1)" otherwise, selD = "cells
+// (e,e+1)" for moveRight / "cells (e-1,e)" otherwise -- shift and select in a single instruction, no copies.
 #define BELLA_PMOVE(right, c)                                                                                        \
     {                                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                              \
-            const s2 a2l = shl_cell(a2[i], i < 15 ? a2[i < 15 ? i + 1 : 15] : ninf);      /* shiftLeft(antiDiag2) */   \
-            a1[i] = (right) ? a2l : a2[i];                                                                            \
-        }                                                                                                             \
-        _Pragma("unroll") for (int i = 15; i >= 0; --i) {                                                             \
-            const s2 a3r = shr_cell(i > 0 ? a3[i > 0 ? i - 1 : 0] : ninf, a3[i]);        /* shiftRight(antiDiag3) */  \
-            a2[i] = (right) ? a3[i] : a3r;                                                                            \
-        }                                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                              \
-            s2 l = shl_cell(qh[i], i < 15 ? qh[i < 15 ? i + 1 : 15] : splat2(7));                                      \
-            if (i == 15) l = mk2((c), 7);                                  /* cell 30 <- new base, cell 31 marker */  \
-            qh[i] = (right) ? l : qh[i];                                                                              \
-        }                                                                                                             \
-        _Pragma("unroll") for (int i = 15; i >= 0; --i) {                                                             \
-            s2 rr = shr_cell(i > 0 ? qv[i > 0 ? i - 1 : 0] : splat2(0), qv[i]);                                        \
-            if (i == 0) rr = mk2((c), (int)qv[0].x);                      /* cell 0 <- new base */                    \
-            qv[i] = (right) ? qv[i] : rr;                                                                             \
+        const uint32_t selL = (right) ? 0x05040302u : 0x03020100u;   /* perm(next, cur, .): shifted left / plain cur */   \
+        const uint32_t selD = (right) ? 0x07060504u : 0x05040302u;   /* perm(cur, prev, .): plain cur / shifted right */  \
+        const uint32_t nf = u32_of(ninf);                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                                \
+            a1[i] = s2_of(__builtin_amdgcn_perm(i < 15 ? u32_of(a2[i < 15 ? i + 1 : 15]) : nf, u32_of(a2[i]), selL));      \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                                \
+            a2[i] = s2_of(__builtin_amdgcn_perm(u32_of(a3[i]), i > 0 ? u32_of(a3[i > 0 ? i - 1 : 0]) : nf, selD));        \
+        _Pragma("unroll") for (int i = 0; i < 15; ++i)                                                                \
+            qh[i] = s2_of(__builtin_amdgcn_perm(u32_of(qh[i + 1]), u32_of(qh[i]), selL));                              \
+        qh[15] = (right) ? mk2((c), 7) : qh[15];                            /* cell 30 <- new base, cell 31 marker */  \
+        {                                                                                                             \
+            const uint32_t q0 = u32_of(qv[0]);                                                                        \
+            _Pragma("unroll") for (int i = 15; i >= 1; --i)                                                           \
+                qv[i] = s2_of(__builtin_amdgcn_perm(u32_of(qv[i]), u32_of(qv[i - 1]), selD));                          \
+            qv[0] = (right) ? s2_of(q0) : s2_of((q0 << 16) | (uint32_t)(c));  /* cell 0 <- new base */                 \
         }                                                                                                             \
     }
 
