@@ -63,7 +63,7 @@ struct bella_ctx {
     Buf t_kmer, t_read, t_pos, tstart, Bk_tmp, Bpos_tmp, rowcnt, asm_ws;
     Buf Brow, deg, minread, colstart, fill, ori, w, wscan, Atmp;
     // overlap
-    uint64_t flops = 0, npairs = 0;
+    uint64_t flops = 0, npairs = 0, F_full = 0;
     Buf flopsr, flopptr, nnzC, colptrC, tierflag, rowlists, tiercnt, tiercaps, tmp_pairs, tmp_ext, pairs, ext, sortscr, ws,
         status, cubtmp, plist_hv, plist_ov, desc, overflow, ctl, dbg, retry;
     uint32_t n_retry = 0;
@@ -207,11 +207,19 @@ int build_layout(bella_ctx* c) {
                                                          ptr<uint2>(c->Aent), ptr<uint2>(c->Bent), ptr<uint32_t>(c->status));
         KCHK(c);
     }
+    HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 2, 0, 8, c->stream));
+    if (nk) {
+        k_total_products<<<nblk(nk), 256, 0, c->stream>>>(ptr<uint32_t>(c->deg), nk, (unsigned long long*)(ptr<uint32_t>(c->status) + 2));
+        KCHK(c);
+    }
+    unsigned long long ffull = 0;
+    HIPCHK(c, hipMemcpyAsync(&ffull, ptr<uint32_t>(c->status) + 2, 8, hipMemcpyDeviceToHost, c->stream));
     uint32_t st = 0;
     int rc = read_status(c, &st);
     if (rc) return rc;
     rc = status_to_error(c, st);
     if (rc) return rc;
+    c->F_full = ffull;
     // assembly temporaries are large (tens of bytes per nonzero): give them back
     release(c->Brow); release(c->deg); release(c->minread); release(c->colstart); release(c->fill); release(c->ori);
     release(c->w); release(c->wscan); release(c->Atmp);
@@ -563,21 +571,48 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     const uint32_t nr = c->nreads;
     const bool force_global = (c->debug & 1u) != 0;
     const bool want_ext = (c->debug & 2u) == 0;
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    // every size below derives from F_full (known since assembly): no host round trip inside the pass
+    const uint64_t Fub = c->F_full;
+    uint64_t bbase[kNumBuckets];
+    uint64_t ndesc = 0;
+    for (uint32_t b = 0; b < kNumBuckets; ++b) { bbase[b] = ndesc; ndesc += b ? (Fub >> b) + 64 : 0; }
+    const uint64_t ws_stride = (row_mem_bytes(65535, 65535) + 255) & ~(size_t)255;
     ENSURE(c, c->flopsr, 4 * ((size_t)nr + 2));
     ENSURE(c, c->flopptr, 8 * ((size_t)nr + 2));
     ENSURE(c, c->nnzC, 4 * ((size_t)nr + 2));
     ENSURE(c, c->colptrC, 8 * ((size_t)nr + 2));
-    ENSURE(c, c->tierflag, (size_t)kNumTiers * nr);
     ENSURE(c, c->rowlists, 4 * (size_t)kNumTiers * nr);
     ENSURE(c, c->tiercnt, 4 * kNumTiers);
     ENSURE(c, c->tiercaps, 4 * kNumTiers);
     ENSURE(c, c->ctl, 4 * kCtlWords + 8 * kNumBuckets + 64);
+    ENSURE(c, c->tmp_pairs, sizeof(bella_pair) * Fub);
+    if (want_ext) ENSURE(c, c->tmp_ext, sizeof(bella_pair_ext) * Fub);
+    ENSURE(c, c->plist_hv, 8 * Fub);
+    ENSURE(c, c->desc, 16 * ndesc);
+    ENSURE(c, c->overflow, 16 * ((Fub >> 1) + 64));
+    ENSURE(c, c->sortscr, 2 * Fub);
+    ENSURE(c, c->ws, ws_stride * kGlobalGrid);
+    ENSURE(c, c->retry, 4 * ((size_t)nr + 1));
+    // nnz(C) <= products; a column cannot have more pairs than reads after it
+    const uint64_t Pub = Fub;
+    ENSURE(c, c->pairs, sizeof(bella_pair) * Pub);
+    if (want_ext) ENSURE(c, c->ext, sizeof(bella_pair_ext) * Pub);
+    size_t tb1 = 0;
+    {
+        hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> it(ptr<uint32_t>(c->flopsr), CastU64());
+        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, it, ptr<uint64_t>(c->flopptr), (int)nr + 1, c->stream));
+    }
+    ENSURE(c, c->cubtmp, tb1 + 256);
+
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     uint32_t caps[kNumTiers];
     for (uint32_t t = 0; t < kNumTiers; ++t) caps[t] = force_global && t + 1 < kNumTiers ? 0 : kTierCaps[t];
     HIPCHK(c, hipMemcpyAsync(c->tiercaps.p, caps, sizeof(caps), hipMemcpyHostToDevice, c->stream));
+    uint64_t* d_bbase = (uint64_t*)(ptr<uint32_t>(c->ctl) + kCtlWords);
+    HIPCHK(c, hipMemcpyAsync(d_bbase, bbase, sizeof(bbase), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * kCtlWords, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->tiercnt.p, 0, 4 * kNumTiers, c->stream));
     HIPCHK(c, hipMemsetAsync(c->flopsr.p, 0, 4 * ((size_t)nr + 2), c->stream));
     HIPCHK(c, hipMemsetAsync(c->nnzC.p, 0, 4 * ((size_t)nr + 2), c->stream));
     k_row_flops<<<nblk(nr, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint2>(c->Bent), nr, c->part_first,
@@ -585,37 +620,14 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     KCHK(c);
     int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->flopsr), ptr<uint64_t>(c->flopptr), (uint64_t)nr + 1);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->tiercnt.p, 0, 4 * kNumTiers, c->stream));
     k_tier_lists<<<nblk(nr), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, ptr<uint32_t>(c->tiercaps), kNumTiers,
                                                   ptr<uint32_t>(c->rowlists), ptr<uint32_t>(c->tiercnt), ptr<uint32_t>(c->status));
     KCHK(c);
+    // the one host round trip before the row kernels: the tiers' lengths (exact grids; 24 bytes)
     uint32_t tcnt[kNumTiers];
-    uint64_t F = 0;
     HIPCHK(c, hipMemcpyAsync(tcnt, c->tiercnt.p, sizeof(tcnt), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&F, ptr<uint64_t>(c->flopptr) + nr, 8, hipMemcpyDeviceToHost, c->stream));
-    uint32_t st = 0;
-    rc = read_status(c, &st);
-    if (rc) return rc;
-    rc = status_to_error(c, st);
-    if (rc) return rc;
-    c->flops = F;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-
-    // bucket b (2^b <= products of a pair < 2^(b+1)) can hold at most F >> b descriptors
-    uint64_t bbase[kNumBuckets];
-    uint64_t ndesc = 0;
-    for (uint32_t b = 0; b < kNumBuckets; ++b) { bbase[b] = ndesc; ndesc += b ? (F >> b) + 64 : 0; }
-    ENSURE(c, c->tmp_pairs, sizeof(bella_pair) * F);
-    if (want_ext) ENSURE(c, c->tmp_ext, sizeof(bella_pair_ext) * F);
-    ENSURE(c, c->plist_hv, 8 * F);
-    ENSURE(c, c->desc, 16 * ndesc);
-    ENSURE(c, c->overflow, 16 * ((F >> 1) + 64));
-    ENSURE(c, c->sortscr, 2 * F);
-    uint64_t* d_bbase = (uint64_t*)(ptr<uint32_t>(c->ctl) + kCtlWords);
-    HIPCHK(c, hipMemcpyAsync(d_bbase, bbase, sizeof(bbase), hipMemcpyHostToDevice, c->stream));
-    const uint64_t ws_stride = (row_mem_bytes(65535, 65535) + 255) & ~(size_t)255;
-    ENSURE(c, c->ws, ws_stride * kGlobalGrid);
-    ENSURE(c, c->retry, 4 * ((size_t)nr + 1));
 
     SpgemmArgs a;
     a.Bptr = ptr<uint32_t>(c->Bptr);
@@ -635,6 +647,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     a.nrows_dev = nullptr;
     a.ws = ptr<uint8_t>(c->ws);
     a.ws_stride = ws_stride;
+    a.nrows = 0;
     a.k = p->kmer_size;
     a.binSize = p->bin_size;
     a.phase = nullptr;
@@ -645,8 +658,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     }
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     uint32_t launches = 0;
-    // the tiers are independent launches of the same kernel with different LDS budgets: fork them onto side streams
-    // (largest columns first) so that their tails overlap, then join
+    // the tiers are independent persistent launches of the same kernel with different LDS budgets, forked onto side streams
+    // (largest columns first) so that they run concurrently; their column counts stay on the device
     HIPCHK(c, hipEventRecord(c->fork, c->stream));
     for (int t = (int)kNumTiers - 1; t >= 0; --t) {
         if (!tcnt[t]) continue;
@@ -654,6 +667,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         HIPCHK(c, hipStreamWaitEvent(sst, c->fork, 0));
         a.rowlist = ptr<uint32_t>(c->rowlists) + (size_t)t * nr;
         a.nrows = tcnt[t];
+        a.nrows_dev = nullptr;
         a.cap = kTierCaps[t];
         if (t + 1 < (int)kNumTiers) {
             const size_t lds = row_mem_bytes(a.cap, a.cap / 2);
@@ -670,7 +684,6 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     }
     // columns whose pair count overflowed an LDS tier's key table (list and count produced on the device)
     a.rowlist = ptr<uint32_t>(c->retry);
-    a.nrows = 0;
     a.nrows_dev = ptr<uint32_t>(c->ctl) + kCtlRetry;
     k_spgemm_rows_global<<<kGlobalGrid, kRowBlock, 0, c->stream>>>(a);
     KCHK(c);
@@ -690,13 +703,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     fa.k = a.k;
     fa.binSize = a.binSize;
     fa.dbg = nullptr;
-    if (phase_timers) {
-        ENSURE(c, c->dbg, 8 * 48);
-        HIPCHK(c, hipMemsetAsync(c->dbg.p, 0, 8 * 48, c->stream));
-        fa.dbg = ptr<unsigned long long>(c->dbg);
-    }
-    if (F) {
-        // heavy pairs on the main stream, light pairs concurrently on a side stream
+    {
+        // heaviest pairs (cooperative) on the main stream, the two lane-per-pair instances concurrently on side streams
         HIPCHK(c, hipEventRecord(c->fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side[kNumTiers], c->fork, 0));
         HIPCHK(c, hipStreamWaitEvent(c->side[0], c->fork, 0));
@@ -716,18 +724,6 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
     rc = scan_u32_to_u64(c, ptr<uint32_t>(c->nnzC), ptr<uint64_t>(c->colptrC), (uint64_t)nr + 1);
     if (rc) return rc;
-    uint64_t P = 0;
-    uint32_t ctl_host[kCtlWords];
-    HIPCHK(c, hipMemcpyAsync(&P, ptr<uint64_t>(c->colptrC) + nr, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(ctl_host, c->ctl.p, sizeof(ctl_host), hipMemcpyDeviceToHost, c->stream));
-    rc = read_status(c, &st);
-    if (rc) return rc;
-    *status_out = ctl_host[kCtlStatus];
-    c->n_overflow = ctl_host[kCtlOverflow];
-    c->n_retry = ctl_host[kCtlRetry];
-    c->npairs = P;
-    ENSURE(c, c->pairs, sizeof(bella_pair) * P);
-    if (want_ext) ENSURE(c, c->ext, sizeof(bella_pair_ext) * P);
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     if (nr) {
         k_compact_pairs<<<nblk(nr, kWaves), kBlock, 0, c->stream>>>(ptr<uint64_t>(c->flopptr), ptr<uint64_t>(c->colptrC),
@@ -738,7 +734,23 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         KCHK(c);
     }
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
-    HIPCHK(c, hipEventSynchronize(c->ev[7]));
+    // the pass's only host round trip: counters, totals and status
+    uint64_t P = 0, F = 0;
+    uint32_t ctl_host[kCtlWords], st = 0;
+    HIPCHK(c, hipMemcpyAsync(&P, ptr<uint64_t>(c->colptrC) + nr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&F, ptr<uint64_t>(c->flopptr) + nr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ctl_host, c->ctl.p, sizeof(ctl_host), hipMemcpyDeviceToHost, c->stream));
+    rc = read_status(c, &st);
+    if (rc) return rc;
+    rc = status_to_error(c, st);
+    if (rc) return rc;
+    *status_out = ctl_host[kCtlStatus];
+    c->n_overflow = ctl_host[kCtlOverflow];
+    c->n_retry = ctl_host[kCtlRetry];
+    c->npairs = P;
+    c->flops = F;
+    if (F > Fub) return fail(c, BELLA_ERR_STATE, "internal: product total %llu above the assembly-time bound %llu",
+                             (unsigned long long)F, (unsigned long long)Fub);
     c->tm.symbolic_ms = ev_ms(c->ev[2], c->ev[3]);
     c->tm.spgemm_ms = ev_ms(c->ev[4], c->ev[5]);
     c->tm.fold_ms = ev_ms(c->ev[5], c->ev[8]);
@@ -753,11 +765,6 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
                         "rows %.3f ms (retried columns %u), fold %.3f ms (overflow pairs %u), symbolic %.3f ms, compact %.3f ms\n",
                 100.0 * ph[0] / tot, 100.0 * ph[1] / tot, 100.0 * ph[2] / tot, 100.0 * ph[3] / tot, 100.0 * ph[4] / tot,
                 c->tm.spgemm_ms, c->n_retry, c->tm.fold_ms, c->n_overflow, c->tm.symbolic_ms, c->tm.compact_ms);
-        unsigned long long dbg[48];
-        HIPCHK(c, hipMemcpy(dbg, c->dbg.p, sizeof(dbg), hipMemcpyDeviceToHost));
-        for (int b = 1; b < 16; ++b)
-            if (dbg[b * 3 + 2]) fprintf(stderr, "[bella_hip]   fold bucket %2d: chunks %7llu  mean wave cycles/chunk %9.0f  max %9llu\n", b, dbg[b * 3 + 2],
-                                        (double)dbg[b * 3] / dbg[b * 3 + 2], dbg[b * 3 + 1]);
     }
     return 0;
 }

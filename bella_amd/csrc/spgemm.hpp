@@ -347,7 +347,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     return true;
 }
 
-// LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap, cap/2)
+// LDS tiers: one column per workgroup (the hardware dispatcher interleaves the tiers' workgroups better than persistent
+// loops do when their LDS sizes differ); dynamic LDS = row_mem_bytes(cap, cap/2)
 __global__ __launch_bounds__(kRowBlock) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t i = a.rowlist[blockIdx.x];
@@ -657,6 +658,17 @@ __global__ __launch_bounds__(64) void k_fold_overflow(FoldArgs a) {
         if (fr.many_bins) atomicOr(&a.ctl[kCtlStatus], 1u);
         write_pair(a, ds, fr);
     }
+}
+
+// sum over k-mers of deg*(deg-1)/2 = the products of the whole lower triangle: sizes every F-dependent buffer at assembly
+// time, so that a pass needs no host round trip for them (a partition only lowers it)
+__global__ void k_total_products(const uint32_t* deg, uint32_t nkmers, unsigned long long* out) {
+    const uint32_t km = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (km < nkmers) { const unsigned long long dg = deg[km]; v = dg * (dg - 1) / 2; }
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) v += __shfl_xor(v, dlt, 64);
+    if (lane_id() == 0 && v) atomicAdd(out, v);
 }
 
 // estimateFLOP (overlap.hpp:157-202, lowtri): products of column i = sum of the suffix counts of its entries.
