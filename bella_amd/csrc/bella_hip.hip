@@ -287,8 +287,8 @@ int bella_hip_init(int device, bella_ctx** out) {
     for (auto& st : c->side) (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
     for (auto& e : c->join) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    if (ensure_bytes(c, c->status, 64)) { delete c; return BELLA_ERR_NOMEM; }
-    (void)hipMemset(c->status.p, 0, 64);
+    if (ensure_bytes(c, c->status, 256)) { delete c; return BELLA_ERR_NOMEM; }
+    (void)hipMemset(c->status.p, 0, 256);
     *out = c;
     return 0;
 }
@@ -576,7 +576,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     uint64_t bbase[kNumBuckets];
     uint64_t ndesc = 0;
     for (uint32_t b = 0; b < kNumBuckets; ++b) { bbase[b] = ndesc; ndesc += b ? (Fub >> b) + 64 : 0; }
-    const uint64_t ws_stride = (row_mem_bytes(65535, 65535) + 255) & ~(size_t)255;
+    const uint64_t ws_stride = (row_mem_bytes(65535, 65535, false) + 255) & ~(size_t)255;
     ENSURE(c, c->flopsr, 4 * ((size_t)nr + 2));
     ENSURE(c, c->flopptr, 8 * ((size_t)nr + 2));
     ENSURE(c, c->nnzC, 4 * ((size_t)nr + 2));
@@ -653,7 +653,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     a.phase = nullptr;
     const bool phase_timers = getenv("BELLA_HIP_PHASE_TIMERS") != nullptr;
     if (phase_timers) {
-        HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 4, 0, 40, c->stream));
+        HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 4, 0, 48, c->stream));
         a.phase = (unsigned long long*)(ptr<uint32_t>(c->status) + 4);
     }
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
@@ -670,7 +670,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         a.nrows_dev = nullptr;
         a.cap = kTierCaps[t];
         if (t + 1 < (int)kNumTiers) {
-            const size_t lds = row_mem_bytes(a.cap, a.cap / 2);
+            const size_t lds = row_mem_bytes(a.cap, a.cap / 2, true);
             HIPCHK(c, hipFuncSetAttribute((const void*)k_spgemm_rows_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             k_spgemm_rows_lds<<<tcnt[t], kRowBlock, lds, sst>>>(a);
         } else {
@@ -704,20 +704,10 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     fa.binSize = a.binSize;
     fa.dbg = nullptr;
     {
-        // heaviest pairs (cooperative) on the main stream, the two lane-per-pair instances concurrently on side streams
-        HIPCHK(c, hipEventRecord(c->fork, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->side[kNumTiers], c->fork, 0));
-        HIPCHK(c, hipStreamWaitEvent(c->side[0], c->fork, 0));
-        k_fold_coop<7, 15, kCtlWork><<<kFoldGrid / 4, 64 * kFoldWavesPerBlock, 0, c->stream>>>(fa);
+        // only the pairs whose value does not stay single-bin (~1 %) reach these kernels: one wavefront per pair keeps their
+        // latency low (list staged through LDS); states beyond its LDS budget finish in k_fold_overflow
+        k_fold_coop<64, 128, 1, 15, kCtlWork><<<kFoldGrid, 64 * kFoldWavesPerBlock, 0, c->stream>>>(fa);
         KCHK(c);
-        k_fold<64, 5, 6, kCtlWorkMid><<<kFoldGrid, 64 * kFoldWavesPerBlock, 0, c->side[0]>>>(fa);
-        KCHK(c);
-        k_fold<32, 1, kFoldLightMaxBucket, kCtlWorkLight><<<2 * kFoldGrid, 64 * kFoldWavesPerBlock, 0, c->side[kNumTiers]>>>(fa);
-        KCHK(c);
-        HIPCHK(c, hipEventRecord(c->join[0], c->side[0]));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[0], 0));
-        HIPCHK(c, hipEventRecord(c->join[kNumTiers], c->side[kNumTiers]));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[kNumTiers], 0));
         k_fold_overflow<<<256, 64, 0, c->stream>>>(fa);
         KCHK(c);
     }
@@ -758,12 +748,12 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     c->tm.overlap_total_ms = ev_ms(c->ev[2], c->ev[7]);
     c->tm.spgemm_launches = launches;
     if (phase_timers) {
-        unsigned long long ph[5];
-        HIPCHK(c, hipMemcpy(ph, ptr<uint32_t>(c->status) + 4, 40, hipMemcpyDeviceToHost));
-        const double tot = (double)(ph[0] + ph[1] + ph[2] + ph[3] + ph[4]) + 1e-9;
-        fprintf(stderr, "[bella_hip] row-kernel phase cycles: expand %.1f%% order %.1f%% scatter %.1f%% rank/emit %.1f%% describe %.1f%% ; "
+        unsigned long long ph[6];
+        HIPCHK(c, hipMemcpy(ph, ptr<uint32_t>(c->status) + 4, 48, hipMemcpyDeviceToHost));
+        const double tot = (double)(ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) + 1e-9;
+        fprintf(stderr, "[bella_hip] row-kernel phase cycles: expand %.1f%% order %.1f%% scatter %.1f%% rank %.1f%% parallel-fold %.1f%% emit %.1f%% ; "
                         "rows %.3f ms (retried columns %u), fold %.3f ms (overflow pairs %u), symbolic %.3f ms, compact %.3f ms\n",
-                100.0 * ph[0] / tot, 100.0 * ph[1] / tot, 100.0 * ph[2] / tot, 100.0 * ph[3] / tot, 100.0 * ph[4] / tot,
+                100.0 * ph[0] / tot, 100.0 * ph[1] / tot, 100.0 * ph[2] / tot, 100.0 * ph[3] / tot, 100.0 * ph[4] / tot, 100.0 * ph[5] / tot,
                 c->tm.spgemm_ms, c->n_retry, c->tm.fold_ms, c->n_overflow, c->tm.symbolic_ms, c->tm.compact_ms);
     }
     return 0;

@@ -54,6 +54,7 @@ constexpr uint32_t kCtlWork2 = 18;        // k_fold_overflow counter
 constexpr uint32_t kCtlStatus = 19;
 constexpr uint32_t kCtlWorkLight = 20;    // chunk counter of the light k_fold instance
 constexpr uint32_t kCtlWorkMid = 22;      // chunk counter of the mid k_fold instance
+constexpr uint32_t kCtlWorkCoop2 = 23;    // chunk counter of a second cooperative instance
 constexpr uint32_t kCtlRetry = 21;        // columns whose key table overflowed in an LDS tier (rerun on the global path)       // bit0: a pair ended with > 16 bins and no scratch was given
 constexpr uint32_t kCtlWords = 32;
 
@@ -86,8 +87,11 @@ struct SpgemmArgs {
 constexpr uint32_t kRowScratchBytes = 256;                   // block scan scratch, counters, bucket histogram
 // cap = products held, dcap = distinct keys (pairs) held.  LDS tiers budget dcap = cap/2: a column with more pairs than
 // that (never seen on PacBio-like sets: pairs/products is 0.03 at 10k reads, 0.28 at 100k) is rerun on the global path.
-__host__ __device__ inline size_t row_mem_bytes(uint32_t cap, uint32_t dcap) {
-    return kRowScratchBytes + (size_t)8 * cap + (size_t)20 * dcap + 2 * (size_t)((dcap + 1) & ~1u) + ((cap + 3) & ~3u);
+// overlay: the product-order arrays (A_hv, A_gov) are reused for the rank-order lists (LDS tiers: the values travel through
+// registers between two barriers); without it (global path, any size) the lists get their own 8*cap bytes.
+__host__ __device__ inline size_t row_mem_bytes(uint32_t cap, uint32_t dcap, bool overlay) {
+    return kRowScratchBytes + (size_t)8 * cap + (size_t)24 * dcap + 4 * (size_t)((dcap + 1) & ~1u) + ((cap + 3) & ~3u) +
+           (overlay ? 0 : (size_t)8 * cap);
 }
 
 struct RowMem {
@@ -98,12 +102,16 @@ struct RowMem {
     uint32_t* T1first;  // [dcap]  first product index ; after phase O: list start | rank << 16
     uint32_t* T1cnt;    // [dcap]  products | scatter cursor << 16
     uint32_t* T2;       // [2*dcap] slot-order table ; after phase O reused: S_p (u16 [cap]) product index lists (dcap >= cap/4)
+    uint32_t* Gaux;     // [dcap]  surviving positions of the pair (low 16 bits) | bit31: not a single-bin pair
     uint16_t* G;        // [dcap]  rank -> T1 slot
+    uint16_t* Glast;    // [dcap]  product index of the pair's last product (its seed if single-bin)
     uint8_t* A_fl;      // [cap]  bit0 oriented (checkstrand), bit1 palindromic k-mer
+    uint32_t* L_hv;     // [cap]  rank-order lists: posH | posV << 16           (== A_hv when overlaid)
+    uint32_t* L_gov;    // [cap]  rank-order lists: T1 slot << 16 | estimate     (== A_gov when overlaid)
     uint32_t cap, dcap;
 };
 
-__device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dcap) {
+__device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dcap, bool overlay) {
     RowMem m;
     m.scr = (uint32_t*)base;
     uint32_t* w = (uint32_t*)(base + kRowScratchBytes);
@@ -113,14 +121,19 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dc
     m.T1first = w;         w += dcap;
     m.T1cnt = w;           w += dcap;
     m.T2 = w;              w += 2 * dcap;
+    m.Gaux = w;            w += dcap;
     m.G = (uint16_t*)w;    w += (dcap + 1) / 2;
-    m.A_fl = (uint8_t*)w;
+    m.Glast = (uint16_t*)w; w += (dcap + 1) / 2;
+    m.A_fl = (uint8_t*)w;  w += (cap + 3) / 4;
+    if (overlay) { m.L_hv = m.A_hv; m.L_gov = m.A_gov; }
+    else { m.L_hv = w; w += cap; m.L_gov = w; }
     m.cap = cap;
     m.dcap = dcap;
     return m;
 }
 
 // returns false if the key table overflowed (no global side effect happened yet; the caller queues the column again)
+template <bool OVERLAY>
 __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t i, const RowMem& m) {
     const uint32_t tid = threadIdx.x;
     const uint32_t H1 = m.dcap;
@@ -133,13 +146,14 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
     const uint32_t k = (uint32_t)a.k;
 
-    for (uint32_t s = tid; s < H1; s += kRowBlock) { m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0; }
+    for (uint32_t s = tid; s < H1; s += kRowBlock) { m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0; m.Gaux[s] = 0; }
     if (tid == 0) { *s_d = 0; *s_fail = 0; }
     if (tid < 16) bcount[tid] = 0;
     __syncthreads();
     long long tc = 0;
     if (a.phase && tid == 0) tc = clock64();
-#define BELLA_PHASE(n) if (a.phase && tid == 0) { const long long t2 = clock64(); atomicAdd(a.phase + (n), (unsigned long long)(t2 - tc)); tc = t2; }
+    unsigned long long phc[6] = {0, 0, 0, 0, 0, 0};
+#define BELLA_PHASE(n) if (a.phase && tid == 0) { const long long t2 = clock64(); phc[n] = (unsigned long long)(t2 - tc); tc = t2; }
 
     // ---- X: expand products in reference order, group keys --------------------------------------------
     // X1/X2: each thread owns a CONTIGUOUS run of B' entries (so one block scan orders all products); it only records,
@@ -256,8 +270,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 
     // ---- S: product indices into per-pair lists.  Wavefront 0 appends 64 products at a time in product order (LDS
     // atomics of one wavefront execute in program order), so a list is ordered ACROSS 64-product chunks and only
-    // chunk-mates can be swapped; phase R repairs that.  The other wavefronts meanwhile build the bucket histogram of
-    // the multi-product pairs.  (T2 is dead: its memory becomes S_p.) -----------------------------------------------
+    // chunk-mates can be swapped; phase R repairs that.  (T2 is dead: its memory becomes S_p.) -----------------------
     uint16_t* S_p = (uint16_t*)m.T2;
     if (wave_id() == 0) {
         for (uint32_t base = 0; base < F; base += 4 * kScatterChunk) {
@@ -273,34 +286,25 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             for (uint32_t u = 0; u < 4; ++u)
                 if (g[u] != 0xFFFFFFFFu) S_p[(m.T1first[g[u]] & 0xFFFFu) + (old[u] >> 16)] = (uint16_t)(base + u * kScatterChunk + tid);
         }
-    } else {
-        for (uint32_t r = tid - 64; r < d; r += kRowBlock - 64) {
-            const uint32_t mm = m.T1cnt[m.G[r]] & 0xFFFFu;
-            if (mm >= 2) atomicAdd(&bcount[31 - __clz(mm)], 1u);
-        }
     }
     __syncthreads();
-    // reservation in the global bucket lists: issued now, the returned bases are only needed in phase D, so the
-    // device-scope atomics' latency hides under phase R
-    uint32_t my_bbase = 0;
-    if (tid < kNumBuckets) {
-        const uint32_t c = bcount[tid];
-        if (c) my_bbase = atomicAdd(&a.ctl[kCtlBucketCnt + tid], c);
-    }
     BELLA_PHASE(2)
 
-    // ---- R: list-position-parallel.  Inside a list only the members of one 256-product chunk can be out of order:
-    // rank = position corrected by the chunk-mates on the wrong side. ------------------------------------------------
+    // ---- R: exact rank of every product inside its pair's list (list position corrected by the chunk-mates on the wrong
+    // side) and the lists in rank order: L_hv / L_gov.  Single-product pairs are finished here. ---------------------
     const uint64_t obase = a.flopptr[i];
-    for (uint32_t x = tid; x < F; x += kRowBlock) {
+    constexpr uint32_t NX = 8;                               // list positions per thread in the LDS tiers (cap <= 4096)
+    uint32_t dstv[NX], hvv[NX], govv[NX];
+    auto rank_one = [&](uint32_t x, uint32_t& dst, uint32_t& hvq, uint32_t& govq) {
         const uint32_t p = S_p[x];
         const uint32_t gov = m.A_gov[p];
         const uint32_t g = gov >> 16;
         const uint32_t fr = m.T1first[g];
         const uint32_t st = fr & 0xFFFFu;
         const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
-        if (mm == 1) {                                    // multiop only: count 1, one bin, seed = this k-mer
-            const uint32_t hv = m.A_hv[p];
+        const uint32_t hv = m.A_hv[p];
+        uint32_t rk = 0;
+        if (mm == 1) {                                        // multiop only: count 1, one bin, seed = this k-mer
             const uint32_t fl = m.A_fl[p];
             bella_pair pr;
             pr.rid = m.T1key[g]; pr.cid = i; pr.count = 1; pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
@@ -313,47 +317,137 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             }
         } else {
             const uint32_t ch = p / kScatterChunk;
-            uint32_t rk = x - st;
-            for (uint32_t y = x; y > st; --y) {           // chunk-mates on the left that belong after p
+            rk = x - st;
+            for (uint32_t y = x; y > st; --y) {               // chunk-mates on the left that belong after p
                 const uint32_t o = S_p[y - 1];
                 if (o / kScatterChunk != ch) break;
                 rk -= (o > p);
             }
-            for (uint32_t y = x + 1; y < st + mm; ++y) {  // chunk-mates on the right that belong before p
+            for (uint32_t y = x + 1; y < st + mm; ++y) {      // chunk-mates on the right that belong before p
                 const uint32_t o = S_p[y];
                 if (o / kScatterChunk != ch) break;
                 rk += (o < p);
             }
-            a.plist[obase + st + rk] = make_uint2(m.A_hv[p], gov & 0xFFFFu);
+            if (rk == mm - 1) m.Glast[g] = (uint16_t)p;
+        }
+        dst = st + rk; hvq = hv; govq = gov;
+    };
+    if (OVERLAY) {
+#pragma unroll
+        for (uint32_t u = 0; u < NX; ++u) {
+            const uint32_t x = tid + u * kRowBlock;
+            dstv[u] = 0xFFFFFFFFu; hvv[u] = 0; govv[u] = 0;
+            if (x < F) rank_one(x, dstv[u], hvv[u], govv[u]);
+        }
+        __syncthreads();                                      // every A_hv / A_gov read is done: reuse them as L_hv / L_gov
+#pragma unroll
+        for (uint32_t u = 0; u < NX; ++u)
+            if (dstv[u] != 0xFFFFFFFFu) { m.L_hv[dstv[u]] = hvv[u]; m.L_gov[dstv[u]] = govv[u]; }
+    } else {
+        for (uint32_t x = tid; x < F; x += kRowBlock) {
+            uint32_t dst, hvq, govq;
+            rank_one(x, dst, hvq, govq);
+            m.L_hv[dst] = hvq; m.L_gov[dst] = govq;
         }
     }
+    __syncthreads();
     BELLA_PHASE(3)
 
-    // ---- D: descriptors of multi-product pairs, bucketed by floor(log2(m)) -----------------------------
+    // ---- P: the parallel fold.  While consecutive overlap estimates of a pair differ by less than binSize (chain.hpp:114)
+    // its value keeps ONE bin, and chainop degenerates to "the new k-mer q_t removes every surviving position within k of it
+    // in either coordinate, then joins the list" (chain.hpp:116-126,137-142).  Position s then dies at
+    //     D_s = min { t > s : not far_apart(x_s, q_t) }      (never: D_s = m)          independently of all others, and
+    //     count = m + sum_s (D_s - s - 1) (mod 2^16)   [chain.hpp:104,140],   support = #{s : D_s = m},   seed = last product.
+    // One list position per lane, forward scan over the rest of its pair's list in LDS; the per-pair sums land in the (dead)
+    // cursor half of T1cnt, which already holds m.  Pairs that break the condition are flagged for the serial kernels. -------
+    for (uint32_t y = tid; y < F; y += kRowBlock) {
+        const uint32_t gov = m.L_gov[y];
+        const uint32_t g = gov >> 16;
+        const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
+        if (mm == 1) continue;
+        const uint32_t st = m.T1first[g] & 0xFFFFu;
+        const uint32_t s_ = y - st;
+        const uint32_t x = m.L_hv[y];
+        if (s_ >= 1 && iabs_((int)(m.L_gov[y - 1] & 0xFFFFu) - (int)(gov & 0xFFFFu)) >= a.binSize) atomicOr(&m.Gaux[g], 0x80000000u);
+        uint32_t dth = mm;
+        const uint32_t* lst = m.L_hv + st;
+        uint32_t t = s_ + 1;
+        for (; t + 4 <= mm; t += 4) {                         // four independent LDS reads per round
+            const uint32_t q0 = lst[t], q1 = lst[t + 1], q2 = lst[t + 2], q3 = lst[t + 3];
+            const uint32_t n0 = far_apart(x, q0, a.k) ^ 1u, n1 = far_apart(x, q1, a.k) ^ 1u, n2 = far_apart(x, q2, a.k) ^ 1u,
+                           n3 = far_apart(x, q3, a.k) ^ 1u;
+            if (n0 | n1 | n2 | n3) { dth = n0 ? t : (n1 ? t + 1 : (n2 ? t + 2 : t + 3)); break; }
+        }
+        if (dth == mm)
+            for (; t < mm; ++t)
+                if (!far_apart(x, lst[t], a.k)) { dth = t; break; }
+        atomicAdd(&m.T1cnt[g], ((dth - s_ - 1) & 0xFFFFu) << 16);
+        if (dth == mm) atomicAdd(&m.Gaux[g], 1u);
+    }
     __syncthreads();
-    if (tid < kNumBuckets) { bbase[tid] = my_bbase; bcount[tid] = 0; }
-    __syncthreads();
+    BELLA_PHASE(4)
+
+    // ---- E: one record per single-bin pair; the others (rare) leave their list and a bucketed descriptor for k_fold* -------
     for (uint32_t r = tid; r < d; r += kRowBlock) {
         const uint32_t g = m.G[r];
-        const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
+        const uint32_t cw = m.T1cnt[g];
+        const uint32_t mm = cw & 0xFFFFu;
         if (mm < 2) continue;
-        const uint32_t b = 31 - __clz(mm);
-        const uint32_t loc = atomicAdd(&bcount[b], 1u);
-        a.desc[a.bucket_base[b] + bbase[b] + loc] = make_uint4(i, m.T1key[g], (m.T1first[g] & 0xFFFFu) | (mm << 16), r);
+        const uint32_t aux = m.Gaux[g];
+        if (aux >> 31) { atomicAdd(&bcount[31 - __clz(mm)], 1u); continue; }
+        const uint32_t st = m.T1first[g] & 0xFFFFu;
+        const uint32_t hv = m.L_hv[st + mm - 1];
+        const uint32_t fl = m.A_fl[m.Glast[g]];
+        bella_pair pr;
+        pr.rid = m.T1key[g]; pr.cid = i; pr.count = (uint16_t)(cw >> 16); pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
+        pr.flags = (uint16_t)((fl & 1u) | ((((fl & 1u) ^ 1u) | (fl >> 1)) << 1));
+        a.tmp_pairs[obase + r] = pr;
+        if (a.tmp_ext) {
+            bella_pair_ext ex;
+            ex.nbins = 1; ex.support = (uint16_t)(aux & 0xFFFFu); ex.binov = (uint16_t)(m.L_gov[st + mm - 1] & 0xFFFFu); ex.pad = 0;
+            a.tmp_ext[obase + r] = ex;
+        }
+    }
+    __syncthreads();
+    uint32_t nbad = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < kNumBuckets; ++b) nbad += bcount[b];
+    if (nbad) {                                               // block-uniform
+        __syncthreads();
+        if (tid < kNumBuckets) {
+            const uint32_t c = bcount[tid];
+            bbase[tid] = c ? atomicAdd(&a.ctl[kCtlBucketCnt + tid], c) : 0u;
+            bcount[tid] = 0;
+        }
+        __syncthreads();
+        for (uint32_t r = tid; r < d; r += kRowBlock) {
+            const uint32_t g = m.G[r];
+            const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
+            if (mm < 2 || !(m.Gaux[g] >> 31)) continue;
+            const uint32_t st = m.T1first[g] & 0xFFFFu;
+            for (uint32_t t = 0; t < mm; ++t) a.plist[obase + st + t] = make_uint2(m.L_hv[st + t], m.L_gov[st + t] & 0xFFFFu);
+            const uint32_t b = 31 - __clz(mm);
+            const uint32_t loc = atomicAdd(&bcount[b], 1u);
+            a.desc[a.bucket_base[b] + bbase[b] + loc] = make_uint4(i, m.T1key[g], st | (mm << 16), r);
+        }
     }
     if (tid == 0) a.nnzC[i] = d;
-    if (a.phase) { __syncthreads(); BELLA_PHASE(4) }
+    if (a.phase) {
+        __syncthreads();
+        BELLA_PHASE(5)
+        if (tid == 0)
+            for (int n = 0; n < 6; ++n) atomicAdd(a.phase + n, phc[n]);
+    }
 #undef BELLA_PHASE
     return true;
 }
 
-// LDS tiers: one column per workgroup (the hardware dispatcher interleaves the tiers' workgroups better than persistent
-// loops do when their LDS sizes differ); dynamic LDS = row_mem_bytes(cap, cap/2)
-__global__ __launch_bounds__(kRowBlock) void k_spgemm_rows_lds(SpgemmArgs a) {
+// LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap, cap/2)
+__global__ __launch_bounds__(kRowBlock, 6) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t i = a.rowlist[blockIdx.x];
-    const RowMem m = carve(smem, a.cap, a.cap / 2);
-    if (!process_row(a, i, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
+    const RowMem m = carve(smem, a.cap, a.cap / 2, true);
+    if (!process_row<true>(a, i, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
 }
 
 // Global-workspace path: columns with more products than the largest LDS tier (< 65536), and -- second launch, list and
@@ -365,8 +459,8 @@ __global__ __launch_bounds__(kRowBlock) void k_spgemm_rows_global(SpgemmArgs a) 
         const uint32_t i = a.rowlist[x];
         uint32_t f = (uint32_t)(a.flopptr[i + 1] - a.flopptr[i]);
         if (f < 16u) f = 16u;                             // T2 needs >= 16 slots
-        const RowMem m = carve(ws, f, f);
-        (void)process_row(a, i, m);
+        const RowMem m = carve(ws, f, f, false);
+        (void)process_row<false>(a, i, m);
         __syncthreads();
     }
 }
@@ -506,21 +600,24 @@ __global__ __launch_bounds__(64 * kFoldWavesPerBlock) void k_fold(FoldArgs a) {
 // chain.hpp:114-126), and compact with group ballots + popcounts: new state = orphans, then kept, then the new k-mer --
 // exactly fold_core's layout.  A step costs ~100 instructions whatever the state size, so the heaviest pair of a
 // column no longer decides the kernel's tail.  Same overflow rule as k_fold.
-constexpr uint32_t kCoopLanes = 8;
-constexpr uint32_t kCoopCapP = 64;
 constexpr uint32_t kCoopCapB = 8;
-constexpr uint32_t kCoopSlots = kCoopCapP / kCoopLanes;
 
-template <int BMIN, int BMAX, uint32_t WORK>
+// LPP lanes own one pair (64/LPP pairs per wavefront); the state holds up to CAPP positions (CAPP/LPP per lane)
+template <uint32_t LPP, uint32_t CAPP, int BMIN, int BMAX, uint32_t WORK>
 __global__ __launch_bounds__(64 * kFoldWavesPerBlock) void k_fold_coop(FoldArgs a) {
-    constexpr uint32_t GPW = 64 / kCoopLanes;                       // pairs per wavefront
-    constexpr uint32_t GW = kCoopCapP + kCoopCapB;                  // LDS words per pair
+    constexpr uint32_t GPW = 64 / LPP;                               // pairs per wavefront
+    constexpr uint32_t STG = 4 * LPP;                                // products staged in LDS per refill (one load round trip)
+    constexpr uint32_t GW = CAPP + kCoopCapB + 2 * STG;              // LDS words per pair
+    constexpr uint32_t SLOTS = CAPP / LPP;
+    constexpr unsigned long long GMASK = LPP == 64 ? ~0ull : ((1ull << LPP) - 1ull);
     __shared__ uint32_t lds[GW * GPW * kFoldWavesPerBlock];
     const uint32_t lane = lane_id();
-    const uint32_t grp = lane / kCoopLanes, j = lane % kCoopLanes;
+    const uint32_t grp = lane / LPP, j = lane % LPP;
     uint32_t* P = lds + (wave_id() * GPW + grp) * GW;
-    uint32_t* Bm = P + kCoopCapP;
-    const uint32_t ltmask = (1u << j) - 1u;
+    uint32_t* Bm = P + CAPP;
+    uint32_t* Shv = Bm + kCoopCapB;                                  // staged products: posH | posV << 16
+    uint32_t* Sov = Shv + STG;                                       //                  overlap estimates
+    const unsigned long long ltmask = (1ull << j) - 1ull;
     uint32_t cnt_b = 0, nch_b = 0;
     if ((int)lane >= BMIN && (int)lane <= BMAX) { cnt_b = a.ctl[kCtlBucketCnt + lane]; nch_b = (cnt_b + GPW - 1) / GPW; }
     uint32_t total = 0;
@@ -547,16 +644,26 @@ __global__ __launch_bounds__(64 * kFoldWavesPerBlock) void k_fold_coop(FoldArgs 
         const uint2* base = a.plist + (valid ? a.flopptr[ds.x] + (ds.z & 0xFFFFu) : 0ull);
         uint32_t np = 1, nb = 1, count = 1;
         bool ovf = false;
-        uint2 nxt = make_uint2(0u, 0u);
-        if (valid) {
-            const uint2 p0 = base[0];
-            if (j == 0) { P[0] = p0.x; Bm[0] = (p0.y & 0xFFFFu) | (1u << 16); }
-            if (mm > 1) nxt = base[1];
+        // the serial chain must never wait on HBM: the list is staged through LDS, 4*LPP products per (coalesced) round trip
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t t = j + u * LPP;
+            if (t < mm) { const uint2 v = base[t]; Shv[t] = v.x; Sov[t] = v.y & 0xFFFFu; }
         }
         __builtin_amdgcn_wave_barrier();
+        if (valid && j == 0) { P[0] = Shv[0]; Bm[0] = Sov[0] | (1u << 16); }
+        __builtin_amdgcn_wave_barrier();
         for (uint32_t t = 1; t < mm && !ovf; ++t) {
-            const uint32_t q = nxt.x, ovq = nxt.y & 0xFFFFu;
-            if (t + 1 < mm) nxt = base[t + 1];
+            if ((t % STG) == 0) {                                     // group-uniform: refill the staging buffer
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) {
+                    const uint32_t tt = t + j + u * LPP;
+                    if (tt < mm) { const uint2 v = base[tt]; Shv[j + u * LPP] = v.x; Sov[j + u * LPP] = v.y & 0xFFFFu; }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            const uint32_t q = Shv[t % STG], ovq = Sov[t % STG];
             // bins: which are dissolved, and where each one ends in the position array
             uint32_t closemask = 0, ce[kCoopCapB];
             const bool onebin = __all(nb == 1u);                      // wave-uniform fast path (99 % of the pairs)
@@ -575,15 +682,15 @@ __global__ __launch_bounds__(64 * kFoldWavesPerBlock) void k_fold_coop(FoldArgs 
                     }
                 }
             }
-            uint32_t reg[kCoopSlots], dst[kCoopSlots];
+            uint32_t reg[SLOTS], dst[SLOTS];
             uint32_t norph = 0, nkept = 0;
 #pragma unroll
-            for (uint32_t s = 0; s < kCoopSlots; ++s) {
-                const uint32_t ix = s * kCoopLanes + j;
+            for (uint32_t s = 0; s < SLOTS; ++s) {
+                const uint32_t ix = s * LPP + j;
                 const bool act = ix < np;
                 dst[s] = 0xFFFFFFFFu;
                 reg[s] = 0;
-                if (__ballot(act) == 0ull) continue;                  // no pair of this wavefront has a position in this slot
+                if (SLOTS > 1 && __ballot(act) == 0ull) continue;     // no pair of this wavefront has a position in this slot
                 const uint32_t v = act ? P[ix] : 0u;
                 reg[s] = v;
                 uint32_t binid = 0;
@@ -594,19 +701,20 @@ __global__ __launch_bounds__(64 * kFoldWavesPerBlock) void k_fold_coop(FoldArgs 
                 const bool isclose = (closemask >> binid) & 1u;
                 const bool orph = act && !isclose;
                 const bool kept = act && isclose && far_apart(v, q, a.k) != 0u;
-                const uint32_t mo = (uint32_t)(__ballot(orph) >> (grp * kCoopLanes)) & 0xFFu;
-                const uint32_t mk = (uint32_t)(__ballot(kept) >> (grp * kCoopLanes)) & 0xFFu;
+                const unsigned long long mo = (__ballot(orph) >> (grp * LPP)) & GMASK;
+                const unsigned long long mk = (__ballot(kept) >> (grp * LPP)) & GMASK;
                 // destination: orphans keep their order in front; kept ones follow (offset by the orphan total, added below)
-                dst[s] = orph ? (norph + __popc(mo & ltmask)) : (kept ? (0x80000000u | (nkept + __popc(mk & ltmask))) : 0xFFFFFFFFu);
-                norph += __popc(mo);
-                nkept += __popc(mk);
+                dst[s] = orph ? (norph + (uint32_t)__popcll(mo & ltmask))
+                              : (kept ? (0x80000000u | (nkept + (uint32_t)__popcll(mk & ltmask))) : 0xFFFFFFFFu);
+                norph += (uint32_t)__popcll(mo);
+                nkept += (uint32_t)__popcll(mk);
             }
             __builtin_amdgcn_wave_barrier();
             const uint32_t newnp = norph + nkept + 1;
             const uint32_t newnb = __popc(~closemask & ((1u << nb) - 1u)) + 1;
-            if (newnp > kCoopCapP || newnb > kCoopCapB) { ovf = true; break; }
+            if (newnp > CAPP || newnb > kCoopCapB) { ovf = true; break; }
 #pragma unroll
-            for (uint32_t s = 0; s < kCoopSlots; ++s) {
+            for (uint32_t s = 0; s < SLOTS; ++s) {
                 const uint32_t dd = dst[s];
                 if (dd != 0xFFFFFFFFu) P[(dd & 0x80000000u) ? norph + (dd & 0x7FFFFFFFu) : dd] = reg[s];
             }
