@@ -64,6 +64,7 @@ struct bella_ctx {
     Buf Brow, deg, minread, colstart, fill, ori, w, wscan, Atmp;
     // overlap
     uint64_t flops = 0, npairs = 0, F_full = 0;
+    uint32_t pair_ratio1024 = 1024;   // max over sampled columns of 1024 * pairs/products
     Buf flopsr, flopptr, nnzC, colptrC, tierflag, rowlists, tiercnt, tiercaps, tmp_pairs, tmp_ext, pairs, ext, sortscr, ws,
         status, cubtmp, plist_hv, plist_ov, desc, overflow, ctl, dbg, retry;
     uint32_t n_retry = 0;
@@ -214,12 +215,26 @@ int build_layout(bella_ctx* c) {
     }
     unsigned long long ffull = 0;
     HIPCHK(c, hipMemcpyAsync(&ffull, ptr<uint32_t>(c->status) + 2, 8, hipMemcpyDeviceToHost, c->stream));
+    // pairs/products on a sample of columns -> key-table budget of the LDS tiers (see k_sample_pair_ratio)
+    uint32_t ratio1024 = 1024;
+    const size_t bitmap_bytes = 4 * (((size_t)c->nreads + 31) / 32);
+    if (nnz && bitmap_bytes <= 128 * 1024) {
+        HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 6, 0, 4, c->stream));
+        const uint32_t nsample = c->nreads < 512 ? c->nreads : 512;
+        const uint32_t stride = c->nreads / nsample ? c->nreads / nsample : 1;
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_sample_pair_ratio, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bitmap_bytes));
+        k_sample_pair_ratio<<<nsample, kBlock, bitmap_bytes, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint2>(c->Bent), ptr<uint2>(c->Aent),
+                                                                         c->nreads, stride, ptr<uint32_t>(c->status) + 6);
+        KCHK(c);
+        HIPCHK(c, hipMemcpyAsync(&ratio1024, ptr<uint32_t>(c->status) + 6, 4, hipMemcpyDeviceToHost, c->stream));
+    }
     uint32_t st = 0;
     int rc = read_status(c, &st);
     if (rc) return rc;
     rc = status_to_error(c, st);
     if (rc) return rc;
     c->F_full = ffull;
+    c->pair_ratio1024 = ratio1024;
     // assembly temporaries are large (tens of bytes per nonzero): give them back
     release(c->Brow); release(c->deg); release(c->minread); release(c->colstart); release(c->fill); release(c->ori);
     release(c->w); release(c->wscan); release(c->Atmp);
@@ -669,8 +684,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         a.nrows = tcnt[t];
         a.nrows_dev = nullptr;
         a.cap = kTierCaps[t];
+        a.dcap = (c->pair_ratio1024 * 5 < 1024) ? a.cap / 4 : a.cap / 2;   // sampled pairs/products below 1/5: quarter-size key tables
         if (t + 1 < (int)kNumTiers) {
-            const size_t lds = row_mem_bytes(a.cap, a.cap / 2, true);
+            const size_t lds = row_mem_bytes(a.cap, a.dcap, true);
             HIPCHK(c, hipFuncSetAttribute((const void*)k_spgemm_rows_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             k_spgemm_rows_lds<<<tcnt[t], kRowBlock, lds, sst>>>(a);
         } else {

@@ -79,6 +79,7 @@ struct SpgemmArgs {
     uint8_t* ws;
     uint64_t ws_stride;
     uint32_t cap;
+    uint32_t dcap;               // LDS tiers: pairs (distinct keys) the tier holds: cap/4 or cap/2
     int k;
     int binSize;
     unsigned long long* phase;   // optional per-phase cycle counters (development aid, BELLA_HIP_PHASE_TIMERS=1)
@@ -446,7 +447,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 __global__ __launch_bounds__(kRowBlock, 6) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t i = a.rowlist[blockIdx.x];
-    const RowMem m = carve(smem, a.cap, a.cap / 2, true);
+    const RowMem m = carve(smem, a.cap, a.dcap, true);
     if (!process_row<true>(a, i, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
 }
 
@@ -766,6 +767,37 @@ __global__ __launch_bounds__(64) void k_fold_overflow(FoldArgs a) {
         if (fr.many_bins) atomicOr(&a.ctl[kCtlStatus], 1u);
         write_pair(a, ds, fr);
     }
+}
+
+// pairs/products of a sample of columns (a property of the operands, taken once at assembly): picks the key-table budget of
+// the LDS tiers (cap/4 when at most ~1/5 of a column's products open a new pair, else cap/2).  One workgroup per sampled
+// column, the distinct row ids counted with a bitmap in LDS.  out[0] = max over the sample of 1024*d/F.
+__global__ __launch_bounds__(kBlock) void k_sample_pair_ratio(const uint32_t* Bptr, const uint2* Bent, const uint2* Aent, uint32_t nreads,
+                                                              uint32_t stride, uint32_t* out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t* bits = (uint32_t*)smem;
+    __shared__ uint32_t s_d, s_f;
+    const uint32_t i = blockIdx.x * stride;
+    if (i >= nreads) return;
+    const uint32_t words = (nreads + 31) / 32;
+    for (uint32_t w = threadIdx.x; w < words; w += kBlock) bits[w] = 0;
+    if (threadIdx.x == 0) { s_d = 0; s_f = 0; }
+    __syncthreads();
+    uint32_t d = 0, f = 0;
+    for (uint32_t e = Bptr[i] + threadIdx.x; e < Bptr[i + 1]; e += kBlock) {
+        const uint2 be = Bent[e];
+        const uint32_t cnt = (be.y >> 16) & 0x3FFFu;
+        f += cnt;
+        for (uint32_t t = 0; t < cnt; ++t) {
+            const uint32_t key = Aent[(uint64_t)be.x + t].x & 0x7FFFFFFFu;
+            const uint32_t bit = 1u << (key & 31);
+            if (!(atomicOr(&bits[key >> 5], bit) & bit)) d++;
+        }
+    }
+    atomicAdd(&s_d, d);
+    atomicAdd(&s_f, f);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_f >= 64) atomicMax(out, (uint32_t)(((uint64_t)s_d << 10) / s_f));
 }
 
 // sum over k-mers of deg*(deg-1)/2 = the products of the whole lower triangle: sizes every F-dependent buffer at assembly
