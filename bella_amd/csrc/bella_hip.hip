@@ -66,7 +66,7 @@ struct bella_ctx {
     uint64_t flops = 0, npairs = 0, F_full = 0;
     uint32_t pair_ratio1024 = 1024;   // max over sampled columns of 1024 * pairs/products
     Buf flopsr, flopptr, nnzC, colptrC, tierflag, rowlists, tiercnt, tiercaps, tmp_pairs, tmp_ext, pairs, ext, sortscr, ws,
-        status, cubtmp, plist_hv, plist_ov, desc, overflow, ctl, dbg, retry;
+        status, cubtmp, plist_hv, overflow, ctl, retry;
     uint32_t n_retry = 0;
     uint32_t n_overflow = 0;
     // alignment
@@ -316,7 +316,7 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->Brow, &c->deg, &c->minread, &c->colstart,
                   &c->fill, &c->ori, &c->w, &c->wscan, &c->Atmp, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC, &c->tierflag,
                   &c->rowlists, &c->tiercnt, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
-                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->plist_ov, &c->desc, &c->overflow, &c->ctl, &c->dbg, &c->retry, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres};
+                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& st : c->side) (void)hipStreamDestroy(st);
@@ -588,9 +588,6 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     const bool want_ext = (c->debug & 2u) == 0;
     // every size below derives from F_full (known since assembly): no host round trip inside the pass
     const uint64_t Fub = c->F_full;
-    uint64_t bbase[kNumBuckets];
-    uint64_t ndesc = 0;
-    for (uint32_t b = 0; b < kNumBuckets; ++b) { bbase[b] = ndesc; ndesc += b ? (Fub >> b) + 64 : 0; }
     const uint64_t ws_stride = (row_mem_bytes(65535, 65535, false) + 255) & ~(size_t)255;
     ENSURE(c, c->flopsr, 4 * ((size_t)nr + 2));
     ENSURE(c, c->flopptr, 8 * ((size_t)nr + 2));
@@ -599,12 +596,11 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     ENSURE(c, c->rowlists, 4 * (size_t)kNumTiers * nr);
     ENSURE(c, c->tiercnt, 4 * kNumTiers);
     ENSURE(c, c->tiercaps, 4 * kNumTiers);
-    ENSURE(c, c->ctl, 4 * kCtlWords + 8 * kNumBuckets + 64);
+    ENSURE(c, c->ctl, 4 * kCtlWords + 64);
     ENSURE(c, c->tmp_pairs, sizeof(bella_pair) * Fub);
     if (want_ext) ENSURE(c, c->tmp_ext, sizeof(bella_pair_ext) * Fub);
     ENSURE(c, c->plist_hv, 8 * Fub);
-    ENSURE(c, c->desc, 16 * ndesc);
-    ENSURE(c, c->overflow, 16 * ((Fub >> 1) + 64));
+    ENSURE(c, c->overflow, 16 * ((Fub >> 4) + 64));   // a pair on this list has > 16 products
     ENSURE(c, c->sortscr, 2 * Fub);
     ENSURE(c, c->ws, ws_stride * kGlobalGrid);
     ENSURE(c, c->retry, 4 * ((size_t)nr + 1));
@@ -623,8 +619,6 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     uint32_t caps[kNumTiers];
     for (uint32_t t = 0; t < kNumTiers; ++t) caps[t] = force_global && t + 1 < kNumTiers ? 0 : kTierCaps[t];
     HIPCHK(c, hipMemcpyAsync(c->tiercaps.p, caps, sizeof(caps), hipMemcpyHostToDevice, c->stream));
-    uint64_t* d_bbase = (uint64_t*)(ptr<uint32_t>(c->ctl) + kCtlWords);
-    HIPCHK(c, hipMemcpyAsync(d_bbase, bbase, sizeof(bbase), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * kCtlWords, c->stream));
     HIPCHK(c, hipMemsetAsync(c->tiercnt.p, 0, 4 * kNumTiers, c->stream));
@@ -655,8 +649,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     a.tmp_ext = want_ext ? ptr<bella_pair_ext>(c->tmp_ext) : nullptr;
     a.nnzC = ptr<uint32_t>(c->nnzC);
     a.plist = ptr<uint2>(c->plist_hv);
-    a.desc = ptr<uint4>(c->desc);
-    a.bucket_base = d_bbase;
+    a.overflow = ptr<uint4>(c->overflow);
     a.ctl = ptr<uint32_t>(c->ctl);
     a.retry = ptr<uint32_t>(c->retry);
     a.nrows_dev = nullptr;
@@ -705,10 +698,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     KCHK(c);
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     FoldArgs fa;
-    fa.desc = a.desc;
-    fa.bucket_base = d_bbase;
     fa.ctl = a.ctl;
-    fa.overflow = ptr<uint4>(c->overflow);
+    fa.overflow = a.overflow;
     fa.flopptr = a.flopptr;
     fa.plist = a.plist;
     fa.roff = a.roff;
@@ -718,15 +709,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     fa.sort_scratch = ptr<uint16_t>(c->sortscr);
     fa.k = a.k;
     fa.binSize = a.binSize;
-    fa.dbg = nullptr;
-    {
-        // only the pairs whose value does not stay single-bin (~1 %) reach these kernels: one wavefront per pair keeps their
-        // latency low (list staged through LDS); states beyond its LDS budget finish in k_fold_overflow
-        k_fold_coop<64, 128, 1, 15, kCtlWork><<<kFoldGrid, 64 * kFoldWavesPerBlock, 0, c->stream>>>(fa);
-        KCHK(c);
-        k_fold_overflow<<<256, 64, 0, c->stream>>>(fa);
-        KCHK(c);
-    }
+    // the row kernels fold every pair themselves; only pairs that end with > 16 bins are left (their count stays on the device)
+    k_fold_overflow<<<256, 64, 0, c->stream>>>(fa);
+    KCHK(c);
     HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
     rc = scan_u32_to_u64(c, ptr<uint32_t>(c->nnzC), ptr<uint64_t>(c->colptrC), (uint64_t)nr + 1);
     if (rc) return rc;

@@ -71,8 +71,7 @@ struct SpgemmArgs {
     bella_pair_ext* tmp_ext;
     uint32_t* nnzC;
     uint2* plist;                // [F] per-pair product lists {posH | posV << 16, overlap estimate}, product order
-    uint4* desc;                 // bucketed pair descriptors {cid, key, start | m << 16, rank}
-    const uint64_t* bucket_base; // [16] start of each bucket inside desc
+    uint4* overflow;             // descriptors {cid, key, start | m << 16, rank} of the pairs left to k_fold_overflow
     uint32_t* ctl;
     uint32_t* retry;             // [nreads] columns to rerun on the global path
     const uint32_t* nrows_dev;   // if set, the row count of this launch lives on the device
@@ -91,8 +90,8 @@ constexpr uint32_t kRowScratchBytes = 256;                   // block scan scrat
 // overlay: the product-order arrays (A_hv, A_gov) are reused for the rank-order lists (LDS tiers: the values travel through
 // registers between two barriers); without it (global path, any size) the lists get their own 8*cap bytes.
 __host__ __device__ inline size_t row_mem_bytes(uint32_t cap, uint32_t dcap, bool overlay) {
-    return kRowScratchBytes + (size_t)8 * cap + (size_t)24 * dcap + 4 * (size_t)((dcap + 1) & ~1u) + ((cap + 3) & ~3u) +
-           (overlay ? 0 : (size_t)8 * cap);
+    return kRowScratchBytes + (size_t)8 * cap + (size_t)24 * dcap + 2 * (size_t)((dcap + 1) & ~1u) + (size_t)((cap + 3) & ~3u) +
+           2 * (size_t)((cap + 1) & ~1u) + (overlay ? 0 : (size_t)8 * cap + ((cap + 3) & ~3u));
 }
 
 struct RowMem {
@@ -103,10 +102,11 @@ struct RowMem {
     uint32_t* T1first;  // [dcap]  first product index ; after phase O: list start | rank << 16
     uint32_t* T1cnt;    // [dcap]  products | scatter cursor << 16
     uint32_t* T2;       // [2*dcap] slot-order table ; after phase O reused: S_p (u16 [cap]) product index lists (dcap >= cap/4)
-    uint32_t* Gaux;     // [dcap]  surviving positions of the pair (low 16 bits) | bit31: not a single-bin pair
+    uint32_t* Gaux;     // [dcap]  plain-chain pair: surviving positions (diagnostics) ; else (bins - 1) << 16
     uint16_t* G;        // [dcap]  rank -> T1 slot
-    uint16_t* Glast;    // [dcap]  product index of the pair's last product (its seed if single-bin)
+    uint16_t* Sup;      // [cap]  rank order: positions that ended in the bin this product heads (pairs off the plain chain)
     uint8_t* A_fl;      // [cap]  bit0 oriented (checkstrand), bit1 palindromic k-mer
+    uint8_t* L_fl;      // [cap]  the same in rank order (overlays A_fl in the LDS tiers)
     uint32_t* L_hv;     // [cap]  rank-order lists: posH | posV << 16           (== A_hv when overlaid)
     uint32_t* L_gov;    // [cap]  rank-order lists: T1 slot << 16 | estimate     (== A_gov when overlaid)
     uint32_t cap, dcap;
@@ -124,10 +124,10 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dc
     m.T2 = w;              w += 2 * dcap;
     m.Gaux = w;            w += dcap;
     m.G = (uint16_t*)w;    w += (dcap + 1) / 2;
-    m.Glast = (uint16_t*)w; w += (dcap + 1) / 2;
+    m.Sup = (uint16_t*)w;  w += (cap + 1) / 2;
     m.A_fl = (uint8_t*)w;  w += (cap + 3) / 4;
-    if (overlay) { m.L_hv = m.A_hv; m.L_gov = m.A_gov; }
-    else { m.L_hv = w; w += cap; m.L_gov = w; }
+    if (overlay) { m.L_hv = m.A_hv; m.L_gov = m.A_gov; m.L_fl = m.A_fl; }
+    else { m.L_hv = w; w += cap; m.L_gov = w; w += cap; m.L_fl = (uint8_t*)w; }
     m.cap = cap;
     m.dcap = dcap;
     return m;
@@ -140,8 +140,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     const uint32_t H1 = m.dcap;
     uint32_t* s_d = m.scr + 48;
     uint32_t* s_fail = m.scr + 49;
-    uint32_t* bcount = m.scr + 16;
-    uint32_t* bbase = m.scr + 32;
     const uint32_t b0 = a.Bptr[i];
     const uint32_t n = a.Bptr[i + 1] - b0;
     const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
@@ -149,7 +147,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 
     for (uint32_t s = tid; s < H1; s += kRowBlock) { m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0; m.Gaux[s] = 0; }
     if (tid == 0) { *s_d = 0; *s_fail = 0; }
-    if (tid < 16) bcount[tid] = 0;
     __syncthreads();
     long long tc = 0;
     if (a.phase && tid == 0) tc = clock64();
@@ -295,8 +292,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // side) and the lists in rank order: L_hv / L_gov.  Single-product pairs are finished here. ---------------------
     const uint64_t obase = a.flopptr[i];
     constexpr uint32_t NX = 8;                               // list positions per thread in the LDS tiers (cap <= 4096)
-    uint32_t dstv[NX], hvv[NX], govv[NX];
-    auto rank_one = [&](uint32_t x, uint32_t& dst, uint32_t& hvq, uint32_t& govq) {
+    uint32_t dstv[NX], hvv[NX], govv[NX], flv[NX];
+    auto rank_one = [&](uint32_t x, uint32_t& dst, uint32_t& hvq, uint32_t& govq, uint32_t& flq) {
         const uint32_t p = S_p[x];
         const uint32_t gov = m.A_gov[p];
         const uint32_t g = gov >> 16;
@@ -304,9 +301,9 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         const uint32_t st = fr & 0xFFFFu;
         const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
         const uint32_t hv = m.A_hv[p];
+        const uint32_t fl = m.A_fl[p];
         uint32_t rk = 0;
         if (mm == 1) {                                        // multiop only: count 1, one bin, seed = this k-mer
-            const uint32_t fl = m.A_fl[p];
             bella_pair pr;
             pr.rid = m.T1key[g]; pr.cid = i; pr.count = 1; pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
             pr.flags = (uint16_t)((fl & 1u) | ((((fl & 1u) ^ 1u) | (fl >> 1)) << 1));   // bit1: revcomp(seedH)==seedV
@@ -329,107 +326,147 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
                 if (o / kScatterChunk != ch) break;
                 rk += (o < p);
             }
-            if (rk == mm - 1) m.Glast[g] = (uint16_t)p;
         }
-        dst = st + rk; hvq = hv; govq = gov;
+        dst = st + rk; hvq = hv; govq = gov; flq = fl;
     };
     if (OVERLAY) {
 #pragma unroll
         for (uint32_t u = 0; u < NX; ++u) {
             const uint32_t x = tid + u * kRowBlock;
-            dstv[u] = 0xFFFFFFFFu; hvv[u] = 0; govv[u] = 0;
-            if (x < F) rank_one(x, dstv[u], hvv[u], govv[u]);
+            dstv[u] = 0xFFFFFFFFu; hvv[u] = 0; govv[u] = 0; flv[u] = 0;
+            if (x < F) rank_one(x, dstv[u], hvv[u], govv[u], flv[u]);
         }
         __syncthreads();                                      // every A_hv / A_gov read is done: reuse them as L_hv / L_gov
 #pragma unroll
         for (uint32_t u = 0; u < NX; ++u)
-            if (dstv[u] != 0xFFFFFFFFu) { m.L_hv[dstv[u]] = hvv[u]; m.L_gov[dstv[u]] = govv[u]; }
+            if (dstv[u] != 0xFFFFFFFFu) { m.L_hv[dstv[u]] = hvv[u]; m.L_gov[dstv[u]] = govv[u]; m.L_fl[dstv[u]] = (uint8_t)flv[u]; }
     } else {
         for (uint32_t x = tid; x < F; x += kRowBlock) {
-            uint32_t dst, hvq, govq;
-            rank_one(x, dst, hvq, govq);
-            m.L_hv[dst] = hvq; m.L_gov[dst] = govq;
+            uint32_t dst, hvq, govq, flq;
+            rank_one(x, dst, hvq, govq, flq);
+            m.L_hv[dst] = hvq; m.L_gov[dst] = govq; m.L_fl[dst] = (uint8_t)flq;
         }
     }
     __syncthreads();
     BELLA_PHASE(3)
 
-    // ---- P: the parallel fold.  While consecutive overlap estimates of a pair differ by less than binSize (chain.hpp:114)
-    // its value keeps ONE bin, and chainop degenerates to "the new k-mer q_t removes every surviving position within k of it
-    // in either coordinate, then joins the list" (chain.hpp:116-126,137-142).  Position s then dies at
-    //     D_s = min { t > s : not far_apart(x_s, q_t) }      (never: D_s = m)          independently of all others, and
-    //     count = m + sum_s (D_s - s - 1) (mod 2^16)   [chain.hpp:104,140],   support = #{s : D_s = m},   seed = last product.
-    // One list position per lane, forward scan over the rest of its pair's list in LDS; the per-pair sums land in the (dead)
-    // cursor half of T1cnt, which already holds m.  Pairs that break the condition are flagged for the serial kernels. -------
+    // ---- P: the fold, in parallel.  chainop (chain.hpp:100-150) on a pair's products in order has a closed form:
+    //  * every product t opens a bin with overlap ov_t and itself as first position; a bin lives, unchanged, until the first
+    //    later product whose estimate is within binSize of ITS overlap (chain.hpp:114) dissolves it into that product's bin:
+    //        parent(l) = min { t > l : |ov_l - ov_t| < binSize }          (none: the bin survives = a final bin, a "root")
+    //  * a position s is only ever compared with the products on its ancestor path s -> parent(s) -> parent(parent(s)) ...;
+    //    at each of them it is dropped if within k in either coordinate (chain.hpp:88-97,121) and otherwise moves along:
+    //        count = m + sum_s #(ancestors passed alive)   (mod 2^16)     (chain.hpp:104,140)
+    //        support(root) = #(positions that reach it alive, the root's own product included)
+    //  * the final bins in the reference's order are the roots by descending product index (a new bin is inserted in front,
+    //    orphans keep their order: chain.hpp:137-149), each headed by its own product: choose()'s seed (common.h:162-170).
+    // Every step is a "first later match" search: no serial dependency between the products of a pair.  For the usual
+    // single-bin pair parent(l) = l+1 and the walk is a forward scan.
+    // Bookkeeping: bit 31 of T1key marks a pair whose path is not the plain chain l -> l+1 (then Gaux >> 16 counts its roots
+    // other than the last product, and Sup[] collects the support of each root).
+    uint16_t* Par = (uint16_t*)m.T2;                          // S_p is dead
     for (uint32_t y = tid; y < F; y += kRowBlock) {
         const uint32_t gov = m.L_gov[y];
         const uint32_t g = gov >> 16;
         const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
         if (mm == 1) continue;
         const uint32_t st = m.T1first[g] & 0xFFFFu;
-        const uint32_t s_ = y - st;
-        const uint32_t x = m.L_hv[y];
-        if (s_ >= 1 && iabs_((int)(m.L_gov[y - 1] & 0xFFFFu) - (int)(gov & 0xFFFFu)) >= a.binSize) atomicOr(&m.Gaux[g], 0x80000000u);
-        uint32_t dth = mm;
-        const uint32_t* lst = m.L_hv + st;
-        uint32_t t = s_ + 1;
-        for (; t + 4 <= mm; t += 4) {                         // four independent LDS reads per round
-            const uint32_t q0 = lst[t], q1 = lst[t + 1], q2 = lst[t + 2], q3 = lst[t + 3];
-            const uint32_t n0 = far_apart(x, q0, a.k) ^ 1u, n1 = far_apart(x, q1, a.k) ^ 1u, n2 = far_apart(x, q2, a.k) ^ 1u,
-                           n3 = far_apart(x, q3, a.k) ^ 1u;
-            if (n0 | n1 | n2 | n3) { dth = n0 ? t : (n1 ? t + 1 : (n2 ? t + 2 : t + 3)); break; }
+        const int ovs = (int)(gov & 0xFFFFu);
+        uint32_t par = 0xFFFFu;
+        for (uint32_t t = y + 1; t < st + mm; ++t)
+            if (iabs_((int)(m.L_gov[t] & 0xFFFFu) - ovs) < a.binSize) { par = t - st; break; }
+        Par[y] = (uint16_t)par;
+        m.Sup[y] = 0;
+        if (y + 1 != st + mm && par != y + 1 - st) {
+            atomicOr(&m.T1key[g], 0x80000000u);
+            if (par == 0xFFFFu) atomicAdd(&m.Gaux[g], 0x10000u);
         }
-        if (dth == mm)
-            for (; t < mm; ++t)
-                if (!far_apart(x, lst[t], a.k)) { dth = t; break; }
-        atomicAdd(&m.T1cnt[g], ((dth - s_ - 1) & 0xFFFFu) << 16);
-        if (dth == mm) atomicAdd(&m.Gaux[g], 1u);
+    }
+    __syncthreads();
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 kk2 = {(unsigned short)a.k, (unsigned short)a.k};
+    const us2 lim2 = {(unsigned short)(2 * a.k + 1), (unsigned short)(2 * a.k + 1)};
+    const uint32_t lim = __builtin_bit_cast(uint32_t, lim2);
+    for (uint32_t y = tid; y < F; y += kRowBlock) {
+        const uint32_t g = m.L_gov[y] >> 16;
+        const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
+        if (mm == 1) continue;
+        const uint32_t st = m.T1first[g] & 0xFFFFu;
+        const uint32_t x = m.L_hv[y];
+        const uint32_t* lst = m.L_hv + st;
+        const uint32_t s = y - st;
+        if (!(m.T1key[g] >> 31)) {
+            // plain chain: the position is compared with every later product until one is within k of it.
+            // within k  <=>  (x + k - q) mod 2^16 <= 2k  in either half (k-mer starts are <= 65535 - k): eight products per test
+            const us2 xk = __builtin_bit_cast(us2, x) + kk2;
+            uint32_t t = s + 1;
+            while (t + 8 <= mm) {
+                us2 acc = lim2;
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u) acc = __builtin_elementwise_min(acc, (us2)(xk - __builtin_bit_cast(us2, lst[t + u])));
+                if (__builtin_bit_cast(uint32_t, acc) != lim) break;
+                t += 8;
+            }
+            for (; t < mm; ++t) {
+                const us2 dd = __builtin_elementwise_min(lim2, (us2)(xk - __builtin_bit_cast(us2, lst[t])));
+                if (__builtin_bit_cast(uint32_t, dd) != lim) break;
+            }
+            const uint32_t contrib = t - s - 1;
+            if (contrib) atomicAdd(&m.T1cnt[g], (contrib & 0xFFFFu) << 16);   // the cursor half already holds m
+            if (a.tmp_ext && t == mm) atomicAdd(&m.Gaux[g], 1u);
+        } else {
+            const uint16_t* pr = Par + st;
+            uint32_t root = s, contrib = 0, t = pr[s];
+            bool dead = false;
+            while (t != 0xFFFFu) {
+                if (!far_apart(x, lst[t], a.k)) { dead = true; break; }
+                contrib++; root = t; t = pr[t];
+            }
+            if (contrib) atomicAdd(&m.T1cnt[g], (contrib & 0xFFFFu) << 16);
+            if (!dead) atomicAdd((uint32_t*)m.Sup + ((st + root) >> 1), ((st + root) & 1u) ? 0x10000u : 1u);
+        }
     }
     __syncthreads();
     BELLA_PHASE(4)
 
-    // ---- E: one record per single-bin pair; the others (rare) leave their list and a bucketed descriptor for k_fold* -------
+    // ---- E: one record per pair --------------------------------------------------------------------------------------
     for (uint32_t r = tid; r < d; r += kRowBlock) {
         const uint32_t g = m.G[r];
         const uint32_t cw = m.T1cnt[g];
         const uint32_t mm = cw & 0xFFFFu;
         if (mm < 2) continue;
         const uint32_t aux = m.Gaux[g];
-        if (aux >> 31) { atomicAdd(&bcount[31 - __clz(mm)], 1u); continue; }
         const uint32_t st = m.T1first[g] & 0xFFFFu;
-        const uint32_t hv = m.L_hv[st + mm - 1];
-        const uint32_t fl = m.A_fl[m.Glast[g]];
+        const uint32_t keyw = m.T1key[g];
+        uint32_t win = mm - 1, sup = aux & 0xFFFFu, nroots = 1;   // plain chain: one bin, headed by the last product
+        if (keyw >> 31) {
+            nroots = (aux >> 16) + 1;
+            if (nroots > 16) {
+                // std::sort is not stable past 16 elements (common.h:145): hand the pair's list to the serial fold, which
+                // reproduces libstdc++'s order exactly
+                for (uint32_t t = 0; t < mm; ++t) a.plist[obase + st + t] = make_uint2(m.L_hv[st + t], m.L_gov[st + t] & 0xFFFFu);
+                a.overflow[atomicAdd(&a.ctl[kCtlOverflow], 1u)] = make_uint4(i, keyw & 0x7FFFFFFFu, st | (mm << 16), r);
+                continue;
+            }
+            // bins in the reference's order = roots by descending product index; std::sort by support (desc) on <= 16 bins is
+            // an insertion sort: the first maximum wins
+            sup = 0;
+            for (uint32_t l = mm; l-- > 0;) {
+                if (Par[st + l] != 0xFFFFu) continue;
+                const uint32_t cnt = m.Sup[st + l];
+                if (cnt > sup) { sup = cnt; win = l; }
+            }
+        }
+        const uint32_t hv = m.L_hv[st + win];
+        const uint32_t fl = m.L_fl[st + win];
         bella_pair pr;
-        pr.rid = m.T1key[g]; pr.cid = i; pr.count = (uint16_t)(cw >> 16); pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
+        pr.rid = keyw & 0x7FFFFFFFu; pr.cid = i; pr.count = (uint16_t)(cw >> 16); pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
         pr.flags = (uint16_t)((fl & 1u) | ((((fl & 1u) ^ 1u) | (fl >> 1)) << 1));
         a.tmp_pairs[obase + r] = pr;
         if (a.tmp_ext) {
             bella_pair_ext ex;
-            ex.nbins = 1; ex.support = (uint16_t)(aux & 0xFFFFu); ex.binov = (uint16_t)(m.L_gov[st + mm - 1] & 0xFFFFu); ex.pad = 0;
+            ex.nbins = (uint16_t)nroots; ex.support = (uint16_t)sup; ex.binov = (uint16_t)(m.L_gov[st + win] & 0xFFFFu); ex.pad = 0;
             a.tmp_ext[obase + r] = ex;
-        }
-    }
-    __syncthreads();
-    uint32_t nbad = 0;
-#pragma unroll
-    for (uint32_t b = 0; b < kNumBuckets; ++b) nbad += bcount[b];
-    if (nbad) {                                               // block-uniform
-        __syncthreads();
-        if (tid < kNumBuckets) {
-            const uint32_t c = bcount[tid];
-            bbase[tid] = c ? atomicAdd(&a.ctl[kCtlBucketCnt + tid], c) : 0u;
-            bcount[tid] = 0;
-        }
-        __syncthreads();
-        for (uint32_t r = tid; r < d; r += kRowBlock) {
-            const uint32_t g = m.G[r];
-            const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
-            if (mm < 2 || !(m.Gaux[g] >> 31)) continue;
-            const uint32_t st = m.T1first[g] & 0xFFFFu;
-            for (uint32_t t = 0; t < mm; ++t) a.plist[obase + st + t] = make_uint2(m.L_hv[st + t], m.L_gov[st + t] & 0xFFFFu);
-            const uint32_t b = 31 - __clz(mm);
-            const uint32_t loc = atomicAdd(&bcount[b], 1u);
-            a.desc[a.bucket_base[b] + bbase[b] + loc] = make_uint4(i, m.T1key[g], st | (mm << 16), r);
         }
     }
     if (tid == 0) a.nnzC[i] = d;
@@ -468,10 +505,8 @@ __global__ __launch_bounds__(kRowBlock) void k_spgemm_rows_global(SpgemmArgs a) 
 
 // ---- the fold ---------------------------------------------------------------------------------------------------
 struct FoldArgs {
-    const uint4* desc;
-    const uint64_t* bucket_base;
     uint32_t* ctl;
-    uint4* overflow;             // descriptors of pairs whose state outgrew the LDS budget
+    const uint4* overflow;       // descriptors of the pairs with more than 16 final bins
     const uint64_t* flopptr;
     uint2* plist;
     const uint64_t* roff;
@@ -479,41 +514,8 @@ struct FoldArgs {
     bella_pair* tmp_pairs;
     bella_pair_ext* tmp_ext;
     uint16_t* sort_scratch;      // [F] (k_fold_overflow only)
-    unsigned long long* dbg;     // optional [16][3]: per bucket sum / max cycles per chunk, chunks (development aid)
     int k;
     int binSize;
-};
-
-constexpr uint32_t kFoldCapB = 8;    // bins of one pair's state held in LDS
-constexpr uint32_t kFoldWavesPerBlock = 4;
-constexpr uint32_t kFoldLightMaxBucket = 4;   // pairs with < 32 products: state fits 32 positions by construction
-
-struct LanePtr {                     // element e of this lane: word e*64 of the wave's region (bank = lane)
-    uint32_t* base;
-    __device__ __forceinline__ uint32_t& operator[](uint32_t e) const { return base[e * 64u]; }
-};
-
-// The lane's product list streamed from HBM through a double register buffer: batch t/8+1 is in flight while batch t/8
-// is folded, so the fold never waits on a single dependent load.
-struct ProductStream {
-    const uint2* base;
-    uint32_t m;
-    uint2 cur[8], nxt[8];
-    __device__ __forceinline__ void fill(uint2 (&dst)[8], uint32_t t0) {
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) dst[u] = (t0 + u < m) ? base[t0 + u] : make_uint2(0u, 0u);
-    }
-    __device__ __forceinline__ void operator()(uint32_t t, uint32_t& q, uint32_t& o) {
-        if ((t & 7u) == 0) {
-#pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) cur[u] = nxt[u];
-            fill(nxt, t + 8);
-        }
-        uint2 v = cur[0];
-#pragma unroll
-        for (uint32_t u = 1; u < 8; ++u) if ((t & 7u) == u) v = cur[u];
-        q = v.x; o = v.y;
-    }
 };
 
 struct Stride2Ptr {                  // word e of an interleaved {x,y} list: base[2e]
@@ -540,219 +542,8 @@ __device__ __forceinline__ void write_pair(const FoldArgs& a, const uint4 ds, co
     }
 }
 
-// CAPP = positions of one pair's state held in LDS; the instance serves buckets BMIN..BMAX (work counter WORK)
-template <uint32_t CAPP, int BMIN, int BMAX, uint32_t WORK>
-__global__ __launch_bounds__(64 * kFoldWavesPerBlock) void k_fold(FoldArgs a) {
-    constexpr uint32_t kWaveWords = (CAPP + kFoldCapB) * 64;
-    __shared__ uint32_t lds[kWaveWords * kFoldWavesPerBlock];
-    const uint32_t lane = lane_id();
-    uint32_t* wl = lds + wave_id() * kWaveWords + lane;
-    const LanePtr P{wl}, Bm{wl + CAPP * 64u};
-    // chunk table: heaviest bucket first
-    uint32_t cnt_b = 0, nch_b = 0;
-    if ((int)lane >= BMIN && (int)lane <= BMAX) { cnt_b = a.ctl[kCtlBucketCnt + lane]; nch_b = (cnt_b + 63u) / 64u; }
-    uint32_t total = 0;
-#pragma unroll
-    for (int b = 0; b < (int)kNumBuckets; ++b) total += __shfl(nch_b, b, 64);
-    long long tprev = 0;
-    int bprev = -1;
-    for (;;) {
-        if (a.dbg) {                 // wave-level chunk time: all lanes are converged here
-            const long long tn = clock64();
-            if (bprev >= 0 && lane == 0) {
-                const unsigned long long dt = (unsigned long long)(tn - tprev);
-                atomicAdd(a.dbg + bprev * 3 + 0, dt);
-                atomicMax(a.dbg + bprev * 3 + 1, dt);
-                atomicAdd(a.dbg + bprev * 3 + 2, 1ull);
-            }
-            tprev = tn;
-        }
-        uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(&a.ctl[WORK], 1u);
-        c = __shfl(c, 0, 64);
-        if (c >= total) break;
-        int bsel = BMIN;
-        uint32_t rem = c;
-        for (int b = BMAX; b >= BMIN; --b) {
-            const uint32_t nb = __shfl(nch_b, b, 64);
-            if (rem < nb) { bsel = b; break; }
-            rem -= nb;
-        }
-        bprev = bsel;
-        const uint32_t cntsel = __shfl(cnt_b, bsel, 64);
-        const uint32_t idx = rem * 64u + lane;
-        if (idx >= cntsel) continue;
-        const uint4 ds = a.desc[a.bucket_base[bsel] + idx];
-        const uint32_t mm = ds.z >> 16;
-        ProductStream prod;
-        prod.base = a.plist + a.flopptr[ds.x] + (ds.z & 0xFFFFu);
-        prod.m = mm;
-        prod.fill(prod.nxt, 0);
-        FoldResult fr;
-        const bool ok = fold_core(P, Bm, mm, prod, CAPP, kFoldCapB, a.k, a.binSize, (uint16_t*)nullptr, fr);
-        if (ok) write_pair(a, ds, fr);
-        else a.overflow[atomicAdd(&a.ctl[kCtlOverflow], 1u)] = ds;
-    }
-}
-
-// Cooperative fold for pairs with many products: 8 lanes own one pair (8 pairs per wavefront).  Per product the 8 lanes
-// scan the whole state in parallel (position idx = 8*slot + lane), classify every position as orphan (its bin is far from
-// the new overlap estimate: survives, chain.hpp:131-149) or kept/dropped (its bin is dissolved into the new head bin,
-// chain.hpp:114-126), and compact with group ballots + popcounts: new state = orphans, then kept, then the new k-mer --
-// exactly fold_core's layout.  A step costs ~100 instructions whatever the state size, so the heaviest pair of a
-// column no longer decides the kernel's tail.  Same overflow rule as k_fold.
-constexpr uint32_t kCoopCapB = 8;
-
-// LPP lanes own one pair (64/LPP pairs per wavefront); the state holds up to CAPP positions (CAPP/LPP per lane)
-template <uint32_t LPP, uint32_t CAPP, int BMIN, int BMAX, uint32_t WORK>
-__global__ __launch_bounds__(64 * kFoldWavesPerBlock) void k_fold_coop(FoldArgs a) {
-    constexpr uint32_t GPW = 64 / LPP;                               // pairs per wavefront
-    constexpr uint32_t STG = 4 * LPP;                                // products staged in LDS per refill (one load round trip)
-    constexpr uint32_t GW = CAPP + kCoopCapB + 2 * STG;              // LDS words per pair
-    constexpr uint32_t SLOTS = CAPP / LPP;
-    constexpr unsigned long long GMASK = LPP == 64 ? ~0ull : ((1ull << LPP) - 1ull);
-    __shared__ uint32_t lds[GW * GPW * kFoldWavesPerBlock];
-    const uint32_t lane = lane_id();
-    const uint32_t grp = lane / LPP, j = lane % LPP;
-    uint32_t* P = lds + (wave_id() * GPW + grp) * GW;
-    uint32_t* Bm = P + CAPP;
-    uint32_t* Shv = Bm + kCoopCapB;                                  // staged products: posH | posV << 16
-    uint32_t* Sov = Shv + STG;                                       //                  overlap estimates
-    const unsigned long long ltmask = (1ull << j) - 1ull;
-    uint32_t cnt_b = 0, nch_b = 0;
-    if ((int)lane >= BMIN && (int)lane <= BMAX) { cnt_b = a.ctl[kCtlBucketCnt + lane]; nch_b = (cnt_b + GPW - 1) / GPW; }
-    uint32_t total = 0;
-#pragma unroll
-    for (int b = 0; b < (int)kNumBuckets; ++b) total += __shfl(nch_b, b, 64);
-    for (;;) {
-        uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(&a.ctl[WORK], 1u);
-        c = __shfl(c, 0, 64);
-        if (c >= total) break;
-        int bsel = BMIN;
-        uint32_t rem = c;
-        for (int b = BMAX; b >= BMIN; --b) {
-            const uint32_t nb_ = __shfl(nch_b, b, 64);
-            if (rem < nb_) { bsel = b; break; }
-            rem -= nb_;
-        }
-        const uint32_t cntsel = __shfl(cnt_b, bsel, 64);
-        const uint32_t idx = rem * GPW + grp;
-        const bool valid = idx < cntsel;
-        uint4 ds = make_uint4(0u, 0u, 0u, 0u);
-        if (valid) ds = a.desc[a.bucket_base[bsel] + idx];
-        const uint32_t mm = ds.z >> 16;
-        const uint2* base = a.plist + (valid ? a.flopptr[ds.x] + (ds.z & 0xFFFFu) : 0ull);
-        uint32_t np = 1, nb = 1, count = 1;
-        bool ovf = false;
-        // the serial chain must never wait on HBM: the list is staged through LDS, 4*LPP products per (coalesced) round trip
-#pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
-            const uint32_t t = j + u * LPP;
-            if (t < mm) { const uint2 v = base[t]; Shv[t] = v.x; Sov[t] = v.y & 0xFFFFu; }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (valid && j == 0) { P[0] = Shv[0]; Bm[0] = Sov[0] | (1u << 16); }
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t t = 1; t < mm && !ovf; ++t) {
-            if ((t % STG) == 0) {                                     // group-uniform: refill the staging buffer
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) {
-                    const uint32_t tt = t + j + u * LPP;
-                    if (tt < mm) { const uint2 v = base[tt]; Shv[j + u * LPP] = v.x; Sov[j + u * LPP] = v.y & 0xFFFFu; }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            const uint32_t q = Shv[t % STG], ovq = Sov[t % STG];
-            // bins: which are dissolved, and where each one ends in the position array
-            uint32_t closemask = 0, ce[kCoopCapB];
-            const bool onebin = __all(nb == 1u);                      // wave-uniform fast path (99 % of the pairs)
-            if (onebin) {
-                if (iabs_((int)(Bm[0] & 0xFFFFu) - (int)ovq) < a.binSize) closemask = 1u;
-            } else {
-                uint32_t run = 0;
-#pragma unroll
-                for (uint32_t b = 0; b < kCoopCapB; ++b) {
-                    ce[b] = 0xFFFFFFFFu;
-                    if (b < nb) {
-                        const uint32_t meta = Bm[b];
-                        run += meta >> 16;
-                        ce[b] = run;
-                        if (iabs_((int)(meta & 0xFFFFu) - (int)ovq) < a.binSize) closemask |= 1u << b;
-                    }
-                }
-            }
-            uint32_t reg[SLOTS], dst[SLOTS];
-            uint32_t norph = 0, nkept = 0;
-#pragma unroll
-            for (uint32_t s = 0; s < SLOTS; ++s) {
-                const uint32_t ix = s * LPP + j;
-                const bool act = ix < np;
-                dst[s] = 0xFFFFFFFFu;
-                reg[s] = 0;
-                if (SLOTS > 1 && __ballot(act) == 0ull) continue;     // no pair of this wavefront has a position in this slot
-                const uint32_t v = act ? P[ix] : 0u;
-                reg[s] = v;
-                uint32_t binid = 0;
-                if (!onebin) {
-#pragma unroll
-                    for (uint32_t b = 0; b < kCoopCapB; ++b) binid += (ix >= ce[b]);
-                }
-                const bool isclose = (closemask >> binid) & 1u;
-                const bool orph = act && !isclose;
-                const bool kept = act && isclose && far_apart(v, q, a.k) != 0u;
-                const unsigned long long mo = (__ballot(orph) >> (grp * LPP)) & GMASK;
-                const unsigned long long mk = (__ballot(kept) >> (grp * LPP)) & GMASK;
-                // destination: orphans keep their order in front; kept ones follow (offset by the orphan total, added below)
-                dst[s] = orph ? (norph + (uint32_t)__popcll(mo & ltmask))
-                              : (kept ? (0x80000000u | (nkept + (uint32_t)__popcll(mk & ltmask))) : 0xFFFFFFFFu);
-                norph += (uint32_t)__popcll(mo);
-                nkept += (uint32_t)__popcll(mk);
-            }
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t newnp = norph + nkept + 1;
-            const uint32_t newnb = __popc(~closemask & ((1u << nb) - 1u)) + 1;
-            if (newnp > CAPP || newnb > kCoopCapB) { ovf = true; break; }
-#pragma unroll
-            for (uint32_t s = 0; s < SLOTS; ++s) {
-                const uint32_t dd = dst[s];
-                if (dd != 0xFFFFFFFFu) P[(dd & 0x80000000u) ? norph + (dd & 0x7FFFFFFFu) : dd] = reg[s];
-            }
-            if (j == 0) {
-                P[newnp - 1] = q;
-                uint32_t bw = 0;
-                for (uint32_t b = 0; b < nb; ++b)
-                    if (!((closemask >> b) & 1u)) { const uint32_t mt = Bm[b]; Bm[bw++] = mt; }
-                Bm[bw] = ovq | ((nkept + 1) << 16);
-            }
-            __builtin_amdgcn_wave_barrier();
-            np = newnp; nb = newnb;
-            count = (count + 1 + nkept) & 0xFFFFu;
-        }
-        if (valid) {
-            if (ovf) {
-                if (j == 0) a.overflow[atomicAdd(&a.ctl[kCtlOverflow], 1u)] = ds;
-            } else if (j == 0) {
-                uint32_t win = 0, best = 0;
-                for (uint32_t l = 0; l < nb; ++l) {                    // <= 8 bins: std::sort is an insertion sort => first maximum
-                    const uint32_t sp = Bm[nb - 1 - l] >> 16;
-                    if (l == 0 || sp > best) { best = sp; win = l; }
-                }
-                const uint32_t wm = nb - 1 - win;
-                uint32_t end = 0;
-                for (uint32_t b = 0; b <= wm; ++b) end += Bm[b] >> 16;
-                FoldResult fr;
-                fr.count = (uint16_t)count; fr.nbins = (uint16_t)nb; fr.support = (uint16_t)(Bm[wm] >> 16);
-                fr.binov = (uint16_t)(Bm[wm] & 0xFFFFu); fr.seed = P[end - 1]; fr.many_bins = 0;
-                write_pair(a, ds, fr);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// rare: states larger than the LDS budget (or > 8 bins).  In place in HBM on the pair's own list.
+// pairs that end with more than 16 bins (choose()'s std::sort leaves the insertion-sort regime, common.h:145): the serial
+// fold, in place in HBM on the pair's own list, with libstdc++'s introsort restated (core.hpp).  Rare by construction.
 __global__ __launch_bounds__(64) void k_fold_overflow(FoldArgs a) {
     const uint32_t n = a.ctl[kCtlOverflow];
     for (;;) {
