@@ -659,6 +659,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     a.k = p->kmer_size;
     a.binSize = p->bin_size;
     a.phase = nullptr;
+    a.stop = getenv("BELLA_HIP_STOP_PHASE") ? atoi(getenv("BELLA_HIP_STOP_PHASE")) : -1;
     const bool phase_timers = getenv("BELLA_HIP_PHASE_TIMERS") != nullptr;
     if (phase_timers) {
         HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 4, 0, 48, c->stream));

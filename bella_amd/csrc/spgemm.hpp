@@ -33,6 +33,7 @@
 //                                                          appearance in B' (streaming for the owner row)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "../../include/bella_hip.h"
 #include "core.hpp"
 #include "util.hpp"
@@ -81,6 +82,7 @@ struct SpgemmArgs {
     uint32_t dcap;               // LDS tiers: pairs (distinct keys) the tier holds: cap/4 or cap/2
     int k;
     int binSize;
+    int stop;                    // development aid: leave process_row after this phase (results are garbage), -1 = off
     unsigned long long* phase;   // optional per-phase cycle counters (development aid, BELLA_HIP_PHASE_TIMERS=1)
 };
 
@@ -90,23 +92,22 @@ constexpr uint32_t kRowScratchBytes = 256;                   // block scan scrat
 // overlay: the product-order arrays (A_hv, A_gov) are reused for the rank-order lists (LDS tiers: the values travel through
 // registers between two barriers); without it (global path, any size) the lists get their own 8*cap bytes.
 __host__ __device__ inline size_t row_mem_bytes(uint32_t cap, uint32_t dcap, bool overlay) {
-    return kRowScratchBytes + (size_t)8 * cap + (size_t)24 * dcap + 2 * (size_t)((dcap + 1) & ~1u) + (size_t)((cap + 3) & ~3u) +
-           2 * (size_t)((cap + 1) & ~1u) + (overlay ? 0 : (size_t)8 * cap + ((cap + 3) & ~3u));
+    return kRowScratchBytes + (size_t)8 * cap + (size_t)24 * dcap + 2 * (size_t)((dcap + 1) & ~1u) +
+           (overlay ? 0 : (size_t)8 * cap + 2 * (size_t)((cap + 3) & ~3u));
 }
 
 struct RowMem {
     uint32_t* scr;      // 64 words: [0..15] scan, [16..31] bucket counts, [32..47] bucket bases, [48] distinct keys
     uint32_t* A_hv;     // [cap]  posH | posV << 16, product order
-    uint32_t* A_gov;    // [cap]  T1 slot << 16 | overlap estimate
+    uint32_t* A_gov;    // [cap]  T1 slot << 16 | overlap estimate ; LDS tiers (T1 slot < 2^14): flags << 30 on top
     uint32_t* T1key;    // [dcap]
     uint32_t* T1first;  // [dcap]  first product index ; after phase O: list start | rank << 16
     uint32_t* T1cnt;    // [dcap]  products | scatter cursor << 16
     uint32_t* T2;       // [2*dcap] slot-order table ; after phase O reused: S_p (u16 [cap]) product index lists (dcap >= cap/4)
     uint32_t* Gaux;     // [dcap]  plain-chain pair: surviving positions (diagnostics) ; else (bins - 1) << 16
     uint16_t* G;        // [dcap]  rank -> T1 slot
-    uint16_t* Sup;      // [cap]  rank order: positions that ended in the bin this product heads (pairs off the plain chain)
-    uint8_t* A_fl;      // [cap]  bit0 oriented (checkstrand), bit1 palindromic k-mer
-    uint8_t* L_fl;      // [cap]  the same in rank order (overlays A_fl in the LDS tiers)
+    uint8_t* A_fl;      // [cap]  flags: bit0 oriented (checkstrand), bit1 palindromic k-mer   (global path only)
+    uint8_t* L_fl;      // [cap]  the same in rank order                                        (global path only)
     uint32_t* L_hv;     // [cap]  rank-order lists: posH | posV << 16           (== A_hv when overlaid)
     uint32_t* L_gov;    // [cap]  rank-order lists: T1 slot << 16 | estimate     (== A_gov when overlaid)
     uint32_t cap, dcap;
@@ -124,10 +125,8 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dc
     m.T2 = w;              w += 2 * dcap;
     m.Gaux = w;            w += dcap;
     m.G = (uint16_t*)w;    w += (dcap + 1) / 2;
-    m.Sup = (uint16_t*)w;  w += (cap + 1) / 2;
-    m.A_fl = (uint8_t*)w;  w += (cap + 3) / 4;
-    if (overlay) { m.L_hv = m.A_hv; m.L_gov = m.A_gov; m.L_fl = m.A_fl; }
-    else { m.L_hv = w; w += cap; m.L_gov = w; w += cap; m.L_fl = (uint8_t*)w; }
+    if (overlay) { m.L_hv = m.A_hv; m.L_gov = m.A_gov; m.A_fl = nullptr; m.L_fl = nullptr; }
+    else { m.L_hv = w; w += cap; m.L_gov = w; w += cap; m.A_fl = (uint8_t*)w; w += (cap + 3) / 4; m.L_fl = (uint8_t*)w; }
     m.cap = cap;
     m.dcap = dcap;
     return m;
@@ -144,6 +143,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     const uint32_t n = a.Bptr[i + 1] - b0;
     const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
     const uint32_t k = (uint32_t)a.k;
+    constexpr uint32_t GMASK = OVERLAY ? 0x3FFFu : 0xFFFFu;   // LDS tiers: the flags ride on top of the T1 slot
 
     for (uint32_t s = tid; s < H1; s += kRowBlock) { m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0; m.Gaux[s] = 0; }
     if (tid == 0) { *s_d = 0; *s_fail = 0; }
@@ -151,7 +151,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     long long tc = 0;
     if (a.phase && tid == 0) tc = clock64();
     unsigned long long phc[6] = {0, 0, 0, 0, 0, 0};
-#define BELLA_PHASE(n) if (a.phase && tid == 0) { const long long t2 = clock64(); phc[n] = (unsigned long long)(t2 - tc); tc = t2; }
+#define BELLA_PHASE(n) if (a.phase && tid == 0) { const long long t2 = clock64(); phc[n] = (unsigned long long)(t2 - tc); tc = t2; } \
+    if (a.stop == n) return true;
 
     // ---- X: expand products in reference order, group keys --------------------------------------------
     // X1/X2: each thread owns a CONTIGUOUS run of B' entries (so one block scan orders all products); it only records,
@@ -214,8 +215,9 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             atomicMin(&m.T1first[h], p);
             atomicAdd(&m.T1cnt[h], 1u);
             m.A_hv[p] = posH | (posV << 16);
-            m.A_gov[p] = (h << 16) | ov;
-            m.A_fl[p] = (uint8_t)((oriented ? 1u : 0u) | (pal << 1));
+            const uint32_t fl = (oriented ? 1u : 0u) | (pal << 1);
+            if (OVERLAY) m.A_gov[p] = (fl << 30) | (h << 16) | ov;
+            else { m.A_gov[p] = (h << 16) | ov; m.A_fl[p] = (uint8_t)fl; }
         }
     }
     __syncthreads();
@@ -276,7 +278,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {
                 const uint32_t p = base + u * kScatterChunk + tid;
-                g[u] = p < F ? (m.A_gov[p] >> 16) : 0xFFFFFFFFu;
+                g[u] = p < F ? ((m.A_gov[p] >> 16) & GMASK) : 0xFFFFFFFFu;
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) old[u] = g[u] != 0xFFFFFFFFu ? atomicAdd(&m.T1cnt[g[u]], 0x10000u) : 0u;
@@ -292,16 +294,16 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // side) and the lists in rank order: L_hv / L_gov.  Single-product pairs are finished here. ---------------------
     const uint64_t obase = a.flopptr[i];
     constexpr uint32_t NX = 8;                               // list positions per thread in the LDS tiers (cap <= 4096)
-    uint32_t dstv[NX], hvv[NX], govv[NX], flv[NX];
+    uint32_t dstv[NX], hvv[NX], govv[NX];
     auto rank_one = [&](uint32_t x, uint32_t& dst, uint32_t& hvq, uint32_t& govq, uint32_t& flq) {
         const uint32_t p = S_p[x];
         const uint32_t gov = m.A_gov[p];
-        const uint32_t g = gov >> 16;
+        const uint32_t g = (gov >> 16) & GMASK;
         const uint32_t fr = m.T1first[g];
         const uint32_t st = fr & 0xFFFFu;
         const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
         const uint32_t hv = m.A_hv[p];
-        const uint32_t fl = m.A_fl[p];
+        const uint32_t fl = OVERLAY ? gov >> 30 : (uint32_t)m.A_fl[p];
         uint32_t rk = 0;
         if (mm == 1) {                                        // multiop only: count 1, one bin, seed = this k-mer
             bella_pair pr;
@@ -333,13 +335,14 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 #pragma unroll
         for (uint32_t u = 0; u < NX; ++u) {
             const uint32_t x = tid + u * kRowBlock;
-            dstv[u] = 0xFFFFFFFFu; hvv[u] = 0; govv[u] = 0; flv[u] = 0;
-            if (x < F) rank_one(x, dstv[u], hvv[u], govv[u], flv[u]);
+            uint32_t flq;
+            dstv[u] = 0xFFFFFFFFu; hvv[u] = 0; govv[u] = 0;
+            if (x < F) rank_one(x, dstv[u], hvv[u], govv[u], flq);
         }
         __syncthreads();                                      // every A_hv / A_gov read is done: reuse them as L_hv / L_gov
 #pragma unroll
         for (uint32_t u = 0; u < NX; ++u)
-            if (dstv[u] != 0xFFFFFFFFu) { m.L_hv[dstv[u]] = hvv[u]; m.L_gov[dstv[u]] = govv[u]; m.L_fl[dstv[u]] = (uint8_t)flv[u]; }
+            if (dstv[u] != 0xFFFFFFFFu) { m.L_hv[dstv[u]] = hvv[u]; m.L_gov[dstv[u]] = govv[u]; }
     } else {
         for (uint32_t x = tid; x < F; x += kRowBlock) {
             uint32_t dst, hvq, govq, flq;
@@ -364,22 +367,24 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // single-bin pair parent(l) = l+1 and the walk is a forward scan.
     // Bookkeeping: bit 31 of T1key marks a pair whose path is not the plain chain l -> l+1 (then Gaux >> 16 counts its roots
     // other than the last product, and Sup[] collects the support of each root).
-    uint16_t* Par = (uint16_t*)m.T2;                          // S_p is dead
+    // Par[y]: parent of position y (index inside its pair's list) or kRoot | support.  LDS tiers: u16 (lists <= 4096 long)
+    typedef typename std::conditional<OVERLAY, uint16_t, uint32_t>::type par_t;
+    constexpr uint32_t kRoot = OVERLAY ? 0x8000u : 0x80000000u;
+    par_t* Par = (par_t*)m.T2;                                // S_p is dead
     for (uint32_t y = tid; y < F; y += kRowBlock) {
         const uint32_t gov = m.L_gov[y];
-        const uint32_t g = gov >> 16;
+        const uint32_t g = (gov >> 16) & GMASK;
         const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
         if (mm == 1) continue;
         const uint32_t st = m.T1first[g] & 0xFFFFu;
         const int ovs = (int)(gov & 0xFFFFu);
-        uint32_t par = 0xFFFFu;
+        uint32_t par = kRoot;
         for (uint32_t t = y + 1; t < st + mm; ++t)
             if (iabs_((int)(m.L_gov[t] & 0xFFFFu) - ovs) < a.binSize) { par = t - st; break; }
-        Par[y] = (uint16_t)par;
-        m.Sup[y] = 0;
+        Par[y] = (par_t)par;
         if (y + 1 != st + mm && par != y + 1 - st) {
             atomicOr(&m.T1key[g], 0x80000000u);
-            if (par == 0xFFFFu) atomicAdd(&m.Gaux[g], 0x10000u);
+            if (par == kRoot) atomicAdd(&m.Gaux[g], 0x10000u);
         }
     }
     __syncthreads();
@@ -388,7 +393,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     const us2 lim2 = {(unsigned short)(2 * a.k + 1), (unsigned short)(2 * a.k + 1)};
     const uint32_t lim = __builtin_bit_cast(uint32_t, lim2);
     for (uint32_t y = tid; y < F; y += kRowBlock) {
-        const uint32_t g = m.L_gov[y] >> 16;
+        const uint32_t g = (m.L_gov[y] >> 16) & GMASK;
         const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
         if (mm == 1) continue;
         const uint32_t st = m.T1first[g] & 0xFFFFu;
@@ -415,15 +420,18 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             if (contrib) atomicAdd(&m.T1cnt[g], (contrib & 0xFFFFu) << 16);   // the cursor half already holds m
             if (a.tmp_ext && t == mm) atomicAdd(&m.Gaux[g], 1u);
         } else {
-            const uint16_t* pr = Par + st;
+            const par_t* pr = Par + st;
             uint32_t root = s, contrib = 0, t = pr[s];
             bool dead = false;
-            while (t != 0xFFFFu) {
+            while (!(t & kRoot)) {
                 if (!far_apart(x, lst[t], a.k)) { dead = true; break; }
                 contrib++; root = t; t = pr[t];
             }
             if (contrib) atomicAdd(&m.T1cnt[g], (contrib & 0xFFFFu) << 16);
-            if (!dead) atomicAdd((uint32_t*)m.Sup + ((st + root) >> 1), ((st + root) & 1u) ? 0x10000u : 1u);
+            if (!dead) {                                      // the root's support (a u16 counter is half of an LDS word)
+                if (OVERLAY) atomicAdd((uint32_t*)Par + ((st + root) >> 1), ((st + root) & 1u) ? 0x10000u : 1u);
+                else atomicAdd((uint32_t*)Par + st + root, 1u);
+            }
         }
     }
     __syncthreads();
@@ -452,13 +460,14 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             // an insertion sort: the first maximum wins
             sup = 0;
             for (uint32_t l = mm; l-- > 0;) {
-                if (Par[st + l] != 0xFFFFu) continue;
-                const uint32_t cnt = m.Sup[st + l];
+                const uint32_t pw = Par[st + l];
+                if (!(pw & kRoot)) continue;
+                const uint32_t cnt = pw & (kRoot - 1);
                 if (cnt > sup) { sup = cnt; win = l; }
             }
         }
         const uint32_t hv = m.L_hv[st + win];
-        const uint32_t fl = m.L_fl[st + win];
+        const uint32_t fl = OVERLAY ? m.L_gov[st + win] >> 30 : (uint32_t)m.L_fl[st + win];
         bella_pair pr;
         pr.rid = keyw & 0x7FFFFFFFu; pr.cid = i; pr.count = (uint16_t)(cw >> 16); pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
         pr.flags = (uint16_t)((fl & 1u) | ((((fl & 1u) ^ 1u) | (fl >> 1)) << 1));
