@@ -28,10 +28,13 @@ struct Buf {
     size_t cap = 0;
 };
 
-constexpr uint32_t kNumTiers = 6;  // 5 LDS tiers + the global-workspace tier
-const uint32_t kTierCaps[kNumTiers] = {768, 1280, 2048, 3072, 4096, 65535};
+// Column tiers by product count: LDS tiers (one workgroup per column, 14.5 B of LDS per product: <= 2752 products keeps four
+// workgroups on a CU, <= 3712 three) and last the global-workspace tier.  BELLA_HIP_TIERS=a,b,c overrides the LDS caps (tuning aid).
+constexpr uint32_t kNumTiers = 8;  // at most
+uint32_t g_ntiers = 6;
+uint32_t kTierCaps[kNumTiers] = {768, 1280, 2048, 3072, 4096, 65535, 0, 0};
 constexpr uint32_t kGlobalGrid = 256;
-constexpr uint32_t kFoldGrid = 512;       // persistent k_fold workgroups (2 per CU at 72 KB LDS)
+constexpr uint32_t kFoldGrid = 512;
 constexpr uint32_t kAsmGrid = 1024;
 
 struct CastU64 {
@@ -65,7 +68,7 @@ struct bella_ctx {
     // overlap
     uint64_t flops = 0, npairs = 0, F_full = 0;
     uint32_t pair_ratio1024 = 1024;   // max over sampled columns of 1024 * pairs/products
-    Buf flopsr, flopptr, nnzC, colptrC, tierflag, rowlists, tiercnt, tiercaps, tmp_pairs, tmp_ext, pairs, ext, sortscr, ws,
+    Buf flopsr, flopptr, nnzC, colptrC, tierflag, rowlists, tiercaps, tmp_pairs, tmp_ext, pairs, ext, sortscr, ws,
         status, cubtmp, plist_hv, overflow, ctl, retry;
     uint32_t n_retry = 0;
     uint32_t n_overflow = 0;
@@ -74,6 +77,8 @@ struct bella_ctx {
     Buf alns, seeds, xest, xest2, xids, xorder, xres;
     bella_timings tm{};
     hipEvent_t ev[10]{};
+    uint32_t* pinned = nullptr;          // 128 host words the per-pass read backs land in
+    int caps_state = 0;
     hipStream_t side[kNumTiers + 1]{};   // independent tier launches / fold instances run concurrently
     hipEvent_t fork = nullptr, join[kNumTiers + 1]{};
 };
@@ -295,6 +300,16 @@ int bella_hip_init(int device, bella_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BELLA_ERR_NO_DEVICE;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BELLA_ERR_NO_DEVICE;
+    if (const char* tv = getenv("BELLA_HIP_TIERS")) {             // tuning aid: ascending LDS caps, each <= 4096
+        uint32_t n = 0;
+        for (const char* q = tv; *q && n + 1 < kNumTiers;) {
+            const uint32_t v = (uint32_t)strtoul(q, nullptr, 10);
+            if (v >= 16 && v <= 4096 && (n == 0 || v > kTierCaps[n - 1])) kTierCaps[n++] = v;
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+        if (n) { kTierCaps[n] = 65535; g_ntiers = n + 1; }
+    }
     bella_ctx* c = new bella_ctx();
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return BELLA_ERR_HIP; }
@@ -302,6 +317,7 @@ int bella_hip_init(int device, bella_ctx** out) {
     for (auto& st : c->side) (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
     for (auto& e : c->join) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (hipHostMalloc((void**)&c->pinned, 512, hipHostMallocDefault) != hipSuccess) { delete c; return BELLA_ERR_NOMEM; }
     if (ensure_bytes(c, c->status, 256)) { delete c; return BELLA_ERR_NOMEM; }
     (void)hipMemset(c->status.p, 0, 256);
     *out = c;
@@ -315,7 +331,7 @@ void bella_hip_destroy(bella_ctx* c) {
     Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Aent, &c->t_kmer, &c->t_read, &c->t_pos,
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->Brow, &c->deg, &c->minread, &c->colstart,
                   &c->fill, &c->ori, &c->w, &c->wscan, &c->Atmp, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC, &c->tierflag,
-                  &c->rowlists, &c->tiercnt, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
+                  &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
                   &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -323,6 +339,7 @@ void bella_hip_destroy(bella_ctx* c) {
     (void)hipEventDestroy(c->fork);
     for (auto& e : c->join) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
 }
 
@@ -594,9 +611,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     ENSURE(c, c->nnzC, 4 * ((size_t)nr + 2));
     ENSURE(c, c->colptrC, 8 * ((size_t)nr + 2));
     ENSURE(c, c->rowlists, 4 * (size_t)kNumTiers * nr);
-    ENSURE(c, c->tiercnt, 4 * kNumTiers);
     ENSURE(c, c->tiercaps, 4 * kNumTiers);
-    ENSURE(c, c->ctl, 4 * kCtlWords + 64);
+    ENSURE(c, c->ctl, 4 * kCtlWords);
     ENSURE(c, c->tmp_pairs, sizeof(bella_pair) * Fub);
     if (want_ext) ENSURE(c, c->tmp_ext, sizeof(bella_pair_ext) * Fub);
     ENSURE(c, c->plist_hv, 8 * Fub);
@@ -616,25 +632,27 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     ENSURE(c, c->cubtmp, tb1 + 256);
 
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    uint32_t caps[kNumTiers];
-    for (uint32_t t = 0; t < kNumTiers; ++t) caps[t] = force_global && t + 1 < kNumTiers ? 0 : kTierCaps[t];
-    HIPCHK(c, hipMemcpyAsync(c->tiercaps.p, caps, sizeof(caps), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * kCtlWords, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->tiercnt.p, 0, 4 * kNumTiers, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->flopsr.p, 0, 4 * ((size_t)nr + 2), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->nnzC.p, 0, 4 * ((size_t)nr + 2), c->stream));
-    k_row_flops<<<nblk(nr, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint2>(c->Bent), nr, c->part_first,
-                                                            c->part_stride, ptr<uint32_t>(c->flopsr));
+    uint32_t caps[kNumTiers] = {};
+    for (uint32_t t = 0; t < g_ntiers; ++t) caps[t] = force_global && t + 1 < g_ntiers ? 0 : kTierCaps[t];
+    if (c->caps_state != (force_global ? 2 : 1)) {              // the tier caps only change with the debug switch
+        HIPCHK(c, hipMemcpyAsync(c->tiercaps.p, caps, sizeof(caps), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));            // caps[] is a stack array
+        c->caps_state = force_global ? 2 : 1;
+    }
+    // one control block per pass (counters, tier lengths, status, totals): one fill, one read back
+    uint32_t* d_ctl = ptr<uint32_t>(c->ctl);
+    HIPCHK(c, hipMemsetAsync(d_ctl, 0, 4 * kCtlWords, c->stream));
+    k_row_flops<<<nblk(nr + 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint2>(c->Bent), nr, c->part_first,
+                                                                c->part_stride, ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC));
     KCHK(c);
     int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->flopsr), ptr<uint64_t>(c->flopptr), (uint64_t)nr + 1);
     if (rc) return rc;
-    k_tier_lists<<<nblk(nr), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, ptr<uint32_t>(c->tiercaps), kNumTiers,
-                                                  ptr<uint32_t>(c->rowlists), ptr<uint32_t>(c->tiercnt), ptr<uint32_t>(c->status));
+    k_tier_lists<<<nblk(nr), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, ptr<uint32_t>(c->tiercaps), g_ntiers,
+                                                  ptr<uint32_t>(c->rowlists), d_ctl + kCtlTierCnt, d_ctl + kCtlStatus);
     KCHK(c);
-    // the one host round trip before the row kernels: the tiers' lengths (exact grids; 24 bytes)
-    uint32_t tcnt[kNumTiers];
-    HIPCHK(c, hipMemcpyAsync(tcnt, c->tiercnt.p, sizeof(tcnt), hipMemcpyDeviceToHost, c->stream));
+    // the one host round trip before the row kernels: the tiers' lengths (exact grids; 32 bytes into pinned memory)
+    uint32_t* const tcnt = c->pinned;
+    HIPCHK(c, hipMemcpyAsync(tcnt, d_ctl + kCtlTierCnt, 4 * kNumTiers, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
 
@@ -670,7 +688,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     // the tiers are independent persistent launches of the same kernel with different LDS budgets, forked onto side streams
     // (largest columns first) so that they run concurrently; their column counts stay on the device
     HIPCHK(c, hipEventRecord(c->fork, c->stream));
-    for (int t = (int)kNumTiers - 1; t >= 0; --t) {
+    for (int t = (int)g_ntiers - 1; t >= 0; --t) {
         if (!tcnt[t]) continue;
         hipStream_t sst = c->side[t];
         HIPCHK(c, hipStreamWaitEvent(sst, c->fork, 0));
@@ -679,7 +697,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         a.nrows_dev = nullptr;
         a.cap = kTierCaps[t];
         a.dcap = (c->pair_ratio1024 * 5 < 1024) ? a.cap / 4 : a.cap / 2;   // sampled pairs/products below 1/5: quarter-size key tables
-        if (t + 1 < (int)kNumTiers) {
+        if (t + 1 < (int)g_ntiers) {
             const size_t lds = row_mem_bytes(a.cap, a.dcap, true);
             HIPCHK(c, hipFuncSetAttribute((const void*)k_spgemm_rows_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             k_spgemm_rows_lds<<<tcnt[t], kRowBlock, lds, sst>>>(a);
@@ -722,19 +740,19 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
                                                                     ptr<uint32_t>(c->nnzC), nr, ptr<bella_pair>(c->tmp_pairs),
                                                                     want_ext ? ptr<bella_pair_ext>(c->tmp_ext) : nullptr,
                                                                     ptr<bella_pair>(c->pairs),
-                                                                    want_ext ? ptr<bella_pair_ext>(c->ext) : nullptr);
+                                                                    want_ext ? ptr<bella_pair_ext>(c->ext) : nullptr,
+                                                                    (uint64_t*)(d_ctl + kCtlTotals));
         KCHK(c);
     }
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     // the pass's only host round trip: counters, totals and status
+    uint32_t* const ctl_host = c->pinned + 16;
+    HIPCHK(c, hipMemcpyAsync(ctl_host, d_ctl, 4 * kCtlWords, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     uint64_t P = 0, F = 0;
-    uint32_t ctl_host[kCtlWords], st = 0;
-    HIPCHK(c, hipMemcpyAsync(&P, ptr<uint64_t>(c->colptrC) + nr, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&F, ptr<uint64_t>(c->flopptr) + nr, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(ctl_host, c->ctl.p, sizeof(ctl_host), hipMemcpyDeviceToHost, c->stream));
-    rc = read_status(c, &st);
-    if (rc) return rc;
-    rc = status_to_error(c, st);
+    std::memcpy(&P, ctl_host + kCtlTotals, 8);
+    std::memcpy(&F, ctl_host + kCtlTotals + 2, 8);
+    rc = status_to_error(c, ctl_host[kCtlStatus] & ~1u);
     if (rc) return rc;
     *status_out = ctl_host[kCtlStatus];
     c->n_overflow = ctl_host[kCtlOverflow];

@@ -57,7 +57,9 @@ constexpr uint32_t kCtlWorkLight = 20;    // chunk counter of the light k_fold i
 constexpr uint32_t kCtlWorkMid = 22;      // chunk counter of the mid k_fold instance
 constexpr uint32_t kCtlWorkCoop2 = 23;    // chunk counter of a second cooperative instance
 constexpr uint32_t kCtlRetry = 21;        // columns whose key table overflowed in an LDS tier (rerun on the global path)       // bit0: a pair ended with > 16 bins and no scratch was given
-constexpr uint32_t kCtlWords = 32;
+constexpr uint32_t kCtlTierCnt = 32;      // [8] columns per tier
+constexpr uint32_t kCtlTotals = 42;       // u64[2]: nnz(C), products (8-byte aligned)
+constexpr uint32_t kCtlWords = 64;
 
 struct SpgemmArgs {
     const uint32_t* rowlist;
@@ -293,7 +295,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // ---- R: exact rank of every product inside its pair's list (list position corrected by the chunk-mates on the wrong
     // side) and the lists in rank order: L_hv / L_gov.  Single-product pairs are finished here. ---------------------
     const uint64_t obase = a.flopptr[i];
-    constexpr uint32_t NX = 8;                               // list positions per thread in the LDS tiers (cap <= 4096)
+    constexpr uint32_t NX = 4096 / kRowBlock;                               // list positions per thread in the LDS tiers (cap <= 4096)
     uint32_t dstv[NX], hvv[NX], govv[NX];
     auto rank_one = [&](uint32_t x, uint32_t& dst, uint32_t& hvq, uint32_t& govq, uint32_t& flq) {
         const uint32_t p = S_p[x];
@@ -614,9 +616,11 @@ __global__ void k_total_products(const uint32_t* deg, uint32_t nkmers, unsigned 
 // estimateFLOP (overlap.hpp:157-202, lowtri): products of column i = sum of the suffix counts of its entries.
 // One wavefront per column.  Columns outside this context's partition get 0.
 __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, const uint2* Bent, uint32_t nreads,
-                                                      uint32_t first, uint32_t stride, uint32_t* flops) {
+                                                      uint32_t first, uint32_t stride, uint32_t* flops, uint32_t* nnzC) {
     const uint32_t i = blockIdx.x * kWaves + wave_id();
-    if (i >= nreads) return;
+    if (i > nreads) return;
+    if (lane_id() == 0) nnzC[i] = 0;                          // this pass's pair counts start from zero (entry nreads: scan tail)
+    if (i == nreads) { if (lane_id() == 0) flops[i] = 0; return; }
     uint32_t s = 0;
     if (i % stride == first) {
         const uint32_t b0 = Bptr[i], b1 = Bptr[i + 1];
@@ -652,8 +656,9 @@ __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, ui
 __global__ __launch_bounds__(kBlock) void k_compact_pairs(const uint64_t* flopptr, const uint64_t* colptrC,
                                                           const uint32_t* nnzC, uint32_t nreads,
                                                           const bella_pair* tmp_pairs, const bella_pair_ext* tmp_ext,
-                                                          bella_pair* pairs, bella_pair_ext* ext) {
+                                                          bella_pair* pairs, bella_pair_ext* ext, uint64_t* totals) {
     const uint32_t i = blockIdx.x * kWaves + wave_id();
+    if (i == 0 && lane_id() == 0) { totals[0] = colptrC[nreads]; totals[1] = flopptr[nreads]; }   // nnz(C), products: read back once
     if (i >= nreads) return;
     const uint32_t cnt = nnzC[i];
     const uint64_t src = flopptr[i], dst = colptrC[i];

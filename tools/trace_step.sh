@@ -7,7 +7,7 @@ python - <<PY
 import csv
 rows=list(csv.DictReader(open("$R/gpurun_out/pf/f_kernel_trace.csv")))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-last=[i for i,r in enumerate(rows) if "k_row_flops" in r["Kernel_Name"]][-1]
+last=[i for i,r in enumerate(rows) if "k_row_flops" in r["Kernel_Name"]][-2]-6
 t0=int(rows[last]["Start_Timestamp"])
 for r in rows[last:]:
     k=r["Kernel_Name"].split("(")[0]
