@@ -184,6 +184,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     }
     const uint32_t F = running;
     __syncthreads();
+    if (a.stop == 6) return true;
     // X3: product-parallel gather of the A' entries (balanced: every lane has work; four independent loads in flight)
     for (uint32_t base = 0; base < F; base += 4 * kRowBlock) {
         uint2 ae[4];
@@ -406,17 +407,40 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             // plain chain: the position is compared with every later product until one is within k of it.
             // within k  <=>  (x + k - q) mod 2^16 <= 2k  in either half (k-mer starts are <= 65535 - k): eight products per test
             const us2 xk = __builtin_bit_cast(us2, x) + kk2;
+            const uint32_t farq = x ^ 0x80008000u;            // a product 32768 away in both coordinates: never within k
             uint32_t t = s + 1;
+            uint32_t q[8];
+            bool hit = false;
             while (t + 8 <= mm) {
                 us2 acc = lim2;
 #pragma unroll
-                for (uint32_t u = 0; u < 8; ++u) acc = __builtin_elementwise_min(acc, (us2)(xk - __builtin_bit_cast(us2, lst[t + u])));
-                if (__builtin_bit_cast(uint32_t, acc) != lim) break;
+                for (uint32_t u = 0; u < 8; ++u) {
+                    q[u] = lst[t + u];
+                    acc = __builtin_elementwise_min(acc, (us2)(xk - __builtin_bit_cast(us2, q[u])));
+                }
+                if (__builtin_bit_cast(uint32_t, acc) != lim) { hit = true; break; }
                 t += 8;
             }
-            for (; t < mm; ++t) {
-                const us2 dd = __builtin_elementwise_min(lim2, (us2)(xk - __builtin_bit_cast(us2, lst[t])));
-                if (__builtin_bit_cast(uint32_t, dd) != lim) break;
+            if (!hit && t < mm) {                             // the last, partial group of eight: one more round trip, masked
+                us2 acc = lim2;
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u) {
+                    const uint32_t idx = t + u;
+                    const uint32_t v = lst[idx < mm ? idx : mm - 1];
+                    q[u] = idx < mm ? v : farq;
+                    acc = __builtin_elementwise_min(acc, (us2)(xk - __builtin_bit_cast(us2, q[u])));
+                }
+                if (__builtin_bit_cast(uint32_t, acc) != lim) hit = true;
+                else t = mm;
+            }
+            if (hit) {                                        // first product of the group that is within k
+                uint32_t f = 7;
+#pragma unroll
+                for (int u = 6; u >= 0; --u) {
+                    const us2 dd = __builtin_elementwise_min(lim2, (us2)(xk - __builtin_bit_cast(us2, q[u])));
+                    f = __builtin_bit_cast(uint32_t, dd) != lim ? (uint32_t)u : f;
+                }
+                t += f;
             }
             const uint32_t contrib = t - s - 1;
             if (contrib) atomicAdd(&m.T1cnt[g], (contrib & 0xFFFFu) << 16);   // the cursor half already holds m
