@@ -5,7 +5,7 @@ set -euo pipefail
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/traffic
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -o t -- python "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/bench_$C.json" 2> "$OUT/bench_$C.err" || true
 done
@@ -22,9 +22,25 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     out[c] = {k: {"sum_kb": v[0], "dispatches": v[1]} for k, v in agg.items() if "bella::" in k}
 json.dump(out, open("$OUT/traffic_raw.json", "w"), indent=1)
+bench = json.loads([l for l in open("$OUT/bench_FETCH_SIZE.json") if l.startswith("{")][-1])
 steps = 5
 def tot(c, pred):
     return sum(v["sum_kb"] for k, v in out.get(c, {}).items() if pred(k)) * 1024 / steps
 sp = lambda k: "k_spgemm_rows" in k or "k_fold" in k
-print("per step (5 dispatch groups): FETCH raw %.1f MB, WRITE raw %.1f MB (spgemm rows + fold kernels)" % (tot("FETCH_SIZE", sp) / 1e6, tot("WRITE_SIZE", sp) / 1e6))
+fetch, write = tot("FETCH_SIZE", sp), tot("WRITE_SIZE", sp)
+# calibration of FETCH_SIZE on our own coalesced 8-byte stream: k_row_flops reads 8 B per nonzero of B'
+nnz = bench["config"]["nnzA"]
+rf = tot("FETCH_SIZE", lambda k: "k_row_flops" in k)
+ratio = rf / (8.0 * nnz)
+summary = {
+ "workload": "configs[1] %d reads, 1 GPU" % bench["config"]["reads"],
+ "kernels": "k_spgemm_rows_* + k_fold_overflow", "per": "step (= one launch set)",
+ "FETCH_SIZE_raw_bytes": fetch, "WRITE_SIZE_raw_bytes": write,
+ "fetch_calibration": {"kernel": "k_row_flops", "expected_bytes": 8 * nnz, "ratio_measured_over_expected": ratio,
+                       "note": "FETCH_SIZE reads 1/2 of the streamed bytes on gfx950 (MI355X_MICROARCH.md, HBM); checked on our own 8-byte coalesced stream"},
+ "hbm_bytes_corrected": 2.0 * fetch + write,
+ "algorithmic_bytes": bench["roofline"]["algorithmic_bytes_per_step"],
+}
+json.dump(summary, open("$OUT/hbm_traffic.json", "w"), indent=1)
+print(json.dumps(summary))
 PY
