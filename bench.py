@@ -208,9 +208,9 @@ def main():
                    "reads": nreads, "nkmers": tup.nkmers, "nnzA": nnz, "flops": int(tot_flops), "pairs": int(tot_pairs),
                    "partition": "columns i %% %d == rank" % n_gpus},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "kernel": "SpGEMM = k_spgemm_rows_* + k_fold*", "kernel_ms_per_step": k_ms,
+                     "traffic": None, "kernel": "SpGEMM = k_spgemm_rows_* (one launch set = the concurrent tier launches of a pass) + k_fold_overflow", "kernel_ms_per_step": k_ms,
                      "launches_per_step": launches / a.steps, "algorithmic_bytes_per_step": alg_bytes},
-        "phases_ms_per_step": {"symbolic+tiering": sym_ms / a.steps, "row_kernels": rows_ms / a.steps, "fold_kernels": fold_ms / a.steps,
+        "phases_ms_per_step": {"symbolic+tiering": sym_ms / a.steps, "row_kernels": rows_ms / a.steps, "overflow_fold": fold_ms / a.steps,
                                "compaction": comp_ms / a.steps},
         "assemble_ms": asm_ms, "panel_allgather_ms": xchg_ms,
     }
