@@ -26,7 +26,8 @@ class Params(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [("assemble_ms", C.c_float), ("symbolic_ms", C.c_float), ("spgemm_ms", C.c_float), ("fold_ms", C.c_float),
-                ("compact_ms", C.c_float), ("xdrop_ms", C.c_float), ("overlap_total_ms", C.c_float), ("spgemm_launches", C.c_uint32)]
+                ("compact_ms", C.c_float), ("xdrop_ms", C.c_float), ("overlap_total_ms", C.c_float), ("spgemm_launches", C.c_uint32),
+                ("kcount_ms", C.c_float)]
 
 
 # every symbol include/bella_hip.h declares: (name, restype, argtypes)
@@ -39,6 +40,11 @@ SIGNATURES = [
     ("bella_hip_strerror", C.c_char_p, [C.c_int]),
     ("bella_hip_last_error", C.c_char_p, [vp]),
     ("bella_hip_set_reads", C.c_int, [vp, vp, vp, C.c_uint32]),
+    ("bella_hip_count_kmers", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_uint64)]),
+    ("bella_hip_get_dictionary", C.c_int, [vp, vp, vp]),
+    ("bella_hip_get_tuples", C.c_int, [vp, vp, vp, vp]),
+    ("bella_hip_assemble_counted", C.c_int, [vp]),
     ("bella_hip_assemble_tuples", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint64, vp, vp, vp]),
     ("bella_hip_set_B", C.c_int, [vp, C.c_uint16, C.c_uint32, vp, vp, vp]),
     ("bella_hip_assemble_panel", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp]),

@@ -82,6 +82,29 @@ class Engine:
         self.lengths = np.diff(offs).astype(np.uint32)
         self.names = names
 
+    # ---- SplitCount + tuple generation (kmercount.hpp:467-677, main.cpp:393-416) ----
+    def count_kmers(self, k=17, lower=2, upper=8):
+        """reliable dictionary and tuples of the reads on the device; returns (nkmers, ntuples, ndistinct)"""
+        nk, nt, nd = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+        self._chk(self.lib.bella_hip_count_kmers(self.h, k, lower, upper, C.byref(nk), C.byref(nt), C.byref(nd)))
+        self.nkmers_counted, self.ntuples_counted = nk.value, nt.value
+        return nk.value, nt.value, nd.value
+
+    def get_dictionary(self):
+        codes = np.zeros(max(self.nkmers_counted, 1), np.uint64)
+        counts = np.zeros(max(self.nkmers_counted, 1), np.uint16)
+        self._chk(self.lib.bella_hip_get_dictionary(self.h, codes.ctypes.data, counts.ctypes.data))
+        return codes[:self.nkmers_counted], counts[:self.nkmers_counted]
+
+    def get_tuples(self):
+        n = self.ntuples_counted
+        tk, tr, tp = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint16)
+        self._chk(self.lib.bella_hip_get_tuples(self.h, tk.ctypes.data, tr.ctypes.data, tp.ctypes.data))
+        return tk[:n], tr[:n], tp[:n]
+
+    def assemble_counted(self):
+        self._chk(self.lib.bella_hip_assemble_counted(self.h))
+
     # ---- operands ----
     def assemble_tuples(self, k, nkmers, tk, tr, tp):
         tk = np.ascontiguousarray(tk, np.uint32); tr = np.ascontiguousarray(tr, np.uint32); tp = np.ascontiguousarray(tp, np.uint16)

@@ -14,6 +14,7 @@
 #include "../../include/bella_hip.h"
 #include "assemble.hpp"
 #include "core.hpp"
+#include "kcount.hpp"
 #include "spgemm.hpp"
 #include "util.hpp"
 #include "xdrop.hpp"
@@ -57,6 +58,11 @@ struct bella_ctx {
     uint32_t nkmers = 0, kmer_size = 0;
     uint64_t nnz = 0;
     bool have_reads = false, have_matrix = false, have_pairs = false, have_alns = false;
+    bool have_tuples = false;            // device-resident tuples + dictionary of bella_hip_count_kmers
+    uint64_t kc_ntuples = 0;
+    uint32_t kc_nkmers = 0, kc_k = 0;
+    Buf kc_nk, kc_koff, kc_hist, kc_keys, kc_alt, kc_runlen, kc_flag, kc_slot, kc_nruns, kc_dcode, kc_dcount, kc_hkey, kc_hval, kc_found,
+        kc_tstart, kc_cursor;
     Buf Bptr, Bk, Bpos, Bent, Aent;
     uint32_t part_first = 0, part_stride = 1;
     bool have_panel = false;
@@ -332,7 +338,8 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->Brow, &c->deg, &c->minread, &c->colstart,
                   &c->fill, &c->ori, &c->w, &c->wscan, &c->Atmp, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC, &c->tierflag,
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
-                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres};
+                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
+                  &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& st : c->side) (void)hipStreamDestroy(st);
@@ -393,6 +400,7 @@ int bella_hip_set_reads(bella_ctx* c, const uint8_t* bases, const uint64_t* offs
     c->total_bases = total;
     c->have_reads = true;
     c->have_matrix = c->have_pairs = c->have_alns = false;
+    c->have_tuples = false;
     return 0;
 }
 
@@ -437,7 +445,7 @@ static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint6
     ENSURE(c, c->Bptr, 4 * ((size_t)nr + 2));
     const uint64_t ws_stride = (uint64_t)16 * 65536;
     ENSURE(c, c->asm_ws, ws_stride * kAsmGrid);
-    if (ntuples) {
+    if (ntuples && t_kmer) {                          // nullptr: the tuples are already there (bella_hip_count_kmers)
         HIPCHK(c, hipMemcpyAsync(c->t_kmer.p, t_kmer, 4 * ntuples, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->t_read.p, t_read, 4 * ntuples, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->t_pos.p, t_pos, 2 * ntuples, hipMemcpyHostToDevice, c->stream));
@@ -500,6 +508,7 @@ int bella_hip_assemble_tuples(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers,
     HIPCHK(c, hipSetDevice(c->device));
     c->have_matrix = c->have_pairs = c->have_alns = false;
     c->have_panel = false;
+    c->have_tuples = false;
     uint64_t nnz = 0;
     int rc = assemble_rows_device(c, 0, c->nreads, ntuples, t_kmer, t_read, t_pos, &nnz);
     if (rc) return rc;
@@ -515,6 +524,203 @@ int bella_hip_assemble_tuples(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers,
     return 0;
 }
 
+// ---- k-mer counting, dictionary, tuples (kcount.hpp) ----------------------------------------------------------------------
+static int grow_keep(bella_ctx* c, Buf& b, size_t need, size_t used) {
+    if (b.cap >= need) return 0;
+    Buf nb;
+    int rc = ensure_bytes(c, nb, need + need / 4);
+    if (rc) return rc;
+    if (used) HIPCHK(c, hipMemcpyAsync(nb.p, b.p, used, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    release(b);
+    b = nb;
+    return 0;
+}
+
+int bella_hip_count_kmers(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t* nkmers_out, uint64_t* ntuples_out,
+                          uint64_t* ndistinct_out) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    if (!c->have_reads) return fail(c, BELLA_ERR_STATE, "set_reads first");
+    if (kmer_size < 1 || kmer_size > 32) return fail(c, BELLA_ERR_BAD_ARG, "k must be in [1,32]");
+    if (lower < 2 || upper < lower || upper > 65535) return fail(c, BELLA_ERR_BAD_ARG, "need 2 <= lower <= upper <= 65535");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->have_tuples = false;
+    const uint32_t nr = c->nreads, k = kmer_size;
+    const unsigned rgrid = nr < 16384u ? (nr ? nr : 1u) : 16384u;
+    ENSURE(c, c->kc_nk, 4 * ((size_t)nr + 2));
+    ENSURE(c, c->kc_koff, 8 * ((size_t)nr + 2));
+    ENSURE(c, c->kc_hist, 8 * kCountBins);
+    ENSURE(c, c->kc_found, 4 * ((size_t)nr + 2));
+    ENSURE(c, c->kc_tstart, 8 * ((size_t)nr + 2));
+    ENSURE(c, c->kc_nruns, 16);
+    ENSURE(c, c->kc_cursor, 16);
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    k_kmers_per_read<<<nblk((uint64_t)nr + 1), 256, 0, c->stream>>>(ptr<uint64_t>(c->roff), nr, k, ptr<uint32_t>(c->kc_nk));
+    KCHK(c);
+    int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->kc_nk), ptr<uint64_t>(c->kc_koff), (uint64_t)nr + 1);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->kc_hist.p, 0, 8 * kCountBins, c->stream));
+    k_code_hist<<<rgrid, kBlock, 0, c->stream>>>(ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), ptr<uint32_t>(c->kc_nk), nr, k,
+                                                 (unsigned long long*)c->kc_hist.p);
+    KCHK(c);
+    uint64_t hist[kCountBins], ntot = 0;
+    HIPCHK(c, hipMemcpyAsync(hist, c->kc_hist.p, sizeof(hist), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&ntot, ptr<uint64_t>(c->kc_koff) + nr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // passes = runs of consecutive bins holding at most `budget` k-mers (28 bytes of HBM per k-mer in flight)
+    uint64_t budget = 1ull << 30;
+    if (const char* e = getenv("BELLA_HIP_KCOUNT_BUDGET")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) budget = v; }
+    if (budget > 0x7FFF0000ull) budget = 0x7FFF0000ull;               // rocPRIM item counts are 32-bit
+    std::vector<uint32_t> pass_lo, pass_hi;
+    std::vector<uint64_t> pass_n;
+    for (uint32_t b = 0; b < kCountBins;) {
+        uint64_t n = hist[b];
+        if (n > 0x7FFF0000ull) return fail(c, BELLA_ERR_NOMEM, "k-mer counting: one bin of canonical k-mers holds %llu words", (unsigned long long)n);
+        uint32_t e = b + 1;
+        while (e < kCountBins && n + hist[e] <= budget) n += hist[e++];
+        pass_lo.push_back(b); pass_hi.push_back(e); pass_n.push_back(n);
+        b = e;
+    }
+    uint64_t nk_total = 0, ndistinct = 0;
+    const bool single = pass_n.size() == 1;
+    for (size_t p = 0; p < pass_n.size(); ++p) {
+        const uint64_t np = pass_n[p];
+        if (!np) continue;
+        ENSURE(c, c->kc_keys, 8 * np);
+        ENSURE(c, c->kc_alt, 8 * np);
+        ENSURE(c, c->kc_runlen, 4 * (np + 1));
+        ENSURE(c, c->kc_flag, 4 * (np + 2));
+        ENSURE(c, c->kc_slot, 4 * (np + 2));
+        if (!single) HIPCHK(c, hipMemsetAsync(c->kc_cursor.p, 0, 8, c->stream));
+        k_emit_codes<<<rgrid, kBlock, 0, c->stream>>>(ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), ptr<uint32_t>(c->kc_nk),
+                                                      ptr<uint64_t>(c->kc_koff), nr, k, pass_lo[p], pass_hi[p], ptr<uint64_t>(c->kc_keys),
+                                                      single ? nullptr : (unsigned long long*)c->kc_cursor.p);
+        KCHK(c);
+        hipcub::DoubleBuffer<uint64_t> db(ptr<uint64_t>(c->kc_keys), ptr<uint64_t>(c->kc_alt));
+        size_t tb = 0;
+        HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, db, (int)np, 0, 2 * (int)k, c->stream));
+        ENSURE(c, c->cubtmp, tb);
+        HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(c->cubtmp.p, tb, db, (int)np, 0, 2 * (int)k, c->stream));
+        uint64_t* sorted = db.Current();
+        uint64_t* run_code = sorted == ptr<uint64_t>(c->kc_keys) ? ptr<uint64_t>(c->kc_alt) : ptr<uint64_t>(c->kc_keys);
+        size_t tb2 = 0;
+        HIPCHK(c, hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, sorted, run_code, ptr<uint32_t>(c->kc_runlen),
+                                                       ptr<uint32_t>(c->kc_nruns), (int)np, c->stream));
+        ENSURE(c, c->cubtmp, tb2);
+        HIPCHK(c, hipcub::DeviceRunLengthEncode::Encode(c->cubtmp.p, tb2, sorted, run_code, ptr<uint32_t>(c->kc_runlen),
+                                                       ptr<uint32_t>(c->kc_nruns), (int)np, c->stream));
+        uint32_t nruns = 0;
+        HIPCHK(c, hipMemcpyAsync(&nruns, c->kc_nruns.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        k_flag_reliable<<<nblk((uint64_t)nruns + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->kc_runlen), nruns, lower, upper, ptr<uint32_t>(c->kc_flag));
+        KCHK(c);
+        rc = scan_u32(c, ptr<uint32_t>(c->kc_flag), ptr<uint32_t>(c->kc_slot), (uint64_t)nruns + 1);
+        if (rc) return rc;
+        uint32_t nrel = 0;
+        HIPCHK(c, hipMemcpyAsync(&nrel, ptr<uint32_t>(c->kc_slot) + nruns, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (nk_total + nrel >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "more than 2^32 reliable k-mers");
+        rc = grow_keep(c, c->kc_dcode, 8 * (nk_total + nrel), 8 * nk_total);
+        if (rc) return rc;
+        rc = grow_keep(c, c->kc_dcount, 2 * (nk_total + nrel), 2 * nk_total);
+        if (rc) return rc;
+        if (nruns) {
+            k_write_dict<<<nblk(nruns), 256, 0, c->stream>>>(run_code, ptr<uint32_t>(c->kc_runlen), ptr<uint32_t>(c->kc_flag), ptr<uint32_t>(c->kc_slot),
+                                                             nruns, ptr<uint64_t>(c->kc_dcode) + nk_total, ptr<uint16_t>(c->kc_dcount) + nk_total);
+            KCHK(c);
+        }
+        nk_total += nrel;
+        ndistinct += nruns;
+    }
+    release(c->kc_alt); release(c->kc_runlen); release(c->kc_flag); release(c->kc_slot);
+    // countsreliable: open addressing at load factor <= 1/2
+    uint64_t slots = 1024;
+    while (slots < 2 * nk_total) slots <<= 1;
+    ENSURE(c, c->kc_hkey, 8 * slots);
+    ENSURE(c, c->kc_hval, 4 * slots);
+    k_hash_fill<<<nblk(slots), 256, 0, c->stream>>>(ptr<uint64_t>(c->kc_hkey), slots);
+    KCHK(c);
+    if (nk_total) {
+        k_hash_build<<<nblk(nk_total), 256, 0, c->stream>>>(ptr<uint64_t>(c->kc_dcode), (uint32_t)nk_total, ptr<uint64_t>(c->kc_hkey),
+                                                            ptr<uint32_t>(c->kc_hval), slots - 1);
+        KCHK(c);
+    }
+    ENSURE(c, c->kc_keys, 4 * ntot);                                  // now: the id of every position
+    k_lookup_ids<<<rgrid, kBlock, 0, c->stream>>>(ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), ptr<uint32_t>(c->kc_nk),
+                                                  ptr<uint64_t>(c->kc_koff), nr, k, ptr<uint64_t>(c->kc_hkey), ptr<uint32_t>(c->kc_hval),
+                                                  slots - 1, ptr<uint32_t>(c->kc_keys), ptr<uint32_t>(c->kc_found));
+    KCHK(c);
+    HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->kc_found) + nr, 0, 4, c->stream));
+    rc = scan_u32_to_u64(c, ptr<uint32_t>(c->kc_found), ptr<uint64_t>(c->kc_tstart), (uint64_t)nr + 1);
+    if (rc) return rc;
+    uint64_t nt = 0;
+    HIPCHK(c, hipMemcpyAsync(&nt, ptr<uint64_t>(c->kc_tstart) + nr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nt >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "tuple count must be < 2^32");
+    ENSURE(c, c->t_kmer, 4 * nt);
+    ENSURE(c, c->t_read, 4 * nt);
+    ENSURE(c, c->t_pos, 2 * nt);
+    k_write_tuples<<<rgrid, kBlock, 0, c->stream>>>(ptr<uint32_t>(c->kc_keys), ptr<uint32_t>(c->kc_nk), ptr<uint64_t>(c->kc_koff),
+                                                    ptr<uint64_t>(c->kc_tstart), nr, ptr<uint32_t>(c->t_kmer), ptr<uint32_t>(c->t_read),
+                                                    ptr<uint16_t>(c->t_pos));
+    KCHK(c);
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    c->tm.kcount_ms = ev_ms(c->ev[0], c->ev[1]);
+    release(c->kc_keys); release(c->kc_hkey); release(c->kc_hval);
+    c->kc_ntuples = nt;
+    c->kc_nkmers = (uint32_t)nk_total;
+    c->kc_k = k;
+    c->have_tuples = true;
+    if (nkmers_out) *nkmers_out = (uint32_t)nk_total;
+    if (ntuples_out) *ntuples_out = nt;
+    if (ndistinct_out) *ndistinct_out = ndistinct;
+    return 0;
+}
+
+int bella_hip_get_dictionary(bella_ctx* c, uint64_t* codes, uint16_t* counts) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    if (!c->have_tuples) return fail(c, BELLA_ERR_STATE, "count_kmers first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (codes && c->kc_nkmers) HIPCHK(c, hipMemcpyAsync(codes, c->kc_dcode.p, 8 * (size_t)c->kc_nkmers, hipMemcpyDeviceToHost, c->stream));
+    if (counts && c->kc_nkmers) HIPCHK(c, hipMemcpyAsync(counts, c->kc_dcount.p, 2 * (size_t)c->kc_nkmers, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bella_hip_get_tuples(bella_ctx* c, uint32_t* t_kmer, uint32_t* t_read, uint16_t* t_pos) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    if (!c->have_tuples) return fail(c, BELLA_ERR_STATE, "count_kmers first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = c->kc_ntuples;
+    if (t_kmer && n) HIPCHK(c, hipMemcpyAsync(t_kmer, c->t_kmer.p, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    if (t_read && n) HIPCHK(c, hipMemcpyAsync(t_read, c->t_read.p, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    if (t_pos && n) HIPCHK(c, hipMemcpyAsync(t_pos, c->t_pos.p, 2 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bella_hip_assemble_counted(bella_ctx* c) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    if (!c->have_tuples) return fail(c, BELLA_ERR_STATE, "count_kmers first");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->have_matrix = c->have_pairs = c->have_alns = false;
+    c->have_panel = false;
+    uint64_t nnz = 0;
+    int rc = assemble_rows_device(c, 0, c->nreads, c->kc_ntuples, nullptr, nullptr, nullptr, &nnz);
+    if (rc) return rc;
+    c->nkmers = c->kc_nkmers;
+    c->nnz = nnz;
+    c->kmer_size = (uint16_t)c->kc_k;
+    rc = build_layout(c);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    c->tm.assemble_ms = ev_ms(c->ev[0], c->ev[1]);
+    release(c->Bk_tmp); release(c->Bpos_tmp); release(c->asm_ws);
+    return 0;
+}
+
 int bella_hip_assemble_panel(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, uint32_t first_read, uint32_t nreads_panel,
                              uint64_t ntuples, const uint32_t* t_kmer, const uint32_t* t_read, const uint16_t* t_pos) {
     if (!c || (ntuples && (!t_kmer || !t_read || !t_pos))) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
@@ -525,6 +731,7 @@ int bella_hip_assemble_panel(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, 
     HIPCHK(c, hipSetDevice(c->device));
     c->have_matrix = c->have_pairs = c->have_alns = false;
     c->have_panel = false;
+    c->have_tuples = false;
     uint64_t nnz = 0;
     int rc = assemble_rows_device(c, first_read, nreads_panel, ntuples, t_kmer, t_read, t_pos, &nnz);
     if (rc) return rc;

@@ -1,0 +1,190 @@
+// kcount.hpp -- k-mer counting, the reliable dictionary and tuple generation on the device.
+//
+// Reference: SplitCount (include/kmercount.hpp:467-677) + the tuple loop of src/main.cpp:393-416.  There: every position of
+// every read -> Kmer::rep(); HyperLogLog + Bloom filter + a libcuckoo table count the k-mers seen at least twice (u16,
+// no saturation); those with lower <= count <= upper get an id; a second parse of the reads emits (id, read, position).
+// Here, for a machine with 288 GB of HBM: all canonical k-mers of the (2-bit, device-resident) reads are written out and
+// radix-sorted on their 2k significant bits (rocPRIM), run lengths give the exact multiplicities, the reliable runs form the
+// dictionary (id = rank in ascending canonical order -- the reference's ids are libcuckoo's iteration order, a label), an
+// open-addressing table over the dictionary serves the lookups of the tuple pass, and the tuples land in the buffers the
+// assembly kernels read: nothing returns to the host.  Inputs larger than the per-pass budget are split by the top bits of the
+// canonical word (an exact histogram first), so the concatenated dictionary stays sorted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "core.hpp"
+#include "util.hpp"
+
+namespace bella {
+
+constexpr uint32_t kCountBins = 256;           // top 8 bits (or all 2k bits when k < 4) of the canonical word
+constexpr uint64_t kHashEmpty = ~0ull;         // TT..T is never canonical (its twin AA..A = 0 is smaller)
+
+__device__ __forceinline__ uint64_t canonical_word(const uint32_t* packed, uint64_t g, uint32_t k) {
+    const uint64_t le = kmer_le(packed, g, k);
+    const uint64_t fw = kmer_fw_from_le(le, k), rc = kmer_rc_from_le(le, k);   // Kmer::rep, Kmer.cpp:314-317
+    return rc < fw ? rc : fw;
+}
+__device__ __forceinline__ uint32_t code_bin(uint64_t code, uint32_t k) {
+    return k >= 4 ? (uint32_t)(code >> (2 * k - 8)) : (uint32_t)code;
+}
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {                        // splitmix64 finaliser
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+
+// nk[r] = k-mers of read r (kmercount.hpp:525: j = 0 .. len-k)
+__global__ void k_kmers_per_read(const uint64_t* roff, uint32_t nreads, uint32_t k, uint32_t* nk) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nreads) return;
+    uint32_t v = 0;
+    if (r < nreads) { const uint64_t len = roff[r + 1] - roff[r]; v = len >= k ? (uint32_t)(len - k + 1) : 0u; }
+    nk[r] = v;
+}
+
+// exact histogram of the canonical words' bins: sizes the passes.  One workgroup per read.
+__global__ __launch_bounds__(kBlock) void k_code_hist(const uint32_t* packed, const uint64_t* roff, const uint32_t* nk, uint32_t nreads,
+                                                      uint32_t k, unsigned long long* hist) {
+    __shared__ uint32_t h[kCountBins];
+    for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
+        h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t g0 = roff[r];
+        const uint32_t n = nk[r];
+        for (uint32_t j = threadIdx.x; j < n; j += kBlock) atomicAdd(&h[code_bin(canonical_word(packed, g0 + j, k), k)], 1u);
+        __syncthreads();
+        if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+        __syncthreads();
+    }
+}
+
+// the canonical words of the bins [b0, b1) of one pass.  Single pass (cursor == nullptr): word j of read r goes to koff[r] + j.
+// Otherwise the order is irrelevant (the words are sorted next): a workgroup reserves room for 1024 positions at a time.
+__global__ __launch_bounds__(kBlock) void k_emit_codes(const uint32_t* packed, const uint64_t* roff, const uint32_t* nk,
+                                                       const uint64_t* koff, uint32_t nreads, uint32_t k, uint32_t b0, uint32_t b1,
+                                                       uint64_t* out, unsigned long long* cursor) {
+    __shared__ uint32_t scr[kWaves];
+    __shared__ unsigned long long s_base;
+    for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
+        const uint64_t g0 = roff[r];
+        const uint32_t n = nk[r];
+        if (!cursor) {
+            const uint64_t o = koff[r];
+            for (uint32_t j = threadIdx.x; j < n; j += kBlock) out[o + j] = canonical_word(packed, g0 + j, k);
+            continue;
+        }
+        for (uint32_t base = 0; base < n; base += 4 * kBlock) {
+            uint64_t w[4];
+            uint32_t take = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t j = base + u * kBlock + threadIdx.x;
+                w[u] = 0;
+                if (j < n) {
+                    w[u] = canonical_word(packed, g0 + j, k);
+                    const uint32_t b = code_bin(w[u], k);
+                    if (b >= b0 && b < b1) take |= 1u << u;
+                }
+            }
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kWaves>((uint32_t)__popc(take), scr, &tot);
+            if (threadIdx.x == 0) s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+            __syncthreads();
+            uint64_t o = s_base + ex;
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) if (take & (1u << u)) out[o++] = w[u];
+            __syncthreads();
+        }
+    }
+}
+
+// run i of the sorted words is reliable if lower <= (length mod 65536) <= upper (kmercount.hpp:632-655: `++num` on an
+// unsigned short, then the range test)
+__global__ void k_flag_reliable(const uint32_t* run_len, uint32_t nruns, uint32_t lower, uint32_t upper, uint32_t* flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nruns) return;
+    uint32_t f = 0;
+    if (i < nruns) { const uint32_t c = run_len[i] & 0xFFFFu; f = (c >= lower && c <= upper) ? 1u : 0u; }
+    flag[i] = f;
+}
+
+__global__ void k_write_dict(const uint64_t* run_code, const uint32_t* run_len, const uint32_t* flag, const uint32_t* slot, uint32_t nruns,
+                             uint64_t* dict_code, uint16_t* dict_count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nruns || !flag[i]) return;
+    dict_code[slot[i]] = run_code[i];
+    dict_count[slot[i]] = (uint16_t)(run_len[i] & 0xFFFFu);
+}
+
+// countsreliable (a CuckooDict in the reference, main.cpp:410 `find`): open addressing over the dictionary, value = id
+__global__ void k_hash_fill(uint64_t* hkey, uint64_t slots) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < slots) hkey[i] = kHashEmpty;
+}
+__global__ void k_hash_build(const uint64_t* dict_code, uint32_t nk, uint64_t* hkey, uint32_t* hval, uint64_t mask) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nk) return;
+    const uint64_t code = dict_code[i];
+    uint64_t h = mix64(code) & mask;
+    for (;;) {
+        const unsigned long long old = atomicCAS((unsigned long long*)&hkey[h], (unsigned long long)kHashEmpty, (unsigned long long)code);
+        if (old == kHashEmpty) { hval[h] = i; break; }
+        h = (h + 1) & mask;
+    }
+}
+
+// tuple pass 1 (main.cpp:393-416): the id of every position's k-mer (0xFFFFFFFF: not reliable) and the tuples per read
+__global__ __launch_bounds__(kBlock) void k_lookup_ids(const uint32_t* packed, const uint64_t* roff, const uint32_t* nk, const uint64_t* koff,
+                                                       uint32_t nreads, uint32_t k, const uint64_t* hkey, const uint32_t* hval, uint64_t mask,
+                                                       uint32_t* ids, uint32_t* found_per_read) {
+    __shared__ uint32_t s_cnt;
+    for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        const uint64_t g0 = roff[r], o = koff[r];
+        const uint32_t n = nk[r];
+        uint32_t mine = 0;
+        for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
+            const uint64_t code = canonical_word(packed, g0 + j, k);
+            uint64_t h = mix64(code) & mask;
+            uint32_t id = 0xFFFFFFFFu;
+            for (;;) {
+                const uint64_t kk = hkey[h];
+                if (kk == code) { id = hval[h]; break; }
+                if (kk == kHashEmpty) break;
+                h = (h + 1) & mask;
+            }
+            ids[o + j] = id;
+            mine += (id != 0xFFFFFFFFu);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+        if (lane_id() == 0 && mine) atomicAdd(&s_cnt, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) found_per_read[r] = s_cnt;
+        __syncthreads();
+    }
+}
+
+// tuple pass 2: (id, read, position) in the reference's generation order -- read by read, positions ascending
+__global__ __launch_bounds__(kBlock) void k_write_tuples(const uint32_t* ids, const uint32_t* nk, const uint64_t* koff, const uint64_t* tstart,
+                                                         uint32_t nreads, uint32_t* t_kmer, uint32_t* t_read, uint16_t* t_pos) {
+    __shared__ uint32_t scr[kWaves];
+    for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
+        const uint64_t o = koff[r];
+        const uint32_t n = nk[r];
+        uint64_t w = tstart[r];
+        for (uint32_t base = 0; base < n; base += kBlock) {
+            const uint32_t j = base + threadIdx.x;
+            const uint32_t id = j < n ? ids[o + j] : 0xFFFFFFFFu;
+            const uint32_t f = id != 0xFFFFFFFFu ? 1u : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kWaves>(f, scr, &tot);
+            if (f) { t_kmer[w + ex] = id; t_read[w + ex] = r; t_pos[w + ex] = (uint16_t)j; }
+            w += tot;
+        }
+    }
+}
+
+}  // namespace bella

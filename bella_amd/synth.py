@@ -44,6 +44,16 @@ class ReadSet:
         asc = BASES[self.codes]
         return [asc[self.offsets[r]:self.offsets[r + 1]].tobytes() for r in range(self.nreads)]
 
+    @staticmethod
+    def from_strings(seqs, names=None) -> "ReadSet":
+        raw = [np.frombuffer(x.encode() if isinstance(x, str) else bytes(x), dtype=np.uint8) for x in seqs]
+        offs = np.zeros(len(raw) + 1, dtype=np.int64)
+        np.cumsum([len(x) for x in raw], out=offs[1:])
+        codes = _CODE[np.concatenate(raw)] if raw else np.zeros(0, np.uint8)
+        if codes.size and codes.max() > 3:
+            raise ValueError("reads must be upper-case ACGT")
+        return ReadSet(codes.astype(np.uint8), offs, list(names) if names is not None else ["r%d" % i for i in range(len(raw))])
+
     def subset(self, n: int) -> "ReadSet":
         return ReadSet(self.codes[: self.offsets[n]], self.offsets[: n + 1].copy(), self.names[:n])
 

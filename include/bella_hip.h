@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define BELLA_HIP_ABI_VERSION 1
+#define BELLA_HIP_ABI_VERSION 2
 
 enum {
     BELLA_OK = 0,
@@ -101,6 +101,7 @@ typedef struct {
     float xdrop_ms;           /* X-drop kernel                                              */
     float overlap_total_ms;   /* bella_hip_overlap, stream time start to end                */
     uint32_t spgemm_launches; /* row-kernel launches (one per non-empty LDS tier)            */
+    float kcount_ms;          /* bella_hip_count_kmers: counting + dictionary + tuples      */
 } bella_timings;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */
@@ -114,6 +115,25 @@ const char* bella_hip_last_error(const bella_ctx* ctx);
 /* ---- reads: readVector_ (common.h:98-109) -------------------------------------------------------- */
 /* `bases` = all reads concatenated, upper-case ASCII ACGT; offsets has nreads+1 entries. */
 int bella_hip_set_reads(bella_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads);
+
+/* ---- k-mer counting, reliable dictionary, tuple generation ---------------------------- */
+/* Replaces SplitCount (include/kmercount.hpp:467-677) and the tuple loop of src/main.cpp:393-416 on the reads given to
+ * bella_hip_set_reads: every position j <= len-k contributes Kmer::rep() (kmercode/Kmer.cpp:314-317); a k-mer is reliable
+ * when lower <= (occurrences mod 65536) <= upper (the reference counts in an unsigned short, kmercount.hpp:632-655;
+ * lower >= 2 as in the reference's defaults: its table only holds k-mers seen twice).  K-mer ids are labels: the reference
+ * numbers in libcuckoo's iteration order, this library in ascending order of the canonical word (first base most
+ * significant, A<C<G<T, the order of Kmer::operator<).  The tuples (id, read, position) are generated in the reference's
+ * order -- read by read, positions ascending -- and stay on the device for bella_hip_assemble_counted.
+ * Out: *nkmers = dictionary size, *ntuples, *ndistinct = distinct canonical k-mers seen (the reference's HyperLogLog
+ * estimates this number, kmercount.hpp:585-590; here it is exact).  Any of them may be NULL. */
+int bella_hip_count_kmers(bella_ctx* ctx, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t* nkmers,
+                          uint64_t* ntuples, uint64_t* ndistinct);
+/* codes[nkmers]: canonical words, ascending (id = index), right-aligned in 2k bits; counts[nkmers].  Either may be NULL. */
+int bella_hip_get_dictionary(bella_ctx* ctx, uint64_t* codes, uint16_t* counts);
+/* the tuple list of the last bella_hip_count_kmers (what the reference's alltranstuples holds, main.cpp:339-423) */
+int bella_hip_get_tuples(bella_ctx* ctx, uint32_t* t_kmer, uint32_t* t_read, uint16_t* t_pos);
+/* bella_hip_assemble_tuples on the device-resident tuples of bella_hip_count_kmers (no host copy) */
+int bella_hip_assemble_counted(bella_ctx* ctx);
 
 /* ---- operands ------------------------------------------------------------------------------------ */
 /* From the (kmer, read, pos) tuple list: replaces the CSC tuple constructor + MergeDuplicates +

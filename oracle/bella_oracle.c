@@ -20,6 +20,81 @@
 #define EMPTY32 0xFFFFFFFFu
 
 /* ---------------------------------------------------------------------------------------------------
+ * K-mer counting, reliable dictionary, tuple generation
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Kmer::set_kmer (kmercode/Kmer.cpp:205-228): A,C,G,T = 0,1,2,3, first base in the most significant bits, so
+ * Kmer::operator< (Kmer.cpp:160-169) is the lexicographic order of the strings; Kmer::rep (Kmer.cpp:314-317) = the smaller
+ * of the k-mer and its reverse complement (Kmer::twin, Kmer.cpp:324-355).  Returns the canonical word, right-aligned. */
+static uint64_t oracle_canonical(const char* s, uint32_t k) {
+    uint64_t fw = 0, rc = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        const uint64_t x = ((uint64_t)(s[i] & 4)) >> 1;
+        const uint64_t code = x + ((x ^ (uint64_t)(s[i] & 2)) >> 1);            /* Kmer.cpp:215-216 */
+        fw = (fw << 2) | code;
+        rc |= (3 - code) << (2 * i);
+    }
+    return rc < fw ? rc : fw;
+}
+
+static int cmp_u64(const void* a, const void* b) {
+    const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* SplitCount (include/kmercount.hpp:467-677): every position j <= len-k of every read contributes rep(kmer) (:525-537); a
+ * k-mer enters the table at its second sighting (Bloom filter, :606-613) and the second pass counts EVERY occurrence in an
+ * unsigned short without saturation (:632-641, `++num`): count = occurrences mod 65536 (a one-off k-mer that slips through
+ * the Bloom filter ends with count 1 -- never reliable for lower >= 2; for lower <= 1 the reference's set would depend on
+ * Bloom false positives, callers use lower >= 2).  Reliable: lower <= count <= upper (:648-655).
+ * The reference numbers the reliable k-mers in libcuckoo's bucket order (:645-656), which depends on the table's insert
+ * history and thread count; the numbering is a LABEL: here id = rank in ascending canonical order.
+ * Tuple generation (src/main.cpp:393-416): read by read, positions ascending, one tuple (id, read, j) per occurrence of a
+ * reliable k-mer.
+ * seqs[r] has lens[r] bases.  dict_codes/dict_counts need room for the distinct k-mers, tuples for the positions; pass NULL
+ * to only count.  Returns the number of reliable k-mers; *ntuples and *ndistinct are set. */
+int64_t oracle_count_kmers(uint32_t nreads, const char* const* seqs, const uint32_t* lens, uint32_t k, uint32_t lower,
+                           uint32_t upper, uint64_t* dict_codes, uint16_t* dict_counts, uint32_t* t_kmer, uint32_t* t_read,
+                           uint16_t* t_pos, uint64_t* ntuples, uint64_t* ndistinct) {
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < nreads; ++r) if (lens[r] >= k) total += lens[r] - k + 1;
+    uint64_t* all = (uint64_t*)malloc(sizeof(uint64_t) * (total ? total : 1));
+    uint64_t n = 0;
+    for (uint32_t r = 0; r < nreads; ++r)
+        for (uint32_t j = 0; j + k <= lens[r]; ++j) all[n++] = oracle_canonical(seqs[r] + j, k);
+    qsort(all, n, sizeof(uint64_t), cmp_u64);
+    uint64_t* rel = (uint64_t*)malloc(sizeof(uint64_t) * (n ? n : 1));
+    uint64_t nrel = 0, ndist = 0;
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i;
+        while (j < n && all[j] == all[i]) ++j;
+        const uint32_t cnt = (uint32_t)((j - i) & 0xFFFFu);                     /* unsigned short, no saturation */
+        ndist++;
+        if (cnt >= lower && cnt <= upper) {
+            if (dict_codes) dict_codes[nrel] = all[i];
+            if (dict_counts) dict_counts[nrel] = (uint16_t)cnt;
+            rel[nrel++] = all[i];
+        }
+        i = j;
+    }
+    uint64_t nt = 0;
+    for (uint32_t r = 0; r < nreads; ++r)
+        for (uint32_t j = 0; j + k <= lens[r]; ++j) {
+            const uint64_t c = oracle_canonical(seqs[r] + j, k);
+            uint64_t lo = 0, hi = nrel;                                        /* countsreliable.find (main.cpp:410) */
+            while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (rel[mid] < c) lo = mid + 1; else hi = mid; }
+            if (lo < nrel && rel[lo] == c) {
+                if (t_kmer) { t_kmer[nt] = (uint32_t)lo; t_read[nt] = r; t_pos[nt] = (uint16_t)j; }
+                nt++;
+            }
+        }
+    free(all); free(rel);
+    if (ntuples) *ntuples = nt;
+    if (ndistinct) *ndistinct = ndist;
+    return (int64_t)nrel;
+}
+
+/* ---------------------------------------------------------------------------------------------------
  * Operand assembly
  * ------------------------------------------------------------------------------------------------- */
 

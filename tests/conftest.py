@@ -39,6 +39,8 @@ class Golden:
         fl = self.meta["flags"]
         self.err = float(fl[fl.index("-e") + 1]) if "-e" in fl else 0.15
         self.k = 17
+        self.lower = int(fl[fl.index("-l") + 1]) if "-l" in fl else 2          # main.cpp:91-92 defaults
+        self.upper = int(fl[fl.index("-u") + 1]) if "-u" in fl else 8
         self.xdrop = 7
 
 

@@ -400,3 +400,88 @@ def test_baseline_config1_full_size_parity(eng):
     assert n == len(exp) == 755378 or n == len(exp)
     assert flops == int(flop.sum())
     check_pairs(pairs, ext, exp, rs.lengths, 17)
+
+
+# ---- k-mer counting, reliable dictionary, tuples on the device ---------------------------------------------
+
+def _relabel_equal(a, b):
+    if len(a) != len(b):
+        return False
+    if len(a) == 0:
+        return True
+    pa, pb = np.unique(a, return_inverse=True)[1], np.unique(b, return_inverse=True)[1]
+    # same partition <=> the pairs (label_a, label_b) are as many as the labels on either side
+    both = np.unique(np.stack([pa, pb], 1), axis=0)
+    return len(both) == pa.max() + 1 == pb.max() + 1
+
+
+def test_count_kmers_matches_oracle_and_reference_dump(eng, golden):
+    g = golden
+    eng.set_reads(g.rs)
+    nk, nt, nd = eng.count_kmers(g.k, g.lower, g.upper)
+    codes, counts, tk, tr, tp, ndist = O.count_kmers(g.seqs, g.k, g.lower, g.upper)
+    assert (nk, nt, nd) == (len(codes), len(tk), ndist)
+    dc, dn = eng.get_dictionary()
+    assert np.array_equal(dc, codes) and np.array_equal(dn, counts)
+    gk, gr, gp = eng.get_tuples()
+    assert np.array_equal(gk, tk) and np.array_equal(gr, tr) and np.array_equal(gp, tp)
+    # the reference's own dump: same reliable set, same tuples up to the k-mer numbering
+    assert nk == g.nkmers and np.array_equal(gr, g.tr) and np.array_equal(gp, g.tp) and _relabel_equal(gk, g.tk)
+
+
+@pytest.mark.parametrize("k,lower,upper", [(17, 2, 8), (11, 2, 4), (32, 2, 8), (3, 2, 65535), (5, 3, 60000), (21, 2, 2)])
+def test_count_kmers_parameter_sweep(eng, k, lower, upper):
+    rs = synth.make_reads(70, read_len=900, coverage=12.0, err=0.1, seed=11)
+    eng.set_reads(rs)
+    nk, nt, nd = eng.count_kmers(k, lower, upper)
+    codes, counts, tk, tr, tp, ndist = O.count_kmers(rs.seqs(), k, lower, upper)
+    assert (nk, nt, nd) == (len(codes), len(tk), ndist)
+    dc, dn = eng.get_dictionary()
+    gk, gr, gp = eng.get_tuples()
+    assert np.array_equal(dc, codes) and np.array_equal(dn, counts)
+    assert np.array_equal(gk, tk) and np.array_equal(gr, tr) and np.array_equal(gp, tp)
+
+
+def test_count_kmers_multi_pass_equals_single_pass(eng, monkeypatch):
+    rs = synth.make_reads(120, read_len=1500, coverage=15.0, err=0.12, seed=3)
+    eng.set_reads(rs)
+    eng.count_kmers(17, 2, 8)
+    one = (eng.get_dictionary(), eng.get_tuples())
+    monkeypatch.setenv("BELLA_HIP_KCOUNT_BUDGET", "20000")           # ~ten passes over the bins of the canonical word
+    eng.count_kmers(17, 2, 8)
+    many = (eng.get_dictionary(), eng.get_tuples())
+    for a, b in zip(one[0] + one[1], many[0] + many[1]):
+        assert np.array_equal(a, b)
+
+
+def test_count_kmers_edge_cases(eng):
+    # reads shorter than k contribute nothing; a u16 count wraps (kmercount.hpp:632-641): 65538 copies of one k-mer count as 2
+    rs = synth.ReadSet.from_strings(["ACGT", "A" * 40000, "A" * 25570, "ACGTACGTTTGACCA"], ["a", "b", "c", "d"])
+    eng.set_reads(rs)
+    k = 17
+    nk, nt, nd = eng.count_kmers(k, 2, 8)
+    codes, counts, tk, tr, tp, ndist = O.count_kmers(rs.seqs(), k, 2, 8)
+    assert (nk, nt, nd) == (len(codes), len(tk), ndist) == (1, 65538, 1) and counts[0] == 2
+    gk, gr, gp = eng.get_tuples()
+    assert np.array_equal(gk, tk) and np.array_equal(gr, tr) and np.array_equal(gp, tp)
+    with pytest.raises(BellaHipError):
+        eng.count_kmers(17, 1, 8)
+    with pytest.raises(BellaHipError):
+        eng.count_kmers(33, 2, 8)
+
+
+def test_counted_pipeline_equals_tuple_pipeline(eng):
+    """count -> assemble -> overlap entirely on the device == the same with host-side tuples (ids agree: ascending canonical order)"""
+    rs = synth.make_reads(300, read_len=2500, coverage=20.0, err=0.15, seed=21)
+    t = synth.count_and_tuples(rs, 17, 2, 8)
+    eng.set_reads(rs)
+    eng.assemble_tuples(17, t.nkmers, t.kmer, t.read, t.pos)
+    n1, f1 = eng.overlap(BellaPars(skipAlignment=True))
+    p1, e1, c1 = eng.get_pairs()
+    nk, nt, _ = eng.count_kmers(17, 2, 8)
+    assert nk == t.nkmers and nt == len(t.kmer)
+    eng.assemble_counted()
+    n2, f2 = eng.overlap(BellaPars(skipAlignment=True))
+    p2, e2, c2 = eng.get_pairs()
+    assert (n1, f1) == (n2, f2) and np.array_equal(p1, p2) and np.array_equal(e1, e2) and np.array_equal(c1, c2)
+    assert eng.timings().kcount_ms > 0

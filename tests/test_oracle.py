@@ -146,3 +146,37 @@ def test_hashspgemm_matches_reference_code_on_fresh_input(tmp_path):
         flagged = {(rs.names[p["cid"]], rs.names[p["rid"]]) for p, a in zip(pairs, alns) if a["flagged"]}
         bad = [l for l in set(got.split(b"\n")) ^ set(data2.split(b"\n")) if l and tuple(l.decode().split("\t")[:2]) not in flagged]
         assert not bad
+
+
+def _same_up_to_relabel(a, b):
+    """two id arrays label the same partition"""
+    if len(a) != len(b):
+        return False
+    fwd, bwd = {}, {}
+    for x, y in zip(a.tolist(), b.tolist()):
+        if fwd.setdefault(x, y) != y or bwd.setdefault(y, x) != x:
+            return False
+    return True
+
+
+def test_count_kmers_matches_reference_tuples(golden):
+    """kmercount.hpp:467-677 + main.cpp:393-416: the reliable set, and the tuples in generation order, equal the
+    reference's dump (k-mer ids are labels: libcuckoo's iteration order there, ascending canonical order here)."""
+    codes, counts, tk, tr, tp, ndist = O.count_kmers(golden.seqs, golden.k, golden.lower, golden.upper)
+    assert len(codes) == golden.nkmers
+    assert np.all(np.diff(codes.astype(np.int64)) > 0) if golden.k <= 31 else True
+    assert np.all((counts >= golden.lower) & (counts <= golden.upper))
+    assert np.array_equal(tr, golden.tr) and np.array_equal(tp, golden.tp)
+    assert _same_up_to_relabel(tk, golden.tk)
+    # every dictionary entry is used, and the counts are the tuples' multiplicities
+    assert np.array_equal(np.bincount(tk, minlength=len(codes)), counts.astype(np.int64))
+
+
+def test_count_kmers_matches_numpy_statement():
+    from bella_amd import synth
+    rs = synth.make_reads(60, read_len=900, coverage=12.0, err=0.1, seed=5)
+    for k, lo, up in ((17, 2, 8), (11, 2, 4), (32, 2, 8), (5, 3, 60000)):
+        codes, counts, tk, tr, tp, _ = O.count_kmers(rs.seqs(), k, lo, up)
+        t = synth.count_and_tuples(rs, k, lo, up)
+        assert t.nkmers == len(codes)
+        assert np.array_equal(t.kmer, tk) and np.array_equal(t.read, tr) and np.array_equal(t.pos, tp)
