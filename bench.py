@@ -146,6 +146,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # measured device-copy ceiling: 1 GiB device-to-device, read + write bytes per second
+    copy_gbps = None
+    if rank == 0:
+        try:
+            src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda:%d" % local)
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbps = 5 * 2.0 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del src, dst
+        except Exception:
+            copy_gbps = None
+
     for _ in range(a.warmup):
         eng.overlap(pars)
     sync()
@@ -213,7 +232,8 @@ def main():
                    "partition": "columns i %% %d == rank" % n_gpus},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": None, "kernel": "SpGEMM = k_spgemm_rows_* (one launch set = the concurrent tier launches of a pass) + k_fold_overflow", "kernel_ms_per_step": k_ms,
-                     "launches_per_step": launches / a.steps, "algorithmic_bytes_per_step": alg_bytes},
+                     "launches_per_step": launches / a.steps, "algorithmic_bytes_per_step": alg_bytes,
+                     "measured_copy_ceiling_GBps": copy_gbps},
         "phases_ms_per_step": {"symbolic+tiering": sym_ms / a.steps, "row_kernels": rows_ms / a.steps, "overflow_fold": fold_ms / a.steps,
                                "compaction": comp_ms / a.steps},
         "kcount_ms": kcount_ms, "assemble_ms": asm_ms, "panel_allgather_ms": xchg_ms,
