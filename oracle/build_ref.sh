@@ -28,7 +28,8 @@ stamp="$O/.stamp"
 ROOTDIR="$(cd "$HERE/.." && pwd)"
 if [ -f "$stamp" ] && [ "$OUT/libbella_ref.so" -nt "$HERE/ref_shim.cpp" ] && [ -x "$OUT/bella_ref" ] \
    && [ -x "$OUT/bella_ref_dump" ] && [ "$OUT/libbella_dropin.so" -nt "$HERE/dropin_shim.cpp" ] \
-   && [ "$OUT/libbella_dropin.so" -nt "$ROOTDIR/bella_amd/host/bella_hip_shim.hpp" ] && [ "${1:-}" != "--force" ]; then
+   && [ "$OUT/libbella_dropin.so" -nt "$ROOTDIR/bella_amd/host/bella_hip_shim.hpp" ] && [ -x "$OUT/bella_eval" ] \
+   && [ "${1:-}" != "--force" ]; then
   echo "build_ref: up to date"; exit 0
 fi
 set -x
@@ -44,6 +45,9 @@ g++ -std=c++14 -w -O3 $INC -mavx2 -fopenmp -fpermissive -o "$OUT/bella_ref" $OBJ
 g++ -std=c++14 -w -O3 $INC -mavx2 -fopenmp -fpermissive -DWRITEDATAMATRIX -o "$OUT/bella_ref_dump" $OBJS "$REF/src/main.cpp" -lpthread &
 g++ -std=c++14 -w -O3 $INC -I"$REF" -DBELLA_REF_ROOT="\"$REF\"" -mavx2 -fopenmp -fpermissive -fPIC -shared \
     -o "$OUT/libbella_ref.so" "$HERE/ref_shim.cpp" $OBJS -lpthread &
+# the reference's quality evaluator (benchmark/evaluation.cpp: recall / precision / F1 against a truth file)
+gcc -O3 -w -c "$REF/optlist/optlist.c" -o "$O/optlist_c.o"     # benchmark/Makefile:7-8 (C linkage here)
+g++ -O3 -w -fopenmp -fpermissive -I"$REF/benchmark" -o "$OUT/bella_eval" "$O/optlist_c.o" "$REF/benchmark/evaluation.cpp" &
 # the drop-in proof: reference headers + the product's shim header, linked against libbella_hip.so (built first by
 # __graft_entry__.build(); located at run time through $ORIGIN)
 if [ -f "$ROOTDIR/bella_amd/libbella_hip.so" ]; then

@@ -195,8 +195,42 @@ def xavier_kats():
     print("xavier KATs:", len(kats), "demo ->", kats[0]["expect"], kats[0]["exit_score"])
 
 
+def eval_kats(sets=("toy120", "toylen80", "toyhifi50"), min_overlaps=(300, 500, 1000)):
+    """known answers of the reference's quality evaluator (benchmark/evaluation.cpp built as oracle/_ref/bella_eval): recall,
+    precision, F1 of each golden aligned output against the truth its read names encode (r<idx>_<start>_<len>_<strand>)"""
+    import gzip
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name in sets:
+            d = os.path.join(GOLD, name)
+            rs = synth.read_fastq(os.path.join(d, "reads.fastq.gz"))
+            truth = os.path.join(tmp, "truth.txt")
+            with open(truth, "w") as f:                     # evaluation.h:93-97 (not simulated): ref read start end
+                for n in rs.names:
+                    _, st, ln, _ = n.rsplit("_", 3)
+                    f.write("genome %s %d %d\n" % (n, int(st), int(st) + int(ln)))
+            bella = os.path.join(tmp, "bella.out")
+            with open(bella, "wb") as f:
+                f.write(gzip.open(os.path.join(d, "align.out.gz"), "rb").read())
+            for mo in min_overlaps:
+                r = subprocess.run([os.path.join(RB, "bella_eval"), "-G", truth, "-B", bella, "-l", str(mo)], stdout=subprocess.PIPE,
+                                   check=True, env=dict(os.environ, OMP_NUM_THREADS="1"))
+                lines = [ln.strip() for ln in r.stdout.decode().splitlines()]
+                nums = [ln for ln in lines if re.fullmatch(r"-?[0-9.]+|-?nan", ln)]
+                g = int(next(ln for ln in lines if "in the ground truth" in ln).split()[0])
+                s2 = int(next(ln for ln in lines if ln.startswith("* ") and "overlaps longer" in ln).split()[1])
+                t2 = int(next(ln for ln in lines if ln.startswith("* ") and "true positives" in ln).split()[1])
+                out["%s/%d" % (name, mo)] = {"truth": g, "reported_x2": s2, "true_positives_x2": t2, "recall": nums[-3],
+                                             "precision": nums[-2], "f1": nums[-1]}
+    json.dump(out, open(os.path.join(GOLD, "eval_kat.json"), "w"), indent=1)
+    return out
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--eval-only" in sys.argv:
+        print(eval_kats())
+        return
     # the reference's own 3-read sanity input is a data file (sanitytests/reversecomptest.fastq)
     rs = synth.read_fastq(os.path.join(REF, "sanitytests", "reversecomptest.fastq"))
     make_set("sanity3", rs, [])
@@ -206,6 +240,7 @@ def main():
              ["-e", "0.005"])
     make_set("toyrep90", repeat_genome_reads(5), ["-e", "0.12", "-u", "30"])
     xavier_kats()
+    eval_kats()
     # read intervals of the reference's E. coli sample (dataset/ecsample-truth.txt, columns 3-4): the FASTQ itself is not in
     # the reference snapshot; the intervals shape the "ecsample-like" synthetic set of BASELINE configs[0]
     iv = np.loadtxt(os.path.join(REF, "dataset", "ecsample-truth.txt"), usecols=(2, 3), dtype=np.int64)
