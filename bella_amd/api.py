@@ -7,6 +7,7 @@ BELLA / PAF format and the stdout protocol numbers."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 import dataclasses
 import sys
 
@@ -73,6 +74,23 @@ class Engine:
         self.nreads = rs.nreads
         self.lengths = rs.lengths
         self.names = rs.names
+
+    def load_fastq(self, path: str):
+        """ParallelFASTQ + get_fq_name (kmercode/fq_reader.c) + 2-bit packing: the file goes straight into the library"""
+        n, nb = C.c_uint32(0), C.c_uint64(0)
+        self._chk(self.lib.bella_hip_load_fastq(self.h, os.fsencode(path), C.byref(n), C.byref(nb)))
+        self.nreads = n.value
+        need = C.c_uint64(0)
+        self._chk(self.lib.bella_hip_get_read_names(self.h, None, 0, None, C.byref(need)))
+        buf = C.create_string_buffer(max(need.value, 1))
+        offs = np.zeros(self.nreads + 1, np.uint64)
+        self._chk(self.lib.bella_hip_get_read_names(self.h, buf, need.value, offs.ctypes.data, None))
+        raw = buf.raw
+        self.names = [raw[int(offs[i]):int(offs[i + 1]) - 1].decode() for i in range(self.nreads)]
+        lens = np.zeros(max(self.nreads, 1), np.uint32)
+        self._chk(self.lib.bella_hip_get_read_lengths(self.h, lens.ctypes.data))
+        self.lengths = lens[:self.nreads]
+        return self.nreads, nb.value
 
     def set_reads_raw(self, ascii_bases: np.ndarray, offsets: np.ndarray, names=None):
         offs = np.ascontiguousarray(offsets, dtype=np.uint64)

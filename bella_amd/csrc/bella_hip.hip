@@ -14,6 +14,7 @@
 #include "../../include/bella_hip.h"
 #include "assemble.hpp"
 #include "core.hpp"
+#include "fastq.hpp"
 #include "kcount.hpp"
 #include "spgemm.hpp"
 #include "util.hpp"
@@ -58,6 +59,8 @@ struct bella_ctx {
     uint32_t nkmers = 0, kmer_size = 0;
     uint64_t nnz = 0;
     bool have_reads = false, have_matrix = false, have_pairs = false, have_alns = false;
+    std::vector<std::string> names;      // read names when the reads came through bella_hip_load_fastq
+    std::vector<uint32_t> host_lens;
     bool have_tuples = false;            // device-resident tuples + dictionary of bella_hip_count_kmers
     uint64_t kc_ntuples = 0;
     uint32_t kc_nkmers = 0, kc_k = 0;
@@ -398,9 +401,53 @@ int bella_hip_set_reads(bella_ctx* c, const uint8_t* bases, const uint64_t* offs
     if (rc) return rc;
     c->nreads = nreads;
     c->total_bases = total;
+    c->names.clear();
+    c->host_lens.resize(nreads);
+    for (uint32_t r = 0; r < nreads; ++r) c->host_lens[r] = (uint32_t)(offsets[r + 1] - offsets[r]);
     c->have_reads = true;
     c->have_matrix = c->have_pairs = c->have_alns = false;
     c->have_tuples = false;
+    return 0;
+}
+
+// ---- FASTQ ingest (fastq.hpp) ---------------------------------------------------------------------------------------------
+int bella_hip_load_fastq(bella_ctx* c, const char* path, uint32_t* nreads, uint64_t* nbases) {
+    if (!c || !path) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+    FastqData fq;
+    std::string err;
+    if (parse_fastq(path, fq, err)) return fail(c, BELLA_ERR_BAD_ARG, "%s", err.c_str());
+    if (fq.names.size() >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "more than 2^32 reads");
+    const uint8_t dummy = 0;
+    int rc = bella_hip_set_reads(c, fq.bases.empty() ? &dummy : fq.bases.data(), fq.offsets.data(), (uint32_t)fq.names.size());
+    if (rc) return rc;
+    c->names = std::move(fq.names);
+    if (nreads) *nreads = c->nreads;
+    if (nbases) *nbases = c->total_bases;
+    return 0;
+}
+
+int bella_hip_get_read_names(bella_ctx* c, char* buf, uint64_t buflen, uint64_t* offsets, uint64_t* needed) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    if (!c->have_reads || c->names.size() != c->nreads) return fail(c, BELLA_ERR_STATE, "the reads were not loaded with bella_hip_load_fastq");
+    uint64_t tot = 0;
+    for (const auto& n : c->names) tot += n.size() + 1;
+    if (needed) *needed = tot;
+    if (!buf) return 0;
+    if (buflen < tot) return fail(c, BELLA_ERR_BAD_ARG, "name buffer too small: %llu < %llu", (unsigned long long)buflen, (unsigned long long)tot);
+    uint64_t o = 0;
+    for (size_t r = 0; r < c->names.size(); ++r) {
+        if (offsets) offsets[r] = o;
+        std::memcpy(buf + o, c->names[r].c_str(), c->names[r].size() + 1);          // NUL-terminated, back to back
+        o += c->names[r].size() + 1;
+    }
+    if (offsets) offsets[c->names.size()] = o;
+    return 0;
+}
+
+int bella_hip_get_read_lengths(bella_ctx* c, uint32_t* lens) {
+    if (!c || !lens) return BELLA_ERR_BAD_ARG;
+    if (!c->have_reads) return fail(c, BELLA_ERR_STATE, "no reads");
+    std::memcpy(lens, c->host_lens.data(), 4 * (size_t)c->nreads);
     return 0;
 }
 

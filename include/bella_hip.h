@@ -115,6 +115,14 @@ const char* bella_hip_last_error(const bella_ctx* ctx);
 /* ---- reads: readVector_ (common.h:98-109) -------------------------------------------------------- */
 /* `bases` = all reads concatenated, upper-case ASCII ACGT; offsets has nreads+1 entries. */
 int bella_hip_set_reads(bella_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads);
+/* FASTQ ingest: replaces ParallelFASTQ::fill_block / get_next_fq_record (kmercode/fq_reader.c:540-610) and the
+ * name handling of get_fq_name (fq_reader.c:88-130) + src/main.cpp:352-360 for one plain (not compressed, as in the
+ * reference's NO_GZIP build) 4-line FASTQ file: parse on the host, pack to 2 bit/base on the device.  Same effect as
+ * bella_hip_set_reads; the names (without '@', cut at the comment as the reference does) stay in the context. */
+int bella_hip_load_fastq(bella_ctx* ctx, const char* path, uint32_t* nreads, uint64_t* nbases);
+/* names back to back, NUL-terminated; offsets[nreads+1] into buf; *needed = bytes required (call with buf = NULL first) */
+int bella_hip_get_read_names(bella_ctx* ctx, char* buf, uint64_t buflen, uint64_t* offsets, uint64_t* needed);
+int bella_hip_get_read_lengths(bella_ctx* ctx, uint32_t* lens);
 
 /* ---- k-mer counting, reliable dictionary, tuple generation ---------------------------- */
 /* Replaces SplitCount (include/kmercount.hpp:467-677) and the tuple loop of src/main.cpp:393-416 on the reads given to

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../bella_amd/csrc/core.hpp"
+#include "../../bella_amd/csrc/fastq.hpp"
 #include "../../bella_amd/csrc/xdrop.hpp"
 
 using namespace bella;
@@ -75,6 +76,28 @@ void h_xdrop_pair(const uint32_t* packed, uint64_t goffH, uint32_t lenH, uint64_
         }
     }
     finish_pair(g, ran[0], res[0], ran[1], res[1], phi, delta, *out);
+}
+
+// FASTQ ingest (fastq.hpp): the parse of a file, flattened.  Returns the read count or -1; names are joined with '\n'.
+long h_parse_fastq(const char* path, uint8_t* bases, uint64_t bases_cap, uint64_t* offsets, uint64_t offsets_cap, char* names,
+                   uint64_t names_cap, uint64_t* nbases) {
+    FastqData fq;
+    std::string err;
+    if (parse_fastq(path, fq, err)) return -1;
+    std::string joined;
+    for (const auto& n : fq.names) { joined += n; joined += '\n'; }
+    *nbases = fq.bases.size();
+    if (fq.bases.size() > bases_cap || fq.offsets.size() > offsets_cap || joined.size() + 1 > names_cap) return -2;
+    std::memcpy(bases, fq.bases.data(), fq.bases.size());
+    std::memcpy(offsets, fq.offsets.data(), 8 * fq.offsets.size());
+    std::memcpy(names, joined.c_str(), joined.size() + 1);
+    return (long)fq.names.size();
+}
+
+void h_fastq_name(const char* header, char* out, uint64_t cap) {
+    const std::string n = fastq_read_name(header);
+    std::strncpy(out, n.c_str(), cap - 1);
+    out[cap - 1] = 0;
 }
 
 }  // extern "C"

@@ -21,7 +21,7 @@ ALN_DT = np.dtype([("score", "<i4"), ("begH", "<i4"), ("endH", "<i4"), ("begV", 
 
 @pytest.fixture(scope="module")
 def H():
-    deps = [HSRC] + [os.path.join(ROOT, "bella_amd", "csrc", f) for f in ("core.hpp", "xdrop.hpp")]
+    deps = [HSRC] + [os.path.join(ROOT, "bella_amd", "csrc", f) for f in ("core.hpp", "xdrop.hpp", "fastq.hpp")]
     if not os.path.exists(HLIB) or any(os.path.getmtime(d) > os.path.getmtime(HLIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", HLIB, HSRC])
     h = C.CDLL(HLIB)
@@ -32,6 +32,9 @@ def H():
                                C.c_int, C.c_double, C.c_double, C.c_void_p]
     h.h_kmer_words.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
     h.h_fold_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
+    h.h_parse_fastq.restype = C.c_long
+    h.h_parse_fastq.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    h.h_fastq_name.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64]
     return h
 
 
@@ -211,3 +214,61 @@ def test_ordered_insertion_fixed_point_equals_sequential():
             ag[1] = (ag[1] + 1) & (ht - 1)
         got = [EMPTY if x == EMPTY else (x & 0xFFFF) for x in T2]
         assert got == seq, trial
+
+
+# ---- FASTQ ingest (bella_amd/csrc/fastq.hpp, host code of the library) -----------------------------------------------------
+
+def _parse(H, path):
+    size = os.path.getsize(path)
+    bases = np.zeros(size + 1, np.uint8)
+    offs = np.zeros(size // 4 + 4, np.uint64)
+    names = C.create_string_buffer(size + 2)
+    nb = C.c_uint64(0)
+    n = H.h_parse_fastq(os.fsencode(path), bases.ctypes.data, bases.size, offs.ctypes.data, offs.size, names, size + 2, C.byref(nb))
+    assert n >= 0, n
+    return n, bases[:nb.value].tobytes(), offs[:n + 1].astype(np.int64), names.value.decode().split("\n")[:-1]
+
+
+def test_fastq_parse_matches_golden_reads_and_reference_names(H, golden, tmp_path):
+    """the names the reference printed in its output files (fq_reader.c get_fq_name, main.cpp:357) and the bases it aligned"""
+    import gzip
+    g = golden
+    p = tmp_path / "r.fastq"
+    p.write_bytes(gzip.open(os.path.join(ROOT, "tests", "golden", g.name, "reads.fastq.gz"), "rb").read())
+    n, bases, offs, names = _parse(H, str(p))
+    assert n == g.rs.nreads and names == g.names
+    assert bases == synth.BASES[g.rs.codes].tobytes() and np.array_equal(offs, g.rs.offsets)
+    used = {ln.split(b"\t")[0].decode() for ln in g.out["skip"].split(b"\n") if ln} | \
+           {ln.split(b"\t")[1].decode() for ln in g.out["skip"].split(b"\n") if ln}
+    assert used <= set(names)
+
+
+def test_fastq_name_rules(H):
+    def nm(h):
+        out = C.create_string_buffer(256)
+        H.h_fastq_name(h.encode(), out, 256)
+        return out.value.decode()
+    assert nm("@read1") == "read1"
+    assert nm("@read1   ") == "read1"
+    assert nm("@m54/12/0_100 RQ=0.8") == "m54/12/0_100"
+    assert nm("@r\tcomment here") == "r"
+    assert nm("@pair 1:N:0:ATCACG") == "pair/1"            # new Illumina comment -> /1 (fq_reader.c:121-124)
+    assert nm("@pair 2:Y:0:ATCACG") == "pair/2"
+    assert nm("@pair 2:Y:18:ATCACG") == "pair"             # two-digit control field: "unknown pairing format" there too
+    assert nm("@pair 3:N:0:ATCACG") == "pair"
+    assert nm("@pair/1") == "pair/1"                       # already in /x form: untouched
+    assert nm("@pair/1 extra") == "pair/1 extra"[:6]
+    assert nm("@name x") == "name"
+
+
+def test_fastq_edge_cases(H, tmp_path):
+    p = tmp_path / "e.fastq"
+    p.write_bytes(b"@a c\nACGT\n+\n!!!!\n@b\nGGCC\r\n+b\n!!!!")           # CRLF bases, no final newline
+    n, bases, offs, names = _parse(H, str(p))
+    assert (n, bases, offs.tolist(), names) == (2, b"ACGTGGCC", [0, 4, 8], ["a", "b"])
+    p.write_bytes(b"@a\nACGT\n+\n!!!!\n\n@b\nGG\n+\n!!\n")                 # an empty line ends the parse (fq_reader.c:567-574)
+    assert _parse(H, str(p))[0] == 1
+    p.write_bytes(b"@a\nACGT\n+\n")                                            # short record is dropped
+    assert _parse(H, str(p))[0] == 0
+    p.write_bytes(b"")
+    assert _parse(H, str(p))[0] == 0
