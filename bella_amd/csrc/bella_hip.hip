@@ -18,6 +18,7 @@
 #include "kcount.hpp"
 #include "spgemm.hpp"
 #include "util.hpp"
+#include "wide.hpp"
 #include "xdrop.hpp"
 #include "xdrop_packed.hpp"
 
@@ -79,6 +80,9 @@ struct bella_ctx {
     uint32_t pair_ratio1024 = 1024;   // max over sampled columns of 1024 * pairs/products
     Buf flopsr, flopptr, nnzC, colptrC, tierflag, rowlists, tiercaps, tmp_pairs, tmp_ext, pairs, ext, sortscr, ws,
         status, cubtmp, plist_hv, overflow, ctl, retry;
+    Buf w_f, w_off, w_key, w_key2, w_idx, w_idx2, w_hv, w_ovfl, w_plist, w_scr, w_rkey, w_rlen, w_rstart, w_rrank, w_segfirst,
+        w_toff, w_table, w_nruns;
+    uint32_t n_wide = 0;
     uint32_t n_retry = 0;
     uint32_t n_overflow = 0;
     // alignment
@@ -341,7 +345,8 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->Brow, &c->deg, &c->minread, &c->colstart,
                   &c->fill, &c->ori, &c->w, &c->wscan, &c->Atmp, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC, &c->tierflag,
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
-                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
+                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx, &c->w_idx2, &c->w_hv, &c->w_ovfl,
+                  &c->w_plist, &c->w_scr, &c->w_rkey, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
                   &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -853,6 +858,97 @@ int bella_hip_get_B(bella_ctx* c, uint64_t* nnz, uint32_t* colptr, uint32_t* row
     return 0;
 }
 
+__global__ void k_wide_sizes(const uint32_t* cols, const uint32_t* flops, uint32_t nw, uint32_t* wf) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > nw) return;
+    wf[s] = s < nw ? flops[cols[s]] : 0u;
+}
+
+// columns with >= 65536 products: expand -> sort by (column, partner) -> pairs -> slot order -> serial fold (wide.hpp)
+static int run_wide(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint32_t* d_cols) {
+    ENSURE(c, c->w_f, 4 * ((size_t)nw + 2));
+    ENSURE(c, c->w_off, 8 * ((size_t)nw + 2));
+    ENSURE(c, c->w_nruns, 16);
+    k_wide_sizes<<<nblk((uint64_t)nw + 1), 256, 0, c->stream>>>(d_cols, ptr<uint32_t>(c->flopsr), nw, ptr<uint32_t>(c->w_f));
+    KCHK(c);
+    int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->w_f), ptr<uint64_t>(c->w_off), (uint64_t)nw + 1);
+    if (rc) return rc;
+    uint64_t T = 0;
+    HIPCHK(c, hipMemcpyAsync(&T, ptr<uint64_t>(c->w_off) + nw, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (T >= 0x7FFF0000ull) return fail(c, BELLA_ERR_ROW_TOO_LARGE, "the columns with >= 65536 products hold %llu products together (limit 2^31)",
+                                        (unsigned long long)T);
+    ENSURE(c, c->w_key, 8 * T); ENSURE(c, c->w_key2, 8 * T);
+    ENSURE(c, c->w_idx, 4 * T); ENSURE(c, c->w_idx2, 4 * T);
+    ENSURE(c, c->w_hv, 4 * T); ENSURE(c, c->w_ovfl, 4 * T);
+    ENSURE(c, c->w_plist, 8 * T); ENSURE(c, c->w_scr, 2 * T);
+    ENSURE(c, c->w_rlen, 4 * (T + 1)); ENSURE(c, c->w_rstart, 4 * (T + 2)); ENSURE(c, c->w_rrank, 4 * T);
+    ENSURE(c, c->w_segfirst, 4 * ((size_t)nw + 2));
+    ENSURE(c, c->w_toff, 8 * ((size_t)nw + 2));
+    WideArgs a{};
+    a.cols = d_cols; a.nw = nw; a.woff = ptr<uint64_t>(c->w_off);
+    a.Bptr = sa.Bptr; a.Bent = sa.Bent; a.Aent = sa.Aent; a.roff = sa.roff; a.packed = sa.packed; a.flopptr = sa.flopptr;
+    a.k = sa.k; a.binSize = sa.binSize;
+    a.W_key = ptr<uint64_t>(c->w_key); a.W_idx = ptr<uint32_t>(c->w_idx); a.W_hv = ptr<uint32_t>(c->w_hv); a.W_ovfl = ptr<uint32_t>(c->w_ovfl);
+    a.plist = ptr<uint2>(c->w_plist); a.sort_scratch = ptr<uint16_t>(c->w_scr);
+    a.tmp_pairs = sa.tmp_pairs; a.tmp_ext = sa.tmp_ext; a.nnzC = sa.nnzC; a.status = sa.ctl + kCtlStatus;
+    k_wide_expand<<<nw < 1024u ? nw : 1024u, kBlock, 0, c->stream>>>(a);
+    KCHK(c);
+    int seg_bits = 1;
+    while ((1u << seg_bits) < nw) ++seg_bits;
+    hipcub::DoubleBuffer<uint64_t> dk(ptr<uint64_t>(c->w_key), ptr<uint64_t>(c->w_key2));
+    hipcub::DoubleBuffer<uint32_t> dv(ptr<uint32_t>(c->w_idx), ptr<uint32_t>(c->w_idx2));
+    size_t tb = 0;
+    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (int)T, 0, 32 + seg_bits, c->stream));
+    ENSURE(c, c->cubtmp, tb);
+    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb, dk, dv, (int)T, 0, 32 + seg_bits, c->stream));
+    a.S_key = dk.Current(); a.S_idx = dv.Current();
+    uint64_t* rkey = dk.Current() == ptr<uint64_t>(c->w_key) ? ptr<uint64_t>(c->w_key2) : ptr<uint64_t>(c->w_key);
+    size_t tb2 = 0;
+    HIPCHK(c, hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, a.S_key, rkey, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_nruns), (int)T, c->stream));
+    ENSURE(c, c->cubtmp, tb2);
+    HIPCHK(c, hipcub::DeviceRunLengthEncode::Encode(c->cubtmp.p, tb2, a.S_key, rkey, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_nruns), (int)T, c->stream));
+    uint32_t np = 0;
+    HIPCHK(c, hipMemcpyAsync(&np, c->w_nruns.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->w_rlen) + np, 0, 4, c->stream));
+    rc = scan_u32(c, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_rstart), (uint64_t)np + 1);
+    if (rc) return rc;
+    a.R_key = rkey; a.R_len = ptr<uint32_t>(c->w_rlen); a.R_start = ptr<uint32_t>(c->w_rstart); a.npairs = np;
+    a.R_rank = ptr<uint32_t>(c->w_rrank); a.seg_first = ptr<uint32_t>(c->w_segfirst);
+    k_wide_gather<<<nblk(T), 256, 0, c->stream>>>(a, T);
+    KCHK(c);
+    k_wide_segments<<<nblk((uint64_t)np + 1), 256, 0, c->stream>>>(a);
+    KCHK(c);
+    std::vector<uint32_t> segf((size_t)nw + 1);
+    HIPCHK(c, hipMemcpyAsync(segf.data(), c->w_segfirst.p, 4 * ((size_t)nw + 1), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> toff((size_t)nw + 1, 0);
+    for (uint32_t s = 0; s < nw; ++s) {
+        const uint64_t d = segf[s + 1] - segf[s];
+        uint64_t ht = 16;
+        while (ht < d) ht <<= 1;                                   // overlap.hpp:291-295
+        toff[s + 1] = toff[s] + ht;
+    }
+    ENSURE(c, c->w_table, 8 * toff[nw]);
+    HIPCHK(c, hipMemcpyAsync(c->w_toff.p, toff.data(), 8 * ((size_t)nw + 1), hipMemcpyHostToDevice, c->stream));
+    a.table = ptr<uint64_t>(c->w_table); a.toff = ptr<uint64_t>(c->w_toff);
+    k_wide_table_fill<<<nblk(toff[nw]), 256, 0, c->stream>>>(a.table, toff[nw]);
+    KCHK(c);
+    if (np) {
+        k_wide_insert<<<nblk(np), 256, 0, c->stream>>>(a);
+        KCHK(c);
+    }
+    k_wide_ranks<<<nw < 1024u ? nw : 1024u, kBlock, 0, c->stream>>>(a);
+    KCHK(c);
+    if (np) {
+        k_wide_fold<<<nblk(np, 64), 64, 0, c->stream>>>(a);
+        KCHK(c);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));                    // toff / segf are host vectors
+    return 0;
+}
+
 static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out) {
     const uint32_t nr = c->nreads;
     const bool force_global = (c->debug & 1u) != 0;
@@ -864,7 +960,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     ENSURE(c, c->flopptr, 8 * ((size_t)nr + 2));
     ENSURE(c, c->nnzC, 4 * ((size_t)nr + 2));
     ENSURE(c, c->colptrC, 8 * ((size_t)nr + 2));
-    ENSURE(c, c->rowlists, 4 * (size_t)kNumTiers * nr);
+    ENSURE(c, c->rowlists, 4 * (size_t)(kNumTiers + 1) * nr);
     ENSURE(c, c->tiercaps, 4 * kNumTiers);
     ENSURE(c, c->ctl, 4 * kCtlWords);
     ENSURE(c, c->tmp_pairs, sizeof(bella_pair) * Fub);
@@ -906,7 +1002,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     KCHK(c);
     // the one host round trip before the row kernels: the tiers' lengths (exact grids; 32 bytes into pinned memory)
     uint32_t* const tcnt = c->pinned;
-    HIPCHK(c, hipMemcpyAsync(tcnt, d_ctl + kCtlTierCnt, 4 * kNumTiers, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(tcnt, d_ctl + kCtlTierCnt, 4 * (kNumTiers + 1), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
 
@@ -969,6 +1065,11 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     a.nrows_dev = ptr<uint32_t>(c->ctl) + kCtlRetry;
     k_spgemm_rows_global<<<kGlobalGrid, kRowBlock, 0, c->stream>>>(a);
     KCHK(c);
+    c->n_wide = tcnt[g_ntiers];
+    if (c->n_wide) {                                              // columns with >= 65536 products (wide.hpp); rare, host-driven
+        rc = run_wide(c, a, c->n_wide, ptr<uint32_t>(c->rowlists) + (size_t)g_ntiers * nr);
+        if (rc) return rc;
+    }
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     FoldArgs fa;
     fa.ctl = a.ctl;

@@ -57,7 +57,7 @@ constexpr uint32_t kCtlWorkLight = 20;    // chunk counter of the light k_fold i
 constexpr uint32_t kCtlWorkMid = 22;      // chunk counter of the mid k_fold instance
 constexpr uint32_t kCtlWorkCoop2 = 23;    // chunk counter of a second cooperative instance
 constexpr uint32_t kCtlRetry = 21;        // columns whose key table overflowed in an LDS tier (rerun on the global path)       // bit0: a pair ended with > 16 bins and no scratch was given
-constexpr uint32_t kCtlTierCnt = 32;      // [8] columns per tier
+constexpr uint32_t kCtlTierCnt = 32;      // [9] columns per tier, last used entry = wide columns
 constexpr uint32_t kCtlTotals = 42;       // u64[2]: nnz(C), products (8-byte aligned)
 constexpr uint32_t kCtlWords = 64;
 
@@ -665,9 +665,9 @@ __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, ui
     if (f > 0) {
         for (uint32_t t = 0; t < ntiers; ++t)
             if (f <= caps[t]) { tier = t; break; }
-        if (tier == 0xFFFFFFFFu) atomicOr(status, 2u);     // >= 65536 products: wide path missing
+        if (tier == 0xFFFFFFFFu) tier = ntiers;            // >= 65536 products: the wide path (wide.hpp), list number ntiers
     }
-    for (uint32_t t = 0; t < ntiers; ++t) {
+    for (uint32_t t = 0; t <= ntiers; ++t) {
         const unsigned long long mask = __ballot(tier == t);
         if (mask == 0) continue;
         uint32_t base = 0;

@@ -1,0 +1,178 @@
+// wide.hpp -- output columns with 65,536 or more products (the row kernels index a column's products with 16 bits).
+//
+// Same computation as spgemm.hpp (overlap.hpp:281-363 LocalSpGEMM + chain.hpp:74-150), arranged for columns of any size:
+// expand the column's products to HBM, radix-sort them by (column, partner read) -- stable, so a pair's products stay in
+// product order --, run-length encode into pairs, reproduce the reference's hash-slot order per column with the same
+// atomicMin insertion as phase O of the row kernel (64-bit items), fold every pair with the serial statement of the
+// semiring (core.hpp:fold_pair, one lane per pair) and write the records at the column's ranks.  Rare by construction
+// (HiFi sets with a raised -u, repeats): clarity over speed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/bella_hip.h"
+#include "core.hpp"
+#include "util.hpp"
+
+namespace bella {
+
+struct WideArgs {
+    const uint32_t* cols;        // [nw] the wide columns
+    uint32_t nw;
+    const uint64_t* woff;        // [nw+1] start of each column's products in the W arrays
+    const uint32_t* Bptr;
+    const uint2* Bent;
+    const uint2* Aent;
+    const uint64_t* roff;
+    const uint32_t* packed;
+    const uint64_t* flopptr;
+    int k;
+    int binSize;
+    // products, product order
+    uint64_t* W_key;             // segment << 32 | partner read
+    uint32_t* W_idx;             // global product index (woff[seg] + p)
+    uint32_t* W_hv;              // posH | posV << 16
+    uint32_t* W_ovfl;            // overlap estimate | flags << 16
+    // sorted
+    const uint64_t* S_key;
+    const uint32_t* S_idx;
+    uint2* plist;                // [totalF] {hv, ov} in sorted order = per-pair lists in product order
+    // pairs (runs of S_key)
+    const uint64_t* R_key;       // [npairs]
+    const uint32_t* R_len;
+    const uint32_t* R_start;     // exclusive scan of R_len
+    uint32_t npairs;
+    uint32_t* seg_first;         // [nw+1] first pair of each segment
+    uint64_t* table;             // slot-order tables, all segments back to back
+    const uint64_t* toff;        // [nw+1]
+    uint32_t* R_rank;            // [npairs] output rank inside the column
+    uint16_t* sort_scratch;      // [totalF]
+    bella_pair* tmp_pairs;
+    bella_pair_ext* tmp_ext;
+    uint32_t* nnzC;
+    uint32_t* status;            // ctl word: bit0 = > 16 bins without scratch (never here)
+};
+
+// products of the wide columns in the reference's order (B' entry order, then the k-mer's read list)
+__global__ __launch_bounds__(kBlock) void k_wide_expand(WideArgs a) {
+    __shared__ uint32_t scr[kWaves];
+    for (uint32_t s = blockIdx.x; s < a.nw; s += gridDim.x) {
+        const uint32_t i = a.cols[s];
+        const uint32_t b0 = a.Bptr[i], n = a.Bptr[i + 1] - b0;
+        const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
+        const uint64_t o = a.woff[s];
+        uint32_t running = 0;
+        for (uint32_t jb = 0; jb < n; jb += kBlock) {
+            const uint32_t j = jb + threadIdx.x;
+            uint2 be = make_uint2(0u, 0u);
+            if (j < n) be = a.Bent[b0 + j];
+            const uint32_t cnt = (be.y >> 16) & 0x3FFFu;
+            uint32_t tot;
+            uint32_t p = running + block_excl_scan<kWaves>(cnt, scr, &tot);
+            const uint32_t posV = be.y & 0xFFFFu, pal = (be.y >> 30) & 1u;
+            for (uint32_t t = 0; t < cnt; ++t, ++p) {
+                const uint2 ae = a.Aent[(uint64_t)be.x + t];
+                const uint32_t key = ae.x & 0x7FFFFFFFu;
+                const uint32_t posH = ae.y & 0xFFFFu, lenH = ae.y >> 16;
+                const bool oriented = (ae.x >> 31) == (be.y >> 31);
+                const uint32_t ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, (uint32_t)a.k) & 0xFFFFu;
+                const uint32_t fl = (oriented ? 1u : 0u) | (pal << 1);
+                a.W_key[o + p] = ((uint64_t)s << 32) | key;
+                a.W_idx[o + p] = (uint32_t)(o + p);
+                a.W_hv[o + p] = posH | (posV << 16);
+                a.W_ovfl[o + p] = ov | (fl << 16);
+            }
+            running += tot;
+        }
+    }
+}
+
+// per-pair lists in product order + first pair of each segment
+__global__ void k_wide_gather(WideArgs a, uint64_t totalF) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= totalF) return;
+    const uint32_t src = a.S_idx[x];
+    a.plist[x] = make_uint2(a.W_hv[src], a.W_ovfl[src]);       // .y keeps the flags in its upper half until the fold
+}
+__global__ void k_wide_segments(WideArgs a) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > a.npairs) return;
+    const uint32_t seg = r < a.npairs ? (uint32_t)(a.R_key[r] >> 32) : a.nw;
+    const uint32_t prev = r == 0 ? 0xFFFFFFFFu : (uint32_t)(a.R_key[r - 1] >> 32);
+    if (r == 0) { for (uint32_t s = 0; s <= seg && s <= a.nw; ++s) a.seg_first[s] = 0; }
+    else if (seg != prev) { for (uint32_t s = prev + 1; s <= seg && s <= a.nw; ++s) a.seg_first[s] = r; }
+}
+
+// the reference's slot order (overlap.hpp:289-361): keys enter a table of pow2 >= max(16, pairs) slots at (key*107) & mask in
+// order of their first product; parallel form: atomicMin on (first product << 32 | pair), the displaced entry probes on
+__global__ void k_wide_table_fill(uint64_t* table, uint64_t n) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n) table[x] = ~0ull;
+}
+__global__ void k_wide_insert(WideArgs a) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.npairs) return;
+    const uint32_t seg = (uint32_t)(a.R_key[r] >> 32);
+    const uint32_t key = (uint32_t)a.R_key[r];
+    const uint64_t ht = a.toff[seg + 1] - a.toff[seg];
+    unsigned long long* T = (unsigned long long*)(a.table + a.toff[seg]);
+    const uint32_t first = a.S_idx[a.R_start[r]] - (uint32_t)a.woff[seg];    // product index inside the column
+    unsigned long long item = ((unsigned long long)first << 32) | r;
+    uint64_t h = (uint64_t)(key * 107u) & (ht - 1);
+    for (;;) {
+        const unsigned long long old = atomicMin(&T[h], item);
+        if (old == ~0ull) break;
+        if (old > item) {                                       // we took the slot: the displaced pair resumes with ITS key
+            item = old;
+        }
+        h = (h + 1) & (ht - 1);
+    }
+}
+// rank = number of occupied slots before the pair's slot.  One workgroup per segment.
+__global__ __launch_bounds__(kBlock) void k_wide_ranks(WideArgs a) {
+    __shared__ uint32_t scr[kWaves];
+    for (uint32_t s = blockIdx.x; s < a.nw; s += gridDim.x) {
+        const uint64_t t0 = a.toff[s], ht = a.toff[s + 1] - t0;
+        uint32_t running = 0;
+        for (uint64_t base = 0; base < ht; base += kBlock) {
+            const uint64_t x = base + threadIdx.x;
+            const uint64_t it = x < ht ? a.table[t0 + x] : ~0ull;
+            const uint32_t occ = it != ~0ull ? 1u : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kWaves>(occ, scr, &tot);
+            if (occ) a.R_rank[(uint32_t)it] = running + ex;
+            running += tot;
+        }
+        if (threadIdx.x == 0) a.nnzC[a.cols[s]] = running;
+    }
+}
+
+// the fold: one lane per pair, serial statement of the semiring on the pair's own list (in place)
+__global__ __launch_bounds__(64) void k_wide_fold(WideArgs a) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.npairs) return;
+    const uint32_t seg = (uint32_t)(a.R_key[r] >> 32), key = (uint32_t)a.R_key[r];
+    const uint32_t cid = a.cols[seg];
+    const uint64_t lo = a.R_start[r];
+    const uint32_t mm = a.R_len[r];
+    uint32_t* w = (uint32_t*)(a.plist + lo);
+    for (uint32_t t = 0; t < mm; ++t) w[2 * t + 1] &= 0xFFFFu;       // drop the flag bits: the fold recomputes them from the reads
+    struct S2 { uint32_t* base; __device__ uint32_t& operator[](uint32_t e) const { return base[2u * e]; } };
+    FoldResult fr;
+    fold_pair(S2{w}, S2{w + 1}, mm, a.k, a.binSize, a.sort_scratch + lo, fr);
+    const uint32_t k = (uint32_t)a.k;
+    const uint32_t seedH = fr.seed & 0xFFFFu, seedV = fr.seed >> 16;
+    const uint64_t leH = kmer_le(a.packed, a.roff[key] + seedH, k);
+    const uint64_t leV = kmer_le(a.packed, a.roff[cid] + seedV, k);
+    const uint32_t flags = (leH == leV ? 1u : 0u) | (kmer_rc_from_le(leH, k) == kmer_fw_from_le(leV, k) ? 2u : 0u);
+    const uint64_t o = a.flopptr[cid] + a.R_rank[r];
+    bella_pair pr;
+    pr.rid = key; pr.cid = cid; pr.count = fr.count; pr.seedH = (uint16_t)seedH; pr.seedV = (uint16_t)seedV; pr.flags = (uint16_t)flags;
+    a.tmp_pairs[o] = pr;
+    if (a.tmp_ext) {
+        bella_pair_ext ex;
+        ex.nbins = fr.nbins; ex.support = fr.support; ex.binov = fr.binov; ex.pad = 0;
+        a.tmp_ext[o] = ex;
+    }
+}
+
+}  // namespace bella

@@ -530,3 +530,31 @@ def test_file_to_file_pipeline_reproduces_reference_up_to_kmer_labels(eng, tmp_p
     G = ev.truth_pairs(ev.truth_from_names(g.names), 500)
     r1, r2 = ev.evaluate(ev.read_bella_output(mine, 500), G), ev.evaluate(ev.read_bella_output(g.out["align"], 500), G)
     assert abs(r1["recall"] - r2["recall"]) < 0.5 and abs(r1["precision"] - r2["precision"]) < 0.5
+
+
+# ---- columns with >= 65,536 products (wide.hpp) -----------------------------------------------------------------------------
+
+def test_wide_columns_bit_exact(eng):
+    """70 near-identical reads with -u 80: every k-mer is shared by all of them, column 0 has ~200k products (the row kernels
+    index products with 16 bits); strands mixed, two reads carry a 700-base deletion plus a random tail (a second overlap bin)"""
+    rng = np.random.default_rng(17)
+    base = rng.integers(0, 4, size=3000, dtype=np.uint8)
+    comp = (3 - base)[::-1]
+    seqs = []
+    for i in range(70):
+        s = base if i % 3 else comp
+        if i in (11, 40):
+            s = np.concatenate([s[:900], s[1600:], rng.integers(0, 4, size=700, dtype=np.uint8)])   # two diagonals, estimates 700 apart
+        seqs.append(synth.BASES[s].tobytes())
+    rs = synth.ReadSet.from_strings(seqs)
+    eng.set_reads(rs)
+    nk, nt, _ = eng.count_kmers(17, 2, 80)
+    tk, tr, tp = eng.get_tuples()
+    eng.assemble_counted()
+    n, flops = eng.overlap(BellaPars(skipAlignment=True))
+    pairs, ext, colptrC = eng.get_pairs()
+    _, flop, ecol, exp = oracle_pairs(rs, rs.seqs(), nk, tk, tr, tp, 17)
+    assert int(flop.max()) >= 65536 and flops == int(flop.sum()) and n == len(exp)
+    assert np.array_equal(colptrC, ecol.astype(np.uint64))
+    check_pairs(pairs, ext, exp, rs.lengths, 17)
+    assert (ext["nbins"] > 1).any()
