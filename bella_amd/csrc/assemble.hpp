@@ -202,7 +202,7 @@ __global__ void k_fill_A(const uint32_t* Bk, const uint32_t* Brow, uint64_t nnz,
 // transpose.h:26-50) and emit the final A' and B' entries
 __global__ void k_finalize_cols(uint32_t nkmers, const uint32_t* deg, const uint32_t* colstart, uint2* Atmp,
                                 const uint16_t* Bpos, const uint8_t* ori, const uint64_t* roff, uint2* Aent,
-                                uint2* Bent, uint32_t* status) {
+                                uint2* Bent, uint16_t* Bcnt, uint32_t* status) {
     const uint32_t km = blockIdx.x * blockDim.x + threadIdx.x;
     if (km >= nkmers) return;
     const uint32_t dg = deg[km];
@@ -222,6 +222,7 @@ __global__ void k_finalize_cols(uint32_t nkmers, const uint32_t* deg, const uint
         const uint32_t len = (uint32_t)(roff[r + 1] - roff[r]);
         Aent[cs + x] = make_uint2(r | (o << 31), pos | (len << 16));
         Bent[e] = make_uint2(cs + x + 1, pos | ((dg - 1 - x) << 16) | (pal << 30) | (o << 31));
+        Bcnt[e] = (uint16_t)(dg - 1 - x);             // the products of the entry once more, compact: estimateFLOP streams 2 B per nonzero
     }
 }
 

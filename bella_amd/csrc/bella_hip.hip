@@ -67,7 +67,7 @@ struct bella_ctx {
     uint32_t kc_nkmers = 0, kc_k = 0;
     Buf kc_nk, kc_koff, kc_hist, kc_keys, kc_alt, kc_runlen, kc_flag, kc_slot, kc_nruns, kc_dcode, kc_dcount, kc_hkey, kc_hval, kc_found,
         kc_tstart, kc_cursor;
-    Buf Bptr, Bk, Bpos, Bent, Aent;
+    Buf Bptr, Bk, Bpos, Bent, Bcnt, Aent;
     uint32_t part_first = 0, part_stride = 1;
     bool have_panel = false;
     uint32_t panel_first = 0, panel_rows = 0;
@@ -159,7 +159,7 @@ int status_to_error(bella_ctx* c, uint32_t st) {
     if (st & 8u) return fail(c, BELLA_ERR_TUPLE_ORDER, "tuples must be grouped by non-decreasing read id < nreads");
     if (st & 16u) return fail(c, BELLA_ERR_READ_TOO_LONG, "a read has >= 65536 tuples");
     if (st & 32u) return fail(c, BELLA_ERR_BAD_ARG, "k-mer id >= nkmers");
-    if (st & 64u) return fail(c, BELLA_ERR_BAD_ARG, "a k-mer occurs in more than 32767 reads");
+    if (st & 64u) return fail(c, BELLA_ERR_BAD_ARG, "a k-mer occurs in more than 16383 reads");
     if (st & 2u) return fail(c, BELLA_ERR_ROW_TOO_LARGE, "an output column has >= 65536 products");
     return 0;
 }
@@ -196,6 +196,7 @@ int build_layout(bella_ctx* c) {
     ENSURE(c, c->wscan, 4 * nnz);
     ENSURE(c, c->Atmp, 8 * nnz);
     ENSURE(c, c->Bent, 8 * nnz);
+    ENSURE(c, c->Bcnt, 2 * nnz);
     ENSURE(c, c->Aent, 8 * nnz + 64);
     HIPCHK(c, hipMemsetAsync(c->deg.p, 0, 4 * (size_t)nk, c->stream));
     HIPCHK(c, hipMemsetAsync(c->minread.p, 0xFF, 4 * (size_t)nk, c->stream));
@@ -223,7 +224,7 @@ int build_layout(bella_ctx* c) {
         KCHK(c);
         k_finalize_cols<<<nblk(nk), 256, 0, c->stream>>>(nk, ptr<uint32_t>(c->deg), ptr<uint32_t>(c->colstart), ptr<uint2>(c->Atmp),
                                                          ptr<uint16_t>(c->Bpos), ptr<uint8_t>(c->ori), ptr<uint64_t>(c->roff),
-                                                         ptr<uint2>(c->Aent), ptr<uint2>(c->Bent), ptr<uint32_t>(c->status));
+                                                         ptr<uint2>(c->Aent), ptr<uint2>(c->Bent), ptr<uint16_t>(c->Bcnt), ptr<uint32_t>(c->status));
         KCHK(c);
     }
     HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 2, 0, 8, c->stream));
@@ -341,7 +342,7 @@ void bella_hip_destroy(bella_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Aent, &c->t_kmer, &c->t_read, &c->t_pos,
+    Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Bcnt, &c->Aent, &c->t_kmer, &c->t_read, &c->t_pos,
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->Brow, &c->deg, &c->minread, &c->colstart,
                   &c->fill, &c->ori, &c->w, &c->wscan, &c->Atmp, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC, &c->tierflag,
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
@@ -992,7 +993,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     // one control block per pass (counters, tier lengths, status, totals): one fill, one read back
     uint32_t* d_ctl = ptr<uint32_t>(c->ctl);
     HIPCHK(c, hipMemsetAsync(d_ctl, 0, 4 * kCtlWords, c->stream));
-    k_row_flops<<<nblk(nr + 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint2>(c->Bent), nr, c->part_first,
+    k_row_flops<<<nblk(nr + 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint16_t>(c->Bcnt), nr, c->part_first,
                                                                 c->part_stride, ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC));
     KCHK(c);
     int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->flopsr), ptr<uint64_t>(c->flopptr), (uint64_t)nr + 1);

@@ -639,7 +639,7 @@ __global__ void k_total_products(const uint32_t* deg, uint32_t nkmers, unsigned 
 
 // estimateFLOP (overlap.hpp:157-202, lowtri): products of column i = sum of the suffix counts of its entries.
 // One wavefront per column.  Columns outside this context's partition get 0.
-__global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, const uint2* Bent, uint32_t nreads,
+__global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, const uint16_t* Bcnt, uint32_t nreads,
                                                       uint32_t first, uint32_t stride, uint32_t* flops, uint32_t* nnzC) {
     const uint32_t i = blockIdx.x * kWaves + wave_id();
     if (i > nreads) return;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, cons
     uint32_t s = 0;
     if (i % stride == first) {
         const uint32_t b0 = Bptr[i], b1 = Bptr[i + 1];
-        for (uint32_t e = b0 + lane_id(); e < b1; e += 64) s += (Bent[e].y >> 16) & 0x3FFFu;
+        for (uint32_t e = b0 + lane_id(); e < b1; e += 64) s += Bcnt[e];
     }
 #pragma unroll
     for (int dlt = 32; dlt > 0; dlt >>= 1) s += __shfl_xor(s, dlt, 64);
