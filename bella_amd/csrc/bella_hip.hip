@@ -961,7 +961,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     ENSURE(c, c->flopptr, 8 * ((size_t)nr + 2));
     ENSURE(c, c->nnzC, 4 * ((size_t)nr + 2));
     ENSURE(c, c->colptrC, 8 * ((size_t)nr + 2));
-    ENSURE(c, c->rowlists, 4 * (size_t)(kNumTiers + 1) * nr);
+    ENSURE(c, c->rowlists, (16 * (size_t)kNumTiers + 4) * nr + 64);   // tier descriptor lists, then the list of wide columns
     ENSURE(c, c->tiercaps, 4 * kNumTiers);
     ENSURE(c, c->ctl, 4 * kCtlWords);
     ENSURE(c, c->tmp_pairs, sizeof(bella_pair) * Fub);
@@ -999,7 +999,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->flopsr), ptr<uint64_t>(c->flopptr), (uint64_t)nr + 1);
     if (rc) return rc;
     k_tier_lists<<<nblk(nr), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, ptr<uint32_t>(c->tiercaps), g_ntiers,
-                                                  ptr<uint32_t>(c->rowlists), d_ctl + kCtlTierCnt, d_ctl + kCtlStatus);
+                                                  ptr<uint32_t>(c->Bptr), ptr<uint64_t>(c->roff), ptr<uint4>(c->rowlists),
+                                                  (uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr), d_ctl + kCtlTierCnt);
     KCHK(c);
     // the one host round trip before the row kernels: the tiers' lengths (exact grids; 32 bytes into pinned memory)
     uint32_t* const tcnt = c->pinned;
@@ -1043,7 +1044,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         if (!tcnt[t]) continue;
         hipStream_t sst = c->side[t];
         HIPCHK(c, hipStreamWaitEvent(sst, c->fork, 0));
-        a.rowlist = ptr<uint32_t>(c->rowlists) + (size_t)t * nr;
+        a.rowlist = nullptr;
+        a.rowdesc = ptr<uint4>(c->rowlists) + (size_t)t * nr;
         a.nrows = tcnt[t];
         a.nrows_dev = nullptr;
         a.cap = kTierCaps[t];
@@ -1063,12 +1065,13 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     }
     // columns whose pair count overflowed an LDS tier's key table (list and count produced on the device)
     a.rowlist = ptr<uint32_t>(c->retry);
+    a.rowdesc = nullptr;
     a.nrows_dev = ptr<uint32_t>(c->ctl) + kCtlRetry;
     k_spgemm_rows_global<<<kGlobalGrid, kRowBlock, 0, c->stream>>>(a);
     KCHK(c);
     c->n_wide = tcnt[g_ntiers];
     if (c->n_wide) {                                              // columns with >= 65536 products (wide.hpp); rare, host-driven
-        rc = run_wide(c, a, c->n_wide, ptr<uint32_t>(c->rowlists) + (size_t)g_ntiers * nr);
+        rc = run_wide(c, a, c->n_wide, (const uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr));
         if (rc) return rc;
     }
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));

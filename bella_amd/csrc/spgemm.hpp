@@ -62,7 +62,9 @@ constexpr uint32_t kCtlTotals = 42;       // u64[2]: nnz(C), products (8-byte al
 constexpr uint32_t kCtlWords = 64;
 
 struct SpgemmArgs {
-    const uint32_t* rowlist;
+    const uint32_t* rowlist;     // columns of this launch (retry launch) ...
+    const uint4* rowdesc;        // ... or their descriptors {column, first B' entry, entries | read length << 16, -} (tier launches):
+                                 // one load instead of a chain of three before the first B' entry can be fetched
     uint32_t nrows;
     const uint32_t* Bptr;
     const uint2* Bent;
@@ -136,14 +138,12 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dc
 
 // returns false if the key table overflowed (no global side effect happened yet; the caller queues the column again)
 template <bool OVERLAY>
-__device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t i, const RowMem& m) {
+__device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t i, const uint32_t b0, const uint32_t n, const uint32_t lenV,
+                                            const RowMem& m) {
     const uint32_t tid = threadIdx.x;
     const uint32_t H1 = m.dcap;
     uint32_t* s_d = m.scr + 48;
     uint32_t* s_fail = m.scr + 49;
-    const uint32_t b0 = a.Bptr[i];
-    const uint32_t n = a.Bptr[i + 1] - b0;
-    const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
     const uint32_t k = (uint32_t)a.k;
     constexpr uint32_t GMASK = OVERLAY ? 0x3FFFu : 0xFFFFu;   // LDS tiers: the flags ride on top of the T1 slot
 
@@ -518,9 +518,10 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 // LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap, cap/2)
 __global__ __launch_bounds__(kRowBlock, 6) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t i = a.rowlist[blockIdx.x];
+    const uint4 ds = a.rowdesc[blockIdx.x];
+    const uint32_t i = ds.x;
     const RowMem m = carve(smem, a.cap, a.dcap, true);
-    if (!process_row<true>(a, i, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
+    if (!process_row<true>(a, i, ds.y, ds.z & 0xFFFFu, ds.z >> 16, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
 }
 
 // Global-workspace path: columns with more products than the largest LDS tier (< 65536), and -- second launch, list and
@@ -529,11 +530,12 @@ __global__ __launch_bounds__(kRowBlock) void k_spgemm_rows_global(SpgemmArgs a) 
     uint8_t* ws = a.ws + (uint64_t)blockIdx.x * a.ws_stride;
     const uint32_t nrows = a.nrows_dev ? *a.nrows_dev : a.nrows;
     for (uint32_t x = blockIdx.x; x < nrows; x += gridDim.x) {
-        const uint32_t i = a.rowlist[x];
+        const uint32_t i = a.rowdesc ? a.rowdesc[x].x : a.rowlist[x];
         uint32_t f = (uint32_t)(a.flopptr[i + 1] - a.flopptr[i]);
         if (f < 16u) f = 16u;                             // T2 needs >= 16 slots
         const RowMem m = carve(ws, f, f, false);
-        (void)process_row<false>(a, i, m);
+        const uint32_t b0 = a.Bptr[i];
+        (void)process_row<false>(a, i, b0, a.Bptr[i + 1] - b0, (uint32_t)(a.roff[i + 1] - a.roff[i]), m);
         __syncthreads();
     }
 }
@@ -658,14 +660,19 @@ __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, cons
 // tier lists: column i with f products goes to the first tier whose cap >= f (caps ascending; last tier = global path).
 // One atomic per wavefront and tier; the order inside a list only affects scheduling.
 __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, uint32_t nreads, const uint32_t* caps, uint32_t ntiers,
-                                                       uint32_t* lists, uint32_t* counts, uint32_t* status) {
+                                                       const uint32_t* Bptr, const uint64_t* roff, uint4* desc, uint32_t* widelist,
+                                                       uint32_t* counts) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t f = i < nreads ? flops[i] : 0u;
     uint32_t tier = 0xFFFFFFFFu;
+    uint4 ds = make_uint4(i, 0u, 0u, 0u);
     if (f > 0) {
+        tier = ntiers;                                     // >= 65536 products: the wide path (wide.hpp), list number ntiers
         for (uint32_t t = 0; t < ntiers; ++t)
             if (f <= caps[t]) { tier = t; break; }
-        if (tier == 0xFFFFFFFFu) tier = ntiers;            // >= 65536 products: the wide path (wide.hpp), list number ntiers
+        const uint32_t b0 = Bptr[i];
+        ds.y = b0;
+        ds.z = (Bptr[i + 1] - b0) | ((uint32_t)(roff[i + 1] - roff[i]) << 16);   // both < 65536 (checked at set_reads / assembly)
     }
     for (uint32_t t = 0; t <= ntiers; ++t) {
         const unsigned long long mask = __ballot(tier == t);
@@ -673,7 +680,11 @@ __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, ui
         uint32_t base = 0;
         if (lane_id() == 0) base = atomicAdd(&counts[t], (uint32_t)__popcll(mask));
         base = __shfl(base, 0, 64);
-        if (tier == t) lists[(uint64_t)t * nreads + base + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull))] = i;
+        if (tier == t) {
+            const uint32_t o = base + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
+            if (t < ntiers) desc[(uint64_t)t * nreads + o] = ds;
+            else widelist[o] = i;
+        }
     }
 }
 
