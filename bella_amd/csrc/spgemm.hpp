@@ -391,6 +391,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
+    if (a.stop == 7) return true;
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     const us2 kk2 = {(unsigned short)a.k, (unsigned short)a.k};
     const us2 lim2 = {(unsigned short)(2 * a.k + 1), (unsigned short)(2 * a.k + 1)};
