@@ -7,7 +7,9 @@
 //     not execute both variants;
 //   * sequences come from a 64-base register window per stream, topped up at wave-uniform checkpoints (every 16 steps, all
 //     lanes at once, the next block prefetched one period ahead): no lane ever makes the wavefront wait on its own reload.
-// int8 saturation is emulated exactly: every add is followed by the clamp the AVX2 instruction applies (simdutils.h:26-27).
+// int8 saturation (simdutils.h:26-27, AVX2 adds/subs) is emulated exactly with one instruction per add: a cell value v lives
+// in its 16-bit half as v*256, so v_pk_add_i16 with the clamp bit saturates at -128*256 exactly; the upper bound
+// (127*256 + 255 after a clamp) is restored by one v_pk_min_i16 against 127*256 where a positive term can be added.
 #pragma once
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -23,7 +25,11 @@ __device__ __forceinline__ uint32_t u32_of(s2 v) { return __builtin_bit_cast(uin
 __device__ __forceinline__ s2 s2_of(uint32_t v) { return __builtin_bit_cast(s2, v); }
 __device__ __forceinline__ s2 pmax(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ s2 pmin(s2 a, s2 b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ s2 sat8p(s2 v) { return pmin(pmax(v, splat2(-128)), splat2(127)); }
+__device__ __forceinline__ s2 adds2(s2 a, s2 b) { return __builtin_elementwise_add_sat(a, b); }   // v_pk_add_i16 clamp
+__device__ __forceinline__ s2 subs2(s2 a, s2 b) { return __builtin_elementwise_sub_sat(a, b); }   // v_pk_sub_i16 clamp
+constexpr int kXScale = 256;            // cell value v is held as v * 256
+constexpr int kXTop = 127 * kXScale;
+constexpr int kQScale = 512;            // base codes are held as code * 512: the xor of two codes is 0 or >= 512
 // cells (e+1, e+2) from words holding (e, e+1) and (e+2, e+3)
 __device__ __forceinline__ s2 shl_cell(s2 cur, s2 next) { return s2_of(__builtin_amdgcn_alignbit(u32_of(next), u32_of(cur), 16)); }
 // cells (e-1, e) from words holding (e-2, e-1) and (e, e+1)
@@ -124,16 +130,16 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
         const int e0 = 2 * i, e1 = 2 * i + 1;
         const int a1x = (int)ex1[e0 * dps], a1y = e1 < kXLW ? (int)ex1[e1 * dps] : kXNinf;
         const int a2x = e0 >= 1 ? (int)ex2[e0 * dps] : kXNinf, a2y = (int)ex2[e1 * dps];
-        a1[i] = mk2(a1x, a1y);
-        a2[i] = mk2(a2x, a2y);
-        a3[i] = splat2(kXNinf);
+        a1[i] = mk2(a1x * kXScale, a1y * kXScale);
+        a2[i] = mk2(a2x * kXScale, a2y * kXScale);
+        a3[i] = splat2(kXNinf * kXScale);
         adm = imax_(adm, a1x);
         if (e1 < kXLW) adm = imax_(adm, a1y);
         // vqueryh[e] = queryh[e+1], vqueryv[e] = queryv[31-e] for e < 31; cell 31 = a marker that equals itself
         const int hx = (int)((hp >> (2 * (e0 + 1))) & 3), hy = e1 < kXLW ? (int)((hp >> (2 * ((e1 + 1) & 31))) & 3) : 7;
         const int vx = (int)((vp >> (2 * (kXLW - e0))) & 3), vy = e1 < kXLW ? (int)((vp >> (2 * (kXLW - e1))) & 3) : 7;
-        qh[i] = mk2(hx, hy);
-        qv[i] = mk2(vx, vy);
+        qh[i] = mk2(hx * kQScale, hy * kQScale);
+        qv[i] = mk2(vx * kQScale, vy * kQScale);
     }
     int best = DPmax, off = 0;
     int hoff = kXLW, voff = kXLW;
@@ -142,23 +148,24 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
 
     H.init((uint32_t)kXLW);
     V.init((uint32_t)kXLW);
-    const s2 one = splat2(1), mone = splat2(-1), ninf = splat2(kXNinf), k32 = splat2(32);
+    const s2 one = splat2(kXScale), mone = splat2(-kXScale), ninf = splat2(kXNinf * kXScale), top = splat2(kXTop), q1 = splat2(kQScale);
 
 #define BELLA_PSTEP()                                                                                               \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                 \
-        const s2 xr = s2_of(u32_of(qh[i]) ^ u32_of(qv[i]));                       /* 0 iff the bases match (codes < 8) */ \
-        const s2 mt = pmax(xr * splat2(-2) + one, mone);                          /* +1 match, -1 mismatch */            \
-        const s2 a1f = sat8p(a1[i] + mt);                                                                             \
+        const s2 xr = s2_of(u32_of(qh[i]) ^ u32_of(qv[i]));                       /* 0 iff the bases match, else >= 512 */ \
+        const s2 mt = one - pmin(xr, q1);                                         /* +1 match, -1 mismatch (x 256) */    \
+        const s2 a1f = pmin(adds2(a1[i], mt), top);                               /* adds_epi8 */                        \
         const s2 shv = shl_cell(a2[i], i < 15 ? a2[i < 15 ? i + 1 : 15] : ninf);  /* shiftLeft(antiDiag2) */            \
-        const s2 a2f = pmax(pmax(shv, a2[i]) + mone, ninf);                                                         \
+        const s2 a2f = adds2(pmax(shv, a2[i]), mone);                             /* lower clamp = NINF exactly */       \
         a3[i] = pmax(a1f, a2f);                                                                                       \
     }                                                                                                                 \
-    a3[15].y = (short)kXNinf;
+    a3[15].y = (short)(kXNinf * kXScale);
 
+// arg-max key: value in the upper byte (the lower byte of a cell is zero), 31 - cell in the lower one: first maximum wins
 #define BELLA_PKEY(keyout)                                                                                           \
     {                                                                                                                 \
-        s2 kk = a3[0] * k32 + mk2(31, 30);                                                                            \
-        _Pragma("unroll") for (int i = 1; i < 16; ++i) kk = pmax(kk, a3[i] * k32 + mk2(31 - 2 * i, 30 - 2 * i));      \
+        s2 kk = a3[0] + mk2(31, 30);                                                                                  \
+        _Pragma("unroll") for (int i = 1; i < 16; ++i) kk = pmax(kk, a3[i] + mk2(31 - 2 * i, 30 - 2 * i));            \
         keyout = imax_((int)kk.x, (int)kk.y);                                                                         \
     }
 
@@ -166,9 +173,9 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
     {                                                                                                                 \
         s2 mn2 = a3[0];                                                                                               \
         _Pragma("unroll") for (int i = 1; i < 15; ++i) mn2 = pmin(mn2, a3[i]);                                        \
-        int mn = imin_(imin_((int)mn2.x, (int)mn2.y), (int)a3[15].x);            /* cells 0..30 (LOGICALWIDTH) */      \
-        const s2 mnv = splat2(mn);                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) { a2[i] = sat8p(a2[i] - mnv); a3[i] = sat8p(a3[i] - mnv); }    \
+        const int mn = imin_(imin_((int)mn2.x, (int)mn2.y), (int)a3[15].x) >> 8; /* cells 0..30 (LOGICALWIDTH) */      \
+        const s2 mnv = splat2(mn * kXScale);                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) { a2[i] = pmin(subs2(a2[i], mnv), top); a3[i] = pmin(subs2(a3[i], mnv), top); } \
         off += mn;                                                                                                    \
     }
 
@@ -186,12 +193,12 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
             a2[i] = s2_of(__builtin_amdgcn_perm(u32_of(a3[i]), i > 0 ? u32_of(a3[i > 0 ? i - 1 : 0]) : nf, selD));        \
         _Pragma("unroll") for (int i = 0; i < 15; ++i)                                                                \
             qh[i] = s2_of(__builtin_amdgcn_perm(u32_of(qh[i + 1]), u32_of(qh[i]), selL));                              \
-        qh[15] = (right) ? mk2((c), 7) : qh[15];                            /* cell 30 <- new base, cell 31 marker */  \
+        qh[15] = (right) ? mk2((c) * kQScale, 7 * kQScale) : qh[15];        /* cell 30 <- new base, cell 31 marker */  \
         {                                                                                                             \
             const uint32_t q0 = u32_of(qv[0]);                                                                        \
             _Pragma("unroll") for (int i = 15; i >= 1; --i)                                                           \
                 qv[i] = s2_of(__builtin_amdgcn_perm(u32_of(qv[i]), u32_of(qv[i - 1]), selD));                          \
-            qv[0] = (right) ? s2_of(q0) : s2_of((q0 << 16) | (uint32_t)(c));  /* cell 0 <- new base */                 \
+            qv[0] = (right) ? s2_of(q0) : s2_of((q0 << 16) | (uint32_t)((c) * kQScale));  /* cell 0 <- new base */     \
         }                                                                                                             \
     }
 
@@ -206,7 +213,7 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
         BELLA_PSTEP()
         int key;
         BELLA_PKEY(key)
-        const int adb = key >> 5;
+        const int adb = key >> 8;
         const int curr = adb + off;
         if (curr < best - X) {
             r.best = best; r.endH = hoff; r.endV = voff; r.steps = (hoff - kXLW) + (voff - kXLW);
@@ -217,7 +224,7 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
             BELLA_PKEY(key)
         }
         if (curr > best) best = curr;
-        if ((key >> 5) > 0) maxpos = 31 - (key & 31);
+        if ((key >> 8) > 0) maxpos = 31 - (key & 31);
         else if (first) r.flagged = 1;
         first = false;
         endH = hoff; endV = voff;
@@ -234,7 +241,7 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
         BELLA_PSTEP()
         int key;
         BELLA_PKEY(key)
-        const int adb = key >> 5;
+        const int adb = key >> 8;
         const int curr = adb + off;
         if (curr < best - X) break;
         if (adb > kXCutoff) { BELLA_PREBASE() }
