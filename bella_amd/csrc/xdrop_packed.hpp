@@ -207,6 +207,7 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
     int endH = hoff, endV = voff;
     bool first = true;
     uint32_t tick = 0;
+    bool dropped = false;
     while (hoff < hl && voff < vl) {
         if ((tick & 15u) == 0u) { H.checkpoint((uint32_t)hoff); V.checkpoint((uint32_t)voff); }
         ++tick;
@@ -215,10 +216,7 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
         BELLA_PKEY(key)
         const int adb = key >> 8;
         const int curr = adb + off;
-        if (curr < best - X) {
-            r.best = best; r.endH = hoff; r.endV = voff; r.steps = (hoff - kXLW) + (voff - kXLW);
-            return;
-        }
+        if (curr < best - X) { dropped = true; break; }        // xavier.h:128-135: X-drop termination
         if (adb > kXCutoff) {
             BELLA_PREBASE()
             BELLA_PKEY(key)
@@ -234,6 +232,7 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
         voff += right ? 0 : 1;
         BELLA_PMOVE(right, c)
     }
+    if (dropped) { r.best = best; r.endH = hoff; r.endV = voff; r.steps = (hoff - kXLW) + (voff - kXLW); return; }
     // ---- Phase 4 (xavier.h:185-251)
     int dir = hoff >= hl ? 1 : 0;
     H.checkpoint((uint32_t)hoff); V.checkpoint((uint32_t)voff);      // 28 more steps: at most 14 per stream, inside the window
