@@ -651,7 +651,9 @@ __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, cons
     uint32_t s = 0;
     if (i % stride == first) {
         const uint32_t b0 = Bptr[i], b1 = Bptr[i + 1];
-        for (uint32_t e = b0 + lane_id(); e < b1; e += 64) s += Bcnt[e];
+        uint32_t e = b0 + lane_id();
+        for (; e + 192 < b1; e += 256) s += (uint32_t)Bcnt[e] + Bcnt[e + 64] + Bcnt[e + 128] + Bcnt[e + 192];   // four loads in flight
+        for (; e < b1; e += 64) s += Bcnt[e];
     }
 #pragma unroll
     for (int dlt = 32; dlt > 0; dlt >>= 1) s += __shfl_xor(s, dlt, 64);
