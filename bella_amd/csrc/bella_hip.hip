@@ -37,7 +37,6 @@ constexpr uint32_t kNumTiers = 8;  // at most
 uint32_t g_ntiers = 6;
 uint32_t kTierCaps[kNumTiers] = {768, 1280, 2048, 3072, 4096, 65535, 0, 0};
 constexpr uint32_t kGlobalGrid = 256;
-constexpr uint32_t kFoldGrid = 512;
 constexpr uint32_t kAsmGrid = 1024;
 
 struct CastU64 {
@@ -866,7 +865,7 @@ __global__ void k_wide_sizes(const uint32_t* cols, const uint32_t* flops, uint32
 }
 
 // columns with >= 65536 products: expand -> sort by (column, partner) -> pairs -> slot order -> serial fold (wide.hpp)
-static int run_wide(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint32_t* d_cols) {
+static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint32_t* d_cols) {
     ENSURE(c, c->w_f, 4 * ((size_t)nw + 2));
     ENSURE(c, c->w_off, 8 * ((size_t)nw + 2));
     ENSURE(c, c->w_nruns, 16);
@@ -947,6 +946,27 @@ static int run_wide(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint3
         KCHK(c);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));                    // toff / segf are host vectors
+    return 0;
+}
+
+// batches of wide columns holding at most `budget` products each (38 bytes of HBM per product in flight)
+static int run_wide(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint32_t* d_cols) {
+    ENSURE(c, c->w_f, 4 * ((size_t)nw + 2));
+    k_wide_sizes<<<nblk((uint64_t)nw + 1), 256, 0, c->stream>>>(d_cols, ptr<uint32_t>(c->flopsr), nw, ptr<uint32_t>(c->w_f));
+    KCHK(c);
+    std::vector<uint32_t> wf((size_t)nw + 1);
+    HIPCHK(c, hipMemcpyAsync(wf.data(), c->w_f.p, 4 * ((size_t)nw + 1), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t budget = 1ull << 30;
+    if (const char* e = getenv("BELLA_HIP_WIDE_BUDGET")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) budget = v; }
+    for (uint32_t b = 0; b < nw;) {
+        uint64_t t = wf[b];
+        uint32_t e = b + 1;
+        while (e < nw && t + wf[e] <= budget) t += wf[e++];
+        int rc = run_wide_batch(c, sa, e - b, d_cols + b);
+        if (rc) return rc;
+        b = e;
+    }
     return 0;
 }
 

@@ -1,9 +1,9 @@
 // spgemm.hpp -- C = A*A^T (strict lower triangle) under BELLA's position-binning semiring, gfx950.
 //
 // Replaces estimateFLOP (include/overlap.hpp:157-202), estimateNNZ_Hash (:205-276) and LocalSpGEMM
-// (:281-363) with multiop/chainop (include/chain.hpp:74-150) of the reference.  Two kernels:
+// (:281-363) with multiop/chainop (include/chain.hpp:74-150) of the reference.
 //
-// k_spgemm_rows_*  one workgroup (4 wavefronts) per output column i (= read i), bulk-synchronous phases in LDS
+// k_spgemm_rows_*  one 512-thread workgroup per output column i (= read i), bulk-synchronous phases in LDS
 //                  (or in a global workspace for columns whose product list does not fit the LDS tiers):
 //   X  expand   stream the column's B' entries (8 B each, coalesced); every entry carries a direct pointer to the
 //               suffix "reads > i" of its k-mer's list in A' (8 B entries, contiguous): no column-pointer
@@ -14,21 +14,20 @@
 //               (first-product-index, key): an entry with an earlier first occurrence displaces a later one,
 //               which resumes probing -- the fixed point is exactly the layout sequential insertion produces.
 //               A scan over the table gives every key its output rank and its list start.
-//   S  scatter  product indices into per-pair lists (unordered inside a list).
-//   R  rank     every product finds its rank inside its pair's list (= product order) and is written to the
-//               pair's list in HBM; single-product pairs (92 % at 100k reads) are finished here: 16-byte record
-//               straight to the output.
-//   D  describe multi-product pairs are appended to a bucket list by floor(log2(#products)).
-//
-// k_fold           persistent wavefronts pull 64 pair descriptors of ONE bucket at a time (similar work per lane),
-//               one lane per pair; the lane streams its product list from HBM and folds it under the
-//               order-dependent semiring (core.hpp: fold_core) with the state (positions + bins) in
-//               lane-interleaved LDS (element e of lane l at word e*64+l: bank = lane, conflict-free at any
-//               per-lane index).  A pair whose state outgrows the LDS budget goes to k_fold_overflow, which
-//               folds in place in HBM (same function), including the libstdc++-exact std::sort for > 16 bins.
+//   S  scatter  wavefront 0 appends product indices to the per-pair lists, 64 products at a time: lists are ordered
+//               across chunks, chunk-mates may be swapped.
+//   R  rank     every product finds its exact rank inside its pair's list from its chunk-mates; the product-order
+//               arrays are overlaid by the rank-order lists; single-product pairs (92 % at 100k reads) are
+//               finished here: 16-byte record straight to the output.
+//   P  fold     chainop in closed form (see the comment at phase P): parent links + independent walks, every
+//               product of every pair is a lane; no per-pair state.
+//   E  emit     one lane per pair writes the record (choose(): first maximum among <= 16 bins).
+// k_fold_overflow  pairs that end with > 16 bins (std::sort's introsort regime): serial fold in HBM (core.hpp).
+// (Columns with >= 65,536 products take the sort-based path of wide.hpp.)
 //
 // Data layout in HBM (built by assemble.hpp):
 //   Bent[e] = { a_ptr, posV | cnt << 16 (14 bit) | pal << 30 | ori << 31 }  e in B' order (MergeDuplicates slot order)
+//   Bcnt[e] = cnt once more as u16 (the estimateFLOP pass streams 2 B per nonzero)
 //   Aent[x] = { read | ori << 31, posH | readlen << 16 }  k-mer lists, ascending read id, stored in order of first
 //                                                          appearance in B' (streaming for the owner row)
 #pragma once
@@ -46,17 +45,11 @@ constexpr uint32_t kScatterChunk = 64;                    // phase S appends one
 #endif
 constexpr int kRowBlock = BELLA_ROW_BLOCK;                // threads per output column in the row kernels
 constexpr int kRowWaves = kRowBlock / 64;
-constexpr uint32_t kNumBuckets = 16;      // bucket b holds pairs with 2^b <= #products < 2^(b+1), b = 1..15
 // control block (u32 words) zeroed before every pass
-constexpr uint32_t kCtlBucketCnt = 0;     // [16]
-constexpr uint32_t kCtlWork = 16;         // k_fold chunk counter
 constexpr uint32_t kCtlOverflow = 17;     // overflow list length
 constexpr uint32_t kCtlWork2 = 18;        // k_fold_overflow counter
-constexpr uint32_t kCtlStatus = 19;
-constexpr uint32_t kCtlWorkLight = 20;    // chunk counter of the light k_fold instance
-constexpr uint32_t kCtlWorkMid = 22;      // chunk counter of the mid k_fold instance
-constexpr uint32_t kCtlWorkCoop2 = 23;    // chunk counter of a second cooperative instance
-constexpr uint32_t kCtlRetry = 21;        // columns whose key table overflowed in an LDS tier (rerun on the global path)       // bit0: a pair ended with > 16 bins and no scratch was given
+constexpr uint32_t kCtlStatus = 19;       // bit0: a pair ended with > 16 bins and no scratch was given
+constexpr uint32_t kCtlRetry = 21;        // columns whose key table overflowed in an LDS tier (rerun on the global path)
 constexpr uint32_t kCtlTierCnt = 32;      // [9] columns per tier, last used entry = wide columns
 constexpr uint32_t kCtlTotals = 42;       // u64[2]: nnz(C), products (8-byte aligned)
 constexpr uint32_t kCtlWords = 64;

@@ -34,7 +34,7 @@ enum {
     BELLA_ERR_READ_TOO_LONG = -5, /* read >= 65,536 bases: u16 positions (common.h:122-126)             */
     BELLA_ERR_TUPLE_ORDER = -6,   /* tuples not grouped by non-decreasing read id                       */
     BELLA_ERR_STATE = -7,         /* call order: reads -> matrix -> overlap -> align                    */
-    BELLA_ERR_ROW_TOO_LARGE = -8, /* the columns with >= 65,536 products hold >= 2^31 products together  */
+    BELLA_ERR_ROW_TOO_LARGE = -8, /* one output column has >= 2^31 products                             */
     BELLA_ERR_BINS = -9,          /* a pair ended with > 16 overlap bins: std::sort tie order path      */
     BELLA_ERR_NOMEM = -10
 };

@@ -534,9 +534,12 @@ def test_file_to_file_pipeline_reproduces_reference_up_to_kmer_labels(eng, tmp_p
 
 # ---- columns with >= 65,536 products (wide.hpp) -----------------------------------------------------------------------------
 
-def test_wide_columns_bit_exact(eng):
+@pytest.mark.parametrize("budget", [None, "300000"])
+def test_wide_columns_bit_exact(eng, monkeypatch, budget):
     """70 near-identical reads with -u 80: every k-mer is shared by all of them, column 0 has ~200k products (the row kernels
     index products with 16 bits); strands mixed, two reads carry a 700-base deletion plus a random tail (a second overlap bin)"""
+    if budget:
+        monkeypatch.setenv("BELLA_HIP_WIDE_BUDGET", budget)           # several batches of wide columns
     rng = np.random.default_rng(17)
     base = rng.integers(0, 4, size=3000, dtype=np.uint8)
     comp = (3 - base)[::-1]
