@@ -34,8 +34,8 @@ struct Buf {
 // Column tiers by product count: LDS tiers (one workgroup per column, 14.5 B of LDS per product: <= 2752 products keeps four
 // workgroups on a CU, <= 3712 three) and last the global-workspace tier.  BELLA_HIP_TIERS=a,b,c overrides the LDS caps (tuning aid).
 constexpr uint32_t kNumTiers = 8;  // at most
-uint32_t g_ntiers = 6;
-uint32_t kTierCaps[kNumTiers] = {768, 1280, 2048, 3072, 4096, 65535, 0, 0};
+uint32_t g_ntiers = 8;
+uint32_t kTierCaps[kNumTiers] = {768, 1280, 2048, 3072, 4096, 6144, 8192, 65535};
 constexpr uint32_t kGlobalGrid = 256;
 constexpr uint32_t kAsmGrid = 1024;
 
@@ -317,7 +317,7 @@ int bella_hip_init(int device, bella_ctx** out) {
         uint32_t n = 0;
         for (const char* q = tv; *q && n + 1 < kNumTiers;) {
             const uint32_t v = (uint32_t)strtoul(q, nullptr, 10);
-            if (v >= 16 && v <= 4096 && (n == 0 || v > kTierCaps[n - 1])) kTierCaps[n++] = v;
+            if (v >= 16 && v <= 8192 && (n == 0 || v > kTierCaps[n - 1])) kTierCaps[n++] = v;
             while (*q && *q != ',') ++q;
             if (*q == ',') ++q;
         }
@@ -1069,11 +1069,17 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         a.nrows = tcnt[t];
         a.nrows_dev = nullptr;
         a.cap = kTierCaps[t];
-        a.dcap = (c->pair_ratio1024 * 5 < 1024) ? a.cap / 4 : a.cap / 2;   // sampled pairs/products below 1/5: quarter-size key tables
+        // sampled pairs/products below 1/5: quarter-size key tables; the big tiers (one workgroup per CU) always
+        a.dcap = (c->pair_ratio1024 * 5 < 1024 || a.cap > 4096) ? a.cap / 4 : a.cap / 2;
         if (t + 1 < (int)g_ntiers) {
             const size_t lds = row_mem_bytes(a.cap, a.dcap, true);
-            HIPCHK(c, hipFuncSetAttribute((const void*)k_spgemm_rows_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_spgemm_rows_lds<<<tcnt[t], kRowBlock, lds, sst>>>(a);
+            if (a.cap <= 8 * kRowBlock) {
+                HIPCHK(c, hipFuncSetAttribute((const void*)k_spgemm_rows_lds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                k_spgemm_rows_lds<8><<<tcnt[t], kRowBlock, lds, sst>>>(a);
+            } else {
+                HIPCHK(c, hipFuncSetAttribute((const void*)k_spgemm_rows_lds<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                k_spgemm_rows_lds<16><<<tcnt[t], kRowBlock, lds, sst>>>(a);
+            }
         } else {
             const unsigned grid = tcnt[t] < kGlobalGrid ? tcnt[t] : kGlobalGrid;
             k_spgemm_rows_global<<<grid, kRowBlock, 0, sst>>>(a);

@@ -130,7 +130,7 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dc
 }
 
 // returns false if the key table overflowed (no global side effect happened yet; the caller queues the column again)
-template <bool OVERLAY>
+template <bool OVERLAY, uint32_t NX>
 __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t i, const uint32_t b0, const uint32_t n, const uint32_t lenV,
                                             const RowMem& m) {
     const uint32_t tid = threadIdx.x;
@@ -289,7 +289,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // ---- R: exact rank of every product inside its pair's list (list position corrected by the chunk-mates on the wrong
     // side) and the lists in rank order: L_hv / L_gov.  Single-product pairs are finished here. ---------------------
     const uint64_t obase = a.flopptr[i];
-    constexpr uint32_t NX = 4096 / kRowBlock;                               // list positions per thread in the LDS tiers (cap <= 4096)
+    // NX = list positions per thread in the LDS tiers (cap <= NX * kRowBlock)
     uint32_t dstv[NX], hvv[NX], govv[NX];
     auto rank_one = [&](uint32_t x, uint32_t& dst, uint32_t& hvq, uint32_t& govq, uint32_t& flq) {
         const uint32_t p = S_p[x];
@@ -509,13 +509,15 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     return true;
 }
 
-// LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap, cap/2)
-__global__ __launch_bounds__(kRowBlock, 6) void k_spgemm_rows_lds(SpgemmArgs a) {
+// LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap, dcap); NX * 512 >= cap (8: the tiers up to 4096 products,
+// 16: the two big tiers that keep HiFi-like columns with long lists off the global path)
+template <uint32_t NX>
+__global__ __launch_bounds__(kRowBlock, (NX <= 8 ? 6 : 2)) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint4 ds = a.rowdesc[blockIdx.x];
     const uint32_t i = ds.x;
     const RowMem m = carve(smem, a.cap, a.dcap, true);
-    if (!process_row<true>(a, i, ds.y, ds.z & 0xFFFFu, ds.z >> 16, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
+    if (!process_row<true, NX>(a, i, ds.y, ds.z & 0xFFFFu, ds.z >> 16, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
 }
 
 // Global-workspace path: columns with more products than the largest LDS tier (< 65536), and -- second launch, list and
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(kRowBlock) void k_spgemm_rows_global(SpgemmArgs a) 
         if (f < 16u) f = 16u;                             // T2 needs >= 16 slots
         const RowMem m = carve(ws, f, f, false);
         const uint32_t b0 = a.Bptr[i];
-        (void)process_row<false>(a, i, b0, a.Bptr[i + 1] - b0, (uint32_t)(a.roff[i + 1] - a.roff[i]), m);
+        (void)process_row<false, 8>(a, i, b0, a.Bptr[i + 1] - b0, (uint32_t)(a.roff[i + 1] - a.roff[i]), m);
         __syncthreads();
     }
 }

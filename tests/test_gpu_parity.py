@@ -561,3 +561,22 @@ def test_wide_columns_bit_exact(eng, monkeypatch, budget):
     assert np.array_equal(colptrC, ecol.astype(np.uint64))
     check_pairs(pairs, ext, exp, rs.lengths, 17)
     assert (ext["nbins"] > 1).any()
+
+
+def test_big_lds_tiers_bit_exact(monkeypatch):
+    """every column through the 8192-product LDS tier (the 16-positions-per-thread instance of the row kernel)"""
+    g = load_golden("toyrep90")
+    try:
+        monkeypatch.setenv("BELLA_HIP_TIERS", "8192")
+        e = Engine(0)
+        e.set_reads(g.rs)
+        e.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
+        n, flops = e.overlap(BellaPars(skipAlignment=True))
+        pairs, ext, colptrC = e.get_pairs()
+        _, flop, ecol, exp = oracle_pairs(g.rs, g.seqs, g.nkmers, g.tk, g.tr, g.tp, g.k)
+        assert flops == int(flop.sum()) and n == len(exp)
+        check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
+        e.close()
+    finally:
+        monkeypatch.setenv("BELLA_HIP_TIERS", "768,1280,2048,3072,4096,6144,8192")
+        Engine(0).close()                                            # the tier table is process-wide: back to the default
