@@ -329,7 +329,10 @@ __global__ void k_xdrop_plan(XdropSortedArgs sa) {
     SeqAcc H, V;
     make_accessors(sa.a.packed, goffH, goffV, g, (int)(e & 1), H, V);
     const bool run = H.len >= (uint32_t)kXW && V.len >= (uint32_t)kXW;
-    sa.est[e] = run ? H.len + V.len : 0u;      // Phase 2 ends when either sequence is exhausted: at most lenH + lenV moves
+    // Phase 2 ends when EITHER sequence is exhausted and the band follows the diagonal: about 2 * min(lenH, lenV) moves (the hard
+    // bound lenH + lenV orders unequal pairs badly; the key only schedules, any value is correct)
+    const uint32_t mn = H.len < V.len ? H.len : V.len;
+    sa.est[e] = run ? 2u * mn : 0u;
     sa.ids[e] = (uint32_t)e;
 }
 
