@@ -94,6 +94,95 @@ int64_t oracle_count_kmers(uint32_t nreads, const char* const* seqs, const uint3
     return (int64_t)nrel;
 }
 
+/* Kmer::hash (kmercode/Kmer.cpp:304-307) = MurmurHash3_x64_64 (kmercode/hash_funcs.c:135-140): the first word of
+ * MurmurHash3_x64_128 (the published algorithm, hash_funcs.c:40-128) with seed 313 over the N_BYTES = 8 bytes of the k-mer,
+ * i.e. over ONE little-endian u64 = the left-aligned 2-bit word (Kmer.hpp:27-28, MAX_KMER_SIZEK 32). */
+static uint64_t rotl64_(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static uint64_t fmix64_(uint64_t k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return k;
+}
+uint64_t oracle_kmer_hash(uint64_t left_aligned_word) {
+    uint64_t h1 = 313, h2 = 313, k1 = left_aligned_word;
+    k1 *= 0x87c37b91114253d5ULL; k1 = rotl64_(k1, 31); k1 *= 0x4cf5ad432745937fULL; h1 ^= k1;     /* tail, len & 15 == 8 */
+    h1 ^= 8; h2 ^= 8;
+    h1 += h2; h2 += h1;
+    h1 = fmix64_(h1); h2 = fmix64_(h2);
+    h1 += h2;
+    return h1;
+}
+
+static uint64_t oracle_forward(const char* s, uint32_t k) {                      /* right-aligned forward word */
+    uint64_t fw = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        const uint64_t x = ((uint64_t)(s[i] & 4)) >> 1;
+        fw = (fw << 2) | (x + ((x ^ (uint64_t)(s[i] & 2)) >> 1));
+    }
+    return fw;
+}
+
+/* isSyncmer (include/syncmer.hpp:47-68), smerlen = 5: the k-mer is kept unless an interior s-mer (offsets 1 .. k-s-1) hashes
+ * below BOTH the first and the last s-mer. */
+int oracle_is_syncmer(const char* s, uint32_t k) {
+    const uint32_t sl = 5;
+    const uint64_t st = oracle_kmer_hash(oracle_forward(s, sl) << (64 - 2 * sl));
+    const uint64_t en = oracle_kmer_hash(oracle_forward(s + k - sl, sl) << (64 - 2 * sl));
+    for (uint32_t i = 1; i + sl < k; ++i) {
+        const uint64_t h = oracle_kmer_hash(oracle_forward(s + i, sl) << (64 - 2 * sl));
+        if (h < st && h < en) return 0;
+    }
+    return 1;
+}
+
+/* -s mode: SyncmerCount (include/kmercount.hpp:845-985) + the tuple loop of src/main.cpp:393-416 (which has no syncmer branch).
+ * Counted: the STRAND-SPECIFIC string of every position that is a syncmer (kmercount.hpp:904-911, no rep()), in an unsigned
+ * short that saturates at 65535 (:853).  Reliable: lower <= count <= upper (:958-966).  Tuples: EVERY position whose
+ * canonical k-mer (rep) is a key of that dictionary (main.cpp:399-415) -- so a dictionary entry that is not its own
+ * canonical form is never hit, and positions that are not syncmers themselves still match.  ids: ascending order of the
+ * (forward) dictionary words.  Same outputs as oracle_count_kmers. */
+int64_t oracle_count_syncmers(uint32_t nreads, const char* const* seqs, const uint32_t* lens, uint32_t k, uint32_t lower,
+                              uint32_t upper, uint64_t* dict_codes, uint16_t* dict_counts, uint32_t* t_kmer, uint32_t* t_read,
+                              uint16_t* t_pos, uint64_t* ntuples, uint64_t* ndistinct) {
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < nreads; ++r) if (lens[r] >= k) total += lens[r] - k + 1;
+    uint64_t* all = (uint64_t*)malloc(sizeof(uint64_t) * (total ? total : 1));
+    uint64_t n = 0;
+    for (uint32_t r = 0; r < nreads; ++r)
+        for (uint32_t j = 0; j + k <= lens[r]; ++j)
+            if (k > 5 && oracle_is_syncmer(seqs[r] + j, k)) all[n++] = oracle_forward(seqs[r] + j, k);
+    qsort(all, n, sizeof(uint64_t), cmp_u64);
+    uint64_t* rel = (uint64_t*)malloc(sizeof(uint64_t) * (n ? n : 1));
+    uint64_t nrel = 0, ndist = 0;
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i;
+        while (j < n && all[j] == all[i]) ++j;
+        const uint64_t run = j - i;
+        const uint32_t cnt = run > 65535 ? 65535u : (uint32_t)run;              /* saturating updatefn */
+        ndist++;
+        if (cnt >= lower && cnt <= upper) {
+            if (dict_codes) dict_codes[nrel] = all[i];
+            if (dict_counts) dict_counts[nrel] = (uint16_t)cnt;
+            rel[nrel++] = all[i];
+        }
+        i = j;
+    }
+    uint64_t nt = 0;
+    for (uint32_t r = 0; r < nreads; ++r)
+        for (uint32_t j = 0; j + k <= lens[r]; ++j) {
+            const uint64_t c = oracle_canonical(seqs[r] + j, k);
+            uint64_t lo = 0, hi = nrel;
+            while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (rel[mid] < c) lo = mid + 1; else hi = mid; }
+            if (lo < nrel && rel[lo] == c) {
+                if (t_kmer) { t_kmer[nt] = (uint32_t)lo; t_read[nt] = r; t_pos[nt] = (uint16_t)j; }
+                nt++;
+            }
+        }
+    free(all); free(rel);
+    if (ntuples) *ntuples = nt;
+    if (ndistinct) *ndistinct = ndist;
+    return (int64_t)nrel;
+}
+
 /* ---------------------------------------------------------------------------------------------------
  * Operand assembly
  * ------------------------------------------------------------------------------------------------- */

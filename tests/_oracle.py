@@ -56,6 +56,10 @@ def lib():
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64)]
         L.oracle_count_kmers.restype = C.c_int64
+        L.oracle_count_syncmers.argtypes = L.oracle_count_kmers.argtypes
+        L.oracle_count_syncmers.restype = C.c_int64
+        L.oracle_kmer_hash.argtypes = [C.c_uint64]
+        L.oracle_kmer_hash.restype = C.c_uint64
         L.oracle_slope.argtypes = [C.c_double]
         L.oracle_choose_bin.restype = C.c_uint32
         L.oracle_choose_bin.argtypes = [u32p, C.c_uint32]
@@ -64,20 +68,21 @@ def lib():
     return _lib
 
 
-def count_kmers(seqs, k=17, lower=2, upper=8):
+def count_kmers(seqs, k=17, lower=2, upper=8, syncmer=False):
     """returns (dict_codes u64[nk] ascending, dict_counts u16[nk], t_kmer, t_read, t_pos, ndistinct)"""
     nreads = len(seqs)
     arr = (C.c_char_p * max(nreads, 1))(*[bytes(s) for s in seqs])
     lens = np.asarray([len(s) for s in seqs] or [0], np.uint32)
     nt, nd = C.c_uint64(0), C.c_uint64(0)
-    nk = lib().oracle_count_kmers(nreads, arr, lens, k, lower, upper, None, None, None, None, None, C.byref(nt), C.byref(nd))
+    fn = lib().oracle_count_syncmers if syncmer else lib().oracle_count_kmers
+    nk = fn(nreads, arr, lens, k, lower, upper, None, None, None, None, None, C.byref(nt), C.byref(nd))
     codes = np.zeros(max(nk, 1), np.uint64)
     counts = np.zeros(max(nk, 1), np.uint16)
     tk = np.zeros(max(nt.value, 1), np.uint32)
     tr = np.zeros(max(nt.value, 1), np.uint32)
     tp = np.zeros(max(nt.value, 1), np.uint16)
-    lib().oracle_count_kmers(nreads, arr, lens, k, lower, upper, codes.ctypes.data, counts.ctypes.data, tk.ctypes.data,
-                             tr.ctypes.data, tp.ctypes.data, C.byref(nt), C.byref(nd))
+    fn(nreads, arr, lens, k, lower, upper, codes.ctypes.data, counts.ctypes.data, tk.ctypes.data, tr.ctypes.data, tp.ctypes.data,
+       C.byref(nt), C.byref(nd))
     n = nt.value
     return codes[:nk].copy(), counts[:nk].copy(), tk[:n].copy(), tr[:n].copy(), tp[:n].copy(), nd.value
 
