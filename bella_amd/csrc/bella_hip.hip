@@ -589,12 +589,13 @@ static int grow_keep(bella_ctx* c, Buf& b, size_t need, size_t used) {
     return 0;
 }
 
-int bella_hip_count_kmers(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t* nkmers_out, uint64_t* ntuples_out,
-                          uint64_t* ndistinct_out) {
+static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t mode, uint32_t* nkmers_out,
+                            uint64_t* ntuples_out, uint64_t* ndistinct_out) {
     if (!c) return BELLA_ERR_BAD_ARG;
     if (!c->have_reads) return fail(c, BELLA_ERR_STATE, "set_reads first");
     if (kmer_size < 1 || kmer_size > 32) return fail(c, BELLA_ERR_BAD_ARG, "k must be in [1,32]");
     if (lower < 2 || upper < lower || upper > 65535) return fail(c, BELLA_ERR_BAD_ARG, "need 2 <= lower <= upper <= 65535");
+    if (mode && kmer_size <= kSmerLen) return fail(c, BELLA_ERR_BAD_ARG, "syncmer selection needs k > 5 (smerlen, syncmer.hpp:45)");
     HIPCHK(c, hipSetDevice(c->device));
     c->have_tuples = false;
     const uint32_t nr = c->nreads, k = kmer_size;
@@ -612,7 +613,7 @@ int bella_hip_count_kmers(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint
     int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->kc_nk), ptr<uint64_t>(c->kc_koff), (uint64_t)nr + 1);
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->kc_hist.p, 0, 8 * kCountBins, c->stream));
-    k_code_hist<<<rgrid, kBlock, 0, c->stream>>>(ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), ptr<uint32_t>(c->kc_nk), nr, k,
+    k_code_hist<<<rgrid, kBlock, 0, c->stream>>>(ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), ptr<uint32_t>(c->kc_nk), nr, k, mode,
                                                  (unsigned long long*)c->kc_hist.p);
     KCHK(c);
     uint64_t hist[kCountBins], ntot = 0;
@@ -634,7 +635,7 @@ int bella_hip_count_kmers(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint
         b = e;
     }
     uint64_t nk_total = 0, ndistinct = 0;
-    const bool single = pass_n.size() == 1;
+    const bool single = pass_n.size() == 1 && mode == 0;    // every position contributes: word j of read r has a fixed place
     for (size_t p = 0; p < pass_n.size(); ++p) {
         const uint64_t np = pass_n[p];
         if (!np) continue;
@@ -645,7 +646,7 @@ int bella_hip_count_kmers(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint
         ENSURE(c, c->kc_slot, 4 * (np + 2));
         if (!single) HIPCHK(c, hipMemsetAsync(c->kc_cursor.p, 0, 8, c->stream));
         k_emit_codes<<<rgrid, kBlock, 0, c->stream>>>(ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), ptr<uint32_t>(c->kc_nk),
-                                                      ptr<uint64_t>(c->kc_koff), nr, k, pass_lo[p], pass_hi[p], ptr<uint64_t>(c->kc_keys),
+                                                      ptr<uint64_t>(c->kc_koff), nr, k, mode, pass_lo[p], pass_hi[p], ptr<uint64_t>(c->kc_keys),
                                                       single ? nullptr : (unsigned long long*)c->kc_cursor.p);
         KCHK(c);
         hipcub::DoubleBuffer<uint64_t> db(ptr<uint64_t>(c->kc_keys), ptr<uint64_t>(c->kc_alt));
@@ -664,7 +665,7 @@ int bella_hip_count_kmers(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint
         uint32_t nruns = 0;
         HIPCHK(c, hipMemcpyAsync(&nruns, c->kc_nruns.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        k_flag_reliable<<<nblk((uint64_t)nruns + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->kc_runlen), nruns, lower, upper, ptr<uint32_t>(c->kc_flag));
+        k_flag_reliable<<<nblk((uint64_t)nruns + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->kc_runlen), nruns, lower, upper, mode, ptr<uint32_t>(c->kc_flag));
         KCHK(c);
         rc = scan_u32(c, ptr<uint32_t>(c->kc_flag), ptr<uint32_t>(c->kc_slot), (uint64_t)nruns + 1);
         if (rc) return rc;
@@ -678,7 +679,7 @@ int bella_hip_count_kmers(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint
         if (rc) return rc;
         if (nruns) {
             k_write_dict<<<nblk(nruns), 256, 0, c->stream>>>(run_code, ptr<uint32_t>(c->kc_runlen), ptr<uint32_t>(c->kc_flag), ptr<uint32_t>(c->kc_slot),
-                                                             nruns, ptr<uint64_t>(c->kc_dcode) + nk_total, ptr<uint16_t>(c->kc_dcount) + nk_total);
+                                                             nruns, mode, ptr<uint64_t>(c->kc_dcode) + nk_total, ptr<uint16_t>(c->kc_dcount) + nk_total);
             KCHK(c);
         }
         nk_total += nrel;
@@ -728,6 +729,16 @@ int bella_hip_count_kmers(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint
     if (ntuples_out) *ntuples_out = nt;
     if (ndistinct_out) *ndistinct_out = ndistinct;
     return 0;
+}
+
+int bella_hip_count_kmers(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t* nkmers, uint64_t* ntuples,
+                          uint64_t* ndistinct) {
+    return count_kmers_impl(c, kmer_size, lower, upper, 0, nkmers, ntuples, ndistinct);
+}
+
+int bella_hip_count_syncmers(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t* nkmers, uint64_t* ntuples,
+                             uint64_t* ndistinct) {
+    return count_kmers_impl(c, kmer_size, lower, upper, 1, nkmers, ntuples, ndistinct);
 }
 
 int bella_hip_get_dictionary(bella_ctx* c, uint64_t* codes, uint16_t* counts) {

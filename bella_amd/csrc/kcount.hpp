@@ -34,6 +34,41 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {                        /
     return x ^ (x >> 31);
 }
 
+// ---- syncmer selection (-s; include/syncmer.hpp:47-79, smerlen = 5) -----------------------------------------------------------
+// Kmer::hash (Kmer.cpp:304-307) = first word of MurmurHash3_x64_128 (published algorithm, kmercode/hash_funcs.c:40-140), seed 313,
+// over the 8 bytes of the left-aligned 2-bit word.  Only s-mers are hashed: all 4^5 of them fit a 8 KB LDS table.
+constexpr uint32_t kSmerLen = 5;
+constexpr uint32_t kSmerCount = 1u << (2 * kSmerLen);
+__device__ __forceinline__ uint64_t kmer_hash_left(uint64_t left_aligned) {
+    auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+    auto fmix = [](uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; };
+    uint64_t h1 = 313, h2 = 313, k1 = left_aligned;
+    k1 *= 0x87c37b91114253d5ull; k1 = rotl(k1, 31); k1 *= 0x4cf5ad432745937full; h1 ^= k1;
+    h1 ^= 8; h2 ^= 8;
+    h1 += h2; h2 += h1;
+    h1 = fmix(h1); h2 = fmix(h2);
+    return h1 + h2;
+}
+__device__ __forceinline__ void smer_table_fill(uint64_t* tab) {              // call by the whole workgroup, then __syncthreads()
+    for (uint32_t v = threadIdx.x; v < kSmerCount; v += blockDim.x) tab[v] = kmer_hash_left((uint64_t)v << (64 - 2 * kSmerLen));
+}
+// isSyncmer on the right-aligned forward word: kept unless an interior s-mer hashes below both end s-mers
+__device__ __forceinline__ bool is_syncmer(const uint64_t* tab, uint64_t fw, uint32_t k) {
+    const uint32_t last = k - kSmerLen;
+    const uint64_t st = tab[(fw >> (2 * last)) & (kSmerCount - 1)], en = tab[fw & (kSmerCount - 1)];
+    const uint64_t lim = st < en ? st : en;
+    bool ok = true;
+    for (uint32_t i = 1; i < last; ++i) ok = ok && !(tab[(fw >> (2 * (last - i))) & (kSmerCount - 1)] < lim);
+    return ok;
+}
+// the word a position contributes to the COUNT and whether it is counted at all: every position's Kmer::rep() (SplitCount), or
+// the strand-specific word of the syncmer positions (SyncmerCount, kmercount.hpp:904-911)
+__device__ __forceinline__ bool counted_word(const uint32_t* packed, uint64_t g, uint32_t k, uint32_t mode, const uint64_t* tab, uint64_t& w) {
+    if (mode == 0) { w = canonical_word(packed, g, k); return true; }
+    w = kmer_fw_from_le(kmer_le(packed, g, k), k);
+    return is_syncmer(tab, w, k);
+}
+
 // nk[r] = k-mers of read r (kmercount.hpp:525: j = 0 .. len-k)
 __global__ void k_kmers_per_read(const uint64_t* roff, uint32_t nreads, uint32_t k, uint32_t* nk) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,14 +80,19 @@ __global__ void k_kmers_per_read(const uint64_t* roff, uint32_t nreads, uint32_t
 
 // exact histogram of the canonical words' bins: sizes the passes.  One workgroup per read.
 __global__ __launch_bounds__(kBlock) void k_code_hist(const uint32_t* packed, const uint64_t* roff, const uint32_t* nk, uint32_t nreads,
-                                                      uint32_t k, unsigned long long* hist) {
+                                                      uint32_t k, uint32_t mode, unsigned long long* hist) {
     __shared__ uint32_t h[kCountBins];
+    __shared__ uint64_t tab[kSmerCount];
+    if (mode) { smer_table_fill(tab); __syncthreads(); }
     for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
         h[threadIdx.x] = 0;
         __syncthreads();
         const uint64_t g0 = roff[r];
         const uint32_t n = nk[r];
-        for (uint32_t j = threadIdx.x; j < n; j += kBlock) atomicAdd(&h[code_bin(canonical_word(packed, g0 + j, k), k)], 1u);
+        for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
+            uint64_t w;
+            if (counted_word(packed, g0 + j, k, mode, tab, w)) atomicAdd(&h[code_bin(w, k)], 1u);
+        }
         __syncthreads();
         if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
         __syncthreads();
@@ -62,10 +102,12 @@ __global__ __launch_bounds__(kBlock) void k_code_hist(const uint32_t* packed, co
 // the canonical words of the bins [b0, b1) of one pass.  Single pass (cursor == nullptr): word j of read r goes to koff[r] + j.
 // Otherwise the order is irrelevant (the words are sorted next): a workgroup reserves room for 1024 positions at a time.
 __global__ __launch_bounds__(kBlock) void k_emit_codes(const uint32_t* packed, const uint64_t* roff, const uint32_t* nk,
-                                                       const uint64_t* koff, uint32_t nreads, uint32_t k, uint32_t b0, uint32_t b1,
-                                                       uint64_t* out, unsigned long long* cursor) {
+                                                       const uint64_t* koff, uint32_t nreads, uint32_t k, uint32_t mode, uint32_t b0,
+                                                       uint32_t b1, uint64_t* out, unsigned long long* cursor) {
     __shared__ uint32_t scr[kWaves];
     __shared__ unsigned long long s_base;
+    __shared__ uint64_t tab[kSmerCount];
+    if (mode) { smer_table_fill(tab); __syncthreads(); }
     for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
         const uint64_t g0 = roff[r];
         const uint32_t n = nk[r];
@@ -81,8 +123,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_codes(const uint32_t* packed, c
             for (uint32_t u = 0; u < 4; ++u) {
                 const uint32_t j = base + u * kBlock + threadIdx.x;
                 w[u] = 0;
-                if (j < n) {
-                    w[u] = canonical_word(packed, g0 + j, k);
+                if (j < n && counted_word(packed, g0 + j, k, mode, tab, w[u])) {
                     const uint32_t b = code_bin(w[u], k);
                     if (b >= b0 && b < b1) take |= 1u << u;
                 }
@@ -101,20 +142,22 @@ __global__ __launch_bounds__(kBlock) void k_emit_codes(const uint32_t* packed, c
 
 // run i of the sorted words is reliable if lower <= (length mod 65536) <= upper (kmercount.hpp:632-655: `++num` on an
 // unsigned short, then the range test)
-__global__ void k_flag_reliable(const uint32_t* run_len, uint32_t nruns, uint32_t lower, uint32_t upper, uint32_t* flag) {
+// (the syncmer counter saturates at 65535 instead: kmercount.hpp:853)
+__device__ __forceinline__ uint32_t count16(uint32_t run, uint32_t saturate) { return saturate ? (run > 65535u ? 65535u : run) : (run & 0xFFFFu); }
+__global__ void k_flag_reliable(const uint32_t* run_len, uint32_t nruns, uint32_t lower, uint32_t upper, uint32_t saturate, uint32_t* flag) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > nruns) return;
     uint32_t f = 0;
-    if (i < nruns) { const uint32_t c = run_len[i] & 0xFFFFu; f = (c >= lower && c <= upper) ? 1u : 0u; }
+    if (i < nruns) { const uint32_t c = count16(run_len[i], saturate); f = (c >= lower && c <= upper) ? 1u : 0u; }
     flag[i] = f;
 }
 
 __global__ void k_write_dict(const uint64_t* run_code, const uint32_t* run_len, const uint32_t* flag, const uint32_t* slot, uint32_t nruns,
-                             uint64_t* dict_code, uint16_t* dict_count) {
+                             uint32_t saturate, uint64_t* dict_code, uint16_t* dict_count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nruns || !flag[i]) return;
     dict_code[slot[i]] = run_code[i];
-    dict_count[slot[i]] = (uint16_t)(run_len[i] & 0xFFFFu);
+    dict_count[slot[i]] = (uint16_t)count16(run_len[i], saturate);
 }
 
 // countsreliable (a CuckooDict in the reference, main.cpp:410 `find`): open addressing over the dictionary, value = id
@@ -126,6 +169,7 @@ __global__ void k_hash_build(const uint64_t* dict_code, uint32_t nk, uint64_t* h
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nk) return;
     const uint64_t code = dict_code[i];
+    if (code == kHashEmpty) return;             // TT..T (k = 32, strand-specific dictionary): never the canonical word of a position
     uint64_t h = mix64(code) & mask;
     for (;;) {
         const unsigned long long old = atomicCAS((unsigned long long*)&hkey[h], (unsigned long long)kHashEmpty, (unsigned long long)code);

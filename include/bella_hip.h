@@ -136,7 +136,14 @@ int bella_hip_get_read_lengths(bella_ctx* ctx, uint32_t* lens);
  * estimates this number, kmercount.hpp:585-590; here it is exact).  Any of them may be NULL. */
 int bella_hip_count_kmers(bella_ctx* ctx, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t* nkmers,
                           uint64_t* ntuples, uint64_t* ndistinct);
-/* codes[nkmers]: canonical words, ascending (id = index), right-aligned in 2k bits; counts[nkmers].  Either may be NULL. */
+/* The same for the reference's syncmer mode (-s): SyncmerCount (include/kmercount.hpp:845-985) with isSyncmer
+ * (include/syncmer.hpp:47-79, s = 5, Kmer::hash = MurmurHash3_x64_64 seed 313) + the tuple loop of src/main.cpp:393-416.
+ * Counted: the strand-specific word of every syncmer position, saturating at 65535; the dictionary holds those words; tuples:
+ * every position whose CANONICAL k-mer is a dictionary key (the reference's tuple loop has no syncmer branch).  k > 5. */
+int bella_hip_count_syncmers(bella_ctx* ctx, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t* nkmers,
+                             uint64_t* ntuples, uint64_t* ndistinct);
+/* codes[nkmers]: the dictionary's words (canonical for count_kmers, strand-specific for count_syncmers), ascending (id = index),
+ * right-aligned in 2k bits; counts[nkmers].  Either may be NULL. */
 int bella_hip_get_dictionary(bella_ctx* ctx, uint64_t* codes, uint16_t* counts);
 /* the tuple list of the last bella_hip_count_kmers (what the reference's alltranstuples holds, main.cpp:339-423) */
 int bella_hip_get_tuples(bella_ctx* ctx, uint32_t* t_kmer, uint32_t* t_read, uint16_t* t_pos);

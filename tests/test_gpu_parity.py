@@ -418,8 +418,8 @@ def _relabel_equal(a, b):
 def test_count_kmers_matches_oracle_and_reference_dump(eng, golden):
     g = golden
     eng.set_reads(g.rs)
-    nk, nt, nd = eng.count_kmers(g.k, g.lower, g.upper)
-    codes, counts, tk, tr, tp, ndist = O.count_kmers(g.seqs, g.k, g.lower, g.upper)
+    nk, nt, nd = eng.count_kmers(g.k, g.lower, g.upper, g.syncmer)
+    codes, counts, tk, tr, tp, ndist = O.count_kmers(g.seqs, g.k, g.lower, g.upper, g.syncmer)
     assert (nk, nt, nd) == (len(codes), len(tk), ndist)
     dc, dn = eng.get_dictionary()
     assert np.array_equal(dc, codes) and np.array_equal(dn, counts)
@@ -440,6 +440,25 @@ def test_count_kmers_parameter_sweep(eng, k, lower, upper):
     gk, gr, gp = eng.get_tuples()
     assert np.array_equal(dc, codes) and np.array_equal(dn, counts)
     assert np.array_equal(gk, tk) and np.array_equal(gr, tr) and np.array_equal(gp, tp)
+
+
+@pytest.mark.parametrize("k,lower,upper", [(17, 2, 8), (6, 2, 60000), (11, 2, 30), (21, 2, 4), (32, 2, 8), (7, 3, 65535)])
+def test_count_syncmers_parameter_sweep(eng, k, lower, upper, monkeypatch):
+    """the reference's -s mode (SyncmerCount + canonical-lookup tuple loop), low-error reads so that syncmers repeat"""
+    rs = synth.make_reads(60, read_len=1200, coverage=10.0, err=0.01, seed=13, mix=(1 / 3, 1 / 3, 1 / 3))
+    eng.set_reads(rs)
+    codes, counts, tk, tr, tp, ndist = O.count_kmers(rs.seqs(), k, lower, upper, True)
+    for budget in (None, "3000"):                                    # one pass, then several passes over the bins
+        if budget:
+            monkeypatch.setenv("BELLA_HIP_KCOUNT_BUDGET", budget)
+        nk, nt, nd = eng.count_kmers(k, lower, upper, True)
+        assert (nk, nt, nd) == (len(codes), len(tk), ndist)
+        dc, dn = eng.get_dictionary()
+        gk, gr, gp = eng.get_tuples()
+        assert np.array_equal(dc, codes) and np.array_equal(dn, counts)
+        assert np.array_equal(gk, tk) and np.array_equal(gr, tr) and np.array_equal(gp, tp)
+    with pytest.raises(BellaHipError):
+        eng.count_kmers(5, 2, 8, True)
 
 
 def test_count_kmers_multi_pass_equals_single_pass(eng, monkeypatch):
