@@ -183,6 +183,90 @@ int64_t oracle_count_syncmers(uint32_t nreads, const char* const* seqs, const ui
     return (int64_t)nrel;
 }
 
+/* getMinimizers (include/minimizer.hpp:49-79) with robustwinnow = 1 (:10): a monotone deque of (position, order), order =
+ * rep().hash() (:23-26).  Restated with the reference's integer conversions: the range test `front.first <=
+ * static_cast<int>(i) - window` (:64) is evaluated in size_t, so for i < window the right side wraps to a huge value and the
+ * deque is emptied at every step -- the first `window` k-mers never become minimizers.  furtherPop (:12-21) skips a run of
+ * equal orders at the front, then one more entry is popped (:67) even if it is still in range.  sample (:28-32) appends the
+ * front's position unless it is the last one appended.  sel[j] = 1 for the sampled positions; returns their number. */
+static uint64_t oracle_minimizers(const char* seq, uint32_t len, uint32_t k, uint32_t window, uint8_t* sel) {
+    if (len < k) return 0;
+    const uint32_t n = len - k + 1;
+    int64_t* dq_pos = (int64_t*)malloc(sizeof(int64_t) * (n + 1));
+    uint64_t* dq_ord = (uint64_t*)malloc(sizeof(uint64_t) * (n + 1));
+    uint64_t head = 0, tail = 0, count = 0;                                    /* deque = [head, tail) */
+    int64_t last = -1;
+    memset(sel, 0, n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t ord = oracle_kmer_hash(oracle_canonical(seq + i, k) << (64 - 2 * k));
+        while (tail > head && dq_ord[tail - 1] > ord) --tail;                   /* :57-60 */
+        dq_pos[tail] = i; dq_ord[tail] = ord; ++tail;                           /* :61 */
+        while (tail > head && (uint64_t)dq_pos[head] <= (uint64_t)((int64_t)(int)i) - (uint64_t)window) {   /* :63 */
+            while (tail - head > 1 && dq_ord[head] == dq_ord[head + 1]) ++head; /* furtherPop */
+            ++head;                                                             /* :66 */
+        }
+        if (tail > head && dq_pos[head] != last) {                             /* :69-72 sample */
+            last = dq_pos[head];
+            sel[last] = 1;
+            ++count;
+        }
+    }
+    free(dq_pos); free(dq_ord);
+    return count;
+}
+
+/* -w mode: MinimizerCount (include/kmercount.hpp:691-835) + the minimizer branch of the tuple loop (src/main.cpp:363-388).
+ * Counted: rep() of every minimizer position (:744-748), unsigned short saturating at 65535 (:699); reliable: lower <= count
+ * <= upper; tuples: the minimizer positions whose rep() is reliable, read by read, positions ascending.  ids: ascending
+ * canonical order.  Same outputs as oracle_count_kmers. */
+int64_t oracle_count_minimizers(uint32_t nreads, const char* const* seqs, const uint32_t* lens, uint32_t k, uint32_t window,
+                                uint32_t lower, uint32_t upper, uint64_t* dict_codes, uint16_t* dict_counts, uint32_t* t_kmer,
+                                uint32_t* t_read, uint16_t* t_pos, uint64_t* ntuples, uint64_t* ndistinct) {
+    uint64_t total = 0, maxlen = 1;
+    for (uint32_t r = 0; r < nreads; ++r) { if (lens[r] >= k) total += lens[r] - k + 1; if (lens[r] > maxlen) maxlen = lens[r]; }
+    uint64_t* all = (uint64_t*)malloc(sizeof(uint64_t) * (total ? total : 1));
+    uint8_t* sel = (uint8_t*)malloc(maxlen + 1);
+    uint64_t n = 0;
+    for (uint32_t r = 0; r < nreads; ++r) {
+        oracle_minimizers(seqs[r], lens[r], k, window, sel);
+        for (uint32_t j = 0; j + k <= lens[r]; ++j) if (sel[j]) all[n++] = oracle_canonical(seqs[r] + j, k);
+    }
+    qsort(all, n, sizeof(uint64_t), cmp_u64);
+    uint64_t* rel = (uint64_t*)malloc(sizeof(uint64_t) * (n ? n : 1));
+    uint64_t nrel = 0, ndist = 0;
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i;
+        while (j < n && all[j] == all[i]) ++j;
+        const uint64_t run = j - i;
+        const uint32_t cnt = run > 65535 ? 65535u : (uint32_t)run;
+        ndist++;
+        if (cnt >= lower && cnt <= upper) {
+            if (dict_codes) dict_codes[nrel] = all[i];
+            if (dict_counts) dict_counts[nrel] = (uint16_t)cnt;
+            rel[nrel++] = all[i];
+        }
+        i = j;
+    }
+    uint64_t nt = 0;
+    for (uint32_t r = 0; r < nreads; ++r) {
+        oracle_minimizers(seqs[r], lens[r], k, window, sel);
+        for (uint32_t j = 0; j + k <= lens[r]; ++j) {
+            if (!sel[j]) continue;
+            const uint64_t c = oracle_canonical(seqs[r] + j, k);
+            uint64_t lo = 0, hi = nrel;
+            while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (rel[mid] < c) lo = mid + 1; else hi = mid; }
+            if (lo < nrel && rel[lo] == c) {
+                if (t_kmer) { t_kmer[nt] = (uint32_t)lo; t_read[nt] = r; t_pos[nt] = (uint16_t)j; }
+                nt++;
+            }
+        }
+    }
+    free(all); free(rel); free(sel);
+    if (ntuples) *ntuples = nt;
+    if (ndistinct) *ndistinct = ndist;
+    return (int64_t)nrel;
+}
+
 /* ---------------------------------------------------------------------------------------------------
  * Operand assembly
  * ------------------------------------------------------------------------------------------------- */

@@ -239,6 +239,9 @@ def main():
     make_set("toyhifi50", synth.make_reads(50, read_len=2500, err=0.005, seed=3, mix=(1 / 3, 1 / 3, 1 / 3), coverage=5.0),
              ["-e", "0.005"])
     make_set("toyrep90", repeat_genome_reads(5), ["-e", "0.12", "-u", "30"])
+    make_set("toysync60", synth.make_reads(60, read_len=2500, err=0.02, seed=9, mix=(1 / 3, 1 / 3, 1 / 3), coverage=7.0),
+             ["-s", "-e", "0.02"])                                                 # syncmer selection
+    make_set("toymin70", synth.make_reads(70, read_len=2200, err=0.06, seed=23, coverage=9.0), ["-w", "7", "-e", "0.06"])   # minimizers
     xavier_kats()
     eval_kats()
     # read intervals of the reference's E. coli sample (dataset/ecsample-truth.txt, columns 3-4): the FASTQ itself is not in

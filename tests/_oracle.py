@@ -58,6 +58,10 @@ def lib():
         L.oracle_count_kmers.restype = C.c_int64
         L.oracle_count_syncmers.argtypes = L.oracle_count_kmers.argtypes
         L.oracle_count_syncmers.restype = C.c_int64
+        L.oracle_count_minimizers.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
+                                              C.POINTER(C.c_uint64)]
+        L.oracle_count_minimizers.restype = C.c_int64
         L.oracle_kmer_hash.argtypes = [C.c_uint64]
         L.oracle_kmer_hash.restype = C.c_uint64
         L.oracle_slope.argtypes = [C.c_double]
@@ -68,13 +72,16 @@ def lib():
     return _lib
 
 
-def count_kmers(seqs, k=17, lower=2, upper=8, syncmer=False):
+def count_kmers(seqs, k=17, lower=2, upper=8, syncmer=False, window=0):
     """returns (dict_codes u64[nk] ascending, dict_counts u16[nk], t_kmer, t_read, t_pos, ndistinct)"""
     nreads = len(seqs)
     arr = (C.c_char_p * max(nreads, 1))(*[bytes(s) for s in seqs])
     lens = np.asarray([len(s) for s in seqs] or [0], np.uint32)
     nt, nd = C.c_uint64(0), C.c_uint64(0)
     fn = lib().oracle_count_syncmers if syncmer else lib().oracle_count_kmers
+    if window and not syncmer:                       # main.cpp:165-171: -s switches the minimizer mode off
+        base = lib().oracle_count_minimizers
+        fn = lambda nr, a, l, kk, lo, up, *rest: base(nr, a, l, kk, window, lo, up, *rest)
     nk = fn(nreads, arr, lens, k, lower, upper, None, None, None, None, None, C.byref(nt), C.byref(nd))
     codes = np.zeros(max(nk, 1), np.uint64)
     counts = np.zeros(max(nk, 1), np.uint16)

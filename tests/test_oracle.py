@@ -162,13 +162,13 @@ def _same_up_to_relabel(a, b):
 def test_count_kmers_matches_reference_tuples(golden):
     """kmercount.hpp:467-677 + main.cpp:393-416: the reliable set, and the tuples in generation order, equal the
     reference's dump (k-mer ids are labels: libcuckoo's iteration order there, ascending canonical order here)."""
-    codes, counts, tk, tr, tp, ndist = O.count_kmers(golden.seqs, golden.k, golden.lower, golden.upper, golden.syncmer)
+    codes, counts, tk, tr, tp, ndist = O.count_kmers(golden.seqs, golden.k, golden.lower, golden.upper, golden.syncmer, golden.window)
     assert len(codes) == golden.nkmers
     assert np.all(np.diff(codes.astype(np.int64)) > 0) if golden.k <= 31 else True
     assert np.all((counts >= golden.lower) & (counts <= golden.upper))
     assert np.array_equal(tr, golden.tr) and np.array_equal(tp, golden.tp)
     assert _same_up_to_relabel(tk, golden.tk)
-    if not golden.syncmer:     # every dictionary entry is used, and the counts are the tuples' multiplicities
+    if not golden.syncmer and not golden.window:     # every dictionary entry is used, and the counts are the tuples' multiplicities
         assert np.array_equal(np.bincount(tk, minlength=len(codes)), counts.astype(np.int64))
 
 
