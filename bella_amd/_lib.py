@@ -47,6 +47,8 @@ SIGNATURES = [
                                         C.POINTER(C.c_uint64)]),
     ("bella_hip_count_syncmers", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                            C.POINTER(C.c_uint64)]),
+    ("bella_hip_count_minimizers", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
+                                             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("bella_hip_get_dictionary", C.c_int, [vp, vp, vp]),
     ("bella_hip_get_tuples", C.c_int, [vp, vp, vp, vp]),
     ("bella_hip_assemble_counted", C.c_int, [vp]),

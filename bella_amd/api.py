@@ -101,12 +101,15 @@ class Engine:
         self.names = names
 
     # ---- SplitCount + tuple generation (kmercount.hpp:467-677, main.cpp:393-416) ----
-    def count_kmers(self, k=17, lower=2, upper=8, syncmer=False):
+    def count_kmers(self, k=17, lower=2, upper=8, syncmer=False, window=0):
         """reliable dictionary and tuples of the reads on the device (syncmer=True: the reference's -s mode);
         returns (nkmers, ntuples, ndistinct)"""
         nk, nt, nd = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
-        fn = self.lib.bella_hip_count_syncmers if syncmer else self.lib.bella_hip_count_kmers
-        self._chk(fn(self.h, k, lower, upper, C.byref(nk), C.byref(nt), C.byref(nd)))
+        if window and not syncmer:                      # main.cpp:165-171: -w selects minimizers unless -s is given
+            self._chk(self.lib.bella_hip_count_minimizers(self.h, k, window, lower, upper, C.byref(nk), C.byref(nt), C.byref(nd)))
+        else:
+            fn = self.lib.bella_hip_count_syncmers if syncmer else self.lib.bella_hip_count_kmers
+            self._chk(fn(self.h, k, lower, upper, C.byref(nk), C.byref(nt), C.byref(nd)))
         self.nkmers_counted, self.ntuples_counted = nk.value, nt.value
         return nk.value, nt.value, nd.value
 

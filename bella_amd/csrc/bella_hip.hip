@@ -65,7 +65,7 @@ struct bella_ctx {
     uint64_t kc_ntuples = 0;
     uint32_t kc_nkmers = 0, kc_k = 0;
     Buf kc_nk, kc_koff, kc_hist, kc_keys, kc_alt, kc_runlen, kc_flag, kc_slot, kc_nruns, kc_dcode, kc_dcount, kc_hkey, kc_hval, kc_found,
-        kc_tstart, kc_cursor;
+        kc_tstart, kc_cursor, kc_sel, kc_ringo, kc_ringp;
     Buf Bptr, Bk, Bpos, Bent, Bcnt, Aent;
     uint32_t part_first = 0, part_stride = 1;
     bool have_panel = false;
@@ -347,7 +347,7 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
                   &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx, &c->w_idx2, &c->w_hv, &c->w_ovfl,
                   &c->w_plist, &c->w_scr, &c->w_rkey, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
-                  &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres};
+                  &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& st : c->side) (void)hipStreamDestroy(st);
@@ -589,13 +589,14 @@ static int grow_keep(bella_ctx* c, Buf& b, size_t need, size_t used) {
     return 0;
 }
 
-static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t mode, uint32_t* nkmers_out,
-                            uint64_t* ntuples_out, uint64_t* ndistinct_out) {
+static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t mode, uint32_t window,
+                            uint32_t* nkmers_out, uint64_t* ntuples_out, uint64_t* ndistinct_out) {
     if (!c) return BELLA_ERR_BAD_ARG;
     if (!c->have_reads) return fail(c, BELLA_ERR_STATE, "set_reads first");
     if (kmer_size < 1 || kmer_size > 32) return fail(c, BELLA_ERR_BAD_ARG, "k must be in [1,32]");
     if (lower < 2 || upper < lower || upper > 65535) return fail(c, BELLA_ERR_BAD_ARG, "need 2 <= lower <= upper <= 65535");
-    if (mode && kmer_size <= kSmerLen) return fail(c, BELLA_ERR_BAD_ARG, "syncmer selection needs k > 5 (smerlen, syncmer.hpp:45)");
+    if (mode == 2 && (window < 1 || window > 65535)) return fail(c, BELLA_ERR_BAD_ARG, "minimizer window must be in [1,65535]");
+    if (mode == 1 && kmer_size <= kSmerLen) return fail(c, BELLA_ERR_BAD_ARG, "syncmer selection needs k > 5 (smerlen, syncmer.hpp:45)");
     HIPCHK(c, hipSetDevice(c->device));
     c->have_tuples = false;
     const uint32_t nr = c->nreads, k = kmer_size;
@@ -612,13 +613,30 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     KCHK(c);
     int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->kc_nk), ptr<uint64_t>(c->kc_koff), (uint64_t)nr + 1);
     if (rc) return rc;
+    // ntot = koff[nr] is needed before the histogram in minimizer mode (the selection flags are per position)
+    uint64_t ntot = 0;
+    HIPCHK(c, hipMemcpyAsync(&ntot, ptr<uint64_t>(c->kc_koff) + nr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint8_t* d_sel = nullptr;
+    if (mode == 2) {
+        const uint32_t cap = window + 2;
+        ENSURE(c, c->kc_sel, ntot + 16);
+        ENSURE(c, c->kc_ringo, 8 * (size_t)cap * (nr ? nr : 1));
+        ENSURE(c, c->kc_ringp, 4 * (size_t)cap * (nr ? nr : 1));
+        HIPCHK(c, hipMemsetAsync(c->kc_sel.p, 0, ntot + 16, c->stream));
+        k_minimizer_select<<<nblk(nr ? nr : 1, 64), 64, 0, c->stream>>>(ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), ptr<uint32_t>(c->kc_nk),
+                                                                    ptr<uint64_t>(c->kc_koff), nr, k, window, cap, ptr<uint64_t>(c->kc_ringo),
+                                                                    ptr<uint32_t>(c->kc_ringp), ptr<uint8_t>(c->kc_sel));
+        KCHK(c);
+        d_sel = ptr<uint8_t>(c->kc_sel);
+        release(c->kc_ringo); release(c->kc_ringp);
+    }
     HIPCHK(c, hipMemsetAsync(c->kc_hist.p, 0, 8 * kCountBins, c->stream));
     k_code_hist<<<rgrid, kBlock, 0, c->stream>>>(ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), ptr<uint32_t>(c->kc_nk), nr, k, mode,
-                                                 (unsigned long long*)c->kc_hist.p);
+                                                 ptr<uint64_t>(c->kc_koff), d_sel, (unsigned long long*)c->kc_hist.p);
     KCHK(c);
-    uint64_t hist[kCountBins], ntot = 0;
+    uint64_t hist[kCountBins];
     HIPCHK(c, hipMemcpyAsync(hist, c->kc_hist.p, sizeof(hist), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&ntot, ptr<uint64_t>(c->kc_koff) + nr, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // passes = runs of consecutive bins holding at most `budget` k-mers (28 bytes of HBM per k-mer in flight)
     uint64_t budget = 1ull << 30;
@@ -646,7 +664,7 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
         ENSURE(c, c->kc_slot, 4 * (np + 2));
         if (!single) HIPCHK(c, hipMemsetAsync(c->kc_cursor.p, 0, 8, c->stream));
         k_emit_codes<<<rgrid, kBlock, 0, c->stream>>>(ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), ptr<uint32_t>(c->kc_nk),
-                                                      ptr<uint64_t>(c->kc_koff), nr, k, mode, pass_lo[p], pass_hi[p], ptr<uint64_t>(c->kc_keys),
+                                                      ptr<uint64_t>(c->kc_koff), nr, k, mode, pass_lo[p], pass_hi[p], d_sel, ptr<uint64_t>(c->kc_keys),
                                                       single ? nullptr : (unsigned long long*)c->kc_cursor.p);
         KCHK(c);
         hipcub::DoubleBuffer<uint64_t> db(ptr<uint64_t>(c->kc_keys), ptr<uint64_t>(c->kc_alt));
@@ -665,7 +683,7 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
         uint32_t nruns = 0;
         HIPCHK(c, hipMemcpyAsync(&nruns, c->kc_nruns.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        k_flag_reliable<<<nblk((uint64_t)nruns + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->kc_runlen), nruns, lower, upper, mode, ptr<uint32_t>(c->kc_flag));
+        k_flag_reliable<<<nblk((uint64_t)nruns + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->kc_runlen), nruns, lower, upper, mode != 0, ptr<uint32_t>(c->kc_flag));
         KCHK(c);
         rc = scan_u32(c, ptr<uint32_t>(c->kc_flag), ptr<uint32_t>(c->kc_slot), (uint64_t)nruns + 1);
         if (rc) return rc;
@@ -679,7 +697,7 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
         if (rc) return rc;
         if (nruns) {
             k_write_dict<<<nblk(nruns), 256, 0, c->stream>>>(run_code, ptr<uint32_t>(c->kc_runlen), ptr<uint32_t>(c->kc_flag), ptr<uint32_t>(c->kc_slot),
-                                                             nruns, mode, ptr<uint64_t>(c->kc_dcode) + nk_total, ptr<uint16_t>(c->kc_dcount) + nk_total);
+                                                             nruns, mode != 0, ptr<uint64_t>(c->kc_dcode) + nk_total, ptr<uint16_t>(c->kc_dcount) + nk_total);
             KCHK(c);
         }
         nk_total += nrel;
@@ -701,7 +719,7 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     ENSURE(c, c->kc_keys, 4 * ntot);                                  // now: the id of every position
     k_lookup_ids<<<rgrid, kBlock, 0, c->stream>>>(ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), ptr<uint32_t>(c->kc_nk),
                                                   ptr<uint64_t>(c->kc_koff), nr, k, ptr<uint64_t>(c->kc_hkey), ptr<uint32_t>(c->kc_hval),
-                                                  slots - 1, ptr<uint32_t>(c->kc_keys), ptr<uint32_t>(c->kc_found));
+                                                  slots - 1, d_sel, ptr<uint32_t>(c->kc_keys), ptr<uint32_t>(c->kc_found));
     KCHK(c);
     HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->kc_found) + nr, 0, 4, c->stream));
     rc = scan_u32_to_u64(c, ptr<uint32_t>(c->kc_found), ptr<uint64_t>(c->kc_tstart), (uint64_t)nr + 1);
@@ -720,7 +738,7 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev[1]));
     c->tm.kcount_ms = ev_ms(c->ev[0], c->ev[1]);
-    release(c->kc_keys); release(c->kc_hkey); release(c->kc_hval);
+    release(c->kc_keys); release(c->kc_hkey); release(c->kc_hval); release(c->kc_sel);
     c->kc_ntuples = nt;
     c->kc_nkmers = (uint32_t)nk_total;
     c->kc_k = k;
@@ -733,12 +751,17 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
 
 int bella_hip_count_kmers(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t* nkmers, uint64_t* ntuples,
                           uint64_t* ndistinct) {
-    return count_kmers_impl(c, kmer_size, lower, upper, 0, nkmers, ntuples, ndistinct);
+    return count_kmers_impl(c, kmer_size, lower, upper, 0, 0, nkmers, ntuples, ndistinct);
 }
 
 int bella_hip_count_syncmers(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t* nkmers, uint64_t* ntuples,
                              uint64_t* ndistinct) {
-    return count_kmers_impl(c, kmer_size, lower, upper, 1, nkmers, ntuples, ndistinct);
+    return count_kmers_impl(c, kmer_size, lower, upper, 1, 0, nkmers, ntuples, ndistinct);
+}
+
+int bella_hip_count_minimizers(bella_ctx* c, uint16_t kmer_size, uint32_t window, uint32_t lower, uint32_t upper, uint32_t* nkmers,
+                               uint64_t* ntuples, uint64_t* ndistinct) {
+    return count_kmers_impl(c, kmer_size, lower, upper, 2, window, nkmers, ntuples, ndistinct);
 }
 
 int bella_hip_get_dictionary(bella_ctx* c, uint64_t* codes, uint16_t* counts) {

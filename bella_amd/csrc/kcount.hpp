@@ -63,10 +63,43 @@ __device__ __forceinline__ bool is_syncmer(const uint64_t* tab, uint64_t fw, uin
 }
 // the word a position contributes to the COUNT and whether it is counted at all: every position's Kmer::rep() (SplitCount), or
 // the strand-specific word of the syncmer positions (SyncmerCount, kmercount.hpp:904-911)
-__device__ __forceinline__ bool counted_word(const uint32_t* packed, uint64_t g, uint32_t k, uint32_t mode, const uint64_t* tab, uint64_t& w) {
-    if (mode == 0) { w = canonical_word(packed, g, k); return true; }
+//   mode 0 every position's rep();  mode 1 syncmers, strand-specific;  mode 2 rep() of the minimizer positions (sel != 0)
+__device__ __forceinline__ bool counted_word(const uint32_t* packed, uint64_t g, uint32_t k, uint32_t mode, const uint64_t* tab, uint32_t selected,
+                                             uint64_t& w) {
+    if (mode != 1) { w = canonical_word(packed, g, k); return mode == 0 || selected != 0; }
     w = kmer_fw_from_le(kmer_le(packed, g, k), k);
     return is_syncmer(tab, w, k);
+}
+
+// ---- minimizer selection (-w; include/minimizer.hpp:49-79, robustwinnow = 1) -------------------------------------------------
+// One lane per read runs the reference's monotone deque over the read's k-mers (order = rep().hash()) in a ring of window + 2
+// entries (slot s of read r at s * nreads + r: lanes of a wavefront touch neighbouring words).  The reference's range test
+// `front.first <= static_cast<int>(i) - window` is size_t arithmetic: for i < window it is always true and the deque is
+// emptied, so the first `window` k-mers are never sampled; furtherPop skips a run of equal orders and one more entry is
+// popped.  sel[koff[r] + j] = 1 for the sampled positions (sample() de-duplicates: the front's position never decreases).
+__global__ void k_minimizer_select(const uint32_t* packed, const uint64_t* roff, const uint32_t* nk, const uint64_t* koff, uint32_t nreads,
+                                   uint32_t k, uint32_t window, uint32_t cap, uint64_t* ring_ord, uint32_t* ring_pos, uint8_t* sel) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nreads) return;
+    const uint64_t g0 = roff[r], o = koff[r];
+    const uint32_t n = nk[r];
+    uint32_t head = 0, len = 0;                                 // deque = ring slots head .. head + len - 1 (mod cap)
+    uint32_t last = 0xFFFFFFFFu;
+    auto slot = [&](uint32_t x) { return (uint64_t)(x >= cap ? x - cap : x) * nreads + r; };
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t ord = kmer_hash_left(canonical_word(packed, g0 + i, k) << (64 - 2 * k));
+        while (len && ring_ord[slot(head + len - 1)] > ord) --len;
+        { const uint64_t sl = slot(head + len); ring_ord[sl] = ord; ring_pos[sl] = i; ++len; }
+        const uint64_t bound = (uint64_t)(int64_t)(int)i - (uint64_t)window;
+        while (len && (uint64_t)ring_pos[slot(head)] <= bound) {
+            while (len > 1 && ring_ord[slot(head)] == ring_ord[slot(head + 1)]) { head = head + 1 == cap ? 0 : head + 1; --len; }
+            head = head + 1 == cap ? 0 : head + 1; --len;
+        }
+        if (len) {
+            const uint32_t p = ring_pos[slot(head)];
+            if (p != last) { last = p; sel[o + p] = 1; }
+        }
+    }
 }
 
 // nk[r] = k-mers of read r (kmercount.hpp:525: j = 0 .. len-k)
@@ -80,18 +113,19 @@ __global__ void k_kmers_per_read(const uint64_t* roff, uint32_t nreads, uint32_t
 
 // exact histogram of the canonical words' bins: sizes the passes.  One workgroup per read.
 __global__ __launch_bounds__(kBlock) void k_code_hist(const uint32_t* packed, const uint64_t* roff, const uint32_t* nk, uint32_t nreads,
-                                                      uint32_t k, uint32_t mode, unsigned long long* hist) {
+                                                      uint32_t k, uint32_t mode, const uint64_t* koff, const uint8_t* sel,
+                                                      unsigned long long* hist) {
     __shared__ uint32_t h[kCountBins];
     __shared__ uint64_t tab[kSmerCount];
     if (mode) { smer_table_fill(tab); __syncthreads(); }
     for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
         h[threadIdx.x] = 0;
         __syncthreads();
-        const uint64_t g0 = roff[r];
+        const uint64_t g0 = roff[r], o = koff[r];
         const uint32_t n = nk[r];
         for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
             uint64_t w;
-            if (counted_word(packed, g0 + j, k, mode, tab, w)) atomicAdd(&h[code_bin(w, k)], 1u);
+            if (counted_word(packed, g0 + j, k, mode, tab, mode == 2 ? sel[o + j] : 1u, w)) atomicAdd(&h[code_bin(w, k)], 1u);
         }
         __syncthreads();
         if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
@@ -103,16 +137,15 @@ __global__ __launch_bounds__(kBlock) void k_code_hist(const uint32_t* packed, co
 // Otherwise the order is irrelevant (the words are sorted next): a workgroup reserves room for 1024 positions at a time.
 __global__ __launch_bounds__(kBlock) void k_emit_codes(const uint32_t* packed, const uint64_t* roff, const uint32_t* nk,
                                                        const uint64_t* koff, uint32_t nreads, uint32_t k, uint32_t mode, uint32_t b0,
-                                                       uint32_t b1, uint64_t* out, unsigned long long* cursor) {
+                                                       uint32_t b1, const uint8_t* sel, uint64_t* out, unsigned long long* cursor) {
     __shared__ uint32_t scr[kWaves];
     __shared__ unsigned long long s_base;
     __shared__ uint64_t tab[kSmerCount];
     if (mode) { smer_table_fill(tab); __syncthreads(); }
     for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
-        const uint64_t g0 = roff[r];
+        const uint64_t g0 = roff[r], o = koff[r];
         const uint32_t n = nk[r];
         if (!cursor) {
-            const uint64_t o = koff[r];
             for (uint32_t j = threadIdx.x; j < n; j += kBlock) out[o + j] = canonical_word(packed, g0 + j, k);
             continue;
         }
@@ -123,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_codes(const uint32_t* packed, c
             for (uint32_t u = 0; u < 4; ++u) {
                 const uint32_t j = base + u * kBlock + threadIdx.x;
                 w[u] = 0;
-                if (j < n && counted_word(packed, g0 + j, k, mode, tab, w[u])) {
+                if (j < n && counted_word(packed, g0 + j, k, mode, tab, mode == 2 ? sel[o + j] : 1u, w[u])) {
                     const uint32_t b = code_bin(w[u], k);
                     if (b >= b0 && b < b1) take |= 1u << u;
                 }
@@ -132,9 +165,9 @@ __global__ __launch_bounds__(kBlock) void k_emit_codes(const uint32_t* packed, c
             const uint32_t ex = block_excl_scan<kWaves>((uint32_t)__popc(take), scr, &tot);
             if (threadIdx.x == 0) s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
             __syncthreads();
-            uint64_t o = s_base + ex;
+            uint64_t wo = s_base + ex;
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) if (take & (1u << u)) out[o++] = w[u];
+            for (uint32_t u = 0; u < 4; ++u) if (take & (1u << u)) out[wo++] = w[u];
             __syncthreads();
         }
     }
@@ -181,7 +214,7 @@ __global__ void k_hash_build(const uint64_t* dict_code, uint32_t nk, uint64_t* h
 // tuple pass 1 (main.cpp:393-416): the id of every position's k-mer (0xFFFFFFFF: not reliable) and the tuples per read
 __global__ __launch_bounds__(kBlock) void k_lookup_ids(const uint32_t* packed, const uint64_t* roff, const uint32_t* nk, const uint64_t* koff,
                                                        uint32_t nreads, uint32_t k, const uint64_t* hkey, const uint32_t* hval, uint64_t mask,
-                                                       uint32_t* ids, uint32_t* found_per_read) {
+                                                       const uint8_t* sel, uint32_t* ids, uint32_t* found_per_read) {
     __shared__ uint32_t s_cnt;
     for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
         if (threadIdx.x == 0) s_cnt = 0;
@@ -193,6 +226,7 @@ __global__ __launch_bounds__(kBlock) void k_lookup_ids(const uint32_t* packed, c
             const uint64_t code = canonical_word(packed, g0 + j, k);
             uint64_t h = mix64(code) & mask;
             uint32_t id = 0xFFFFFFFFu;
+            if (sel && !sel[o + j]) { ids[o + j] = id; continue; }     // -w: only the minimizer positions make tuples (main.cpp:363-388)
             for (;;) {
                 const uint64_t kk = hkey[h];
                 if (kk == code) { id = hval[h]; break; }

@@ -142,6 +142,12 @@ int bella_hip_count_kmers(bella_ctx* ctx, uint16_t kmer_size, uint32_t lower, ui
  * every position whose CANONICAL k-mer is a dictionary key (the reference's tuple loop has no syncmer branch).  k > 5. */
 int bella_hip_count_syncmers(bella_ctx* ctx, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t* nkmers,
                              uint64_t* ntuples, uint64_t* ndistinct);
+/* The reference's minimizer mode (-w window): MinimizerCount (include/kmercount.hpp:691-835) with getMinimizers
+ * (include/minimizer.hpp:49-79: monotone deque on rep().hash(), robust winnowing, the first `window` k-mers of a read are
+ * never sampled -- the reference's size_t range test) + the minimizer branch of the tuple loop (src/main.cpp:363-388).
+ * Counted: rep() of the minimizer positions, saturating at 65535; tuples: the minimizer positions whose rep() is reliable. */
+int bella_hip_count_minimizers(bella_ctx* ctx, uint16_t kmer_size, uint32_t window, uint32_t lower, uint32_t upper,
+                               uint32_t* nkmers, uint64_t* ntuples, uint64_t* ndistinct);
 /* codes[nkmers]: the dictionary's words (canonical for count_kmers, strand-specific for count_syncmers), ascending (id = index),
  * right-aligned in 2k bits; counts[nkmers].  Either may be NULL. */
 int bella_hip_get_dictionary(bella_ctx* ctx, uint64_t* codes, uint16_t* counts);

@@ -418,8 +418,8 @@ def _relabel_equal(a, b):
 def test_count_kmers_matches_oracle_and_reference_dump(eng, golden):
     g = golden
     eng.set_reads(g.rs)
-    nk, nt, nd = eng.count_kmers(g.k, g.lower, g.upper, g.syncmer)
-    codes, counts, tk, tr, tp, ndist = O.count_kmers(g.seqs, g.k, g.lower, g.upper, g.syncmer)
+    nk, nt, nd = eng.count_kmers(g.k, g.lower, g.upper, g.syncmer, g.window)
+    codes, counts, tk, tr, tp, ndist = O.count_kmers(g.seqs, g.k, g.lower, g.upper, g.syncmer, g.window)
     assert (nk, nt, nd) == (len(codes), len(tk), ndist)
     dc, dn = eng.get_dictionary()
     assert np.array_equal(dc, codes) and np.array_equal(dn, counts)
@@ -459,6 +459,25 @@ def test_count_syncmers_parameter_sweep(eng, k, lower, upper, monkeypatch):
         assert np.array_equal(gk, tk) and np.array_equal(gr, tr) and np.array_equal(gp, tp)
     with pytest.raises(BellaHipError):
         eng.count_kmers(5, 2, 8, True)
+
+
+@pytest.mark.parametrize("k,window,lower,upper", [(17, 10, 2, 8), (15, 1, 2, 30), (21, 50, 2, 8), (32, 7, 2, 8), (5, 3, 2, 65535),
+                                                  (17, 3000, 2, 8)])
+def test_count_minimizers_parameter_sweep(eng, k, window, lower, upper, monkeypatch):
+    """the reference's -w mode (getMinimizers' deque incl. its size_t range test, MinimizerCount, minimizer tuple branch);
+    window 3000 exceeds every read: nothing is ever sampled"""
+    rs = synth.make_reads(60, read_len=1200, coverage=10.0, err=0.02, seed=29, mix=(1 / 3, 1 / 3, 1 / 3))
+    eng.set_reads(rs)
+    codes, counts, tk, tr, tp, ndist = O.count_kmers(rs.seqs(), k, lower, upper, False, window)
+    for budget in (None, "2000"):
+        if budget:
+            monkeypatch.setenv("BELLA_HIP_KCOUNT_BUDGET", budget)
+        nk, nt, nd = eng.count_kmers(k, lower, upper, False, window)
+        assert (nk, nt, nd) == (len(codes), len(tk), ndist)
+        dc, dn = eng.get_dictionary()
+        gk, gr, gp = eng.get_tuples()
+        assert np.array_equal(dc, codes) and np.array_equal(dn, counts)
+        assert np.array_equal(gk, tk) and np.array_equal(gr, tr) and np.array_equal(gp, tp)
 
 
 def test_count_kmers_multi_pass_equals_single_pass(eng, monkeypatch):
