@@ -52,6 +52,7 @@ SIGNATURES = [
     ("bella_hip_get_dictionary", C.c_int, [vp, vp, vp]),
     ("bella_hip_get_tuples", C.c_int, [vp, vp, vp, vp]),
     ("bella_hip_assemble_counted", C.c_int, [vp]),
+    ("bella_hip_assemble_counted_panel", C.c_int, [vp, C.c_uint32, C.c_uint32]),
     ("bella_hip_assemble_tuples", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint64, vp, vp, vp]),
     ("bella_hip_set_B", C.c_int, [vp, C.c_uint16, C.c_uint32, vp, vp, vp]),
     ("bella_hip_assemble_panel", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp]),

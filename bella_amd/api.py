@@ -128,6 +128,9 @@ class Engine:
     def assemble_counted(self):
         self._chk(self.lib.bella_hip_assemble_counted(self.h))
 
+    def assemble_counted_panel(self, first_read, nreads_panel):
+        self._chk(self.lib.bella_hip_assemble_counted_panel(self.h, first_read, nreads_panel))
+
     # ---- operands ----
     def assemble_tuples(self, k, nkmers, tk, tr, tp):
         tk = np.ascontiguousarray(tk, np.uint32); tr = np.ascontiguousarray(tr, np.uint32); tp = np.ascontiguousarray(tp, np.uint16)

@@ -485,11 +485,14 @@ int bella_hip_set_B(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, const uin
 }
 
 // tuples of the reads first .. first+nr-1 -> their rows of B (CSR: c->Bptr local offsets, c->Bk, c->Bpos), on device
+// t_kmer == nullptr: the tuples are already on the device (bella_hip_count_kmers), `toff` tuples into the buffers
 static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint64_t ntuples, const uint32_t* t_kmer,
-                                const uint32_t* t_read, const uint16_t* t_pos, uint64_t* nnz_out) {
-    ENSURE(c, c->t_kmer, 4 * ntuples);
-    ENSURE(c, c->t_read, 4 * ntuples);
-    ENSURE(c, c->t_pos, 2 * ntuples);
+                                const uint32_t* t_read, const uint16_t* t_pos, uint64_t* nnz_out, uint64_t toff = 0) {
+    if (t_kmer || !ntuples) {
+        ENSURE(c, c->t_kmer, 4 * ntuples);
+        ENSURE(c, c->t_read, 4 * ntuples);
+        ENSURE(c, c->t_pos, 2 * ntuples);
+    }
     ENSURE(c, c->tstart, 8 * ((size_t)nr + 2));
     ENSURE(c, c->Bk_tmp, 4 * ntuples);
     ENSURE(c, c->Bpos_tmp, 2 * ntuples);
@@ -505,7 +508,7 @@ static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint6
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->rowcnt.p, 0, 4 * ((size_t)nr + 2), c->stream));
-    k_tuple_bounds<<<nblk(ntuples + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->t_read), ntuples, first, nr, ptr<uint64_t>(c->tstart),
+    k_tuple_bounds<<<nblk(ntuples + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->t_read) + toff, ntuples, first, nr, ptr<uint64_t>(c->tstart),
                                                              ptr<uint32_t>(c->status));
     KCHK(c);
     uint32_t st = 0;
@@ -514,8 +517,8 @@ static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint6
     rc = status_to_error(c, st);
     if (rc) return rc;
     AsmArgs a;
-    a.t_kmer = ptr<uint32_t>(c->t_kmer);
-    a.t_pos = ptr<uint16_t>(c->t_pos);
+    a.t_kmer = ptr<uint32_t>(c->t_kmer) + toff;
+    a.t_pos = ptr<uint16_t>(c->t_pos) + toff;
     a.tstart = ptr<uint64_t>(c->tstart);
     a.nreads = nr;
     a.Bk_tmp = ptr<uint32_t>(c->Bk_tmp);
@@ -827,6 +830,33 @@ int bella_hip_assemble_panel(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, 
     release(c->t_kmer); release(c->t_read); release(c->t_pos); release(c->Bk_tmp); release(c->Bpos_tmp); release(c->asm_ws);
     c->nkmers = nkmers;
     c->kmer_size = kmer_size;
+    c->panel_first = first_read;
+    c->panel_rows = nreads_panel;
+    c->panel_nnz = nnz;
+    c->have_panel = true;
+    return 0;
+}
+
+int bella_hip_assemble_counted_panel(bella_ctx* c, uint32_t first_read, uint32_t nreads_panel) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    if (!c->have_tuples) return fail(c, BELLA_ERR_STATE, "count_kmers first");
+    if ((uint64_t)first_read + nreads_panel > c->nreads) return fail(c, BELLA_ERR_BAD_ARG, "panel exceeds the read set");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->have_matrix = c->have_pairs = c->have_alns = false;
+    c->have_panel = false;
+    uint64_t t0 = 0, t1 = 0;                                       // the panel's tuples are contiguous: tstart of its first / last read
+    HIPCHK(c, hipMemcpyAsync(&t0, ptr<uint64_t>(c->kc_tstart) + first_read, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&t1, ptr<uint64_t>(c->kc_tstart) + first_read + nreads_panel, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t nnz = 0;
+    int rc = assemble_rows_device(c, first_read, nreads_panel, t1 - t0, nullptr, nullptr, nullptr, &nnz, t0);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    c->tm.assemble_ms = ev_ms(c->ev[0], c->ev[1]);
+    release(c->Bk_tmp); release(c->Bpos_tmp); release(c->asm_ws);
+    c->nkmers = c->kc_nkmers;
+    c->kmer_size = (uint16_t)c->kc_k;
     c->panel_first = first_read;
     c->panel_rows = nreads_panel;
     c->panel_nnz = nnz;

@@ -105,11 +105,12 @@ def main():
     eng.set_reads(rs)                                   # reads are replicated (2 bit/base)
     nk, nt, ndistinct = eng.count_kmers(17, 2, 8)
     kcount_ms = eng.timings().kcount_ms
-    tup = synth.Tuples(*eng.get_tuples(), nk)           # host copy: the CPU baseline's input (and the panel split for N > 1)
+    # host copy of the tuples only where the CPU baseline needs it (N = 1)
+    tup = synth.Tuples(*eng.get_tuples(), nk) if (world == 1 and not a.no_cpu_baseline) else None
     t2 = time.time()
     if rank == 0:
         log("[bench] reads %d (%.1f s), distinct k-mers %d, reliable %d, tuples %d (device: %.1f ms)"
-            % (nreads, t1 - t0, ndistinct, tup.nkmers, len(tup.kmer), kcount_ms))
+            % (nreads, t1 - t0, ndistinct, nk, nt, kcount_ms))
 
     xchg_ms = None
     if world == 1:
@@ -120,8 +121,7 @@ def main():
         # the whole matrix, which goes back into the library through device pointers
         from bella_amd import dist as bd
         lo, npanel = bd.block_range(rank, world, nreads)
-        sel = (tup.read >= lo) & (tup.read < lo + npanel)
-        eng.assemble_panel(17, tup.nkmers, lo, npanel, tup.kmer[sel], tup.read[sel], tup.pos[sel])
+        eng.assemble_counted_panel(lo, npanel)                 # from the device-resident tuples of this rank's read block
         asm_ms = eng.timings().assemble_ms
         pc, pr, pv = eng.panel_tensors(local)
         if backend != "nccl":
@@ -133,7 +133,7 @@ def main():
         torch.cuda.synchronize()
         xchg_ms = (time.perf_counter() - tx) * 1e3
         dev = torch.device("cuda", local)
-        eng.set_B_device(17, tup.nkmers, colptr_t.to(dev), ids_t.to(dev), val_t.to(dev))
+        eng.set_B_device(17, nk, colptr_t.to(dev), ids_t.to(dev), val_t.to(dev))
         asm_ms += eng.timings().assemble_ms
         del colptr_t, ids_t, val_t
     eng.set_partition(rank, n_gpus)
@@ -228,7 +228,7 @@ def main():
         "dtype": "u16/u32 integer", "data": "synthetic",
         "config": {"workload": "configs[1]: %d synthetic PacBio reads (%d b templates, 15%% err, 30x) k=17 SpGEMM-only "
                                "(--skip-alignment)" % (nreads, a.read_len),
-                   "reads": nreads, "nkmers": tup.nkmers, "nnzA": nnz, "flops": int(tot_flops), "pairs": int(tot_pairs),
+                   "reads": nreads, "nkmers": nk, "nnzA": nnz, "flops": int(tot_flops), "pairs": int(tot_pairs),
                    "partition": "columns i %% %d == rank" % n_gpus},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": None, "kernel": "SpGEMM = k_spgemm_rows_* (one launch set = the concurrent tier launches of a pass) + k_fold_overflow", "kernel_ms_per_step": k_ms,

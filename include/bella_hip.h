@@ -155,6 +155,9 @@ int bella_hip_get_dictionary(bella_ctx* ctx, uint64_t* codes, uint16_t* counts);
 int bella_hip_get_tuples(bella_ctx* ctx, uint32_t* t_kmer, uint32_t* t_read, uint16_t* t_pos);
 /* bella_hip_assemble_tuples on the device-resident tuples of bella_hip_count_kmers (no host copy) */
 int bella_hip_assemble_counted(bella_ctx* ctx);
+/* bella_hip_assemble_panel on the device-resident tuples of the reads [first_read, first_read + nreads_panel) (multi-GPU:
+ * every rank counts, each assembles the rows of its own read block; then the all-gather of bella_hip_panel_device_ptrs) */
+int bella_hip_assemble_counted_panel(bella_ctx* ctx, uint32_t first_read, uint32_t nreads_panel);
 
 /* ---- operands ------------------------------------------------------------------------------------ */
 /* From the (kmer, read, pos) tuple list: replaces the CSC tuple constructor + MergeDuplicates +

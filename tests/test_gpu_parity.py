@@ -618,3 +618,32 @@ def test_big_lds_tiers_bit_exact(monkeypatch):
     finally:
         monkeypatch.setenv("BELLA_HIP_TIERS", "768,1280,2048,3072,4096,6144,8192")
         Engine(0).close()                                            # the tier table is process-wide: back to the default
+
+
+def test_counted_panels_equal_one_shot_assembly(eng):
+    """multi-GPU path without a host copy of the tuples: count on the device, assemble the rows of each read block from the
+    device-resident tuples, concatenate (= the all-gather), set_B_device -> the same B and pairs as assemble_counted"""
+    import torch
+    from bella_amd import dist as bd
+    rs = synth.make_reads(150, read_len=2000, coverage=15.0, err=0.15, seed=41)
+    eng.set_reads(rs)
+    nk, nt, _ = eng.count_kmers(17, 2, 8)
+    eng.assemble_counted()
+    B1 = eng.get_B()
+    eng.overlap(BellaPars(skipAlignment=True))
+    p1 = eng.get_pairs()
+    parts = []
+    for r in range(3):
+        lo, n = bd.block_range(r, 3, rs.nreads)
+        eng.assemble_counted_panel(lo, n)
+        parts.append([t.clone() for t in eng.panel_tensors(0)])
+    cnt = torch.cat([p[0] for p in parts]); ids = torch.cat([p[1] for p in parts]); val = torch.cat([p[2] for p in parts])
+    colptr = torch.zeros(cnt.numel() + 1, dtype=torch.int32, device=cnt.device)
+    colptr[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+    eng.set_B_device(17, nk, colptr, ids, val)
+    for a, b in zip(eng.get_B(), B1):
+        assert np.array_equal(a, b)
+    eng.overlap(BellaPars(skipAlignment=True))
+    p2 = eng.get_pairs()
+    for a, b in zip(p1, p2):
+        assert np.array_equal(a, b)
