@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for S in ${STOPS:-6 0 1 2 3 4 -1}; do
   OUT=$R/gpurun_out/sqp/s$S; rm -rf $OUT; mkdir -p $OUT
-  BELLA_HIP_STOP_PHASE=$S rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT -o t -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  BELLA_HIP_STOP_PHASE=$S rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT -o t -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > /dev/null 2>&1
   python - <<PY
 import csv, collections, glob
 agg = collections.defaultdict(float)
