@@ -1038,8 +1038,6 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     const uint32_t nr = c->nreads;
     const bool force_global = (c->debug & 1u) != 0;
     const bool want_ext = (c->debug & 2u) == 0;
-    // every size below derives from F_full (known since assembly): no host round trip inside the pass
-    const uint64_t Fub = c->F_full;
     const uint64_t ws_stride = (row_mem_bytes(65535, 65535, false) + 255) & ~(size_t)255;
     ENSURE(c, c->flopsr, 4 * ((size_t)nr + 2));
     ENSURE(c, c->flopptr, 8 * ((size_t)nr + 2));
@@ -1048,17 +1046,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     ENSURE(c, c->rowlists, (16 * (size_t)kNumTiers + 4) * nr + 64);   // tier descriptor lists, then the list of wide columns
     ENSURE(c, c->tiercaps, 4 * kNumTiers);
     ENSURE(c, c->ctl, 4 * kCtlWords);
-    ENSURE(c, c->tmp_pairs, sizeof(bella_pair) * Fub);
-    if (want_ext) ENSURE(c, c->tmp_ext, sizeof(bella_pair_ext) * Fub);
-    ENSURE(c, c->plist_hv, 8 * Fub);
-    ENSURE(c, c->overflow, 16 * ((Fub >> 4) + 64));   // a pair on this list has > 16 products
-    ENSURE(c, c->sortscr, 2 * Fub);
     ENSURE(c, c->ws, ws_stride * kGlobalGrid);
     ENSURE(c, c->retry, 4 * ((size_t)nr + 1));
-    // nnz(C) <= products; a column cannot have more pairs than reads after it
-    const uint64_t Pub = Fub;
-    ENSURE(c, c->pairs, sizeof(bella_pair) * Pub);
-    if (want_ext) ENSURE(c, c->ext, sizeof(bella_pair_ext) * Pub);
     size_t tb1 = 0;
     {
         hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> it(ptr<uint32_t>(c->flopsr), CastU64());
@@ -1089,7 +1078,19 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     // the one host round trip before the row kernels: the tiers' lengths (exact grids; 32 bytes into pinned memory)
     uint32_t* const tcnt = c->pinned;
     HIPCHK(c, hipMemcpyAsync(tcnt, d_ctl + kCtlTierCnt, 4 * (kNumTiers + 1), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pinned + 12, ptr<uint64_t>(c->flopptr) + nr, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // the product-sized buffers follow THIS pass's product count (a column partition or a stage only pays for its share; the
+    // reference sizes its stages from the same number, overlap.hpp:365-404,682-710); they only ever grow
+    uint64_t Fub = 0;
+    std::memcpy(&Fub, c->pinned + 12, 8);
+    ENSURE(c, c->tmp_pairs, sizeof(bella_pair) * Fub);
+    if (want_ext) ENSURE(c, c->tmp_ext, sizeof(bella_pair_ext) * Fub);
+    ENSURE(c, c->plist_hv, 8 * Fub);
+    ENSURE(c, c->overflow, 16 * ((Fub >> 4) + 64));   // a pair on this list has > 16 products
+    ENSURE(c, c->sortscr, 2 * Fub);
+    ENSURE(c, c->pairs, sizeof(bella_pair) * Fub);     // nnz(C) <= products
+    if (want_ext) ENSURE(c, c->ext, sizeof(bella_pair_ext) * Fub);
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
 
     SpgemmArgs a;
@@ -1208,7 +1209,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     c->n_retry = ctl_host[kCtlRetry];
     c->npairs = P;
     c->flops = F;
-    if (F > Fub) return fail(c, BELLA_ERR_STATE, "internal: product total %llu above the assembly-time bound %llu",
+    if (F > Fub) return fail(c, BELLA_ERR_STATE, "internal: product total %llu differs from the symbolic pass (%llu)",
                              (unsigned long long)F, (unsigned long long)Fub);
     c->tm.symbolic_ms = ev_ms(c->ev[2], c->ev[3]);
     c->tm.spgemm_ms = ev_ms(c->ev[4], c->ev[5]);
