@@ -1136,15 +1136,14 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         a.cap = kTierCaps[t];
         // sampled pairs/products below 1/5: quarter-size key tables; the big tiers (one workgroup per CU) always
         a.dcap = (c->pair_ratio1024 * 5 < 1024 || a.cap > 4096) ? a.cap / 4 : a.cap / 2;
+        if (getenv("BELLA_HIP_DCAP_HALF") && a.cap <= 4096) a.dcap = a.cap / 2;     // tests: the half-size layout on any input
         if (t + 1 < (int)g_ntiers) {
             const size_t lds = row_mem_bytes(a.cap, a.dcap, true);
-            if (a.cap <= 8 * kRowBlock) {
-                HIPCHK(c, hipFuncSetAttribute((const void*)k_spgemm_rows_lds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                k_spgemm_rows_lds<8><<<tcnt[t], kRowBlock, lds, sst>>>(a);
-            } else {
-                HIPCHK(c, hipFuncSetAttribute((const void*)k_spgemm_rows_lds<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                k_spgemm_rows_lds<16><<<tcnt[t], kRowBlock, lds, sst>>>(a);
-            }
+            const bool ga = gaux_in_t2(a.cap, a.dcap, true);
+            void (*kern)(SpgemmArgs) = a.cap <= 8 * kRowBlock ? (ga ? k_spgemm_rows_lds<8, true> : k_spgemm_rows_lds<8, false>)
+                                                              : (ga ? k_spgemm_rows_lds<16, true> : k_spgemm_rows_lds<16, false>);
+            HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            kern<<<tcnt[t], kRowBlock, lds, sst>>>(a);
         } else {
             const unsigned grid = tcnt[t] < kGlobalGrid ? tcnt[t] : kGlobalGrid;
             k_spgemm_rows_global<<<grid, kRowBlock, 0, sst>>>(a);

@@ -88,8 +88,11 @@ constexpr uint32_t kRowScratchBytes = 256;                   // block scan scrat
 // that (never seen on PacBio-like sets: pairs/products is 0.03 at 10k reads, 0.28 at 100k) is rerun on the global path.
 // overlay: the product-order arrays (A_hv, A_gov) are reused for the rank-order lists (LDS tiers: the values travel through
 // registers between two barriers); without it (global path, any size) the lists get their own 8*cap bytes.
+// With the half-size key tables (dcap >= cap/2) the slot-order table T2 is twice as large as the u16[cap] arrays that reuse it
+// after phase O, and Gaux (first touched in phase P) lives in its upper half: 19 instead of 21 bytes of LDS per product.
+__host__ __device__ inline bool gaux_in_t2(uint32_t cap, uint32_t dcap, bool overlay) { return overlay && 2 * dcap >= (cap + 1) / 2 + dcap; }
 __host__ __device__ inline size_t row_mem_bytes(uint32_t cap, uint32_t dcap, bool overlay) {
-    return kRowScratchBytes + (size_t)8 * cap + (size_t)24 * dcap + 2 * (size_t)((dcap + 1) & ~1u) +
+    return kRowScratchBytes + (size_t)8 * cap + (size_t)(gaux_in_t2(cap, dcap, overlay) ? 20 : 24) * dcap + 2 * (size_t)((dcap + 1) & ~1u) +
            (overlay ? 0 : (size_t)8 * cap + 2 * (size_t)((cap + 3) & ~3u));
 }
 
@@ -110,6 +113,7 @@ struct RowMem {
     uint32_t cap, dcap;
 };
 
+template <bool GALIAS>
 __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dcap, bool overlay) {
     RowMem m;
     m.scr = (uint32_t*)base;
@@ -120,7 +124,8 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dc
     m.T1first = w;         w += dcap;
     m.T1cnt = w;           w += dcap;
     m.T2 = w;              w += 2 * dcap;
-    m.Gaux = w;            w += dcap;
+    if (GALIAS) m.Gaux = m.T2 + (cap + 1) / 2;             // zeroed in phase S, not at the start
+    else { m.Gaux = w; w += dcap; }
     m.G = (uint16_t*)w;    w += (dcap + 1) / 2;
     if (overlay) { m.L_hv = m.A_hv; m.L_gov = m.A_gov; m.A_fl = nullptr; m.L_fl = nullptr; }
     else { m.L_hv = w; w += cap; m.L_gov = w; w += cap; m.A_fl = (uint8_t*)w; w += (cap + 3) / 4; m.L_fl = (uint8_t*)w; }
@@ -130,7 +135,7 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dc
 }
 
 // returns false if the key table overflowed (no global side effect happened yet; the caller queues the column again)
-template <bool OVERLAY, uint32_t NX>
+template <bool OVERLAY, uint32_t NX, bool GALIAS>
 __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t i, const uint32_t b0, const uint32_t n, const uint32_t lenV,
                                             const RowMem& m) {
     const uint32_t tid = threadIdx.x;
@@ -140,7 +145,10 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     const uint32_t k = (uint32_t)a.k;
     constexpr uint32_t GMASK = OVERLAY ? 0x3FFFu : 0xFFFFu;   // LDS tiers: the flags ride on top of the T1 slot
 
-    for (uint32_t s = tid; s < H1; s += kRowBlock) { m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0; m.Gaux[s] = 0; }
+    for (uint32_t s = tid; s < H1; s += kRowBlock) {
+        m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0;
+        if (!GALIAS) m.Gaux[s] = 0;
+    }
     if (tid == 0) { *s_d = 0; *s_fail = 0; }
     __syncthreads();
     long long tc = 0;
@@ -268,6 +276,9 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // atomics of one wavefront execute in program order), so a list is ordered ACROSS 64-product chunks and only
     // chunk-mates can be swapped; phase R repairs that.  (T2 is dead: its memory becomes S_p.) -----------------------
     uint16_t* S_p = (uint16_t*)m.T2;
+    if (GALIAS && wave_id() != 0) {                           // the other wavefronts: Gaux, which shares T2's memory (T2 is dead)
+        for (uint32_t s = tid - 64; s < H1; s += kRowBlock - 64) m.Gaux[s] = 0;
+    }
     if (wave_id() == 0) {
         for (uint32_t base = 0; base < F; base += 4 * kScatterChunk) {
             uint32_t g[4], old[4];
@@ -511,13 +522,13 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 
 // LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap, dcap); NX * 512 >= cap (8: the tiers up to 4096 products,
 // 16: the two big tiers that keep HiFi-like columns with long lists off the global path)
-template <uint32_t NX>
+template <uint32_t NX, bool GALIAS>
 __global__ __launch_bounds__(kRowBlock, (NX <= 8 ? 6 : 2)) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint4 ds = a.rowdesc[blockIdx.x];
     const uint32_t i = ds.x;
-    const RowMem m = carve(smem, a.cap, a.dcap, true);
-    if (!process_row<true, NX>(a, i, ds.y, ds.z & 0xFFFFu, ds.z >> 16, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
+    const RowMem m = carve<GALIAS>(smem, a.cap, a.dcap, true);
+    if (!process_row<true, NX, GALIAS>(a, i, ds.y, ds.z & 0xFFFFu, ds.z >> 16, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
 }
 
 // Global-workspace path: columns with more products than the largest LDS tier (< 65536), and -- second launch, list and
@@ -529,9 +540,9 @@ __global__ __launch_bounds__(kRowBlock) void k_spgemm_rows_global(SpgemmArgs a) 
         const uint32_t i = a.rowdesc ? a.rowdesc[x].x : a.rowlist[x];
         uint32_t f = (uint32_t)(a.flopptr[i + 1] - a.flopptr[i]);
         if (f < 16u) f = 16u;                             // T2 needs >= 16 slots
-        const RowMem m = carve(ws, f, f, false);
+        const RowMem m = carve<false>(ws, f, f, false);
         const uint32_t b0 = a.Bptr[i];
-        (void)process_row<false, 8>(a, i, b0, a.Bptr[i + 1] - b0, (uint32_t)(a.roff[i + 1] - a.roff[i]), m);
+        (void)process_row<false, 8, false>(a, i, b0, a.Bptr[i + 1] - b0, (uint32_t)(a.roff[i + 1] - a.roff[i]), m);
         __syncthreads();
     }
 }

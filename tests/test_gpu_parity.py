@@ -647,3 +647,17 @@ def test_counted_panels_equal_one_shot_assembly(eng):
     p2 = eng.get_pairs()
     for a, b in zip(p1, p2):
         assert np.array_equal(a, b)
+
+
+def test_half_size_key_tables_layout_bit_exact(eng, monkeypatch):
+    """the LDS layout of pair-rich inputs (key tables of cap/2 slots, Gaux inside T2's upper half) on the multi-bin golden set"""
+    monkeypatch.setenv("BELLA_HIP_DCAP_HALF", "1")
+    for name in ("toyrep90", "toy120"):
+        g = load_golden(name)
+        eng.set_reads(g.rs)
+        eng.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
+        n, flops = eng.overlap(BellaPars(skipAlignment=True))
+        pairs, ext, colptrC = eng.get_pairs()
+        _, flop, ecol, exp = oracle_pairs(g.rs, g.seqs, g.nkmers, g.tk, g.tr, g.tp, g.k)
+        assert n == len(exp)
+        check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
