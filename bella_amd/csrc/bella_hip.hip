@@ -36,6 +36,9 @@ struct Buf {
 constexpr uint32_t kNumTiers = 8;  // at most
 uint32_t g_ntiers = 8;
 uint32_t kTierCaps[kNumTiers] = {768, 1280, 2048, 3072, 4096, 6144, 8192, 65535};
+// pair-rich inputs (key tables of cap/2, 19 B of LDS per product): 2688 keeps four workgroups on a CU, 3328 three
+const uint32_t kTierCapsHalf[kNumTiers] = {768, 1280, 2048, 2688, 3328, 4096, 8192, 65535};
+bool g_tiers_from_env = false;
 constexpr uint32_t kGlobalGrid = 256;
 constexpr uint32_t kAsmGrid = 1024;
 
@@ -321,7 +324,7 @@ int bella_hip_init(int device, bella_ctx** out) {
             while (*q && *q != ',') ++q;
             if (*q == ',') ++q;
         }
-        if (n) { kTierCaps[n] = 65535; g_ntiers = n + 1; }
+        if (n) { kTierCaps[n] = 65535; g_ntiers = n + 1; g_tiers_from_env = true; }
     }
     bella_ctx* c = new bella_ctx();
     c->device = device;
@@ -1057,11 +1060,14 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
 
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     uint32_t caps[kNumTiers] = {};
-    for (uint32_t t = 0; t < g_ntiers; ++t) caps[t] = force_global && t + 1 < g_ntiers ? 0 : kTierCaps[t];
-    if (c->caps_state != (force_global ? 2 : 1)) {              // the tier caps only change with the debug switch
+    const bool half_tables = !(c->pair_ratio1024 * 5 < 1024);
+    const uint32_t* tier_caps = (half_tables && !g_tiers_from_env) ? kTierCapsHalf : kTierCaps;
+    for (uint32_t t = 0; t < g_ntiers; ++t) caps[t] = force_global && t + 1 < g_ntiers ? 0 : tier_caps[t];
+    const int want_state = (force_global ? 2 : 1) + (half_tables ? 2 : 0);
+    if (c->caps_state != want_state) {                         // the tier caps only change with the operands or the debug switch
         HIPCHK(c, hipMemcpyAsync(c->tiercaps.p, caps, sizeof(caps), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));            // caps[] is a stack array
-        c->caps_state = force_global ? 2 : 1;
+        c->caps_state = want_state;
     }
     // one control block per pass (counters, tier lengths, status, totals): one fill, one read back
     uint32_t* d_ctl = ptr<uint32_t>(c->ctl);
@@ -1133,9 +1139,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         a.rowdesc = ptr<uint4>(c->rowlists) + (size_t)t * nr;
         a.nrows = tcnt[t];
         a.nrows_dev = nullptr;
-        a.cap = kTierCaps[t];
+        a.cap = tier_caps[t];
         // sampled pairs/products below 1/5: quarter-size key tables; the big tiers (one workgroup per CU) always
-        a.dcap = (c->pair_ratio1024 * 5 < 1024 || a.cap > 4096) ? a.cap / 4 : a.cap / 2;
+        a.dcap = (!half_tables || a.cap > 4096) ? a.cap / 4 : a.cap / 2;
         if (getenv("BELLA_HIP_DCAP_HALF") && a.cap <= 4096) a.dcap = a.cap / 2;     // tests: the half-size layout on any input
         if (t + 1 < (int)g_ntiers) {
             const size_t lds = row_mem_bytes(a.cap, a.dcap, true);

@@ -1,0 +1,3 @@
+for T in "768,1280,2048,3072,4096,6144,8192" "768,1280,2048,2688,3328,4096,8192" "768,1280,1664,2048,2688,4096,8192" "1024,1664,2048,2688,3328,4096,8192"; do
+BELLA_HIP_TIERS=$T python bench.py --reads 100000 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$T', round(d['ms_per_step'],3), round(d['phases_ms_per_step']['row_kernels'],3))"
+done
