@@ -1130,11 +1130,17 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     uint32_t launches = 0;
     // the tiers are independent persistent launches of the same kernel with different LDS budgets, forked onto side streams
     // (largest columns first) so that they run concurrently; their column counts stay on the device
+    // The tier launched last (the smallest columns: it also finishes last) goes on the main stream itself, so the kernels that
+    // follow need no cross-stream hand-over at the end; the waits for the side streams are enqueued after it.
     HIPCHK(c, hipEventRecord(c->fork, c->stream));
+    int last_tier = -1;
+    for (int t = 0; t < (int)g_ntiers; ++t) if (tcnt[t]) { last_tier = t; break; }
+    bool joined[kNumTiers] = {};
     for (int t = (int)g_ntiers - 1; t >= 0; --t) {
         if (!tcnt[t]) continue;
-        hipStream_t sst = c->side[t];
-        HIPCHK(c, hipStreamWaitEvent(sst, c->fork, 0));
+        const bool on_main = t == last_tier;
+        hipStream_t sst = on_main ? c->stream : c->side[t];
+        if (!on_main) HIPCHK(c, hipStreamWaitEvent(sst, c->fork, 0));
         a.rowlist = nullptr;
         a.rowdesc = ptr<uint4>(c->rowlists) + (size_t)t * nr;
         a.nrows = tcnt[t];
@@ -1155,10 +1161,11 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
             k_spgemm_rows_global<<<grid, kRowBlock, 0, sst>>>(a);
         }
         KCHK(c);
-        HIPCHK(c, hipEventRecord(c->join[t], sst));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[t], 0));
+        if (!on_main) { HIPCHK(c, hipEventRecord(c->join[t], sst)); joined[t] = true; }
         launches++;
     }
+    for (int t = 0; t < (int)g_ntiers; ++t)
+        if (joined[t]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[t], 0));
     // columns whose pair count overflowed an LDS tier's key table (list and count produced on the device)
     a.rowlist = ptr<uint32_t>(c->retry);
     a.rowdesc = nullptr;
