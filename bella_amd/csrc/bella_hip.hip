@@ -1075,21 +1075,23 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     k_row_flops<<<nblk(nr + 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint16_t>(c->Bcnt), nr, c->part_first,
                                                                 c->part_stride, ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC));
     KCHK(c);
-    int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->flopsr), ptr<uint64_t>(c->flopptr), (uint64_t)nr + 1);
-    if (rc) return rc;
     k_tier_lists<<<nblk(nr), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, ptr<uint32_t>(c->tiercaps), g_ntiers,
                                                   ptr<uint32_t>(c->Bptr), ptr<uint64_t>(c->roff), ptr<uint4>(c->rowlists),
-                                                  (uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr), d_ctl + kCtlTierCnt);
+                                                  (uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr), d_ctl + kCtlTierCnt,
+                                                  (unsigned long long*)(d_ctl + kCtlTotals) + 1);
     KCHK(c);
-    // the one host round trip before the row kernels: the tiers' lengths (exact grids; 32 bytes into pinned memory)
+    // the one host round trip before the row kernels: the tiers' lengths (exact grids) and the product total, 64 bytes into
+    // pinned memory; the prefix sums the row kernels need (overlap.hpp:110-146) run on the device meanwhile
     uint32_t* const tcnt = c->pinned;
-    HIPCHK(c, hipMemcpyAsync(tcnt, d_ctl + kCtlTierCnt, 4 * (kNumTiers + 1), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->pinned + 12, ptr<uint64_t>(c->flopptr) + nr, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(tcnt, d_ctl + kCtlTierCnt, 4 * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+    int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->flopsr), ptr<uint64_t>(c->flopptr), (uint64_t)nr + 1);
+    if (rc) return rc;
+    HIPCHK(c, hipEventSynchronize(c->ev[9]));
     // the product-sized buffers follow THIS pass's product count (a column partition or a stage only pays for its share; the
     // reference sizes its stages from the same number, overlap.hpp:365-404,682-710); they only ever grow
     uint64_t Fub = 0;
-    std::memcpy(&Fub, c->pinned + 12, 8);
+    std::memcpy(&Fub, c->pinned + (kCtlTotals - kCtlTierCnt) + 2, 8);
     ENSURE(c, c->tmp_pairs, sizeof(bella_pair) * Fub);
     if (want_ext) ENSURE(c, c->tmp_ext, sizeof(bella_pair_ext) * Fub);
     ENSURE(c, c->plist_hv, 8 * Fub);

@@ -670,7 +670,7 @@ __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, cons
 // One atomic per wavefront and tier; the order inside a list only affects scheduling.
 __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, uint32_t nreads, const uint32_t* caps, uint32_t ntiers,
                                                        const uint32_t* Bptr, const uint64_t* roff, uint4* desc, uint32_t* widelist,
-                                                       uint32_t* counts) {
+                                                       uint32_t* counts, unsigned long long* total) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t f = i < nreads ? flops[i] : 0u;
     uint32_t tier = 0xFFFFFFFFu;
@@ -682,6 +682,12 @@ __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, ui
         const uint32_t b0 = Bptr[i];
         ds.y = b0;
         ds.z = (Bptr[i + 1] - b0) | ((uint32_t)(roff[i + 1] - roff[i]) << 16);   // both < 65536 (checked at set_reads / assembly)
+    }
+    {                                                      // the pass's product total (sizes the product buffers on the host)
+        unsigned long long fs = f;
+#pragma unroll
+        for (int dlt = 32; dlt > 0; dlt >>= 1) fs += __shfl_xor(fs, dlt, 64);
+        if (lane_id() == 0 && fs) atomicAdd(total, fs);
     }
     for (uint32_t t = 0; t <= ntiers; ++t) {
         const unsigned long long mask = __ballot(tier == t);
