@@ -78,7 +78,7 @@ struct bella_ctx {
     Buf t_kmer, t_read, t_pos, tstart, Bk_tmp, Bpos_tmp, rowcnt, asm_ws;
     Buf Brow, deg, minread, colstart, fill, ori, w, wscan, Atmp;
     // overlap
-    uint64_t flops = 0, npairs = 0, F_full = 0;
+    uint64_t flops = 0, npairs = 0;
     uint32_t pair_ratio1024 = 1024;   // max over sampled columns of 1024 * pairs/products
     Buf flopsr, flopptr, nnzC, colptrC, rowlists, tiercaps, tmp_pairs, tmp_ext, pairs, ext, sortscr, ws,
         status, cubtmp, plist_hv, overflow, ctl, retry;
@@ -229,13 +229,6 @@ int build_layout(bella_ctx* c) {
                                                          ptr<uint2>(c->Aent), ptr<uint2>(c->Bent), ptr<uint16_t>(c->Bcnt), ptr<uint32_t>(c->status));
         KCHK(c);
     }
-    HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 2, 0, 8, c->stream));
-    if (nk) {
-        k_total_products<<<nblk(nk), 256, 0, c->stream>>>(ptr<uint32_t>(c->deg), nk, (unsigned long long*)(ptr<uint32_t>(c->status) + 2));
-        KCHK(c);
-    }
-    unsigned long long ffull = 0;
-    HIPCHK(c, hipMemcpyAsync(&ffull, ptr<uint32_t>(c->status) + 2, 8, hipMemcpyDeviceToHost, c->stream));
     // pairs/products on a sample of columns -> key-table budget of the LDS tiers (see k_sample_pair_ratio)
     uint32_t ratio1024 = 1024;
     const size_t bitmap_bytes = 4 * (((size_t)c->nreads + 31) / 32);
@@ -254,7 +247,6 @@ int build_layout(bella_ctx* c) {
     if (rc) return rc;
     rc = status_to_error(c, st);
     if (rc) return rc;
-    c->F_full = ffull;
     c->pair_ratio1024 = ratio1024;
     // assembly temporaries are large (tens of bytes per nonzero): give them back
     release(c->Brow); release(c->deg); release(c->minread); release(c->colstart); release(c->fill); release(c->ori);

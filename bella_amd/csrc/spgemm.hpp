@@ -635,17 +635,6 @@ __global__ __launch_bounds__(kBlock) void k_sample_pair_ratio(const uint32_t* Bp
     if (threadIdx.x == 0 && s_f >= 64) atomicMax(out, (uint32_t)(((uint64_t)s_d << 10) / s_f));
 }
 
-// sum over k-mers of deg*(deg-1)/2 = the products of the whole lower triangle: sizes every F-dependent buffer at assembly
-// time, so that a pass needs no host round trip for them (a partition only lowers it)
-__global__ void k_total_products(const uint32_t* deg, uint32_t nkmers, unsigned long long* out) {
-    const uint32_t km = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long v = 0;
-    if (km < nkmers) { const unsigned long long dg = deg[km]; v = dg * (dg - 1) / 2; }
-#pragma unroll
-    for (int dlt = 32; dlt > 0; dlt >>= 1) v += __shfl_xor(v, dlt, 64);
-    if (lane_id() == 0 && v) atomicAdd(out, v);
-}
-
 // estimateFLOP (overlap.hpp:157-202, lowtri): products of column i = sum of the suffix counts of its entries.
 // One wavefront per column.  Columns outside this context's partition get 0.
 __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, const uint16_t* Bcnt, uint32_t nreads,
