@@ -247,6 +247,10 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
+    // Single-product pairs (multiop only: count 1, one bin, seed = the k-mer; 47 % of the pairs at 10k reads, 92 % at 100k) are
+    // finished right here, at their rank, from the product-order arrays; only the other pairs get a list.
+    const uint64_t obase = a.flopptr[i];
+    uint32_t Fm;                                              // products of the multi-product pairs = total list length
     {
         const uint32_t c = (ht + kRowBlock - 1) / kRowBlock;
         const uint32_t lo = tid * c;
@@ -254,18 +258,35 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         uint32_t occ = 0, csum = 0;
         for (uint32_t s = lo; s < hi; ++s) {
             const uint32_t it = T2[s];
-            if (it != kEmpty) { occ++; csum += m.T1cnt[it & 0xFFFFu] & 0xFFFFu; }
+            if (it != kEmpty) { occ++; const uint32_t mm = m.T1cnt[it & 0xFFFFu] & 0xFFFFu; csum += mm > 1 ? mm : 0u; }
         }
         uint32_t tot;
         const uint32_t ex = block_excl_scan<kRowWaves>((occ << 16) | csum, m.scr, &tot);
+        Fm = tot & 0xFFFFu;
         uint32_t rank = ex >> 16, st = ex & 0xFFFFu;
         for (uint32_t s = lo; s < hi; ++s) {
             const uint32_t it = T2[s];
             if (it == kEmpty) continue;
             const uint32_t g = it & 0xFFFFu;
+            const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
             m.G[rank] = (uint16_t)g;
             m.T1first[g] = st | (rank << 16);
-            st += m.T1cnt[g] & 0xFFFFu;
+            if (mm == 1) {
+                const uint32_t p = it >> 16;                  // the pair's only product
+                const uint32_t hv = m.A_hv[p], gov = m.A_gov[p];
+                const uint32_t fl = OVERLAY ? gov >> 30 : (uint32_t)m.A_fl[p];
+                bella_pair pr;
+                pr.rid = m.T1key[g]; pr.cid = i; pr.count = 1; pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
+                pr.flags = (uint16_t)((fl & 1u) | ((((fl & 1u) ^ 1u) | (fl >> 1)) << 1));   // bit1: revcomp(seedH)==seedV
+                a.tmp_pairs[obase + rank] = pr;
+                if (a.tmp_ext) {
+                    bella_pair_ext ex2;
+                    ex2.nbins = 1; ex2.support = 1; ex2.binov = (uint16_t)(gov & 0xFFFFu); ex2.pad = 0;
+                    a.tmp_ext[obase + rank] = ex2;
+                }
+            } else {
+                st += mm;
+            }
             rank++;
         }
     }
@@ -291,15 +312,15 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             for (uint32_t u = 0; u < 4; ++u) old[u] = g[u] != 0xFFFFFFFFu ? atomicAdd(&m.T1cnt[g[u]], 0x10000u) : 0u;
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u)
-                if (g[u] != 0xFFFFFFFFu) S_p[(m.T1first[g[u]] & 0xFFFFu) + (old[u] >> 16)] = (uint16_t)(base + u * kScatterChunk + tid);
+                if (g[u] != 0xFFFFFFFFu && (old[u] & 0xFFFFu) != 1u)      // single-product pairs have no list
+                    S_p[(m.T1first[g[u]] & 0xFFFFu) + (old[u] >> 16)] = (uint16_t)(base + u * kScatterChunk + tid);
         }
     }
     __syncthreads();
     BELLA_PHASE(2)
 
     // ---- R: exact rank of every product inside its pair's list (list position corrected by the chunk-mates on the wrong
-    // side) and the lists in rank order: L_hv / L_gov.  Single-product pairs are finished here. ---------------------
-    const uint64_t obase = a.flopptr[i];
+    // side) and the lists in rank order: L_hv / L_gov. -------------------------------------------------------------
     // NX = list positions per thread in the LDS tiers (cap <= NX * kRowBlock)
     uint32_t dstv[NX], hvv[NX], govv[NX];
     auto rank_one = [&](uint32_t x, uint32_t& dst, uint32_t& hvq, uint32_t& govq, uint32_t& flq) {
@@ -311,18 +332,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
         const uint32_t hv = m.A_hv[p];
         const uint32_t fl = OVERLAY ? gov >> 30 : (uint32_t)m.A_fl[p];
-        uint32_t rk = 0;
-        if (mm == 1) {                                        // multiop only: count 1, one bin, seed = this k-mer
-            bella_pair pr;
-            pr.rid = m.T1key[g]; pr.cid = i; pr.count = 1; pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
-            pr.flags = (uint16_t)((fl & 1u) | ((((fl & 1u) ^ 1u) | (fl >> 1)) << 1));   // bit1: revcomp(seedH)==seedV
-            a.tmp_pairs[obase + (fr >> 16)] = pr;
-            if (a.tmp_ext) {
-                bella_pair_ext ex;
-                ex.nbins = 1; ex.support = 1; ex.binov = (uint16_t)(gov & 0xFFFFu); ex.pad = 0;
-                a.tmp_ext[obase + (fr >> 16)] = ex;
-            }
-        } else {
+        uint32_t rk;
+        {
             const uint32_t ch = p / kScatterChunk;
             rk = x - st;
             for (uint32_t y = x; y > st; --y) {               // chunk-mates on the left that belong after p
@@ -344,14 +355,14 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             const uint32_t x = tid + u * kRowBlock;
             uint32_t flq;
             dstv[u] = 0xFFFFFFFFu; hvv[u] = 0; govv[u] = 0;
-            if (x < F) rank_one(x, dstv[u], hvv[u], govv[u], flq);
+            if (x < Fm) rank_one(x, dstv[u], hvv[u], govv[u], flq);
         }
         __syncthreads();                                      // every A_hv / A_gov read is done: reuse them as L_hv / L_gov
 #pragma unroll
         for (uint32_t u = 0; u < NX; ++u)
             if (dstv[u] != 0xFFFFFFFFu) { m.L_hv[dstv[u]] = hvv[u]; m.L_gov[dstv[u]] = govv[u]; }
     } else {
-        for (uint32_t x = tid; x < F; x += kRowBlock) {
+        for (uint32_t x = tid; x < Fm; x += kRowBlock) {
             uint32_t dst, hvq, govq, flq;
             rank_one(x, dst, hvq, govq, flq);
             m.L_hv[dst] = hvq; m.L_gov[dst] = govq; m.L_fl[dst] = (uint8_t)flq;
@@ -378,7 +389,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     typedef typename std::conditional<OVERLAY, uint16_t, uint32_t>::type par_t;
     constexpr uint32_t kRoot = OVERLAY ? 0x8000u : 0x80000000u;
     par_t* Par = (par_t*)m.T2;                                // S_p is dead
-    for (uint32_t y = tid; y < F; y += kRowBlock) {
+    for (uint32_t y = tid; y < Fm; y += kRowBlock) {
         const uint32_t gov = m.L_gov[y];
         const uint32_t g = (gov >> 16) & GMASK;
         const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
@@ -400,7 +411,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     const us2 kk2 = {(unsigned short)a.k, (unsigned short)a.k};
     const us2 lim2 = {(unsigned short)(2 * a.k + 1), (unsigned short)(2 * a.k + 1)};
     const uint32_t lim = __builtin_bit_cast(uint32_t, lim2);
-    for (uint32_t y = tid; y < F; y += kRowBlock) {
+    for (uint32_t y = tid; y < Fm; y += kRowBlock) {
         const uint32_t g = (m.L_gov[y] >> 16) & GMASK;
         const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
         if (mm == 1) continue;
