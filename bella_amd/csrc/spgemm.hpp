@@ -40,6 +40,9 @@
 namespace bella {
 
 constexpr uint32_t kScatterChunk = 64;                    // phase S appends one wavefront of products at a time
+#ifndef BELLA_WALK_W
+#define BELLA_WALK_W 8
+#endif
 #ifndef BELLA_ROW_BLOCK
 #define BELLA_ROW_BLOCK 512
 #endif
@@ -425,22 +428,23 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             const us2 xk = __builtin_bit_cast(us2, x) + kk2;
             const uint32_t farq = x ^ 0x80008000u;            // a product 32768 away in both coordinates: never within k
             uint32_t t = s + 1;
-            uint32_t q[8];
+            constexpr uint32_t W = BELLA_WALK_W;              // products per test
+            uint32_t q[W];
             bool hit = false;
-            while (t + 8 <= mm) {
+            while (t + W <= mm) {
                 us2 acc = lim2;
 #pragma unroll
-                for (uint32_t u = 0; u < 8; ++u) {
+                for (uint32_t u = 0; u < W; ++u) {
                     q[u] = lst[t + u];
                     acc = __builtin_elementwise_min(acc, (us2)(xk - __builtin_bit_cast(us2, q[u])));
                 }
                 if (__builtin_bit_cast(uint32_t, acc) != lim) { hit = true; break; }
-                t += 8;
+                t += W;
             }
-            if (!hit && t < mm) {                             // the last, partial group of eight: one more round trip, masked
+            if (!hit && t < mm) {                             // the last, partial group: one more round trip, masked
                 us2 acc = lim2;
 #pragma unroll
-                for (uint32_t u = 0; u < 8; ++u) {
+                for (uint32_t u = 0; u < W; ++u) {
                     const uint32_t idx = t + u;
                     const uint32_t v = lst[idx < mm ? idx : mm - 1];
                     q[u] = idx < mm ? v : farq;
@@ -450,9 +454,9 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
                 else t = mm;
             }
             if (hit) {                                        // first product of the group that is within k
-                uint32_t f = 7;
+                uint32_t f = W - 1;
 #pragma unroll
-                for (int u = 6; u >= 0; --u) {
+                for (int u = (int)W - 2; u >= 0; --u) {
                     const us2 dd = __builtin_elementwise_min(lim2, (us2)(xk - __builtin_bit_cast(us2, q[u])));
                     f = __builtin_bit_cast(uint32_t, dd) != lim ? (uint32_t)u : f;
                 }
