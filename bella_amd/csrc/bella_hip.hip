@@ -39,7 +39,7 @@ uint32_t kTierCaps[kNumTiers] = {768, 1280, 2048, 3072, 4096, 6144, 8192, 65535}
 // pair-rich inputs (key tables of cap/2, 19 B of LDS per product): 2688 keeps four workgroups on a CU, 3328 three
 const uint32_t kTierCapsHalf[kNumTiers] = {768, 1280, 2048, 2688, 3328, 4096, 8192, 65535};
 bool g_tiers_from_env = false;
-constexpr uint32_t kGlobalGrid = 256;
+constexpr uint32_t kGlobalGrid = 1024;      // persistent workgroups of the global path: latency-bound, four per CU
 constexpr uint32_t kAsmGrid = 1024;
 
 struct CastU64 {
