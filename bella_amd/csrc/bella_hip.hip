@@ -1114,6 +1114,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     a.k = p->kmer_size;
     a.binSize = p->bin_size;
     a.phase = nullptr;
+    a.inject_unordered = (c->debug & 4u) ? 1 : 0;
     a.stop = getenv("BELLA_HIP_STOP_PHASE") ? atoi(getenv("BELLA_HIP_STOP_PHASE")) : -1;
     const bool phase_timers = getenv("BELLA_HIP_PHASE_TIMERS") != nullptr;
     if (phase_timers) {

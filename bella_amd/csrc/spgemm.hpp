@@ -82,6 +82,7 @@ struct SpgemmArgs {
     uint32_t dcap;               // LDS tiers: pairs (distinct keys) the tier holds: cap/4 or cap/2
     int k;
     int binSize;
+    int inject_unordered;        // tests: pretend every fifth column's lists came out of order in phase S (exercises the fallback)
     int stop;                    // development aid: leave process_row after this phase (results are garbage), -1 = off
     unsigned long long* phase;   // optional per-phase cycle counters (development aid, BELLA_HIP_PHASE_TIMERS=1)
 };
@@ -322,8 +323,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     __syncthreads();
     BELLA_PHASE(2)
 
-    // ---- R: exact rank of every product inside its pair's list (list position corrected by the chunk-mates on the wrong
-    // side) and the lists in rank order: L_hv / L_gov. -------------------------------------------------------------
+    // ---- R: exact rank of every product inside its pair's list (global path: list position corrected by the chunk-mates on
+    // the wrong side; LDS tiers: checked) and the lists in rank order: L_hv / L_gov. -------------------------------------------------------------
     // NX = list positions per thread in the LDS tiers (cap <= NX * kRowBlock)
     uint32_t dstv[NX], hvv[NX], govv[NX];
     auto rank_one = [&](uint32_t x, uint32_t& dst, uint32_t& hvq, uint32_t& govq, uint32_t& flq) {
@@ -332,11 +333,18 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         const uint32_t g = (gov >> 16) & GMASK;
         const uint32_t fr = m.T1first[g];
         const uint32_t st = fr & 0xFFFFu;
-        const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
         const uint32_t hv = m.A_hv[p];
         const uint32_t fl = OVERLAY ? gov >> 30 : (uint32_t)m.A_fl[p];
         uint32_t rk;
-        {
+        if (OVERLAY) {
+            // LDS tiers: verify instead of repair.  On gfx950 the same-address LDS atomics of one wavefront instruction are
+            // applied in lane order (0 of 1.2e7 products ever needed the repair below), but that is not an architectural promise:
+            // a list is in product order iff every entry exceeds its left neighbour; if one does not, the column is redone
+            // on the global path, which repairs.
+            rk = x - st;
+            if (x > st && S_p[x - 1] > p) *s_fail = 1;
+        } else {
+            const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
             const uint32_t ch = p / kScatterChunk;
             rk = x - st;
             for (uint32_t y = x; y > st; --y) {               // chunk-mates on the left that belong after p
@@ -360,7 +368,9 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             dstv[u] = 0xFFFFFFFFu; hvv[u] = 0; govv[u] = 0;
             if (x < Fm) rank_one(x, dstv[u], hvv[u], govv[u], flq);
         }
+        if (a.inject_unordered && i % 5u == 2u && tid == 0) *s_fail = 1;
         __syncthreads();                                      // every A_hv / A_gov read is done: reuse them as L_hv / L_gov
+        if (*s_fail) return false;                            // a list out of order (see above): nothing irreversible happened
 #pragma unroll
         for (uint32_t u = 0; u < NX; ++u)
             if (dstv[u] != 0xFFFFFFFFu) { m.L_hv[dstv[u]] = hvv[u]; m.L_gov[dstv[u]] = govv[u]; }

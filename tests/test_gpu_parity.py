@@ -661,3 +661,20 @@ def test_half_size_key_tables_layout_bit_exact(eng, monkeypatch):
         _, flop, ecol, exp = oracle_pairs(g.rs, g.seqs, g.nkmers, g.tk, g.tr, g.tp, g.k)
         assert n == len(exp)
         check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
+
+
+def test_out_of_order_lists_fall_back_to_the_repairing_path(eng):
+    """the LDS tiers only CHECK that the ordered scatter produced product order (it always does on gfx950) and hand a column
+    to the global path, which repairs, otherwise: inject the failure for every fifth column -> same results"""
+    g = load_golden("toyrep90")
+    eng.set_debug(4)
+    try:
+        eng.set_reads(g.rs)
+        eng.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
+        n, flops = eng.overlap(BellaPars(skipAlignment=True))
+        pairs, ext, colptrC = eng.get_pairs()
+        _, flop, ecol, exp = oracle_pairs(g.rs, g.seqs, g.nkmers, g.tk, g.tr, g.tp, g.k)
+        assert n == len(exp)
+        check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
+    finally:
+        eng.set_debug(0)
