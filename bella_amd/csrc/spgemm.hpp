@@ -39,6 +39,7 @@
 
 namespace bella {
 
+constexpr uint32_t kSU = 4;                               // chunks in flight per round of phase S
 constexpr uint32_t kScatterChunk = 64;                    // phase S appends one wavefront of products at a time
 #ifndef BELLA_WALK_W
 #define BELLA_WALK_W 8
@@ -305,17 +306,17 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         for (uint32_t s = tid - 64; s < H1; s += kRowBlock - 64) m.Gaux[s] = 0;
     }
     if (wave_id() == 0) {
-        for (uint32_t base = 0; base < F; base += 4 * kScatterChunk) {
-            uint32_t g[4], old[4];
+        for (uint32_t base = 0; base < F; base += kSU * kScatterChunk) {
+            uint32_t g[kSU], old[kSU];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            for (uint32_t u = 0; u < kSU; ++u) {
                 const uint32_t p = base + u * kScatterChunk + tid;
                 g[u] = p < F ? ((m.A_gov[p] >> 16) & GMASK) : 0xFFFFFFFFu;
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) old[u] = g[u] != 0xFFFFFFFFu ? atomicAdd(&m.T1cnt[g[u]], 0x10000u) : 0u;
+            for (uint32_t u = 0; u < kSU; ++u) old[u] = g[u] != 0xFFFFFFFFu ? atomicAdd(&m.T1cnt[g[u]], 0x10000u) : 0u;
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u)
+            for (uint32_t u = 0; u < kSU; ++u)
                 if (g[u] != 0xFFFFFFFFu && (old[u] & 0xFFFFu) != 1u)      // single-product pairs have no list
                     S_p[(m.T1first[g[u]] & 0xFFFFu) + (old[u] >> 16)] = (uint16_t)(base + u * kScatterChunk + tid);
         }
