@@ -148,7 +148,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     uint32_t* s_d = m.scr + 48;
     uint32_t* s_fail = m.scr + 49;
     const uint32_t k = (uint32_t)a.k;
-    constexpr uint32_t GMASK = OVERLAY ? 0x3FFFu : 0xFFFFu;   // LDS tiers: the flags ride on top of the T1 slot
+    constexpr uint32_t GMASK = OVERLAY ? 0x1FFFu : 0xFFFFu;   // LDS tiers (<= 2048 slots): flags and the LAST mark ride on top of the T1 slot
+    constexpr uint32_t kLastBit = 1u << 29;                   // L_gov (LDS tiers) / bit 2 of L_fl (global path): last product of its pair's list
 
     for (uint32_t s = tid; s < H1; s += kRowBlock) {
         m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0;
@@ -275,7 +276,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             const uint32_t g = it & 0xFFFFu;
             const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
             m.G[rank] = (uint16_t)g;
-            m.T1first[g] = st | (rank << 16);
+            m.T1first[g] = (st + (mm > 1 ? mm : 0u)) | (rank << 16);   // END of the pair's list: every later phase works from it
             if (mm == 1) {
                 const uint32_t p = it >> 16;                  // the pair's only product
                 const uint32_t hv = m.A_hv[p], gov = m.A_gov[p];
@@ -318,7 +319,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 #pragma unroll
             for (uint32_t u = 0; u < kSU; ++u)
                 if (g[u] != 0xFFFFFFFFu && (old[u] & 0xFFFFu) != 1u)      // single-product pairs have no list
-                    S_p[(m.T1first[g[u]] & 0xFFFFu) + (old[u] >> 16)] = (uint16_t)(base + u * kScatterChunk + tid);
+                    S_p[(m.T1first[g[u]] & 0xFFFFu) - (old[u] & 0xFFFFu) + (old[u] >> 16)] = (uint16_t)(base + u * kScatterChunk + tid);
         }
     }
     __syncthreads();
@@ -332,34 +333,34 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         const uint32_t p = S_p[x];
         const uint32_t gov = m.A_gov[p];
         const uint32_t g = (gov >> 16) & GMASK;
-        const uint32_t fr = m.T1first[g];
-        const uint32_t st = fr & 0xFFFFu;
+        const uint32_t end = m.T1first[g] & 0xFFFFu;
         const uint32_t hv = m.A_hv[p];
-        const uint32_t fl = OVERLAY ? gov >> 30 : (uint32_t)m.A_fl[p];
-        uint32_t rk;
+        uint32_t fl = OVERLAY ? gov >> 30 : (uint32_t)m.A_fl[p];
         if (OVERLAY) {
             // LDS tiers: verify instead of repair.  On gfx950 the same-address LDS atomics of one wavefront instruction are
             // applied in lane order (0 of 1.2e7 products ever needed the repair below), but that is not an architectural promise:
-            // a list is in product order iff every entry exceeds its left neighbour; if one does not, the column is redone
+            // a list is in product order iff every entry is below its right neighbour; if one is not, the column is redone
             // on the global path, which repairs.
-            rk = x - st;
-            if (x > st && S_p[x - 1] > p) *s_fail = 1;
+            const bool last = x + 1 == end;
+            if (!last && S_p[x + 1] < p) *s_fail = 1;
+            dst = x; hvq = hv; govq = last ? (gov | kLastBit) : gov; flq = fl;
         } else {
             const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
+            const uint32_t st = end - mm;
             const uint32_t ch = p / kScatterChunk;
-            rk = x - st;
+            uint32_t rk = x - st;
             for (uint32_t y = x; y > st; --y) {               // chunk-mates on the left that belong after p
                 const uint32_t o = S_p[y - 1];
                 if (o / kScatterChunk != ch) break;
                 rk -= (o > p);
             }
-            for (uint32_t y = x + 1; y < st + mm; ++y) {      // chunk-mates on the right that belong before p
+            for (uint32_t y = x + 1; y < end; ++y) {          // chunk-mates on the right that belong before p
                 const uint32_t o = S_p[y];
                 if (o / kScatterChunk != ch) break;
                 rk += (o < p);
             }
+            dst = st + rk; hvq = hv; govq = gov; flq = fl | (dst + 1 == end ? 4u : 0u);
         }
-        dst = st + rk; hvq = hv; govq = gov; flq = fl;
     };
     if (OVERLAY) {
 #pragma unroll
@@ -403,21 +404,26 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     typedef typename std::conditional<OVERLAY, uint16_t, uint32_t>::type par_t;
     constexpr uint32_t kRoot = OVERLAY ? 0x8000u : 0x80000000u;
     par_t* Par = (par_t*)m.T2;                                // S_p is dead
+    // (Par holds ABSOLUTE list positions; a list ends at the entry carrying the LAST mark: no per-pair look-up on the fast path)
+    auto is_last = [&](uint32_t y, uint32_t gov) -> bool { return OVERLAY ? (gov & kLastBit) != 0 : (m.L_fl[y] & 4u) != 0; };
     for (uint32_t y = tid; y < Fm; y += kRowBlock) {
         const uint32_t gov = m.L_gov[y];
-        const uint32_t g = (gov >> 16) & GMASK;
-        const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
-        if (mm == 1) continue;
-        const uint32_t st = m.T1first[g] & 0xFFFFu;
-        const int ovs = (int)(gov & 0xFFFFu);
+        uint32_t gt = y + 1 < Fm ? m.L_gov[y + 1] : 0u;       // the usual parent: in flight together with the entry itself
         uint32_t par = kRoot;
-        for (uint32_t t = y + 1; t < st + mm; ++t)
-            if (iabs_((int)(m.L_gov[t] & 0xFFFFu) - ovs) < a.binSize) { par = t - st; break; }
-        Par[y] = (par_t)par;
-        if (y + 1 != st + mm && par != y + 1 - st) {
-            atomicOr(&m.T1key[g], 0x80000000u);
-            if (par == kRoot) atomicAdd(&m.Gaux[g], 0x10000u);
+        if (!is_last(y, gov)) {
+            const int ovs = (int)(gov & 0xFFFFu);
+            for (uint32_t t = y + 1;; ++t) {
+                if (iabs_((int)(gt & 0xFFFFu) - ovs) < a.binSize) { par = t; break; }
+                if (is_last(t, gt)) break;
+                gt = m.L_gov[t + 1];
+            }
+            if (par != y + 1) {
+                const uint32_t g = (gov >> 16) & GMASK;
+                atomicOr(&m.T1key[g], 0x80000000u);
+                if (par == kRoot) atomicAdd(&m.Gaux[g], 0x10000u);
+            }
         }
+        Par[y] = (par_t)par;
     }
     __syncthreads();
     if (a.stop == 7) return true;
@@ -426,13 +432,13 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     const us2 lim2 = {(unsigned short)(2 * a.k + 1), (unsigned short)(2 * a.k + 1)};
     const uint32_t lim = __builtin_bit_cast(uint32_t, lim2);
     for (uint32_t y = tid; y < Fm; y += kRowBlock) {
-        const uint32_t g = (m.L_gov[y] >> 16) & GMASK;
-        const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
-        if (mm == 1) continue;
-        const uint32_t st = m.T1first[g] & 0xFFFFu;
+        const uint32_t gov = m.L_gov[y];
         const uint32_t x = m.L_hv[y];
-        const uint32_t* lst = m.L_hv + st;
-        const uint32_t s = y - st;
+        if (is_last(y, gov)) continue;                        // nothing after it: no comparison, no contribution
+        const uint32_t g = (gov >> 16) & GMASK;
+        const uint32_t mm = m.T1first[g] & 0xFFFFu;           // END of the list: the walk runs on absolute positions s = y .. mm
+        const uint32_t* lst = m.L_hv;
+        const uint32_t s = y;
         if (!(m.T1key[g] >> 31)) {
             // plain chain: the position is compared with every later product until one is within k of it.
             // within k  <=>  (x + k - q) mod 2^16 <= 2k  in either half (k-mer starts are <= 65535 - k): eight products per test
@@ -477,7 +483,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             if (contrib) atomicAdd(&m.T1cnt[g], (contrib & 0xFFFFu) << 16);   // the cursor half already holds m
             if (a.tmp_ext && t == mm) atomicAdd(&m.Gaux[g], 1u);
         } else {
-            const par_t* pr = Par + st;
+            const par_t* pr = Par;
             uint32_t root = s, contrib = 0, t = pr[s];
             bool dead = false;
             while (!(t & kRoot)) {
@@ -486,8 +492,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             }
             if (contrib) atomicAdd(&m.T1cnt[g], (contrib & 0xFFFFu) << 16);
             if (!dead) {                                      // the root's support (a u16 counter is half of an LDS word)
-                if (OVERLAY) atomicAdd((uint32_t*)Par + ((st + root) >> 1), ((st + root) & 1u) ? 0x10000u : 1u);
-                else atomicAdd((uint32_t*)Par + st + root, 1u);
+                if (OVERLAY) atomicAdd((uint32_t*)Par + (root >> 1), (root & 1u) ? 0x10000u : 1u);
+                else atomicAdd((uint32_t*)Par + root, 1u);
             }
         }
     }
@@ -501,9 +507,10 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         const uint32_t mm = cw & 0xFFFFu;
         if (mm < 2) continue;
         const uint32_t aux = m.Gaux[g];
-        const uint32_t st = m.T1first[g] & 0xFFFFu;
+        const uint32_t st = (m.T1first[g] & 0xFFFFu) - mm;
         const uint32_t keyw = m.T1key[g];
-        uint32_t win = mm - 1, sup = aux & 0xFFFFu, nroots = 1;   // plain chain: one bin, headed by the last product
+        // plain chain: one bin, headed by the last product (which phase P skips: it always survives)
+        uint32_t win = mm - 1, sup = (aux & 0xFFFFu) + 1, nroots = 1;
         if (keyw >> 31) {
             nroots = (aux >> 16) + 1;
             if (nroots > 16) {
@@ -519,12 +526,12 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             for (uint32_t l = mm; l-- > 0;) {
                 const uint32_t pw = Par[st + l];
                 if (!(pw & kRoot)) continue;
-                const uint32_t cnt = pw & (kRoot - 1);
+                const uint32_t cnt = (pw & (kRoot - 1)) + (l + 1 == mm ? 1u : 0u);   // the last product counts itself
                 if (cnt > sup) { sup = cnt; win = l; }
             }
         }
         const uint32_t hv = m.L_hv[st + win];
-        const uint32_t fl = OVERLAY ? m.L_gov[st + win] >> 30 : (uint32_t)m.L_fl[st + win];
+        const uint32_t fl = OVERLAY ? m.L_gov[st + win] >> 30 : (uint32_t)m.L_fl[st + win] & 3u;
         bella_pair pr;
         pr.rid = keyw & 0x7FFFFFFFu; pr.cid = i; pr.count = (uint16_t)(cw >> 16); pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
         pr.flags = (uint16_t)((fl & 1u) | ((((fl & 1u) ^ 1u) | (fl >> 1)) << 1));
