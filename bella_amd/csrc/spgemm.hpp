@@ -153,6 +153,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 
     for (uint32_t s = tid; s < H1; s += kRowBlock) {
         m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0;
+        m.T2[s] = kEmpty; m.T2[s + H1] = kEmpty;             // the slot-order table of phase O (<= 2 * dcap slots), untouched until then
         if (!GALIAS) m.Gaux[s] = 0;
     }
     if (tid == 0) { *s_d = 0; *s_fail = 0; }
@@ -238,8 +239,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // ---- O: the reference's slot order (overlap.hpp:289-361) -----------------------------------------
     const uint32_t ht = pow2_at_least(16u, d);
     uint32_t* T2 = m.T2;
-    for (uint32_t s = tid; s < ht; s += kRowBlock) T2[s] = kEmpty;
-    __syncthreads();
     for (uint32_t s = tid; s < H1; s += kRowBlock) {
         const uint32_t key = m.T1key[s];
         if (key == kEmpty) continue;
