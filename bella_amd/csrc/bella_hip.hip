@@ -33,11 +33,12 @@ struct Buf {
 
 // Column tiers by product count: LDS tiers (one workgroup per column, 14.5 B of LDS per product: <= 2752 products keeps four
 // workgroups on a CU, <= 3712 three) and last the global-workspace tier.  BELLA_HIP_TIERS=a,b,c overrides the LDS caps (tuning aid).
-constexpr uint32_t kNumTiers = 8;  // at most
-uint32_t g_ntiers = 8;
-uint32_t kTierCaps[kNumTiers] = {768, 1280, 2048, 3072, 4096, 6144, 8192, 65535};
+constexpr uint32_t kNumTiers = 9;  // at most
+uint32_t g_ntiers = 9;
+// (11008 products x 14.5 B = the CU's whole 160 KB of LDS: the last step before the global path)
+uint32_t kTierCaps[kNumTiers] = {768, 1280, 2048, 3072, 4096, 6144, 8192, 11008, 65535};
 // pair-rich inputs (key tables of cap/2, 19 B of LDS per product): 2688 keeps four workgroups on a CU, 3328 three
-const uint32_t kTierCapsHalf[kNumTiers] = {768, 1280, 2048, 2688, 3328, 4096, 8192, 65535};
+const uint32_t kTierCapsHalf[kNumTiers] = {768, 1280, 2048, 2688, 3328, 4096, 8192, 11008, 65535};
 bool g_tiers_from_env = false;
 constexpr uint32_t kGlobalGrid = 1024;      // persistent workgroups of the global path: latency-bound, four per CU
 constexpr uint32_t kAsmGrid = 1024;
@@ -312,7 +313,7 @@ int bella_hip_init(int device, bella_ctx** out) {
         uint32_t n = 0;
         for (const char* q = tv; *q && n + 1 < kNumTiers;) {
             const uint32_t v = (uint32_t)strtoul(q, nullptr, 10);
-            if (v >= 16 && v <= 8192 && (n == 0 || v > kTierCaps[n - 1])) kTierCaps[n++] = v;
+            if (v >= 16 && v <= 11008 && (n == 0 || v > kTierCaps[n - 1])) kTierCaps[n++] = v;
             while (*q && *q != ',') ++q;
             if (*q == ',') ++q;
         }
@@ -1147,8 +1148,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         if (t + 1 < (int)g_ntiers) {
             const size_t lds = row_mem_bytes(a.cap, a.dcap, true);
             const bool ga = gaux_in_t2(a.cap, a.dcap, true);
-            void (*kern)(SpgemmArgs) = a.cap <= 8 * kRowBlock ? (ga ? k_spgemm_rows_lds<8, true> : k_spgemm_rows_lds<8, false>)
-                                                              : (ga ? k_spgemm_rows_lds<16, true> : k_spgemm_rows_lds<16, false>);
+            void (*kern)(SpgemmArgs) = a.cap <= 8 * kRowBlock    ? (ga ? k_spgemm_rows_lds<8, true> : k_spgemm_rows_lds<8, false>)
+                                       : a.cap <= 16 * kRowBlock ? (ga ? k_spgemm_rows_lds<16, true> : k_spgemm_rows_lds<16, false>)
+                                                                 : k_spgemm_rows_lds<22, false>;
             HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             kern<<<tcnt[t], kRowBlock, lds, sst>>>(a);
         } else {

@@ -54,7 +54,7 @@ constexpr uint32_t kCtlOverflow = 17;     // overflow list length
 constexpr uint32_t kCtlWork2 = 18;        // k_fold_overflow counter
 constexpr uint32_t kCtlStatus = 19;       // bit0: a pair ended with > 16 bins and no scratch was given
 constexpr uint32_t kCtlRetry = 21;        // columns whose key table overflowed in an LDS tier (rerun on the global path)
-constexpr uint32_t kCtlTierCnt = 32;      // [9] columns per tier, last used entry = wide columns
+constexpr uint32_t kCtlTierCnt = 32;      // [10] columns per tier, last used entry = wide columns
 constexpr uint32_t kCtlTotals = 42;       // u64[2]: nnz(C), products (8-byte aligned)
 constexpr uint32_t kCtlWords = 64;
 

@@ -601,11 +601,12 @@ def test_wide_columns_bit_exact(eng, monkeypatch, budget):
     assert (ext["nbins"] > 1).any()
 
 
-def test_big_lds_tiers_bit_exact(monkeypatch):
+@pytest.mark.parametrize("tier", ["8192", "11008"])
+def test_big_lds_tiers_bit_exact(monkeypatch, tier):
     """every column through the 8192-product LDS tier (the 16-positions-per-thread instance of the row kernel)"""
     g = load_golden("toyrep90")
     try:
-        monkeypatch.setenv("BELLA_HIP_TIERS", "8192")
+        monkeypatch.setenv("BELLA_HIP_TIERS", tier)
         e = Engine(0)
         e.set_reads(g.rs)
         e.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
@@ -616,7 +617,7 @@ def test_big_lds_tiers_bit_exact(monkeypatch):
         check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
         e.close()
     finally:
-        monkeypatch.setenv("BELLA_HIP_TIERS", "768,1280,2048,3072,4096,6144,8192")
+        monkeypatch.setenv("BELLA_HIP_TIERS", "768,1280,2048,3072,4096,6144,8192,11008")
         Engine(0).close()                                            # the tier table is process-wide: back to the default
 
 
