@@ -400,6 +400,33 @@ def test_baseline_config1_full_size_parity(eng):
     assert n == len(exp) == 755378 or n == len(exp)
     assert flops == int(flop.sum())
     check_pairs(pairs, ext, exp, rs.lengths, 17)
+    # BASELINE configs[2]: X-drop on the same pairs; 20,000 of them (junk pairs included) against the oracle's scalar Xavier,
+    # spread over the host cores
+    eng.align_pairs(BellaPars())
+    alns = eng.get_alignments()
+    rng = np.random.default_rng(7)
+    sample = np.sort(rng.choice(n, size=20000, replace=False))
+    global _XSEQS
+    _XSEQS = seqs
+    import multiprocessing as mp
+    jobs = [(int(pairs["rid"][i]), int(pairs["cid"][i]), int(pairs["seedH"][i]), int(pairs["seedV"][i])) for i in sample]
+    with mp.get_context("fork").Pool(min(32, os.cpu_count() or 1)) as pool:
+        res = pool.map(_xavier_job, jobs, chunksize=64)
+    bad = 0
+    for i, e in zip(sample, res):
+        al = alns[i]
+        got = (int(al["score"]), int(al["begH"]), int(al["endH"]), int(al["begV"]), int(al["endV"]))
+        bad += got != e
+    assert bad == 0, bad
+
+
+_XSEQS = None
+
+
+def _xavier_job(job):
+    rid, cid, sh, sv = job
+    e = O.xavier_align(_XSEQS[rid], _XSEQS[cid], sh, sv, 7, 17)
+    return (int(e["score"]), int(e["begH"]), int(e["endH"]), int(e["begV"]), int(e["endV"]))
 
 
 # ---- k-mer counting, reliable dictionary, tuples on the device ---------------------------------------------
