@@ -61,6 +61,7 @@ SIGNATURES = [
     ("bella_hip_set_B_device", C.c_int, [vp, C.c_uint16, C.c_uint32, vp, vp, vp, C.c_uint64]),
     ("bella_hip_get_B", C.c_int, [vp, C.POINTER(C.c_uint64), vp, vp, vp]),
     ("bella_hip_set_partition", C.c_int, [vp, C.c_uint32, C.c_uint32]),
+    ("bella_hip_set_column_range", C.c_int, [vp, C.c_uint32, C.c_uint32]),
     ("bella_hip_overlap", C.c_int, [vp, C.POINTER(Params), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("bella_hip_get_pairs", C.c_int, [vp, vp, vp, vp]),
     ("bella_hip_align_pairs", C.c_int, [vp, C.POINTER(Params), C.POINTER(C.c_uint64)]),

@@ -184,6 +184,9 @@ class Engine:
     def set_partition(self, first, stride):
         self._chk(self.lib.bella_hip_set_partition(self.h, first, stride))
 
+    def set_column_range(self, first, count):
+        self._chk(self.lib.bella_hip_set_column_range(self.h, first, count))
+
     def set_debug(self, flags):
         self._chk(self.lib.bella_hip_set_debug(self.h, flags))
 
@@ -272,19 +275,33 @@ def format_aligned(names, lengths, pairs, alns, paf=False) -> bytes:
     return "".join(out).encode()
 
 
-def hash_spgemm(engine: Engine, pars: BellaPars, filename: str, stdout=sys.stdout):
+def hash_spgemm(engine: Engine, pars: BellaPars, filename: str, stdout=sys.stdout, stages: int = 1):
     """HashSpGEMM-shaped driver (include/overlap.hpp:650-789): the operands and reads are already in `engine`.
-    Writes `filename` and the stdout protocol lines nnz(C) (:686) and, when aligning, outputted (:771)."""
-    npairs, _ = engine.overlap(pars)
-    print(npairs, file=stdout)
-    pairs, _, _ = engine.get_pairs(ext=False)
-    if pars.skipAlignment:
-        data = format_skip(engine.names, engine.lengths, pairs, pars.kmerSize)
-    else:
-        outputted = engine.align_pairs(pars)
-        alns = engine.get_alignments()
-        data = format_aligned(engine.names, engine.lengths, pairs, alns, pars.outputPaf)
-        print(outputted, file=stdout)
+    Writes `filename` and the stdout protocol lines nnz(C) (:686) and, when aligning, outputted per stage (:771).
+    stages > 1: the output is formed in stages of consecutive columns like the reference does under a memory budget
+    (:682-789); the file is the same, every pass only holds its own columns."""
+    nreads = engine.nreads
+    bounds = [(nreads * b) // stages for b in range(stages + 1)]
+    chunks, outputted, total = [], [], 0
+    try:
+        for b in range(stages):
+            if stages > 1:
+                engine.set_column_range(bounds[b], bounds[b + 1] - bounds[b])
+            npairs, _ = engine.overlap(pars)
+            total += npairs
+            pairs, _, _ = engine.get_pairs(ext=False)
+            if pars.skipAlignment:
+                chunks.append(format_skip(engine.names, engine.lengths, pairs, pars.kmerSize))
+            else:
+                outputted.append(engine.align_pairs(pars))
+                chunks.append(format_aligned(engine.names, engine.lengths, pairs, engine.get_alignments(), pars.outputPaf))
+    finally:
+        if stages > 1:
+            engine.set_column_range(0, 0xFFFFFFFF)
+    print(total, file=stdout)
+    for o in outputted:
+        print(o, file=stdout)
     with open(filename, "wb") as f:
-        f.write(data)
-    return npairs
+        for c in chunks:
+            f.write(c)
+    return total

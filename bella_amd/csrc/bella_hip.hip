@@ -72,6 +72,7 @@ struct bella_ctx {
         kc_tstart, kc_cursor, kc_sel, kc_ringo, kc_ringp;
     Buf Bptr, Bk, Bpos, Bent, Bcnt, Aent;
     uint32_t part_first = 0, part_stride = 1;
+    uint32_t range_lo = 0, range_hi = 0xFFFFFFFFu;   // stage: the contiguous column range computed by the next passes
     bool have_panel = false;
     uint32_t panel_first = 0, panel_rows = 0;
     uint64_t panel_nnz = 0;
@@ -357,6 +358,14 @@ void bella_hip_destroy(bella_ctx* c) {
 int bella_hip_set_debug(bella_ctx* c, uint32_t flags) {
     if (!c) return BELLA_ERR_BAD_ARG;
     c->debug = flags;
+    return 0;
+}
+
+int bella_hip_set_column_range(bella_ctx* c, uint32_t first, uint32_t count) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    c->range_lo = first;
+    c->range_hi = (uint64_t)first + count > 0xFFFFFFFFull ? 0xFFFFFFFFu : first + count;
+    c->have_pairs = c->have_alns = false;
     return 0;
 }
 
@@ -1066,7 +1075,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     uint32_t* d_ctl = ptr<uint32_t>(c->ctl);
     HIPCHK(c, hipMemsetAsync(d_ctl, 0, 4 * kCtlWords, c->stream));
     k_row_flops<<<nblk(nr + 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint16_t>(c->Bcnt), nr, c->part_first,
-                                                                c->part_stride, ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC));
+                                                                c->part_stride, c->range_lo, c->range_hi, ptr<uint32_t>(c->flopsr),
+                                                                ptr<uint32_t>(c->nnzC));
     KCHK(c);
     k_tier_lists<<<nblk(nr), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, ptr<uint32_t>(c->tiercaps), g_ntiers,
                                                   ptr<uint32_t>(c->Bptr), ptr<uint64_t>(c->roff), ptr<uint4>(c->rowlists),

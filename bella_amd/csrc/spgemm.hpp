@@ -668,15 +668,16 @@ __global__ __launch_bounds__(kBlock) void k_sample_pair_ratio(const uint32_t* Bp
 }
 
 // estimateFLOP (overlap.hpp:157-202, lowtri): products of column i = sum of the suffix counts of its entries.
-// One wavefront per column.  Columns outside this context's partition get 0.
+// One wavefront per column.  Columns outside this context's partition (i % stride == first) or stage ([lo, hi)) get 0.
 __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, const uint16_t* Bcnt, uint32_t nreads,
-                                                      uint32_t first, uint32_t stride, uint32_t* flops, uint32_t* nnzC) {
+                                                      uint32_t first, uint32_t stride, uint32_t lo, uint32_t hi, uint32_t* flops,
+                                                      uint32_t* nnzC) {
     const uint32_t i = blockIdx.x * kWaves + wave_id();
     if (i > nreads) return;
     if (lane_id() == 0) nnzC[i] = 0;                          // this pass's pair counts start from zero (entry nreads: scan tail)
     if (i == nreads) { if (lane_id() == 0) flops[i] = 0; return; }
     uint32_t s = 0;
-    if (i % stride == first) {
+    if (i % stride == first && i >= lo && i < hi) {
         const uint32_t b0 = Bptr[i], b1 = Bptr[i + 1];
         uint32_t e = b0 + lane_id();
         for (; e + 192 < b1; e += 256) s += (uint32_t)Bcnt[e] + Bcnt[e + 64] + Bcnt[e + 128] + Bcnt[e + 192];   // four loads in flight

@@ -189,6 +189,11 @@ int bella_hip_get_B(bella_ctx* ctx, uint64_t* nnz, uint32_t* colptr, uint32_t* r
 /* Multi-GPU (one context per GPU/process): this context computes output columns i with
  * i % stride == first.  Default (0,1) = all columns.  Every rank holds the full operands. */
 int bella_hip_set_partition(bella_ctx* ctx, uint32_t first, uint32_t stride);
+/* Stages (the reference forms the output in stages of consecutive columns when it does not fit the -m budget:
+ * estimateMemory, overlap.hpp:365-404, stage loop :682-789): the next passes compute only the output columns
+ * [first, first + count) (intersected with the partition above); default = all.  Running the ranges in ascending order and
+ * appending their outputs reproduces the single-stage output, and every pass only holds its own columns' records. */
+int bella_hip_set_column_range(bella_ctx* ctx, uint32_t first, uint32_t count);
 
 /* ---- HashSpGEMM (overlap.hpp:650-789): estimateFLOP + estimateNNZ_Hash + LocalSpGEMM ---------------- */
 int bella_hip_overlap(bella_ctx* ctx, const bella_params* p, uint64_t* npairs, uint64_t* flops);

@@ -706,3 +706,22 @@ def test_out_of_order_lists_fall_back_to_the_repairing_path(eng):
         check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
     finally:
         eng.set_debug(0)
+
+
+def test_staged_output_equals_single_stage(eng, golden, tmp_path):
+    """the reference forms its output in stages of consecutive columns under a memory budget (overlap.hpp:682-789): three
+    stages through bella_hip_set_column_range write the same files"""
+    import io
+    g = golden
+    eng.set_reads(g.rs)
+    eng.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
+    f = str(tmp_path / "o.out")
+    so = io.StringIO()
+    api.hash_spgemm(eng, BellaPars(skipAlignment=True, errorRate=g.err), f, stdout=so, stages=3)
+    assert open(f, "rb").read() == g.out["skip"] and so.getvalue().split()[0] == g.stdout["skip"][2]
+    one = str(tmp_path / "one.out")
+    api.hash_spgemm(eng, BellaPars(errorRate=g.err), one, stdout=io.StringIO())
+    so = io.StringIO()
+    api.hash_spgemm(eng, BellaPars(errorRate=g.err), f, stdout=so, stages=3)
+    assert open(f, "rb").read() == open(one, "rb").read()
+    assert int(so.getvalue().split()[0]) == int(g.stdout["align"][2])
