@@ -705,23 +705,36 @@ __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, ui
         ds.y = b0;
         ds.z = (Bptr[i + 1] - b0) | ((uint32_t)(roff[i + 1] - roff[i]) << 16);   // both < 65536 (checked at set_reads / assembly)
     }
+    // One global atomic per tier and WORKGROUP (a few hot counters serve all columns): the wavefronts first reserve their places
+    // inside the workgroup in LDS.
+    __shared__ uint32_t s_cnt[16], s_base[16];
+    __shared__ unsigned long long s_tot;
+    if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_tot = 0;
+    __syncthreads();
     {                                                      // the pass's product total (sizes the product buffers on the host)
         unsigned long long fs = f;
 #pragma unroll
         for (int dlt = 32; dlt > 0; dlt >>= 1) fs += __shfl_xor(fs, dlt, 64);
-        if (lane_id() == 0 && fs) atomicAdd(total, fs);
+        if (lane_id() == 0 && fs) atomicAdd(&s_tot, fs);
     }
+    uint32_t my = 0;                                       // place inside the workgroup's share of my tier's list
     for (uint32_t t = 0; t <= ntiers; ++t) {
         const unsigned long long mask = __ballot(tier == t);
         if (mask == 0) continue;
         uint32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(&counts[t], (uint32_t)__popcll(mask));
+        if (lane_id() == 0) base = atomicAdd(&s_cnt[t], (uint32_t)__popcll(mask));
         base = __shfl(base, 0, 64);
-        if (tier == t) {
-            const uint32_t o = base + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
-            if (t < ntiers) desc[(uint64_t)t * nreads + o] = ds;
-            else widelist[o] = i;
-        }
+        if (tier == t) my = base + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
+    }
+    __syncthreads();
+    if (threadIdx.x <= ntiers && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+    if (threadIdx.x == 0 && s_tot) atomicAdd(total, s_tot);
+    __syncthreads();
+    if (tier != 0xFFFFFFFFu) {
+        const uint32_t o = s_base[tier] + my;
+        if (tier < ntiers) desc[(uint64_t)tier * nreads + o] = ds;
+        else widelist[o] = i;
     }
 }
 
