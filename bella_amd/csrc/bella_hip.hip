@@ -72,6 +72,8 @@ struct bella_ctx {
         kc_tstart, kc_cursor, kc_sel, kc_ringo, kc_ringp;
     Buf Bptr, Bk, Bpos, Bent, Bcnt, Aent;
     uint32_t part_first = 0, part_stride = 1;
+    uint64_t sym_sig[6] = {};            // what flops / nnzC were last cleared for
+    uint64_t layout_gen = 0;             // bumped by every build of the device layout
     uint32_t range_lo = 0, range_hi = 0xFFFFFFFFu;   // stage: the contiguous column range computed by the next passes
     bool have_panel = false;
     uint32_t panel_first = 0, panel_rows = 0;
@@ -254,6 +256,7 @@ int build_layout(bella_ctx* c) {
     release(c->Brow); release(c->deg); release(c->minread); release(c->colstart); release(c->fill); release(c->ori);
     release(c->w); release(c->wscan); release(c->Atmp);
     c->have_matrix = true;
+    c->layout_gen++;
     c->have_pairs = c->have_alns = false;
     return 0;
 }
@@ -1074,11 +1077,27 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     // one control block per pass (counters, tier lengths, status, totals): one fill, one read back
     uint32_t* d_ctl = ptr<uint32_t>(c->ctl);
     HIPCHK(c, hipMemsetAsync(d_ctl, 0, 4 * kCtlWords, c->stream));
-    k_row_flops<<<nblk(nr + 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint16_t>(c->Bcnt), nr, c->part_first,
-                                                                c->part_stride, c->range_lo, c->range_hi, ptr<uint32_t>(c->flopsr),
-                                                                ptr<uint32_t>(c->nnzC));
-    KCHK(c);
-    k_tier_lists<<<nblk(nr), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, ptr<uint32_t>(c->tiercaps), g_ntiers,
+    // the columns of this context: i0 + j * stride, j < nown.  The symbolic kernels only visit those; the entries of all other
+    // columns in flops / nnzC are zero from the one clear made when the operands, the partition or the stage changed.
+    const uint32_t hi = c->range_hi < nr ? c->range_hi : nr;
+    uint32_t i0 = c->range_lo + (c->part_first + c->part_stride - c->range_lo % c->part_stride) % c->part_stride;
+    const uint32_t nown = i0 < hi ? (hi - i0 + c->part_stride - 1) / c->part_stride : 0;
+    if (!nown) i0 = 0;
+    {
+        const uint64_t sig[6] = {(uint64_t)(uintptr_t)c->flopsr.p, (uint64_t)(uintptr_t)c->nnzC.p, c->layout_gen, ((uint64_t)c->part_first << 32) | c->part_stride,
+                                 ((uint64_t)c->range_lo << 32) | c->range_hi, nr};
+        if (std::memcmp(sig, c->sym_sig, sizeof(sig)) != 0) {
+            HIPCHK(c, hipMemsetAsync(c->flopsr.p, 0, 4 * ((size_t)nr + 2), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->nnzC.p, 0, 4 * ((size_t)nr + 2), c->stream));
+            std::memcpy(c->sym_sig, sig, sizeof(sig));
+        }
+    }
+    if (nown) {
+        k_row_flops<<<nblk(nown, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint16_t>(c->Bcnt), i0, c->part_stride, nown,
+                                                                  ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC));
+        KCHK(c);
+    }
+    k_tier_lists<<<nblk(nown ? nown : 1), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, i0, c->part_stride, nown, ptr<uint32_t>(c->tiercaps), g_ntiers,
                                                   ptr<uint32_t>(c->Bptr), ptr<uint64_t>(c->roff), ptr<uint4>(c->rowlists),
                                                   (uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr), d_ctl + kCtlTierCnt,
                                                   (unsigned long long*)(d_ctl + kCtlTotals) + 1);

@@ -668,21 +668,19 @@ __global__ __launch_bounds__(kBlock) void k_sample_pair_ratio(const uint32_t* Bp
 }
 
 // estimateFLOP (overlap.hpp:157-202, lowtri): products of column i = sum of the suffix counts of its entries.
-// One wavefront per column.  Columns outside this context's partition (i % stride == first) or stage ([lo, hi)) get 0.
-__global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, const uint16_t* Bcnt, uint32_t nreads,
-                                                      uint32_t first, uint32_t stride, uint32_t lo, uint32_t hi, uint32_t* flops,
-                                                      uint32_t* nnzC) {
-    const uint32_t i = blockIdx.x * kWaves + wave_id();
-    if (i > nreads) return;
-    if (lane_id() == 0) nnzC[i] = 0;                          // this pass's pair counts start from zero (entry nreads: scan tail)
-    if (i == nreads) { if (lane_id() == 0) flops[i] = 0; return; }
+// One wavefront per column of this context (partition i % stride == first, stage [lo, hi)): column j is i0 + j * stride.  The
+// entries of the other columns are zero: the host clears the arrays when the operands, the partition or the stage change.
+__global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, const uint16_t* Bcnt, uint32_t i0, uint32_t stride, uint32_t nown,
+                                                      uint32_t* flops, uint32_t* nnzC) {
+    const uint32_t j = blockIdx.x * kWaves + wave_id();       // the j-th column of this context: i0 + j * stride
+    if (j >= nown) return;
+    const uint32_t i = i0 + j * stride;
+    if (lane_id() == 0) nnzC[i] = 0;                          // this pass's pair counts start from zero
     uint32_t s = 0;
-    if (i % stride == first && i >= lo && i < hi) {
-        const uint32_t b0 = Bptr[i], b1 = Bptr[i + 1];
-        uint32_t e = b0 + lane_id();
-        for (; e + 192 < b1; e += 256) s += (uint32_t)Bcnt[e] + Bcnt[e + 64] + Bcnt[e + 128] + Bcnt[e + 192];   // four loads in flight
-        for (; e < b1; e += 64) s += Bcnt[e];
-    }
+    const uint32_t b0 = Bptr[i], b1 = Bptr[i + 1];
+    uint32_t e = b0 + lane_id();
+    for (; e + 192 < b1; e += 256) s += (uint32_t)Bcnt[e] + Bcnt[e + 64] + Bcnt[e + 128] + Bcnt[e + 192];   // four loads in flight
+    for (; e < b1; e += 64) s += Bcnt[e];
 #pragma unroll
     for (int dlt = 32; dlt > 0; dlt >>= 1) s += __shfl_xor(s, dlt, 64);
     if (lane_id() == 0) flops[i] = s;
@@ -690,11 +688,13 @@ __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, cons
 
 // tier lists: column i with f products goes to the first tier whose cap >= f (caps ascending; last tier = global path).
 // One atomic per wavefront and tier; the order inside a list only affects scheduling.
-__global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, uint32_t nreads, const uint32_t* caps, uint32_t ntiers,
+__global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, uint32_t nreads, uint32_t i0, uint32_t stride, uint32_t nown,
+                                                       const uint32_t* caps, uint32_t ntiers,
                                                        const uint32_t* Bptr, const uint64_t* roff, uint4* desc, uint32_t* widelist,
                                                        uint32_t* counts, unsigned long long* total) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t f = i < nreads ? flops[i] : 0u;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;      // the j-th column of this context
+    const uint32_t i = i0 + j * stride;
+    const uint32_t f = j < nown ? flops[i] : 0u;
     uint32_t tier = 0xFFFFFFFFu;
     uint4 ds = make_uint4(i, 0u, 0u, 0u);
     if (f > 0) {
