@@ -1224,8 +1224,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     if (nr) {
-        k_compact_pairs<<<nblk(nr, kWaves), kBlock, 0, c->stream>>>(ptr<uint64_t>(c->flopptr), ptr<uint64_t>(c->colptrC),
-                                                                    ptr<uint32_t>(c->nnzC), nr, ptr<bella_pair>(c->tmp_pairs),
+        k_compact_pairs<<<nblk(nown ? nown : 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint64_t>(c->flopptr), ptr<uint64_t>(c->colptrC),
+                                                                    ptr<uint32_t>(c->nnzC), nr, i0, c->part_stride, nown,
+                                                                    ptr<bella_pair>(c->tmp_pairs),
                                                                     want_ext ? ptr<bella_pair_ext>(c->tmp_ext) : nullptr,
                                                                     ptr<bella_pair>(c->pairs),
                                                                     want_ext ? ptr<bella_pair_ext>(c->ext) : nullptr,

@@ -739,12 +739,13 @@ __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, ui
 }
 
 __global__ __launch_bounds__(kBlock) void k_compact_pairs(const uint64_t* flopptr, const uint64_t* colptrC,
-                                                          const uint32_t* nnzC, uint32_t nreads,
+                                                          const uint32_t* nnzC, uint32_t nreads, uint32_t i0, uint32_t stride, uint32_t nown,
                                                           const bella_pair* tmp_pairs, const bella_pair_ext* tmp_ext,
                                                           bella_pair* pairs, bella_pair_ext* ext, uint64_t* totals) {
-    const uint32_t i = blockIdx.x * kWaves + wave_id();
-    if (i == 0 && lane_id() == 0) { totals[0] = colptrC[nreads]; totals[1] = flopptr[nreads]; }   // nnz(C), products: read back once
-    if (i >= nreads) return;
+    const uint32_t j = blockIdx.x * kWaves + wave_id();       // the j-th column of this context (the others are empty)
+    if (j == 0 && lane_id() == 0) { totals[0] = colptrC[nreads]; totals[1] = flopptr[nreads]; }   // nnz(C), products: read back once
+    if (j >= nown) return;
+    const uint32_t i = i0 + j * stride;
     const uint32_t cnt = nnzC[i];
     const uint64_t src = flopptr[i], dst = colptrC[i];
     for (uint32_t r = lane_id(); r < cnt; r += 64) {
