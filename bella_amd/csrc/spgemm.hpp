@@ -222,7 +222,10 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
                 h = (h + 1 == H1) ? 0 : h + 1;
             }
             if (probes == H1) { *s_fail = 1; continue; }     // more pairs than this tier's key table holds
-            if (old == kEmpty) atomicAdd(s_d, 1u);
+            if (old == kEmpty) {
+                const uint32_t idx = atomicAdd(s_d, 1u);
+                if (GALIAS) m.G[idx] = (uint16_t)h;          // pair-rich layout: the occupied slots, densely (G is rewritten in phase O)
+            }
             atomicMin(&m.T1first[h], p);
             atomicAdd(&m.T1cnt[h], 1u);
             m.A_hv[p] = posH | (posV << 16);
@@ -239,7 +242,9 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // ---- O: the reference's slot order (overlap.hpp:289-361) -----------------------------------------
     const uint32_t ht = pow2_at_least(16u, d);
     uint32_t* T2 = m.T2;
-    for (uint32_t s = tid; s < H1; s += kRowBlock) {
+    // (pair-rich layout: one lane per pair from the dense slot list; otherwise a sweep over the -- small -- key table)
+    for (uint32_t r = tid; r < (GALIAS ? d : H1); r += kRowBlock) {
+        const uint32_t s = GALIAS ? (uint32_t)m.G[r] : r;
         const uint32_t key = m.T1key[s];
         if (key == kEmpty) continue;
         uint32_t item = (m.T1first[s] << 16) | s;
