@@ -165,6 +165,7 @@ __global__ void k_kmer_stats(const uint32_t* Bk, const uint16_t* Bpos, const uin
     if (e >= nnz) return;
     const uint32_t km = Bk[e], r = Brow[e];
     if (km >= nkmers) { atomicOr(status, 32u); return; }
+    if ((uint64_t)Bpos[e] + k > roff[r + 1] - roff[r]) { atomicOr(status, 128u); return; }   // the k-mer would run past the end of its read
     const uint64_t le = kmer_le(packed, roff[r] + Bpos[e], k);
     const uint64_t fw = kmer_fw_from_le(le, k), rc = kmer_rc_from_le(le, k);
     ori[e] = (uint8_t)((fw > rc ? 1u : 0u) | (fw == rc ? 2u : 0u));   // bit0: not the canonical form, bit1: palindrome
@@ -173,11 +174,13 @@ __global__ void k_kmer_stats(const uint32_t* Bk, const uint16_t* Bpos, const uin
 }
 
 // weight of entry e in the "first appearance" layout of A': the owner (smallest read) reserves the whole list
-__global__ void k_first_weight(const uint32_t* Bk, const uint32_t* Brow, uint64_t nnz, const uint32_t* deg,
-                               const uint32_t* minread, uint32_t* w) {
+__global__ void k_first_weight(const uint32_t* Bk, const uint32_t* Brow, uint64_t nnz, uint32_t nkmers, const uint32_t* deg,
+                               const uint32_t* minread, uint32_t* w, uint32_t* status) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nnz) return;
     const uint32_t km = Bk[e];
+    if (km >= nkmers) { w[e] = 0; return; }                     // flagged by k_kmer_stats; the host stops after this kernel
+    if (deg[km] > 16383u) atomicOr(status, 64u);                // Bent's product count field holds 14 bits
     w[e] = (Brow[e] == minread[km]) ? deg[km] : 0u;
 }
 

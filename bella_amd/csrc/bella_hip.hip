@@ -31,15 +31,14 @@ struct Buf {
     size_t cap = 0;
 };
 
-// Column tiers by product count: LDS tiers (one workgroup per column, 14.5 B of LDS per product: <= 2752 products keeps four
-// workgroups on a CU, <= 3712 three) and last the global-workspace tier.  BELLA_HIP_TIERS=a,b,c overrides the LDS caps (tuning aid).
-constexpr uint32_t kNumTiers = 9;  // at most
-uint32_t g_ntiers = 9;
-// (11008 products x 14.5 B = the CU's whole 160 KB of LDS: the last step before the global path)
-uint32_t kTierCaps[kNumTiers] = {768, 1280, 2048, 3072, 4096, 6144, 8192, 11008, 65535};
+// Column tiers by product count: LDS tiers (one 512-thread workgroup per column, 14.5 B of LDS per product: <= 2752 products
+// keeps four workgroups on a CU, <= 3712 three; 11008 products x 14.5 B = the CU's whole 160 KB) and last the global-workspace
+// tier.  BELLA_HIP_TIERS=a,b,c (read once per context; tuning aid / tests) overrides the LDS caps.
+constexpr uint32_t kNumTiers = 12;  // at most
+constexpr uint32_t kDefaultTiers = 9;
+const uint32_t kTierCapsDefault[kNumTiers] = {768, 1280, 2048, 3072, 4096, 6144, 8192, 11008, 65535};
 // pair-rich inputs (key tables of cap/2, 19 B of LDS per product): 2688 keeps four workgroups on a CU, 3328 three
 const uint32_t kTierCapsHalf[kNumTiers] = {768, 1280, 2048, 2688, 3328, 4096, 8192, 11008, 65535};
-bool g_tiers_from_env = false;
 constexpr uint32_t kGlobalGrid = 1024;      // persistent workgroups of the global path: latency-bound, four per CU
 constexpr uint32_t kAsmGrid = 1024;
 
@@ -98,6 +97,10 @@ struct bella_ctx {
     hipEvent_t ev[10]{};
     uint32_t* pinned = nullptr;          // 128 host words the per-pass read backs land in
     int caps_state = 0;
+    uint32_t tier_caps[kNumTiers] = {};  // ascending LDS caps, last = 65535 (global-workspace tier); per context
+    uint32_t ntiers = 0;
+    bool tiers_from_env = false;
+    size_t lds_attr[8] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
     hipStream_t side[kNumTiers + 1]{};   // independent tier launches / fold instances run concurrently
     hipEvent_t fork = nullptr, join[kNumTiers + 1]{};
 };
@@ -166,6 +169,7 @@ int status_to_error(bella_ctx* c, uint32_t st) {
     if (st & 16u) return fail(c, BELLA_ERR_READ_TOO_LONG, "a read has >= 65536 tuples");
     if (st & 32u) return fail(c, BELLA_ERR_BAD_ARG, "k-mer id >= nkmers");
     if (st & 64u) return fail(c, BELLA_ERR_BAD_ARG, "a k-mer occurs in more than 16383 reads");
+    if (st & 128u) return fail(c, BELLA_ERR_BAD_ARG, "a tuple's position + k exceeds the length of its read");
     if (st & 2u) return fail(c, BELLA_ERR_ROW_TOO_LARGE, "an output column has >= 65536 products");
     return 0;
 }
@@ -217,9 +221,16 @@ int build_layout(bella_ctx* c) {
                                                        ptr<uint32_t>(c->deg), ptr<uint32_t>(c->minread), ptr<uint8_t>(c->ori),
                                                        ptr<uint32_t>(c->status));
         KCHK(c);
-        k_first_weight<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bk), ptr<uint32_t>(c->Brow), nnz, ptr<uint32_t>(c->deg),
-                                                         ptr<uint32_t>(c->minread), ptr<uint32_t>(c->w));
+        k_first_weight<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bk), ptr<uint32_t>(c->Brow), nnz, nk, ptr<uint32_t>(c->deg),
+                                                         ptr<uint32_t>(c->minread), ptr<uint32_t>(c->w), ptr<uint32_t>(c->status));
         KCHK(c);
+        // bad input (k-mer id out of range, k-mer past the end of its read, degree > 16383) stops here: the kernels below
+        // index with these values
+        uint32_t st0 = 0;
+        int rc0 = read_status(c, &st0);
+        if (rc0) return rc0;
+        rc0 = status_to_error(c, st0);
+        if (rc0) return rc0;
         int rc = scan_u32(c, ptr<uint32_t>(c->w), ptr<uint32_t>(c->wscan), nnz);
         if (rc) return rc;
         k_col_starts<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bk), ptr<uint32_t>(c->Brow), nnz, ptr<uint32_t>(c->minread),
@@ -271,6 +282,12 @@ int check_params(bella_ctx* c, const bella_params* p) {
     if (!p) return fail(c, BELLA_ERR_BAD_ARG, "params is NULL");
     if (p->kmer_size != c->kmer_size)
         return fail(c, BELLA_ERR_BAD_ARG, "params.kmer_size (%u) differs from the matrix's (%u)", p->kmer_size, c->kmer_size);
+    // (bin_size == 0 is legal: chain.hpp:114 compares |overlap difference| < binSize, so no two products ever share a bin)
+    if (!p->skip_alignment) {
+        if (p->xdrop > 127) return fail(c, BELLA_ERR_BAD_ARG, "params.xdrop must fit Xavier's int8 scores (<= 127)");
+        if (!(p->error_rate >= 0.0 && p->error_rate <= 1.0) || !(p->delta_chernoff >= 0.0 && p->delta_chernoff <= 1.0))
+            return fail(c, BELLA_ERR_BAD_ARG, "params.error_rate and params.delta_chernoff must lie in [0, 1]");
+    }
     return 0;
 }
 
@@ -313,23 +330,33 @@ int bella_hip_init(int device, bella_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BELLA_ERR_NO_DEVICE;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BELLA_ERR_NO_DEVICE;
-    if (const char* tv = getenv("BELLA_HIP_TIERS")) {             // tuning aid: ascending LDS caps, each <= 4096
+    bella_ctx* c = new bella_ctx();
+    c->device = device;
+    for (uint32_t t = 0; t < kDefaultTiers; ++t) c->tier_caps[t] = kTierCapsDefault[t];
+    c->ntiers = kDefaultTiers;
+    if (const char* tv = getenv("BELLA_HIP_TIERS")) {             // tuning aid / tests: ascending LDS caps, each <= 11008
         uint32_t n = 0;
+        uint32_t caps[kNumTiers];
         for (const char* q = tv; *q && n + 1 < kNumTiers;) {
             const uint32_t v = (uint32_t)strtoul(q, nullptr, 10);
-            if (v >= 16 && v <= 11008 && (n == 0 || v > kTierCaps[n - 1])) kTierCaps[n++] = v;
+            if (v >= 16 && v <= 11008 && (n == 0 || v > caps[n - 1])) caps[n++] = v;
             while (*q && *q != ',') ++q;
             if (*q == ',') ++q;
         }
-        if (n) { kTierCaps[n] = 65535; g_ntiers = n + 1; g_tiers_from_env = true; }
+        if (n) {
+            for (uint32_t t = 0; t < n; ++t) c->tier_caps[t] = caps[t];
+            c->tier_caps[n] = 65535;
+            c->ntiers = n + 1;
+            c->tiers_from_env = true;
+        }
     }
-    bella_ctx* c = new bella_ctx();
-    c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return BELLA_ERR_HIP; }
-    for (auto& e : c->ev) (void)hipEventCreate(&e);
-    for (auto& st : c->side) (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-    (void)hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
-    for (auto& e : c->join) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    hipError_t he = hipSetDevice(device);
+    if (he == hipSuccess) he = hipStreamCreate(&c->stream);
+    for (auto& e : c->ev) if (he == hipSuccess) he = hipEventCreate(&e);
+    for (auto& st : c->side) if (he == hipSuccess) he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+    for (auto& e : c->join) if (he == hipSuccess) he = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (he != hipSuccess) { bella_hip_destroy(c); return BELLA_ERR_HIP; }
     if (hipHostMalloc((void**)&c->pinned, 512, hipHostMallocDefault) != hipSuccess) { delete c; return BELLA_ERR_NOMEM; }
     if (ensure_bytes(c, c->status, 256)) { delete c; return BELLA_ERR_NOMEM; }
     (void)hipMemset(c->status.p, 0, 256);
@@ -470,6 +497,14 @@ int bella_hip_set_B(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, const uin
     if (!c->have_reads) return fail(c, BELLA_ERR_STATE, "set_reads first");
     if (kmer_size < 1 || kmer_size > 32) return fail(c, BELLA_ERR_BAD_ARG, "k must be in [1,32] (MAX_KMER_SIZEK, kmercode/common.h:13)");
     HIPCHK(c, hipSetDevice(c->device));
+    c->have_matrix = c->have_pairs = c->have_alns = false;
+    c->have_panel = false;
+    c->have_tuples = false;
+    if (colptr[0] != 0) return fail(c, BELLA_ERR_BAD_ARG, "colptr[0] must be 0");
+    for (uint32_t r = 0; r < c->nreads; ++r) {
+        if (colptr[r + 1] < colptr[r]) return fail(c, BELLA_ERR_BAD_ARG, "colptr must be non-decreasing (column %u)", r);
+        if (colptr[r + 1] - colptr[r] >= 65536u) return fail(c, BELLA_ERR_READ_TOO_LONG, "column %u has >= 65536 entries", r);
+    }
     const uint64_t nnz = colptr[c->nreads];
     if (nnz && (!rowids || !values)) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -1066,7 +1101,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     uint32_t caps[kNumTiers] = {};
     const bool half_tables = !(c->pair_ratio1024 * 5 < 1024);
-    const uint32_t* tier_caps = (half_tables && !g_tiers_from_env) ? kTierCapsHalf : kTierCaps;
+    const uint32_t* tier_caps = (half_tables && !c->tiers_from_env) ? kTierCapsHalf : c->tier_caps;
+    const uint32_t g_ntiers = c->ntiers;
     for (uint32_t t = 0; t < g_ntiers; ++t) caps[t] = force_global && t + 1 < g_ntiers ? 0 : tier_caps[t];
     const int want_state = (force_global ? 2 : 1) + (half_tables ? 2 : 0);
     if (c->caps_state != want_state) {                         // the tier caps only change with the operands or the debug switch
@@ -1105,7 +1141,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     // the one host round trip before the row kernels: the tiers' lengths (exact grids) and the product total, 64 bytes into
     // pinned memory; the prefix sums the row kernels need (overlap.hpp:110-146) run on the device meanwhile
     uint32_t* const tcnt = c->pinned;
-    HIPCHK(c, hipMemcpyAsync(tcnt, d_ctl + kCtlTierCnt, 4 * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(tcnt, d_ctl + kCtlTierCnt, 4 * (kCtlTotals + 4 - kCtlTierCnt), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
     int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->flopsr), ptr<uint64_t>(c->flopptr), (uint64_t)nr + 1);
     if (rc) return rc;
@@ -1143,14 +1179,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     a.nrows = 0;
     a.k = p->kmer_size;
     a.binSize = p->bin_size;
-    a.phase = nullptr;
     a.inject_unordered = (c->debug & 4u) ? 1 : 0;
-    a.stop = getenv("BELLA_HIP_STOP_PHASE") ? atoi(getenv("BELLA_HIP_STOP_PHASE")) : -1;
-    const bool phase_timers = getenv("BELLA_HIP_PHASE_TIMERS") != nullptr;
-    if (phase_timers) {
-        HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 4, 0, 48, c->stream));
-        a.phase = (unsigned long long*)(ptr<uint32_t>(c->status) + 4);
-    }
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     uint32_t launches = 0;
     // the tiers are independent persistent launches of the same kernel with different LDS budgets, forked onto side streams
@@ -1173,14 +1202,17 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         a.cap = tier_caps[t];
         // sampled pairs/products below 1/5: quarter-size key tables; the big tiers (one workgroup per CU) always
         a.dcap = (!half_tables || a.cap > 4096) ? a.cap / 4 : a.cap / 2;
-        if (getenv("BELLA_HIP_DCAP_HALF") && a.cap <= 4096) a.dcap = a.cap / 2;     // tests: the half-size layout on any input
+        if ((c->debug & 16u) && a.cap <= 4096) a.dcap = a.cap / 2;                  // tests: the half-size layout on any input
         if (t + 1 < (int)g_ntiers) {
             const size_t lds = row_mem_bytes(a.cap, a.dcap, true);
             const bool ga = gaux_in_t2(a.cap, a.dcap, true);
-            void (*kern)(SpgemmArgs) = a.cap <= 8 * kRowBlock    ? (ga ? k_spgemm_rows_lds<8, true> : k_spgemm_rows_lds<8, false>)
-                                       : a.cap <= 16 * kRowBlock ? (ga ? k_spgemm_rows_lds<16, true> : k_spgemm_rows_lds<16, false>)
-                                                                 : k_spgemm_rows_lds<22, false>;
-            HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const int ki = a.cap <= 8 * kRowBlock ? (ga ? 0 : 1) : a.cap <= 16 * kRowBlock ? (ga ? 2 : 3) : 4;
+            void (*kern)(SpgemmArgs) = ki == 0 ? k_spgemm_rows_lds<8, true> : ki == 1 ? k_spgemm_rows_lds<8, false>
+                                     : ki == 2 ? k_spgemm_rows_lds<16, true> : ki == 3 ? k_spgemm_rows_lds<16, false> : k_spgemm_rows_lds<22, false>;
+            if (lds > c->lds_attr[ki]) {                         // once per kernel and size, not per launch
+                HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                c->lds_attr[ki] = lds;
+            }
             kern<<<tcnt[t], kRowBlock, lds, sst>>>(a);
         } else {
             const unsigned grid = tcnt[t] < kGlobalGrid ? tcnt[t] : kGlobalGrid;
@@ -1235,7 +1267,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     }
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     // the pass's only host round trip: counters, totals and status
-    uint32_t* const ctl_host = c->pinned + 16;
+    uint32_t* const ctl_host = c->pinned + 32;
     HIPCHK(c, hipMemcpyAsync(ctl_host, d_ctl, 4 * kCtlWords, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     uint64_t P = 0, F = 0;
@@ -1256,15 +1288,6 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     c->tm.compact_ms = ev_ms(c->ev[6], c->ev[7]);
     c->tm.overlap_total_ms = ev_ms(c->ev[2], c->ev[7]);
     c->tm.spgemm_launches = launches;
-    if (phase_timers) {
-        unsigned long long ph[6];
-        HIPCHK(c, hipMemcpy(ph, ptr<uint32_t>(c->status) + 4, 48, hipMemcpyDeviceToHost));
-        const double tot = (double)(ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) + 1e-9;
-        fprintf(stderr, "[bella_hip] row-kernel phase cycles: expand %.1f%% order %.1f%% scatter %.1f%% rank %.1f%% parallel-fold %.1f%% emit %.1f%% ; "
-                        "rows %.3f ms (retried columns %u), fold %.3f ms (overflow pairs %u), symbolic %.3f ms, compact %.3f ms\n",
-                100.0 * ph[0] / tot, 100.0 * ph[1] / tot, 100.0 * ph[2] / tot, 100.0 * ph[3] / tot, 100.0 * ph[4] / tot, 100.0 * ph[5] / tot,
-                c->tm.spgemm_ms, c->n_retry, c->tm.fold_ms, c->n_overflow, c->tm.symbolic_ms, c->tm.compact_ms);
-    }
     return 0;
 }
 
@@ -1276,7 +1299,7 @@ int bella_hip_overlap(bella_ctx* c, const bella_params* p, uint64_t* npairs, uin
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t st = 0;
     rc = run_spgemm(c, p, &st);
-    if (rc) return rc;
+    if (rc) { (void)hipDeviceSynchronize(); return rc; }     // side-stream kernels of the pass may still be in flight
     if (st & 1u) return fail(c, BELLA_ERR_BINS, "internal: > 16 bins without sort scratch");
     c->have_pairs = true;
     c->have_alns = false;

@@ -54,8 +54,8 @@ constexpr uint32_t kCtlOverflow = 17;     // overflow list length
 constexpr uint32_t kCtlWork2 = 18;        // k_fold_overflow counter
 constexpr uint32_t kCtlStatus = 19;       // bit0: a pair ended with > 16 bins and no scratch was given
 constexpr uint32_t kCtlRetry = 21;        // columns whose key table overflowed in an LDS tier (rerun on the global path)
-constexpr uint32_t kCtlTierCnt = 32;      // [10] columns per tier, last used entry = wide columns
-constexpr uint32_t kCtlTotals = 42;       // u64[2]: nnz(C), products (8-byte aligned)
+constexpr uint32_t kCtlTierCnt = 32;      // [14] columns per tier, last used entry = wide columns
+constexpr uint32_t kCtlTotals = 46;       // u64[2]: nnz(C), products (8-byte aligned)
 constexpr uint32_t kCtlWords = 64;
 
 struct SpgemmArgs {
@@ -84,8 +84,6 @@ struct SpgemmArgs {
     int k;
     int binSize;
     int inject_unordered;        // tests: pretend every fifth column's lists came out of order in phase S (exercises the fallback)
-    int stop;                    // development aid: leave process_row after this phase (results are garbage), -1 = off
-    unsigned long long* phase;   // optional per-phase cycle counters (development aid, BELLA_HIP_PHASE_TIMERS=1)
 };
 
 constexpr uint32_t kRowScratchBytes = 256;                   // block scan scratch, counters, bucket histogram
@@ -158,11 +156,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     }
     if (tid == 0) { *s_d = 0; *s_fail = 0; }
     __syncthreads();
-    long long tc = 0;
-    if (a.phase && tid == 0) tc = clock64();
-    unsigned long long phc[6] = {0, 0, 0, 0, 0, 0};
-#define BELLA_PHASE(n) if (a.phase && tid == 0) { const long long t2 = clock64(); phc[n] = (unsigned long long)(t2 - tc); tc = t2; } \
-    if (a.stop == n) return true;
 
     // ---- X: expand products in reference order, group keys --------------------------------------------
     // X1/X2: each thread owns a CONTIGUOUS run of B' entries (so one block scan orders all products); it only records,
@@ -192,7 +185,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     }
     const uint32_t F = running;
     __syncthreads();
-    if (a.stop == 6) return true;
     // X3: product-parallel gather of the A' entries (balanced: every lane has work; four independent loads in flight)
     for (uint32_t base = 0; base < F; base += 4 * kRowBlock) {
         uint2 ae[4];
@@ -237,7 +229,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     __syncthreads();
     if (*s_fail) return false;
     const uint32_t d = *s_d;
-    BELLA_PHASE(0)
 
     // ---- O: the reference's slot order (overlap.hpp:289-361) -----------------------------------------
     const uint32_t ht = pow2_at_least(16u, d);
@@ -301,7 +292,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
-    BELLA_PHASE(1)
 
     // ---- S: product indices into per-pair lists.  Wavefront 0 appends 64 products at a time in product order (LDS
     // atomics of one wavefront execute in program order), so a list is ordered ACROSS 64-product chunks and only
@@ -327,7 +317,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
-    BELLA_PHASE(2)
 
     // ---- R: exact rank of every product inside its pair's list (global path: list position corrected by the chunk-mates on
     // the wrong side; LDS tiers: checked) and the lists in rank order: L_hv / L_gov. -------------------------------------------------------------
@@ -388,7 +377,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
-    BELLA_PHASE(3)
 
     // ---- P: the fold, in parallel.  chainop (chain.hpp:100-150) on a pair's products in order has a closed form:
     //  * every product t opens a bin with overlap ov_t and itself as first position; a bin lives, unchanged, until the first
@@ -430,7 +418,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         Par[y] = (par_t)par;
     }
     __syncthreads();
-    if (a.stop == 7) return true;
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     const us2 kk2 = {(unsigned short)a.k, (unsigned short)a.k};
     const us2 lim2 = {(unsigned short)(2 * a.k + 1), (unsigned short)(2 * a.k + 1)};
@@ -502,7 +489,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
-    BELLA_PHASE(4)
 
     // ---- E: one record per pair --------------------------------------------------------------------------------------
     for (uint32_t r = tid; r < d; r += kRowBlock) {
@@ -547,13 +533,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     if (tid == 0) a.nnzC[i] = d;
-    if (a.phase) {
-        __syncthreads();
-        BELLA_PHASE(5)
-        if (tid == 0)
-            for (int n = 0; n < 6; ++n) atomicAdd(a.phase + n, phc[n]);
-    }
-#undef BELLA_PHASE
     return true;
 }
 

@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--align", action="store_true", help="configs[2]: also run the X-drop stage (not the headline line)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="extra bella_hip_set_debug bits (development A/B, e.g. 8 = workgroup row kernel)")
     ap.add_argument("--cpu-baseline-child", default=None)
     ap.add_argument("--threads", type=int, default=0)
     a = ap.parse_args()
@@ -137,7 +138,7 @@ def main():
         asm_ms += eng.timings().assemble_ms
         del colptr_t, ids_t, val_t
     eng.set_partition(rank, n_gpus)
-    eng.set_debug(2)                 # diagnostics array (pair_ext) off in the timed path
+    eng.set_debug(2 | a.debug_flags)   # diagnostics array (pair_ext) off in the timed path
     pars = BellaPars(skipAlignment=True)
 
     def sync():

@@ -239,6 +239,38 @@ def test_errors_are_loud(eng):
         eng.overlap(BellaPars())              # no matrix after the failed assembly
 
 
+def test_bad_operands_are_rejected_before_they_are_used(eng):
+    """k-mer id >= nkmers, a k-mer running past the end of its read, a k-mer in more than 16383 reads, a malformed colptr:
+    BELLA_ERR_BAD_ARG (-3), no device fault, and the context keeps working afterwards"""
+    rs = synth.readset_from_seqs([b"ACGT" * 20, b"ACGT" * 20, b"ACGT" * 20])
+    eng.set_reads(rs)
+    with pytest.raises(BellaHipError) as e:       # id 5 with nkmers = 5
+        eng.assemble_tuples(17, 5, np.array([5, 1], np.uint32), np.array([0, 1], np.uint32), np.array([0, 0], np.uint16))
+    assert e.value.code == -3 and "k-mer id" in str(e.value)
+    with pytest.raises(BellaHipError) as e:       # position 70 + 17 > 80
+        eng.assemble_tuples(17, 5, np.array([1, 1], np.uint32), np.array([0, 1], np.uint32), np.array([70, 0], np.uint16))
+    assert e.value.code == -3 and "length" in str(e.value)
+    with pytest.raises(BellaHipError):
+        eng.overlap(BellaPars())
+    with pytest.raises(BellaHipError) as e:       # set_B: colptr not monotone / not starting at 0
+        eng.set_B(17, 5, np.array([0, 2, 1, 2], np.uint32), np.array([1, 2], np.uint32), np.array([0, 0], np.uint16))
+    assert e.value.code == -3
+    with pytest.raises(BellaHipError) as e:
+        eng.set_B(17, 5, np.array([1, 1, 2, 2], np.uint32), np.array([1, 2], np.uint32), np.array([0, 0], np.uint16))
+    assert e.value.code == -3
+    n = 16400                                      # one k-mer shared by 16400 reads: the 14-bit product count of B' overflows
+    rs = synth.readset_from_seqs([b"ACGTACGTACGTACGTACGTAAAA"] * n)
+    eng.set_reads(rs)
+    with pytest.raises(BellaHipError) as e:
+        eng.assemble_tuples(17, 3, np.full(n, 2, np.uint32), np.arange(n, dtype=np.uint32), np.zeros(n, np.uint16))
+    assert e.value.code == -3 and "16383" in str(e.value)
+    with pytest.raises(BellaHipError) as e:       # parameters outside their domain
+        eng.assemble_tuples(17, 3, np.array([2, 2], np.uint32), np.array([0, 1], np.uint32), np.zeros(2, np.uint16))
+        eng.overlap(BellaPars(errorRate=1.5))
+    assert e.value.code == -3
+    assert eng.overlap(BellaPars())[0] == 1       # and the context still works
+
+
 def test_dropin_shim_from_reference_call_site(eng, tmp_path):
     """oracle/_ref/libbella_dropin.so = the reference's headers + its own HashSpGEMM call (main.cpp:498-525) compiled with
     bella_amd/host/bella_hip_shim.hpp: the call must land in libbella_hip.so and write the golden file."""
@@ -679,7 +711,7 @@ def test_counted_panels_equal_one_shot_assembly(eng):
 
 def test_half_size_key_tables_layout_bit_exact(eng, monkeypatch):
     """the LDS layout of pair-rich inputs (key tables of cap/2 slots, Gaux inside T2's upper half) on the multi-bin golden set"""
-    monkeypatch.setenv("BELLA_HIP_DCAP_HALF", "1")
+    eng.set_debug(16)
     for name in ("toyrep90", "toy120"):
         g = load_golden(name)
         eng.set_reads(g.rs)
