@@ -31,14 +31,17 @@ struct Buf {
     size_t cap = 0;
 };
 
-// Column tiers by product count: LDS tiers (one 512-thread workgroup per column, 14.5 B of LDS per product: <= 2752 products
-// keeps four workgroups on a CU, <= 3712 three; 11008 products x 14.5 B = the CU's whole 160 KB) and last the global-workspace
+// Column tiers by product count.  A column runs in one 512-thread workgroup with 14.5 B of LDS per product (19 B with the
+// half-size key tables of pair-rich inputs); tiers whose workgroups need the same share of a CU's 160 KB (1/4, 1/3, 1/2, all of
+// it) form one LDS class = ONE launch that walks its tiers' lists from the largest columns down.  Last: the global-workspace
 // tier.  BELLA_HIP_TIERS=a,b,c (read once per context; tuning aid / tests) overrides the LDS caps.
 constexpr uint32_t kNumTiers = 12;  // at most
-constexpr uint32_t kDefaultTiers = 9;
-const uint32_t kTierCapsDefault[kNumTiers] = {768, 1280, 2048, 3072, 4096, 6144, 8192, 11008, 65535};
-// pair-rich inputs (key tables of cap/2, 19 B of LDS per product): 2688 keeps four workgroups on a CU, 3328 three
-const uint32_t kTierCapsHalf[kNumTiers] = {768, 1280, 2048, 2688, 3328, 4096, 8192, 11008, 65535};
+constexpr uint32_t kDefaultTiers = 10;
+const uint32_t kTierCapsDefault[kNumTiers] = {768, 1280, 2048, 2752, 3712, 4600, 5568, 8192, 11008, 65535};
+const uint32_t kTierCapsHalf[kNumTiers] = {768, 1280, 2105, 2789, 3500, 4096, 6144, 8192, 11008, 65535};
+constexpr uint32_t kHalfTableMaxCap = 4096;              // above: quarter-size key tables on any input
+constexpr uint32_t kNumClasses = 4;
+const size_t kClassLds[kNumClasses] = {40160, 54608, 81920, 163840};   // 4, 3, 2, 1 workgroups per CU
 constexpr uint32_t kGlobalGrid = 1024;      // persistent workgroups of the global path: latency-bound, four per CU
 constexpr uint32_t kAsmGrid = 1024;
 
@@ -83,6 +86,9 @@ struct bella_ctx {
     // overlap
     uint64_t flops = 0, npairs = 0;
     uint32_t pair_ratio1024 = 1024;   // max over sampled columns of 1024 * pairs/products
+#ifdef BELLA_DEV_PROF
+    Buf prof;
+#endif
     Buf flopsr, flopptr, nnzC, colptrC, rowlists, tiercaps, tmp_pairs, tmp_ext, pairs, ext, sortscr, ws,
         status, cubtmp, plist_hv, overflow, ctl, retry;
     Buf w_f, w_off, w_key, w_key2, w_idx, w_idx2, w_hv, w_ovfl, w_plist, w_scr, w_rlen, w_rstart, w_rrank, w_segfirst,
@@ -97,10 +103,15 @@ struct bella_ctx {
     hipEvent_t ev[10]{};
     uint32_t* pinned = nullptr;          // 128 host words the per-pass read backs land in
     int caps_state = 0;
+    bool pass_known = false;             // tier lengths and product total of the last pass (valid for pass_sig)
+    uint64_t pass_sig[6] = {};
+    uint32_t pass_tcnt[16] = {};
+    uint64_t pass_products = 0;
+    uint32_t pass_retry = 0, pass_overflow = 0;
     uint32_t tier_caps[kNumTiers] = {};  // ascending LDS caps, last = 65535 (global-workspace tier); per context
     uint32_t ntiers = 0;
     bool tiers_from_env = false;
-    size_t lds_attr[8] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
+    size_t lds_attr[12] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
     hipStream_t side[kNumTiers + 1]{};   // independent tier launches / fold instances run concurrently
     hipEvent_t fork = nullptr, join[kNumTiers + 1]{};
 };
@@ -353,7 +364,15 @@ int bella_hip_init(int device, bella_ctx** out) {
     hipError_t he = hipSetDevice(device);
     if (he == hipSuccess) he = hipStreamCreate(&c->stream);
     for (auto& e : c->ev) if (he == hipSuccess) he = hipEventCreate(&e);
-    for (auto& st : c->side) if (he == hipSuccess) he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    {   // side streams 0 / 1 carry the classes of the largest columns: their workgroups go first whenever a CU has room
+        int least = 0, greatest = 0;
+        if (he == hipSuccess) he = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        int si = 0;
+        for (auto& st : c->side) {
+            if (he == hipSuccess) he = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, si < 2 ? greatest : least);
+            ++si;
+        }
+    }
     if (he == hipSuccess) he = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
     for (auto& e : c->join) if (he == hipSuccess) he = hipEventCreateWithFlags(&e, hipEventDisableTiming);
     if (he != hipSuccess) { bella_hip_destroy(c); return BELLA_ERR_HIP; }
@@ -1091,12 +1110,12 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     ENSURE(c, c->ctl, 4 * kCtlWords);
     ENSURE(c, c->ws, ws_stride * kGlobalGrid);
     ENSURE(c, c->retry, 4 * ((size_t)nr + 1));
-    size_t tb1 = 0;
-    {
-        hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> it(ptr<uint32_t>(c->flopsr), CastU64());
-        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, it, ptr<uint64_t>(c->flopptr), (int)nr + 1, c->stream));
+    {   // temp storage of the pass's one scan (colptrC), so that nothing is allocated between the kernels
+        size_t tb1 = 0;
+        hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> it(ptr<uint32_t>(c->nnzC), CastU64());
+        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, it, ptr<uint64_t>(c->colptrC), (int)nr + 1, c->stream));
+        ENSURE(c, c->cubtmp, tb1 + 256);
     }
-    ENSURE(c, c->cubtmp, tb1 + 256);
 
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     uint32_t caps[kNumTiers] = {};
@@ -1136,20 +1155,28 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     k_tier_lists<<<nblk(nown ? nown : 1), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, i0, c->part_stride, nown, ptr<uint32_t>(c->tiercaps), g_ntiers,
                                                   ptr<uint32_t>(c->Bptr), ptr<uint64_t>(c->roff), ptr<uint4>(c->rowlists),
                                                   (uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr), d_ctl + kCtlTierCnt,
-                                                  (unsigned long long*)(d_ctl + kCtlTotals) + 1);
+                                                  (unsigned long long*)(d_ctl + kCtlTotals) + 1, ptr<uint64_t>(c->flopptr));
     KCHK(c);
-    // the one host round trip before the row kernels: the tiers' lengths (exact grids) and the product total, 64 bytes into
-    // pinned memory; the prefix sums the row kernels need (overlap.hpp:110-146) run on the device meanwhile
-    uint32_t* const tcnt = c->pinned;
-    HIPCHK(c, hipMemcpyAsync(tcnt, d_ctl + kCtlTierCnt, 4 * (kCtlTotals + 4 - kCtlTierCnt), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
-    int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->flopsr), ptr<uint64_t>(c->flopptr), (uint64_t)nr + 1);
-    if (rc) return rc;
-    HIPCHK(c, hipEventSynchronize(c->ev[9]));
+    // The host needs two things from the symbolic kernels before it can launch the row kernels: the tiers' lengths (exact grids)
+    // and the product total (buffer sizes).  Both are functions of the operands, the partition and the stage only, so they are
+    // read back (96 bytes into pinned memory, one host round trip) the first time a pass runs on them and remembered; later
+    // passes on the same operands enqueue everything without waiting.  The final control block is checked against them.
+    const uint64_t psig[6] = {c->layout_gen, ((uint64_t)c->part_first << 32) | c->part_stride, ((uint64_t)c->range_lo << 32) | c->range_hi, nr,
+                              (uint64_t)want_state, (uint64_t)g_ntiers};
+    const bool warm = c->pass_known && std::memcmp(psig, c->pass_sig, sizeof(psig)) == 0;
+    uint32_t* const tcnt = c->pass_tcnt;
+    if (!warm) {
+        c->pass_known = false;
+        HIPCHK(c, hipMemcpyAsync(c->pinned, d_ctl + kCtlTierCnt, 4 * (kCtlTotals + 4 - kCtlTierCnt), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(c->pass_tcnt, c->pinned, sizeof(c->pass_tcnt));
+        std::memcpy(&c->pass_products, c->pinned + (kCtlTotals - kCtlTierCnt) + 2, 8);
+        std::memcpy(c->pass_sig, psig, sizeof(psig));
+    }
     // the product-sized buffers follow THIS pass's product count (a column partition or a stage only pays for its share; the
     // reference sizes its stages from the same number, overlap.hpp:365-404,682-710); they only ever grow
-    uint64_t Fub = 0;
-    std::memcpy(&Fub, c->pinned + (kCtlTotals - kCtlTierCnt) + 2, 8);
+    const uint64_t Fub = c->pass_products;
+    int rc = 0;
     ENSURE(c, c->tmp_pairs, sizeof(bella_pair) * Fub);
     if (want_ext) ENSURE(c, c->tmp_ext, sizeof(bella_pair_ext) * Fub);
     ENSURE(c, c->plist_hv, 8 * Fub);
@@ -1166,6 +1193,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     a.roff = ptr<uint64_t>(c->roff);
     a.packed = ptr<uint32_t>(c->packed);
     a.flopptr = ptr<uint64_t>(c->flopptr);
+    a.flops = ptr<uint32_t>(c->flopsr);
     a.tmp_pairs = ptr<bella_pair>(c->tmp_pairs);
     a.tmp_ext = want_ext ? ptr<bella_pair_ext>(c->tmp_ext) : nullptr;
     a.nnzC = ptr<uint32_t>(c->nnzC);
@@ -1180,62 +1208,128 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     a.k = p->kmer_size;
     a.binSize = p->bin_size;
     a.inject_unordered = (c->debug & 4u) ? 1 : 0;
+#ifdef BELLA_DEV_PROF
+    ENSURE(c, c->prof, 8 * 10 * kNumTiers);
+    HIPCHK(c, hipMemsetAsync(c->prof.p, 0, 8 * 10 * kNumTiers, c->stream));
+    a.prof = nullptr;
+#endif
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     uint32_t launches = 0;
-    // the tiers are independent persistent launches of the same kernel with different LDS budgets, forked onto side streams
-    // (largest columns first) so that they run concurrently; their column counts stay on the device
-    // The tier launched last (the smallest columns: it also finishes last) goes on the main stream itself, so the kernels that
-    // follow need no cross-stream hand-over at the end; the waits for the side streams are enqueued after it.
-    HIPCHK(c, hipEventRecord(c->fork, c->stream));
-    int last_tier = -1;
-    for (int t = 0; t < (int)g_ntiers; ++t) if (tcnt[t]) { last_tier = t; break; }
-    bool joined[kNumTiers] = {};
-    for (int t = (int)g_ntiers - 1; t >= 0; --t) {
-        if (!tcnt[t]) continue;
-        const bool on_main = t == last_tier;
-        hipStream_t sst = on_main ? c->stream : c->side[t];
-        if (!on_main) HIPCHK(c, hipStreamWaitEvent(sst, c->fork, 0));
-        a.rowlist = nullptr;
-        a.rowdesc = ptr<uint4>(c->rowlists) + (size_t)t * nr;
-        a.nrows = tcnt[t];
-        a.nrows_dev = nullptr;
-        a.cap = tier_caps[t];
-        // sampled pairs/products below 1/5: quarter-size key tables; the big tiers (one workgroup per CU) always
-        a.dcap = (!half_tables || a.cap > 4096) ? a.cap / 4 : a.cap / 2;
-        if ((c->debug & 16u) && a.cap <= 4096) a.dcap = a.cap / 2;                  // tests: the half-size layout on any input
-        if (t + 1 < (int)g_ntiers) {
-            const size_t lds = row_mem_bytes(a.cap, a.dcap, true);
-            const bool ga = gaux_in_t2(a.cap, a.dcap, true);
-            const int ki = a.cap <= 8 * kRowBlock ? (ga ? 0 : 1) : a.cap <= 16 * kRowBlock ? (ga ? 2 : 3) : 4;
-            void (*kern)(SpgemmArgs) = ki == 0 ? k_spgemm_rows_lds<8, true> : ki == 1 ? k_spgemm_rows_lds<8, false>
-                                     : ki == 2 ? k_spgemm_rows_lds<16, true> : ki == 3 ? k_spgemm_rows_lds<16, false> : k_spgemm_rows_lds<22, false>;
-            if (lds > c->lds_attr[ki]) {                         // once per kernel and size, not per launch
-                HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                c->lds_attr[ki] = lds;
-            }
-            kern<<<tcnt[t], kRowBlock, lds, sst>>>(a);
-        } else {
-            const unsigned grid = tcnt[t] < kGlobalGrid ? tcnt[t] : kGlobalGrid;
-            k_spgemm_rows_global<<<grid, kRowBlock, 0, sst>>>(a);
+    // LDS classes: consecutive tiers whose workgroups take the same share of a CU; one launch per class (largest class first, on
+    // side streams so that the classes overlap; the class of the smallest columns, which finishes last, on the main stream), and
+    // the global-workspace tier.
+    auto dcap_of = [&](uint32_t cap) -> uint32_t {
+        const bool half = (half_tables || (c->debug & 16u)) && cap <= kHalfTableMaxCap;     // debug bit 4: tests
+        return half ? cap / 2 : cap / 4;
+    };
+    struct Launch { int lo, hi; size_t lds; uint32_t rows; };
+    Launch ln[kNumTiers];
+    int nl = 0;
+    {
+        int cls_prev = -1;
+        for (int t = 0; t + 1 < (int)g_ntiers; ++t) {
+            const size_t lds = row_mem_bytes(tier_caps[t], dcap_of(tier_caps[t]), true);
+            int cls = (int)kNumClasses - 1;
+            for (int k2 = 0; k2 < (int)kNumClasses; ++k2)
+                if (lds <= kClassLds[k2]) { cls = k2; break; }
+            if (cls != cls_prev || nl == 0) { ln[nl++] = Launch{t, t, lds, 0}; cls_prev = cls; }
+            ln[nl - 1].hi = t;
+            ln[nl - 1].lds = lds;                                 // the class is carved for its largest tier
+            ln[nl - 1].rows += tcnt[t];
         }
+    }
+    // Streams: at most four run concurrently on this device (hardware queues), and a workgroup of the whole-CU class only starts
+    // on an EMPTY CU: next to the small classes it starves until they are done.  So the whole-CU class (few columns, if any) runs
+    // first, alone, on the main stream; then the half-CU class goes to side stream 0, the third-of-a-CU class to side stream 1,
+    // the global-workspace tier to side stream 2, and the class of the smallest columns (it finishes last) stays on the main stream.
+    int main_l = -1;
+    for (int l = 0; l < nl; ++l) if (ln[l].rows) { main_l = l; break; }
+    const bool global_tier = tcnt[g_ntiers - 1] != 0;
+    bool used[3] = {};
+    bool forked = false;
+    auto side_stream = [&](int which) -> int {                    // first use: make the stream wait for what the main stream did so far
+        if (!forked) { HIPCHK(c, hipEventRecord(c->fork, c->stream)); forked = true; }
+        if (!used[which]) { HIPCHK(c, hipStreamWaitEvent(c->side[which], c->fork, 0)); used[which] = true; }
+        return 0;
+    };
+    a.rowlist = nullptr;
+    a.nrows_dev = nullptr;
+    a.nreads = nr;
+    int nside = 0;                                                // classes launched off the main stream so far
+    auto launch_class = [&](int l, bool on_main) -> int {
+        hipStream_t sst = c->stream;
+        if (!on_main) {
+            const int which = nside < 1 ? 0 : 1;
+            int r2 = side_stream(which);
+            if (r2) return r2;
+            sst = c->side[which];
+            nside++;
+        }
+        a.rowlist = nullptr;
+        a.nrows_dev = nullptr;
+        a.rowdesc = ptr<uint4>(c->rowlists);
+        a.tier_lo = (uint32_t)ln[l].lo;
+        a.tier_hi = (uint32_t)ln[l].hi;
+        a.nrows = ln[l].rows;
+        a.cap = tier_caps[ln[l].hi];
+        a.dcap = dcap_of(a.cap);
+        const size_t lds = ln[l].lds;
+        const bool ga = gaux_in_t2(a.cap, a.dcap, true);
+        // classes with one or two columns per CU: 1024 threads per column, so that the CU's 32 wavefront slots stay filled
+        const bool big_block = lds > kClassLds[1] && !(c->debug & 8u);
+        int ki;
+        void (*kern)(SpgemmArgs);
+        if (!big_block) {
+            ki = a.cap <= 8 * 512 ? (ga ? 0 : 1) : a.cap <= 16 * 512 ? (ga ? 2 : 3) : 4;
+            kern = ki == 0 ? k_spgemm_rows_lds<8, true, 512> : ki == 1 ? k_spgemm_rows_lds<8, false, 512>
+                 : ki == 2 ? k_spgemm_rows_lds<16, true, 512> : ki == 3 ? k_spgemm_rows_lds<16, false, 512> : k_spgemm_rows_lds<22, false, 512>;
+        } else {
+            ki = a.cap <= 4 * 1024 ? (ga ? 5 : 6) : a.cap <= 8 * 1024 ? (ga ? 7 : 8) : 9;
+            kern = ki == 5 ? k_spgemm_rows_lds<4, true, 1024> : ki == 6 ? k_spgemm_rows_lds<4, false, 1024>
+                 : ki == 7 ? k_spgemm_rows_lds<8, true, 1024> : ki == 8 ? k_spgemm_rows_lds<8, false, 1024> : k_spgemm_rows_lds<11, false, 1024>;
+        }
+        if (lds > c->lds_attr[ki]) {                             // once per kernel and size, not per launch
+            HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            c->lds_attr[ki] = lds;
+        }
+#ifdef BELLA_DEV_PROF
+        a.prof = (unsigned long long*)c->prof.p + 10 * l;
+#endif
+        kern<<<ln[l].rows, big_block ? 1024 : 512, lds, sst>>>(a);
+#ifdef BELLA_DEV_PROF
+        a.prof = nullptr;
+#endif
         KCHK(c);
-        if (!on_main) { HIPCHK(c, hipEventRecord(c->join[t], sst)); joined[t] = true; }
+        launches++;
+        return 0;
+    };
+    auto whole_cu = [&](int l) { return 2 * ln[l].lds > kClassLds[kNumClasses - 1]; };
+    for (int l = nl - 1; l >= 0; --l)
+        if (ln[l].rows && whole_cu(l) && l != main_l) { rc = launch_class(l, true); if (rc) return rc; }
+    if (global_tier) {                                            // the columns above the LDS tiers (or all of them: debug bit 0)
+        hipStream_t sst = c->stream;
+        if (main_l >= 0) { rc = side_stream(2); if (rc) return rc; sst = c->side[2]; }
+        a.rowdesc = ptr<uint4>(c->rowlists) + (size_t)(g_ntiers - 1) * nr;
+        a.nrows = tcnt[g_ntiers - 1];
+        a.cap = tier_caps[g_ntiers - 1];
+        a.dcap = a.cap;
+        const unsigned grid = a.nrows < kGlobalGrid ? a.nrows : kGlobalGrid;
+        k_spgemm_rows_global<<<grid, kRowBlock, 0, sst>>>(a);
+        KCHK(c);
         launches++;
     }
-    for (int t = 0; t < (int)g_ntiers; ++t)
-        if (joined[t]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[t], 0));
-    // columns whose pair count overflowed an LDS tier's key table (list and count produced on the device)
-    a.rowlist = ptr<uint32_t>(c->retry);
-    a.rowdesc = nullptr;
-    a.nrows_dev = ptr<uint32_t>(c->ctl) + kCtlRetry;
-    k_spgemm_rows_global<<<kGlobalGrid, kRowBlock, 0, c->stream>>>(a);
-    KCHK(c);
-    c->n_wide = tcnt[g_ntiers];
-    if (c->n_wide) {                                              // columns with >= 65536 products (wide.hpp); rare, host-driven
-        rc = run_wide(c, a, c->n_wide, (const uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr));
-        if (rc) return rc;
-    }
-    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    for (int l = nl - 1; l >= 0; --l)
+        if (ln[l].rows && (!whole_cu(l) || l == main_l)) { rc = launch_class(l, l == main_l); if (rc) return rc; }
+    for (int w = 0; w < 3; ++w)
+        if (used[w]) {
+            HIPCHK(c, hipEventRecord(c->join[w], c->side[w]));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[w], 0));
+        }
+    // Rarely needed kernels: the rerun of columns whose pair count overflowed an LDS tier's key table or whose lists came out of
+    // order (list and count produced on the device), and the serial fold of pairs with > 16 final bins.  Whether a pass needs them
+    // is again a function of the operands: a warm pass whose predecessor needed neither leaves them out and checks the counters
+    // in the final control block (and runs them after all, plus a second compaction, should they be non-zero).
+    const bool skip_rare = warm && c->pass_retry == 0 && c->pass_overflow == 0 && !(c->debug & 4u);
     FoldArgs fa;
     fa.ctl = a.ctl;
     fa.overflow = a.overflow;
@@ -1248,28 +1342,54 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     fa.sort_scratch = ptr<uint16_t>(c->sortscr);
     fa.k = a.k;
     fa.binSize = a.binSize;
-    // the row kernels fold every pair themselves; only pairs that end with > 16 bins are left (their count stays on the device)
-    k_fold_overflow<<<256, 64, 0, c->stream>>>(fa);
-    KCHK(c);
-    HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
-    rc = scan_u32_to_u64(c, ptr<uint32_t>(c->nnzC), ptr<uint64_t>(c->colptrC), (uint64_t)nr + 1);
-    if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-    if (nr) {
-        k_compact_pairs<<<nblk(nown ? nown : 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint64_t>(c->flopptr), ptr<uint64_t>(c->colptrC),
-                                                                    ptr<uint32_t>(c->nnzC), nr, i0, c->part_stride, nown,
-                                                                    ptr<bella_pair>(c->tmp_pairs),
-                                                                    want_ext ? ptr<bella_pair_ext>(c->tmp_ext) : nullptr,
-                                                                    ptr<bella_pair>(c->pairs),
-                                                                    want_ext ? ptr<bella_pair_ext>(c->ext) : nullptr,
-                                                                    (uint64_t*)(d_ctl + kCtlTotals));
+    auto rerun_columns = [&]() -> int {
+        a.rowlist = ptr<uint32_t>(c->retry);
+        a.rowdesc = nullptr;
+        a.nrows_dev = ptr<uint32_t>(c->ctl) + kCtlRetry;
+        k_spgemm_rows_global<<<kGlobalGrid, kRowBlock, 0, c->stream>>>(a);
         KCHK(c);
-    }
-    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
-    // the pass's only host round trip: counters, totals and status
+        return 0;
+    };
     uint32_t* const ctl_host = c->pinned + 32;
-    HIPCHK(c, hipMemcpyAsync(ctl_host, d_ctl, 4 * kCtlWords, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto finish = [&]() -> int {                                  // colptrC, compaction, the pass's host round trip
+        int r2 = scan_u32_to_u64(c, ptr<uint32_t>(c->nnzC), ptr<uint64_t>(c->colptrC), (uint64_t)nr + 1);
+        if (r2) return r2;
+        HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+        if (nr) {
+            k_compact_pairs<<<nblk(nown ? nown : 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint64_t>(c->flopptr), ptr<uint64_t>(c->colptrC),
+                                                                        ptr<uint32_t>(c->nnzC), nr, i0, c->part_stride, nown,
+                                                                        ptr<bella_pair>(c->tmp_pairs),
+                                                                        want_ext ? ptr<bella_pair_ext>(c->tmp_ext) : nullptr,
+                                                                        ptr<bella_pair>(c->pairs),
+                                                                        want_ext ? ptr<bella_pair_ext>(c->ext) : nullptr,
+                                                                        (uint64_t*)(d_ctl + kCtlTotals));
+            KCHK(c);
+        }
+        HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+        HIPCHK(c, hipMemcpyAsync(ctl_host, d_ctl, 4 * kCtlWords, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    };
+    if (!skip_rare) { rc = rerun_columns(); if (rc) return rc; }
+    c->n_wide = tcnt[g_ntiers];
+    if (c->n_wide) {                                              // columns with >= 65536 products (wide.hpp); rare, host-driven
+        rc = run_wide(c, a, c->n_wide, (const uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr));
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    // the row kernels fold every pair themselves; only pairs that end with > 16 bins are left (their count stays on the device)
+    if (!skip_rare) { k_fold_overflow<<<256, 64, 0, c->stream>>>(fa); KCHK(c); }
+    HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
+    rc = finish();
+    if (rc) return rc;
+    if (skip_rare && (ctl_host[kCtlRetry] || ctl_host[kCtlOverflow])) {
+        rc = rerun_columns();
+        if (rc) return rc;
+        k_fold_overflow<<<256, 64, 0, c->stream>>>(fa);
+        KCHK(c);
+        rc = finish();
+        if (rc) return rc;
+    }
     uint64_t P = 0, F = 0;
     std::memcpy(&P, ctl_host + kCtlTotals, 8);
     std::memcpy(&F, ctl_host + kCtlTotals + 2, 8);
@@ -1280,14 +1400,36 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     c->n_retry = ctl_host[kCtlRetry];
     c->npairs = P;
     c->flops = F;
-    if (F > Fub) return fail(c, BELLA_ERR_STATE, "internal: product total %llu differs from the symbolic pass (%llu)",
-                             (unsigned long long)F, (unsigned long long)Fub);
+    if (F != Fub || std::memcmp(ctl_host + kCtlTierCnt, tcnt, 4 * (g_ntiers + 1)) != 0) {
+        c->pass_known = false;
+        return fail(c, BELLA_ERR_STATE, "internal: product total %llu / tier lengths differ from the ones the pass was sized with (%llu)",
+                    (unsigned long long)F, (unsigned long long)Fub);
+    }
+    c->pass_known = true;
+    c->pass_retry = c->n_retry;
+    c->pass_overflow = c->n_overflow;
     c->tm.symbolic_ms = ev_ms(c->ev[2], c->ev[3]);
     c->tm.spgemm_ms = ev_ms(c->ev[4], c->ev[5]);
     c->tm.fold_ms = ev_ms(c->ev[5], c->ev[8]);
     c->tm.compact_ms = ev_ms(c->ev[6], c->ev[7]);
     c->tm.overlap_total_ms = ev_ms(c->ev[2], c->ev[7]);
     c->tm.spgemm_launches = launches;
+#ifdef BELLA_DEV_PROF
+    {
+        unsigned long long ph[10 * kNumTiers];
+        HIPCHK(c, hipMemcpy(ph, c->prof.p, sizeof(ph), hipMemcpyDeviceToHost));
+        static const char* nm[9] = {"expand", "gather+insert", "slot-order", "ranks+singles", "scatter", "rank/overlay", "parents", "walks", "emit"};
+        for (int l = 0; l < nl; ++l) {
+            const unsigned long long* q = ph + 10 * l;
+            if (!q[9]) continue;
+            double tot = 1e-9;
+            for (int n = 0; n < 9; ++n) tot += (double)q[n];
+            fprintf(stderr, "[bella_hip prof] class cap %u (%llu columns, %.0f cycles each):", tier_caps[ln[l].hi], q[9], tot / (double)q[9]);
+            for (int n = 0; n < 9; ++n) fprintf(stderr, " %s %.1f%%", nm[n], 100.0 * (double)q[n] / tot);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     return 0;
 }
 

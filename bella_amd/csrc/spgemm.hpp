@@ -47,8 +47,8 @@ constexpr uint32_t kScatterChunk = 64;                    // phase S appends one
 #ifndef BELLA_ROW_BLOCK
 #define BELLA_ROW_BLOCK 512
 #endif
-constexpr int kRowBlock = BELLA_ROW_BLOCK;                // threads per output column in the row kernels
-constexpr int kRowWaves = kRowBlock / 64;
+constexpr int kRowBlock = BELLA_ROW_BLOCK;                // threads per output column in the row kernels (1024 in the classes that hold
+                                                          // one or two columns per CU: the CU's 32 wavefront slots stay filled)
 // control block (u32 words) zeroed before every pass
 constexpr uint32_t kCtlOverflow = 17;     // overflow list length
 constexpr uint32_t kCtlWork2 = 18;        // k_fold_overflow counter
@@ -63,12 +63,15 @@ struct SpgemmArgs {
     const uint4* rowdesc;        // ... or their descriptors {column, first B' entry, entries | read length << 16, -} (tier launches):
                                  // one load instead of a chain of three before the first B' entry can be fetched
     uint32_t nrows;
+    uint32_t tier_lo, tier_hi;   // class launches: the tiers tier_hi .. tier_lo (big columns first); their lists are nreads apart
+    uint32_t nreads;
     const uint32_t* Bptr;
     const uint2* Bent;
     const uint2* Aent;
     const uint64_t* roff;
     const uint32_t* packed;
-    const uint64_t* flopptr;     // exclusive scan of per-column products: temporary output / list offsets
+    const uint64_t* flopptr;     // where a column's temporary output / product lists start: flops[i] slots, handed out by k_tier_lists
+    const uint32_t* flops;       // products per column (estimateFLOP)
     bella_pair* tmp_pairs;
     bella_pair_ext* tmp_ext;
     uint32_t* nnzC;
@@ -83,6 +86,9 @@ struct SpgemmArgs {
     uint32_t dcap;               // LDS tiers: pairs (distinct keys) the tier holds: cap/4 or cap/2
     int k;
     int binSize;
+#ifdef BELLA_DEV_PROF
+    unsigned long long* prof;    // development builds only: 10 counters per launch (phase cycles of wavefront 0, columns)
+#endif
     int inject_unordered;        // tests: pretend every fifth column's lists came out of order in phase S (exercises the fallback)
 };
 
@@ -138,10 +144,18 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dc
 }
 
 // returns false if the key table overflowed (no global side effect happened yet; the caller queues the column again)
-template <bool OVERLAY, uint32_t NX, bool GALIAS>
+template <bool OVERLAY, uint32_t NX, bool GALIAS, int BLK = BELLA_ROW_BLOCK>
 __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t i, const uint32_t b0, const uint32_t n, const uint32_t lenV,
                                             const RowMem& m) {
+    constexpr int kRowBlock = BLK;                            // threads of this workgroup
+    constexpr int kRowWaves = BLK / 64;
     const uint32_t tid = threadIdx.x;
+#ifdef BELLA_DEV_PROF                                          // development builds only (tools/prof_build.sh): wavefront 0's clock per phase
+    long long tc_ = clock64();
+#define BELLA_BPROF(n) { const long long t2_ = clock64(); if (tid == 0 && a.prof) atomicAdd(a.prof + (n), (unsigned long long)(t2_ - tc_)); tc_ = clock64(); }
+#else
+#define BELLA_BPROF(n)
+#endif
     const uint32_t H1 = m.dcap;
     uint32_t* s_d = m.scr + 48;
     uint32_t* s_fail = m.scr + 49;
@@ -185,6 +199,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     }
     const uint32_t F = running;
     __syncthreads();
+    BELLA_BPROF(0)
     // X3: product-parallel gather of the A' entries (balanced: every lane has work; four independent loads in flight)
     for (uint32_t base = 0; base < F; base += 4 * kRowBlock) {
         uint2 ae[4];
@@ -227,6 +242,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
+    BELLA_BPROF(1)
     if (*s_fail) return false;
     const uint32_t d = *s_d;
 
@@ -248,6 +264,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
+    BELLA_BPROF(2)
     // Single-product pairs (multiop only: count 1, one bin, seed = the k-mer; 47 % of the pairs at 10k reads, 92 % at 100k) are
     // finished right here, at their rank, from the product-order arrays; only the other pairs get a list.
     const uint64_t obase = a.flopptr[i];
@@ -292,6 +309,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
+    BELLA_BPROF(3)
 
     // ---- S: product indices into per-pair lists.  Wavefront 0 appends 64 products at a time in product order (LDS
     // atomics of one wavefront execute in program order), so a list is ordered ACROSS 64-product chunks and only
@@ -317,6 +335,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
+    BELLA_BPROF(4)
 
     // ---- R: exact rank of every product inside its pair's list (global path: list position corrected by the chunk-mates on
     // the wrong side; LDS tiers: checked) and the lists in rank order: L_hv / L_gov. -------------------------------------------------------------
@@ -377,6 +396,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
+    BELLA_BPROF(5)
 
     // ---- P: the fold, in parallel.  chainop (chain.hpp:100-150) on a pair's products in order has a closed form:
     //  * every product t opens a bin with overlap ov_t and itself as first position; a bin lives, unchanged, until the first
@@ -418,6 +438,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         Par[y] = (par_t)par;
     }
     __syncthreads();
+    BELLA_BPROF(6)
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     const us2 kk2 = {(unsigned short)a.k, (unsigned short)a.k};
     const us2 lim2 = {(unsigned short)(2 * a.k + 1), (unsigned short)(2 * a.k + 1)};
@@ -489,6 +510,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
+    BELLA_BPROF(7)
 
     // ---- E: one record per pair --------------------------------------------------------------------------------------
     for (uint32_t r = tid; r < d; r += kRowBlock) {
@@ -533,18 +555,28 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     if (tid == 0) a.nnzC[i] = d;
+    BELLA_BPROF(8)
+#ifdef BELLA_DEV_PROF
+    if (tid == 0 && a.prof) atomicAdd(a.prof + 9, 1ull);
+#endif
+#undef BELLA_BPROF
     return true;
 }
 
 // LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap, dcap); NX * 512 >= cap (8: the tiers up to 4096 products,
 // 16: the two big tiers that keep HiFi-like columns with long lists off the global path)
-template <uint32_t NX, bool GALIAS>
-__global__ __launch_bounds__(kRowBlock, (NX <= 8 ? 6 : 2)) void k_spgemm_rows_lds(SpgemmArgs a) {
+template <uint32_t NX, bool GALIAS, int BLK = BELLA_ROW_BLOCK>
+__global__ __launch_bounds__(BLK, (BLK == 1024 ? (NX <= 4 ? 8 : 4) : (NX <= 8 ? 6 : 2))) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint4 ds = a.rowdesc[blockIdx.x];
+    // the launch covers the tiers of one LDS class, largest columns first: workgroup x -> (tier, place in the tier's list)
+    const uint32_t* tc = a.ctl + kCtlTierCnt;
+    uint32_t x = blockIdx.x, t = a.tier_hi;
+    while (t > a.tier_lo && x >= tc[t]) { x -= tc[t]; --t; }
+    if (x >= tc[t]) return;
+    const uint4 ds = a.rowdesc[(size_t)t * a.nreads + x];
     const uint32_t i = ds.x;
     const RowMem m = carve<GALIAS>(smem, a.cap, a.dcap, true);
-    if (!process_row<true, NX, GALIAS>(a, i, ds.y, ds.z & 0xFFFFu, ds.z >> 16, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
+    if (!process_row<true, NX, GALIAS, BLK>(a, i, ds.y, ds.z & 0xFFFFu, ds.z >> 16, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
 }
 
 // Global-workspace path: columns with more products than the largest LDS tier (< 65536), and -- second launch, list and
@@ -554,7 +586,7 @@ __global__ __launch_bounds__(kRowBlock) void k_spgemm_rows_global(SpgemmArgs a) 
     const uint32_t nrows = a.nrows_dev ? *a.nrows_dev : a.nrows;
     for (uint32_t x = blockIdx.x; x < nrows; x += gridDim.x) {
         const uint32_t i = a.rowdesc ? a.rowdesc[x].x : a.rowlist[x];
-        uint32_t f = (uint32_t)(a.flopptr[i + 1] - a.flopptr[i]);
+        uint32_t f = a.flops[i];
         if (f < 16u) f = 16u;                             // T2 needs >= 16 slots
         const RowMem m = carve<false>(ws, f, f, false);
         const uint32_t b0 = a.Bptr[i];
@@ -675,7 +707,7 @@ __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, cons
 __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, uint32_t nreads, uint32_t i0, uint32_t stride, uint32_t nown,
                                                        const uint32_t* caps, uint32_t ntiers,
                                                        const uint32_t* Bptr, const uint64_t* roff, uint4* desc, uint32_t* widelist,
-                                                       uint32_t* counts, unsigned long long* total) {
+                                                       uint32_t* counts, unsigned long long* total, uint64_t* obase) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;      // the j-th column of this context
     const uint32_t i = i0 + j * stride;
     const uint32_t f = j < nown ? flops[i] : 0u;
@@ -692,15 +724,21 @@ __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, ui
     // One global atomic per tier and WORKGROUP (a few hot counters serve all columns): the wavefronts first reserve their places
     // inside the workgroup in LDS.
     __shared__ uint32_t s_cnt[16], s_base[16];
-    __shared__ unsigned long long s_tot;
     if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_tot = 0;
     __syncthreads();
-    {                                                      // the pass's product total (sizes the product buffers on the host)
-        unsigned long long fs = f;
+    {   // temporary output space of the column (f slots; prefixsum of overlap.hpp:110-146 in spirit: any disjoint placement does,
+        // the final order comes from colptrC): one atomic per wavefront on the pass's product total, which sizes the buffers
+        unsigned long long inc = f;
 #pragma unroll
-        for (int dlt = 32; dlt > 0; dlt >>= 1) fs += __shfl_xor(fs, dlt, 64);
-        if (lane_id() == 0 && fs) atomicAdd(&s_tot, fs);
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const unsigned long long t = __shfl_up(inc, dlt, 64);
+            if ((int)lane_id() >= dlt) inc += t;
+        }
+        const unsigned long long tot = __shfl(inc, 63, 64);
+        unsigned long long base = 0;
+        if (lane_id() == 0 && tot) base = atomicAdd(total, tot);
+        base = __shfl(base, 0, 64);
+        if (j < nown) obase[i] = base + inc - f;
     }
     uint32_t my = 0;                                       // place inside the workgroup's share of my tier's list
     for (uint32_t t = 0; t <= ntiers; ++t) {
@@ -713,7 +751,6 @@ __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, ui
     }
     __syncthreads();
     if (threadIdx.x <= ntiers && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
-    if (threadIdx.x == 0 && s_tot) atomicAdd(total, s_tot);
     __syncthreads();
     if (tier != 0xFFFFFFFFu) {
         const uint32_t o = s_base[tier] + my;
@@ -727,7 +764,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_pairs(const uint64_t* floppt
                                                           const bella_pair* tmp_pairs, const bella_pair_ext* tmp_ext,
                                                           bella_pair* pairs, bella_pair_ext* ext, uint64_t* totals) {
     const uint32_t j = blockIdx.x * kWaves + wave_id();       // the j-th column of this context (the others are empty)
-    if (j == 0 && lane_id() == 0) { totals[0] = colptrC[nreads]; totals[1] = flopptr[nreads]; }   // nnz(C), products: read back once
+    if (j == 0 && lane_id() == 0) totals[0] = colptrC[nreads];   // nnz(C): read back once with the control block (totals[1] = products, k_tier_lists)
     if (j >= nown) return;
     const uint32_t i = i0 + j * stride;
     const uint32_t cnt = nnzC[i];
