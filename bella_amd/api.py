@@ -166,6 +166,25 @@ class Engine:
         return (t(pc.value, rows.value, "<i4", torch.int32), t(pr.value, nnz.value, "<i4", torch.int32),
                 t(pv.value, nnz.value, "<i2", torch.int16))
 
+    # ---- multi-GPU: the library's own RCCL communicator (include/bella_hip.h) ----
+    def comm_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = self.lib.bella_hip_comm_id(buf)
+        if rc:
+            raise BellaHipError(rc, "librccl could not be loaded")
+        return buf.raw
+
+    def comm_init(self, nranks: int, rank: int, comm_id: bytes):
+        buf = C.create_string_buffer(bytes(comm_id), 128)
+        self._chk(self.lib.bella_hip_comm_init(self.h, nranks, rank, buf))
+
+    def comm_destroy(self):
+        self._chk(self.lib.bella_hip_comm_destroy(self.h))
+
+    def allgather_panels(self):
+        """collective: every rank's row block of B -> the whole matrix on every rank, device layout built"""
+        self._chk(self.lib.bella_hip_allgather_panels(self.h))
+
     def set_B_device(self, k, nkmers, colptr_t, rowids_t, values_t):
         """full B from torch device tensors (int32 colptr[nreads+1], int32 rowids, int16 values)"""
         nnz = int(rowids_t.numel())

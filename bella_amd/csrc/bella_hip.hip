@@ -13,6 +13,7 @@
 
 #include "../../include/bella_hip.h"
 #include "assemble.hpp"
+#include "comm.hpp"
 #include "core.hpp"
 #include "fastq.hpp"
 #include "kcount.hpp"
@@ -103,6 +104,9 @@ struct bella_ctx {
     hipEvent_t ev[10]{};
     uint32_t* pinned = nullptr;          // 128 host words the per-pass read backs land in
     int caps_state = 0;
+    ncclComm_t comm = nullptr;           // RCCL communicator of bella_hip_comm_init (one rank per context)
+    int comm_ranks = 0, comm_rank = 0;
+    Buf comm_meta;
     bool pass_known = false;             // tier lengths and product total of the last pass (valid for pass_sig)
     uint64_t pass_sig[6] = {};
     uint32_t pass_tcnt[16] = {};
@@ -387,6 +391,8 @@ void bella_hip_destroy(bella_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
+    release(c->comm_meta);
     Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Bcnt, &c->Aent, &c->t_kmer, &c->t_read, &c->t_pos,
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->Brow, &c->deg, &c->minread, &c->colstart,
                   &c->fill, &c->ori, &c->w, &c->wscan, &c->Atmp, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC,
@@ -969,6 +975,122 @@ int bella_hip_set_B_device(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, co
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev[1]));
     c->tm.assemble_ms = ev_ms(c->ev[0], c->ev[1]);
+    return 0;
+}
+
+// ---- multi-GPU: RCCL communicator + panel all-gather -------------------------------------------------------------------------
+#define NCCLCHK(c, call)                                                                                          \
+    do {                                                                                                          \
+        ncclResult_t r_ = (call);                                                                                 \
+        if (r_ != ncclSuccess)                                                                                    \
+            return fail(c, BELLA_ERR_HIP, "%s failed: %s", #call, rccl().GetErrorString ? rccl().GetErrorString(r_) : "RCCL error"); \
+    } while (0)
+
+int bella_hip_comm_id(uint8_t id[BELLA_HIP_COMM_ID_BYTES]) {
+    if (!id) return BELLA_ERR_BAD_ARG;
+    if (!rccl().ok()) return BELLA_ERR_STATE;
+    ncclUniqueId u;
+    static_assert(sizeof(u) == BELLA_HIP_COMM_ID_BYTES, "ncclUniqueId size");
+    if (rccl().GetUniqueId(&u) != ncclSuccess) return BELLA_ERR_HIP;
+    std::memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+int bella_hip_comm_init(bella_ctx* c, int nranks, int rank, const uint8_t id[BELLA_HIP_COMM_ID_BYTES]) {
+    if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, BELLA_ERR_BAD_ARG, "bad communicator arguments");
+    if (!rccl().ok()) return fail(c, BELLA_ERR_STATE, "librccl could not be loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    NCCLCHK(c, rccl().CommInitRank(&c->comm, nranks, u, rank));
+    c->comm_ranks = nranks;
+    c->comm_rank = rank;
+    return 0;
+}
+
+int bella_hip_comm_destroy(bella_ctx* c) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
+    c->comm_ranks = 0;
+    return 0;
+}
+
+int bella_hip_allgather_panels(bella_ctx* c) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    if (!c->comm) return fail(c, BELLA_ERR_STATE, "bella_hip_comm_init first");
+    if (!c->have_panel) return fail(c, BELLA_ERR_STATE, "assemble_panel first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int N = c->comm_ranks, me = c->comm_rank;
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    // who holds what: {first read, rows, nnz} of every rank
+    ENSURE(c, c->comm_meta, 8 * 4 * ((size_t)N + 1));
+    uint64_t mine[4] = {c->panel_first, c->panel_rows, c->panel_nnz, c->nkmers};
+    uint64_t* d_meta = ptr<uint64_t>(c->comm_meta);
+    HIPCHK(c, hipMemcpyAsync(d_meta + 4 * (size_t)N, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, rccl().AllGather(d_meta + 4 * (size_t)N, d_meta, 4, ncclUint64, c->comm, c->stream));
+    std::vector<uint64_t> meta(4 * (size_t)N);
+    HIPCHK(c, hipMemcpyAsync(meta.data(), d_meta, 8 * 4 * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> roff((size_t)N + 1, 0), eoff((size_t)N + 1, 0);
+    for (int r = 0; r < N; ++r) {
+        if (meta[4 * r] != roff[r]) return fail(c, BELLA_ERR_BAD_ARG, "panels must be consecutive read blocks in rank order (rank %d starts at %llu, expected %llu)",
+                                                r, (unsigned long long)meta[4 * r], (unsigned long long)roff[r]);
+        if (meta[4 * r + 3] != c->nkmers) return fail(c, BELLA_ERR_BAD_ARG, "rank %d counted a different k-mer dictionary", r);
+        roff[r + 1] = roff[r] + meta[4 * r + 1];
+        eoff[r + 1] = eoff[r] + meta[4 * r + 2];
+    }
+    if (roff[N] != c->nreads) return fail(c, BELLA_ERR_BAD_ARG, "the panels cover %llu of %u reads", (unsigned long long)roff[N], c->nreads);
+    const uint64_t nnz = eoff[N];
+    if (nnz >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "nnz(A) must be < 2^32");
+    Buf nCnt, nBk, nBpos, nBptr;
+    int rc = ensure_bytes(c, nCnt, 4 * ((size_t)c->nreads + 2));
+    if (!rc) rc = ensure_bytes(c, nBptr, 4 * ((size_t)c->nreads + 2));
+    if (!rc) rc = ensure_bytes(c, nBk, 4 * nnz);
+    if (!rc) rc = ensure_bytes(c, nBpos, 2 * nnz + 16);
+    if (rc) { release(nCnt); release(nBk); release(nBpos); release(nBptr); return rc; }
+    // one grouped exchange: to every peer my block, from every peer its block, straight to its place in the full arrays
+    uint32_t* cnt = ptr<uint32_t>(nCnt);
+    uint32_t* bk = ptr<uint32_t>(nBk);
+    uint8_t* bpos = ptr<uint8_t>(nBpos);
+    HIPCHK(c, hipMemsetAsync(cnt + c->nreads, 0, 8, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cnt + roff[me], c->rowcnt.p, 4 * (size_t)c->panel_rows, hipMemcpyDeviceToDevice, c->stream));
+    if (c->panel_nnz) {
+        HIPCHK(c, hipMemcpyAsync(bk + eoff[me], c->Bk.p, 4 * (size_t)c->panel_nnz, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(bpos + 2 * eoff[me], c->Bpos.p, 2 * (size_t)c->panel_nnz, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (N > 1) {
+        NCCLCHK(c, rccl().GroupStart());
+        for (int p = 0; p < N; ++p) {
+            if (p == me) continue;
+            const uint64_t prow = meta[4 * p + 1], pnnz = meta[4 * p + 2];
+            if (c->panel_rows) NCCLCHK(c, rccl().Send(c->rowcnt.p, c->panel_rows, ncclUint32, p, c->comm, c->stream));
+            if (prow) NCCLCHK(c, rccl().Recv(cnt + roff[p], prow, ncclUint32, p, c->comm, c->stream));
+            if (c->panel_nnz) {
+                NCCLCHK(c, rccl().Send(c->Bk.p, c->panel_nnz, ncclUint32, p, c->comm, c->stream));
+                NCCLCHK(c, rccl().Send(c->Bpos.p, 2 * c->panel_nnz, ncclUint8, p, c->comm, c->stream));
+            }
+            if (pnnz) {
+                NCCLCHK(c, rccl().Recv(bk + eoff[p], pnnz, ncclUint32, p, c->comm, c->stream));
+                NCCLCHK(c, rccl().Recv(bpos + 2 * eoff[p], 2 * pnnz, ncclUint8, p, c->comm, c->stream));
+            }
+        }
+        NCCLCHK(c, rccl().GroupEnd());
+    }
+    rc = scan_u32(c, cnt, ptr<uint32_t>(nBptr), (uint64_t)c->nreads + 1);
+    if (!rc) { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) rc = fail(c, BELLA_ERR_HIP, "allgather_panels: %s", hipGetErrorString(e)); }
+    release(nCnt);
+    if (rc) { release(nBk); release(nBpos); release(nBptr); return rc; }
+    release(c->Bptr); release(c->Bk); release(c->Bpos);
+    c->Bptr = nBptr; c->Bk = nBk; c->Bpos = nBpos;
+    c->have_panel = false;
+    c->have_matrix = c->have_pairs = c->have_alns = false;
+    c->nnz = nnz;
+    rc = build_layout(c);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    c->tm.assemble_ms = ev_ms(c->ev[0], c->ev[1]);     // exchange + layout
     return 0;
 }
 

@@ -85,3 +85,32 @@ def allgather_panels(rowcnt, rowids, values, group=None):
     colptr = torch.zeros(cnt.numel() + 1, dtype=torch.int32, device=dev)
     colptr[1:] = torch.cumsum(cnt, 0).to(torch.int32)
     return colptr, ids, val
+
+
+def exchange_panels(eng, device_index: int, backend: str = "nccl", k: int = 17):
+    """All ranks call after Engine.assemble_*_panel: gives every rank the whole matrix.  Preferred path: the library's own
+    RCCL communicator (bella_hip_comm_init + bella_hip_allgather_panels: one grouped point-to-point exchange straight between
+    the device arrays); the 128-byte communicator id travels over torch.distributed.  Falls back to torch.distributed's
+    all_gather (also RCCL with the "nccl" backend; the only path with "gloo").  Returns the name of the path taken."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if backend == "nccl":
+        try:
+            dev = torch.device("cuda", device_index)
+            raw = eng.comm_id() if rank == 0 else bytes(128)
+            t = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=0)
+            eng.comm_init(world, rank, bytes(t.cpu().tolist()))
+            eng.allgather_panels()
+            return "bella_hip_allgather_panels (RCCL send/recv group)"
+        except Exception as e:                              # reported in the bench line
+            import sys
+            print("[bella_amd.dist] C++ RCCL path failed (%r); using torch.distributed" % (e,), file=sys.stderr)
+    pc, pr, pv = eng.panel_tensors(device_index)
+    if backend != "nccl":
+        pc, pr, pv = pc.cpu(), pr.cpu(), pv.cpu()
+    colptr_t, ids_t, val_t = allgather_panels(pc, pr, pv)
+    dev = torch.device("cuda", device_index)
+    eng.set_B_device(k, eng.nkmers_counted, colptr_t.to(dev), ids_t.to(dev), val_t.to(dev))
+    return "torch.distributed all_gather (%s)" % backend

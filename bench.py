@@ -1,16 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py -- candidate overlap pairs/s of the MI355X overlap engine on BASELINE.json's configuration.
+"""bench.py -- candidate overlap pairs/s of the MI355X overlap engine on BASELINE.json's configurations.
 
-N=1 workload = configs[1]: 10k synthetic PacBio reads (10 kb templates, 15 % error, 30x), k=17, SpGEMM-only
-(--skip-alignment).  A "step" is one pass of the hot path (bella_hip_overlap: estimateFLOP + symbolic + numeric
-SpGEMM under the binning semiring + pair compaction) over operands already resident in HBM, i.e. exactly what the
-reference times around HashSpGEMM/LocalSpGEMM (overlap.hpp:650-789).  For N>1 (one rank per GPU, launched by
-torch.distributed.run) the read set grows to 10k*N reads (weak scaling), every rank holds the operands and computes
-the output columns i with i % N == rank: columns are independent, so the timed step has no data-path collective.
+A "step" is one pass of the hot path (bella_hip_overlap: estimateFLOP + tiering + numeric SpGEMM under the binning semiring +
+pair compaction) over operands already resident in HBM, i.e. what the reference times around HashSpGEMM/LocalSpGEMM
+(overlap.hpp:650-789).  The step ends with the pair records in HBM (no D2H of the records, no writer: the reference's
+OverlapTime bracket ends with host-resident vectors; the PCIe-inclusive numbers are in DESIGN.md).
 
-Prints ONE JSON line (rank 0).  Extra keys: roofline (HBM, algorithmic bytes 14*nnzA + 6*F + 16*P per step over the
-row-kernel time measured with HIP events on the library's stream) and cpu_baseline (the reference's own HashSpGEMM,
-compiled into oracle/_ref/libbella_ref.so, timed on this box's host cores; falls back to the C port)."""
+N = 1 (default): the headline line is configs[1] -- 10k synthetic PacBio reads (10 kb templates, 15 % error, 30x), k=17,
+SpGEMM-only.  The same line carries
+  * "xdrop":       configs[2], the X-drop stage on the 10k set's candidate pairs (outside the timed SpGEMM loop),
+  * "config_100k": configs[3]'s read set (100k reads) on ONE GPU: ms/step, pairs/s, roofline, and a CPU baseline on a bounded
+                   sample (the reference cannot finish the whole set within the bench's time budget).
+N > 1 (torch.distributed.run, one rank per GPU): STRONG scaling on the fixed 100k-read set of configs[3]: reads replicated, every
+rank assembles the rows of B of its read block, one all-gather of the panels (RCCL) gives every rank the matrix, rank r computes
+the output columns i % N == r; the timed step has no collective.  Rank 0 also times the whole set on its own GPU, so the line
+carries the same-workload single-GPU time next to the N-GPU one.
+
+Prints ONE JSON line (rank 0).  roofline: HBM, algorithmic bytes 14*nnzA + 6*F + 16*P per step over the row-kernel time measured
+with HIP events on the library's stream.  cpu_baseline: the reference's own HashSpGEMM (oracle/_ref/libbella_ref.so) on this
+box's host cores; falls back to the C port."""
 import argparse
 import json
 import os
@@ -24,6 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+BIG_READS = 100000       # configs[3]
+SAMPLE_READS = 30000     # CPU baseline sample of the 100k set
 
 
 def log(*a):
@@ -62,16 +72,81 @@ def cpu_baseline_child(npz, threads):
     print(json.dumps({"pairs": pairs, "seconds": sec, "wall": wall, "kind": kind, "cores": threads}))
 
 
+def run_cpu_baseline(codes, offsets, tk, tr, tp, nkmers, what):
+    """the reference's HashSpGEMM on the given reads/tuples in a child process; returns the cpu_baseline object"""
+    import tempfile
+    try:
+        cores = os.cpu_count() or 1
+        with tempfile.TemporaryDirectory() as tmp:
+            npz = os.path.join(tmp, "w.npz")
+            np.savez(npz, codes=codes, offsets=offsets, tk=tk, tr=tr, tp=tp, nkmers=np.int64(nkmers))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", npz, "--threads", str(cores)],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
+            cb = json.loads(line)
+        return {"value": cb["pairs"] / cb["seconds"], "unit": "pairs/s", "cores": cb["cores"], "kind": cb["kind"],
+                "sample": "%s: the reference's HashSpGEMM OverlapTime bracket (overlap.hpp:714-727), %.2f s; pairs %d"
+                          % (what, cb["seconds"], cb["pairs"]), "pairs": cb["pairs"]}
+    except Exception as e:  # the baseline is reported, never required
+        return {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,), "pairs": None}
+
+
+def timed_passes(eng, pars, steps, warmup, sync):
+    for _ in range(warmup):
+        eng.overlap(pars)
+    sync()
+    acc = {"rows": 0.0, "fold": 0.0, "sym": 0.0, "comp": 0.0, "launches": 0}
+    ts = time.perf_counter()
+    for _ in range(steps):
+        npairs, flops = eng.overlap(pars)
+        tm = eng.timings()
+        acc["rows"] += tm.spgemm_ms
+        acc["fold"] += tm.fold_ms
+        acc["sym"] += tm.symbolic_ms
+        acc["comp"] += tm.compact_ms
+        acc["launches"] += tm.spgemm_launches
+    sync()
+    acc["elapsed"] = time.perf_counter() - ts
+    acc["npairs"], acc["flops"], acc["steps"] = npairs, flops, steps
+    return acc
+
+
+def roofline_of(acc, nnz_share, copy_gbps, traffic_key):
+    alg_bytes = 14.0 * nnz_share + 6.0 * float(acc["flops"]) + 16.0 * float(acc["npairs"])
+    k_ms = (acc["rows"] + acc["fold"]) / acc["steps"]
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+         "kernel": "SpGEMM = k_spgemm_rows_lds (one launch set = the concurrent LDS-class launches of a pass) + k_fold_overflow",
+         "kernel_ms_per_step": k_ms, "launches_per_step": acc["launches"] / acc["steps"], "algorithmic_bytes_per_step": alg_bytes,
+         "measured_copy_ceiling_GBps": copy_gbps}
+    # HBM traffic of the same kernels from the PMC counters (tools/collect_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes,
+    # gfx950 FETCH_SIZE x2 correction calibrated on our own stream): a profiling run, so read from the committed summary
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))[traffic_key]
+        if abs(tr["algorithmic_bytes"] - alg_bytes) < 1e-3 * alg_bytes:
+            r["traffic"] = tr["hbm_bytes_corrected"]
+            r["traffic_source"] = "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per step)"
+    except Exception:
+        pass
+    return r
+
+
+def phases_of(acc):
+    s = acc["steps"]
+    return {"symbolic+tiering": acc["sym"] / s, "row_kernels": acc["rows"] / s, "overflow_fold": acc["fold"] / s, "compaction": acc["comp"] / s}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=10000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=0, help="override the read count of the headline workload (development)")
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--align", action="store_true", help="configs[2]: also run the X-drop stage (not the headline line)")
-    ap.add_argument("--debug-flags", type=int, default=0, help="extra bella_hip_set_debug bits (development A/B, e.g. 8 = workgroup row kernel)")
+    ap.add_argument("--no-100k", action="store_true", help="N=1: skip the config_100k sub-record")
+    ap.add_argument("--no-xdrop", action="store_true", help="N=1: skip the X-drop record (configs[2])")
+    ap.add_argument("--debug-flags", type=int, default=0, help="extra bella_hip_set_debug bits (development A/B)")
     ap.add_argument("--cpu-baseline-child", default=None)
     ap.add_argument("--threads", type=int, default=0)
     a = ap.parse_args()
@@ -96,50 +171,7 @@ def main():
             dist.init_process_group(backend=backend)
     n_gpus = world
     assert a.gpus == n_gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
-
-    nreads = a.reads * n_gpus
-    t0 = time.time()
-    rs = synth.make_reads(nreads, read_len=a.read_len, coverage=30.0, err=0.15, seed=1)
-    t1 = time.time()
-    # reliable k-mer dictionary + tuples on the device (bella_hip_count_kmers; the reference's SplitCount + tuple loop)
-    eng = Engine(local)
-    eng.set_reads(rs)                                   # reads are replicated (2 bit/base)
-    nk, nt, ndistinct = eng.count_kmers(17, 2, 8)
-    kcount_ms = eng.timings().kcount_ms
-    # host copy of the tuples only where the CPU baseline needs it (N = 1)
-    tup = synth.Tuples(*eng.get_tuples(), nk) if (world == 1 and not a.no_cpu_baseline) else None
-    t2 = time.time()
-    if rank == 0:
-        log("[bench] reads %d (%.1f s), distinct k-mers %d, reliable %d, tuples %d (device: %.1f ms)"
-            % (nreads, t1 - t0, ndistinct, nk, nt, kcount_ms))
-
-    xchg_ms = None
-    if world == 1:
-        eng.assemble_counted()
-        asm_ms = eng.timings().assemble_ms
-    else:
-        # row-block panels: each rank assembles the rows of B of ITS reads, one all-gather (RCCL over xGMI) gives every rank
-        # the whole matrix, which goes back into the library through device pointers
-        from bella_amd import dist as bd
-        lo, npanel = bd.block_range(rank, world, nreads)
-        eng.assemble_counted_panel(lo, npanel)                 # from the device-resident tuples of this rank's read block
-        asm_ms = eng.timings().assemble_ms
-        pc, pr, pv = eng.panel_tensors(local)
-        if backend != "nccl":
-            pc, pr, pv = pc.cpu(), pr.cpu(), pv.cpu()
-        torch.cuda.synchronize()
-        dist.barrier()
-        tx = time.perf_counter()
-        colptr_t, ids_t, val_t = bd.allgather_panels(pc, pr, pv)
-        torch.cuda.synchronize()
-        xchg_ms = (time.perf_counter() - tx) * 1e3
-        dev = torch.device("cuda", local)
-        eng.set_B_device(17, nk, colptr_t.to(dev), ids_t.to(dev), val_t.to(dev))
-        asm_ms += eng.timings().assemble_ms
-        del colptr_t, ids_t, val_t
-    eng.set_partition(rank, n_gpus)
-    eng.set_debug(2 | a.debug_flags)   # diagnostics array (pair_ext) off in the timed path
-    pars = BellaPars(skipAlignment=True)
+    dev = "cuda:%d" % local
 
     def sync():
         torch.cuda.synchronize()
@@ -147,11 +179,41 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def prepare(nreads, want_host_tuples):
+        """reads -> reliable k-mer dictionary + tuples on the device (bella_hip_count_kmers: the reference's SplitCount + tuple
+        loop) -> B (N = 1: whole; N > 1: this rank's row-block panel, then the all-gather) -> device layout"""
+        t0 = time.time()
+        rs = synth.make_reads(nreads, read_len=a.read_len, coverage=30.0, err=0.15, seed=1)
+        t1 = time.time()
+        eng = Engine(local)
+        eng.set_reads(rs)                                   # reads are replicated (2 bit/base; SURVEY 8e)
+        nk, nt, ndistinct = eng.count_kmers(17, 2, 8)
+        info = {"rs": rs, "nk": nk, "kcount_ms": eng.timings().kcount_ms, "xchg_ms": None, "xchg_path": None}
+        info["tup"] = synth.Tuples(*eng.get_tuples(), nk) if want_host_tuples else None
+        if rank == 0:
+            log("[bench] reads %d (%.1f s), distinct k-mers %d, reliable %d, tuples %d (device: %.1f ms)"
+                % (nreads, t1 - t0, ndistinct, nk, nt, info["kcount_ms"]))
+        if world == 1:
+            eng.assemble_counted()
+            info["asm_ms"] = eng.timings().assemble_ms
+        else:
+            from bella_amd import dist as bd
+            lo, npanel = bd.block_range(rank, world, nreads)
+            eng.assemble_counted_panel(lo, npanel)             # from the device-resident tuples of this rank's read block
+            info["asm_ms"] = eng.timings().assemble_ms
+            sync()
+            tx = time.perf_counter()
+            info["xchg_path"] = bd.exchange_panels(eng, local, backend)     # C++ RCCL entry of the library, or torch.distributed
+            sync()
+            info["xchg_ms"] = (time.perf_counter() - tx) * 1e3
+            info["asm_ms"] += eng.timings().assemble_ms
+        return eng, info
+
     # measured device-copy ceiling (SURVEY 8d): 1 GiB device-to-device, read + write bytes per second
     copy_gbps = None
     if rank == 0:
         try:
-            src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda:%d" % local)
+            src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
             dst = torch.empty_like(src)
             dst.copy_(src)
             torch.cuda.synchronize()
@@ -166,108 +228,118 @@ def main():
         except Exception:
             copy_gbps = None
 
-    for _ in range(a.warmup):
-        eng.overlap(pars)
-    sync()
-    kern_ms = 0.0
-    rows_ms = 0.0
-    fold_ms = 0.0
-    sym_ms = 0.0
-    comp_ms = 0.0
-    launches = 0
-    ts = time.perf_counter()
-    for _ in range(a.steps):
-        npairs, flops = eng.overlap(pars)
-        tm = eng.timings()
-        kern_ms += tm.spgemm_ms + tm.fold_ms
-        rows_ms += tm.spgemm_ms
-        fold_ms += tm.fold_ms
-        sym_ms += tm.symbolic_ms
-        comp_ms += tm.compact_ms
-        launches += tm.spgemm_launches
-    sync()
-    elapsed = time.perf_counter() - ts
-    tt = torch.tensor([elapsed, float(npairs), float(flops), kern_ms], dtype=torch.float64,
-                      device=("cuda:%d" % local) if backend == "nccl" else "cpu")
-    if world > 1:
-        mx = tt.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tt.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[0])
-        tot_pairs, tot_flops = float(sm[1]), float(sm[2])
-        kern_ms_max = float(mx[3])
-    else:
-        tot_pairs, tot_flops, kern_ms_max = float(npairs), float(flops), kern_ms
+    pars = BellaPars(skipAlignment=True)
+    if world == 1:
+        nreads = a.reads or 10000
+        eng, info = prepare(nreads, not a.no_cpu_baseline)
+        eng.set_debug(2 | a.debug_flags)                     # diagnostics array (pair_ext) off in the timed path
+        acc = timed_passes(eng, pars, a.steps, a.warmup, sync)
+        colptr, _, _ = eng.get_B()
+        nnz = int(colptr[-1])
+        elapsed = acc["elapsed"]
+        out = {
+            "metric": "candidate overlap pairs/sec", "value": acc["npairs"] / (elapsed / a.steps), "unit": "pairs/s", "n_gpus": 1,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u16/u32 integer", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d synthetic PacBio reads (%d b templates, 15%% err, 30x) k=17 SpGEMM-only "
+                                   "(--skip-alignment); the step leaves the pair records in HBM" % (nreads, a.read_len),
+                       "reads": nreads, "nkmers": info["nk"], "nnzA": nnz, "flops": int(acc["flops"]), "pairs": int(acc["npairs"]),
+                       "partition": "all columns on one GPU"},
+            "roofline": roofline_of(acc, nnz, copy_gbps, "10k"),
+            "phases_ms_per_step": phases_of(acc),
+            "kcount_ms": info["kcount_ms"], "assemble_ms": info["asm_ms"], "panel_allgather_ms": None,
+        }
+        if not a.no_xdrop:
+            # configs[2]: the X-drop stage on the same candidate pairs (one pass, outside the SpGEMM timing)
+            apars = BellaPars()
+            eng.overlap(apars)
+            npass = eng.align_pairs(apars)
+            xms = eng.timings().xdrop_ms
+            al = eng.get_alignments()
+            steps_tot = float(al["steps"].astype(np.float64).sum())
+            out["xdrop"] = {"workload": "configs[2]: X-drop (xdrop=7) on the %d candidate pairs of the 10k set" % len(al), "pairs": int(len(al)),
+                            "passed": int(npass), "ms": xms, "pairs_per_s": len(al) / (xms * 1e-3) if xms else None,
+                            "antidiagonal_steps": steps_tot, "gcups": 31 * steps_tot / (xms * 1e-3) / 1e9 if xms else None,
+                            "flagged": int(al["flagged"].sum()), "bound": "VALU issue (profiles/r02_xdrop_sq.txt)"}
+            del al
+        if not a.no_cpu_baseline:
+            tup = info["tup"]
+            cb = run_cpu_baseline(info["rs"].codes, info["rs"].offsets, tup.kmer, tup.read, tup.pos, tup.nkmers, "the whole workload (%d reads)" % nreads)
+            cb["pairs_match_gpu"] = cb.pop("pairs") == int(acc["npairs"])
+            out["cpu_baseline"] = cb
+        eng.close()
+        del eng, info
+        if not a.no_100k and not a.reads:
+            # configs[3]'s read set on ONE GPU: the configuration the 40 % HBM-roofline target is quoted on
+            eng, info = prepare(BIG_READS, False)
+            eng.set_debug(2 | a.debug_flags)
+            acc = timed_passes(eng, pars, 5, 2, sync)
+            colptr, _, _ = eng.get_B()
+            nnz = int(colptr[-1])
+            sub = {"workload": "configs[3]'s read set on one GPU: %d synthetic PacBio reads, k=17, SpGEMM-only" % BIG_READS, "steps": 5, "warmup": 2,
+                   "ms_per_step": acc["elapsed"] * 1e3 / 5, "value": acc["npairs"] / (acc["elapsed"] / 5), "unit": "pairs/s",
+                   "reads": BIG_READS, "nkmers": info["nk"], "nnzA": nnz, "flops": int(acc["flops"]), "pairs": int(acc["npairs"]),
+                   "roofline": roofline_of(acc, nnz, copy_gbps, "100k"), "phases_ms_per_step": phases_of(acc),
+                   "kcount_ms": info["kcount_ms"], "assemble_ms": info["asm_ms"]}
+            if not a.no_cpu_baseline:
+                # bounded sample: the sub-problem of the first SAMPLE_READS reads (their rows of B, the 100k set's k-mer dictionary)
+                tk, tr, tp = eng.get_tuples()
+                keep = tr < SAMPLE_READS
+                rs = info["rs"]
+                cut = int(rs.offsets[SAMPLE_READS])
+                cb = run_cpu_baseline(rs.codes[:cut], rs.offsets[:SAMPLE_READS + 1], tk[keep], tr[keep], tp[keep], info["nk"],
+                                      "bounded sample: reads 0..%d of the 100k set with the set's own k-mer dictionary" % (SAMPLE_READS - 1))
+                cb.pop("pairs")
+                sub["cpu_baseline"] = cb
+            out["config_100k"] = sub
+            eng.close()
+        print(json.dumps(out))
+        return
+
+    # ---- N > 1: strong scaling on the fixed 100k-read set ----
+    nreads = a.reads or BIG_READS
+    eng, info = prepare(nreads, False)
+    eng.set_partition(rank, n_gpus)
+    eng.set_debug(2 | a.debug_flags)
+    acc = timed_passes(eng, pars, a.steps, a.warmup, sync)
+    tdev = dev if backend == "nccl" else "cpu"
+    tt = torch.tensor([acc["elapsed"], float(acc["npairs"]), float(acc["flops"]), acc["rows"] + acc["fold"], info["kcount_ms"], info["asm_ms"]],
+                      dtype=torch.float64, device=tdev)
+    mx = tt.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    sm = tt.clone()
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    elapsed = float(mx[0])
+    tot_pairs, tot_flops = float(sm[1]), float(sm[2])
+    single = None
+    if rank == 0:
+        # the same workload on ONE GPU (rank 0 holds all operands): the denominator of the speed-up
+        eng.set_partition(0, 1)
+        acc1 = timed_passes(eng, pars, 3, 1, torch.cuda.synchronize)
+        single = {"ms_per_step": acc1["elapsed"] * 1e3 / 3, "value": acc1["npairs"] / (acc1["elapsed"] / 3), "pairs": int(acc1["npairs"])}
+    dist.barrier()
     if rank != 0:
         dist.destroy_process_group()
         return
-    if a.align:
-        apars = BellaPars()
-        eng.overlap(apars)
-        t0 = time.perf_counter()
-        npass = eng.align_pairs(apars)
-        t_al = time.perf_counter() - t0
-        al = eng.get_alignments()
-        steps_tot = float(al["steps"].astype(np.float64).sum())
-        xms = eng.timings().xdrop_ms
-        log("[bench] X-drop: %d pairs, %d pass, kernel %.1f ms (wall %.1f ms) -> %.3g pairs/s, %.3g anti-diagonal steps/s, %.1f GCUPS (31 cells/step), flagged %d"
-            % (len(al), npass, xms, t_al * 1e3, len(al) / (xms * 1e-3), steps_tot / (xms * 1e-3), 31 * steps_tot / (xms * 1e-3) / 1e9,
-               int(al["flagged"].sum())))
-
     colptr, _, _ = eng.get_B()
     nnz = int(colptr[-1])
-    ms_per_step = elapsed * 1e3 / a.steps
-    value = tot_pairs / (elapsed / a.steps)
-    # roofline of the dominant kernel (the row kernels; all tiers are the same kernel): this rank's share
-    alg_bytes = 14.0 * nnz / n_gpus + 6.0 * float(flops) + 16.0 * float(npairs)
-    k_ms = kern_ms / a.steps
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     out = {
-        "metric": "candidate overlap pairs/sec", "value": value, "unit": "pairs/s", "n_gpus": n_gpus, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "candidate overlap pairs/sec", "value": tot_pairs / (elapsed / a.steps), "unit": "pairs/s", "n_gpus": n_gpus, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": elapsed * 1e3 / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u16/u32 integer", "data": "synthetic",
-        "config": {"workload": "configs[1]: %d synthetic PacBio reads (%d b templates, 15%% err, 30x) k=17 SpGEMM-only "
-                               "(--skip-alignment)" % (nreads, a.read_len),
-                   "reads": nreads, "nkmers": nk, "nnzA": nnz, "flops": int(tot_flops), "pairs": int(tot_pairs),
+        "config": {"workload": "configs[3]: %d synthetic PacBio reads (%d b templates, 15%% err, 30x) k=17, row-block panels + one all-gather, "
+                               "SpGEMM-only step on %d GPUs (fixed set: strong scaling)" % (nreads, a.read_len, n_gpus),
+                   "reads": nreads, "nkmers": info["nk"], "nnzA": nnz, "flops": int(tot_flops), "pairs": int(tot_pairs),
                    "partition": "columns i %% %d == rank" % n_gpus},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "kernel": "SpGEMM = k_spgemm_rows_* (one launch set = the concurrent tier launches of a pass) + k_fold_overflow", "kernel_ms_per_step": k_ms,
-                     "launches_per_step": launches / a.steps, "algorithmic_bytes_per_step": alg_bytes,
-                     "measured_copy_ceiling_GBps": copy_gbps},
-        "phases_ms_per_step": {"symbolic+tiering": sym_ms / a.steps, "row_kernels": rows_ms / a.steps, "overflow_fold": fold_ms / a.steps,
-                               "compaction": comp_ms / a.steps},
-        "kcount_ms": kcount_ms, "assemble_ms": asm_ms, "panel_allgather_ms": xchg_ms,
+        "roofline": roofline_of(acc, nnz / n_gpus, copy_gbps, "none"),
+        "phases_ms_per_step": phases_of(acc),
+        "kcount_ms_max": float(mx[4]), "assemble_ms_max": float(mx[5]), "panel_allgather_ms": info["xchg_ms"], "panel_allgather_path": info["xchg_path"],
+        "single_gpu_same_workload": single,
+        "speedup_vs_single_gpu": (single["ms_per_step"] / (elapsed * 1e3 / a.steps)) if single else None,
+        "pairs_match_single_gpu": (single["pairs"] == int(tot_pairs)) if single else None,
     }
-    # HBM traffic of the same kernels from the PMC counters (tools/collect_traffic.sh, separate FETCH_SIZE / WRITE_SIZE passes,
-    # gfx950 FETCH_SIZE x2 correction calibrated on our own stream): a profiling run, so read from the committed summary
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-        if n_gpus == 1 and nreads == 10000 and abs(tr["algorithmic_bytes"] - alg_bytes) < 1e-3 * alg_bytes:
-            out["roofline"]["traffic"] = tr["hbm_bytes_corrected"]
-            out["roofline"]["traffic_source"] = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per step)"
-    except Exception:
-        pass
-    if n_gpus == 1 and not a.no_cpu_baseline:
-        try:
-            import tempfile
-            cores = os.cpu_count() or 1
-            with tempfile.TemporaryDirectory() as tmp:
-                npz = os.path.join(tmp, "w.npz")
-                np.savez(npz, codes=rs.codes, offsets=rs.offsets, tk=tup.kmer, tr=tup.read, tp=tup.pos, nkmers=np.int64(tup.nkmers))
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", npz, "--threads", str(cores)],
-                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-                line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
-                cb = json.loads(line)
-            out["cpu_baseline"] = {"value": cb["pairs"] / cb["seconds"], "unit": "pairs/s", "cores": cb["cores"], "kind": cb["kind"],
-                                   "sample": "the whole workload (%d reads): the reference's HashSpGEMM OverlapTime bracket "
-                                             "(overlap.hpp:714-727), %.2f s; pairs %d" % (nreads, cb["seconds"], cb["pairs"]),
-                                   "pairs_match_gpu": cb["pairs"] == int(tot_pairs)}
-        except Exception as e:  # the baseline is reported, never required
-            out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

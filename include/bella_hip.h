@@ -207,6 +207,21 @@ int bella_hip_get_alignments(bella_ctx* ctx, bella_aln* out);
 int bella_hip_xdrop_batch(bella_ctx* ctx, const bella_seed* seeds, uint64_t n, const bella_params* p,
                           bella_aln* out);
 
+/* ---- multi-GPU: one context per GPU, RCCL over xGMI ------------------------------------------------
+ * The reference's multi-GPU path hands alignment batches to the devices inside one call (loganGPU/functions.cuh:441-443,
+ * 498-637; include/align.hpp:226-229) and has no collective.  Here reads are 1D row-block partitioned: context r assembles the
+ * rows of B of its read block (bella_hip_assemble_panel / _counted_panel), bella_hip_allgather_panels exchanges the panels with
+ * ONE grouped point-to-point all-gather (every peer pair uses its own xGMI link; the blocks land directly at their offsets of
+ * the full arrays, no padding, no staging) and builds the device layout; bella_hip_set_partition then gives every context its
+ * output columns.  The communicator is RCCL's: rank 0 makes the 128-byte id (bella_hip_comm_id), the host program hands it to
+ * every rank (MPI, torch.distributed, a file ...), every rank calls bella_hip_comm_init (collective). */
+#define BELLA_HIP_COMM_ID_BYTES 128
+int bella_hip_comm_id(uint8_t id[BELLA_HIP_COMM_ID_BYTES]);
+int bella_hip_comm_init(bella_ctx* ctx, int nranks, int rank, const uint8_t id[BELLA_HIP_COMM_ID_BYTES]);
+int bella_hip_comm_destroy(bella_ctx* ctx);
+/* collective: needs a panel (rank r: rows [first_r, first_r + rows_r), the blocks in rank order covering all reads) */
+int bella_hip_allgather_panels(bella_ctx* ctx);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 int bella_hip_get_timings(bella_ctx* ctx, bella_timings* t);
 /* 0 = default; bit0 = force the global-memory row path (tests); bit1 = no pair_ext output; bit2 = tests: treat every fifth

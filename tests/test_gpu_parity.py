@@ -709,6 +709,37 @@ def test_counted_panels_equal_one_shot_assembly(eng):
         assert np.array_equal(a, b)
 
 
+def test_library_communicator_allgather_single_rank(eng):
+    """the C-ABI multi-GPU entry points on the one GPU there is: a 1-rank RCCL communicator, the whole read set as this rank's
+    panel, bella_hip_allgather_panels -> the same B and pairs as the one-shot assembly; and the argument checks"""
+    rs = synth.make_reads(150, read_len=2000, coverage=15.0, err=0.15, seed=43)
+    eng.set_reads(rs)
+    nk, nt, _ = eng.count_kmers(17, 2, 8)
+    eng.assemble_counted()
+    B1 = eng.get_B()
+    eng.overlap(BellaPars(skipAlignment=True))
+    p1 = eng.get_pairs()
+    with pytest.raises(BellaHipError):
+        eng.allgather_panels()                     # no communicator yet
+    cid = eng.comm_id()
+    assert len(cid) == 128 and any(cid)
+    eng.comm_init(1, 0, cid)
+    with pytest.raises(BellaHipError):
+        eng.allgather_panels()                     # no panel
+    eng.assemble_counted_panel(0, rs.nreads - 10)
+    with pytest.raises(BellaHipError) as e:
+        eng.allgather_panels()                     # the panels do not cover the read set
+    assert e.value.code == -3
+    eng.assemble_counted_panel(0, rs.nreads)
+    eng.allgather_panels()
+    for a, b in zip(eng.get_B(), B1):
+        assert np.array_equal(a, b)
+    eng.overlap(BellaPars(skipAlignment=True))
+    for a, b in zip(p1, eng.get_pairs()):
+        assert np.array_equal(a, b)
+    eng.comm_destroy()
+
+
 def test_half_size_key_tables_layout_bit_exact(eng, monkeypatch):
     """the LDS layout of pair-rich inputs (key tables of cap/2 slots, Gaux inside T2's upper half) on the multi-bin golden set"""
     eng.set_debug(16)
