@@ -539,11 +539,12 @@ typedef struct {
 
 /* Phase 1: flops per column (estimateFLOP, lowtri) and nnz per column (estimateNNZ_Hash).
  * colflop/colnnz have nreads entries. */
-void oracle_symbolic(uint32_t nreads, const uint32_t* Bcolptr, const uint32_t* Browids, const uint32_t* Acolptr,
-                     const uint32_t* Arowids, uint32_t* colflop, uint32_t* colnnz) {
+void oracle_symbolic_range(uint32_t lo, uint32_t hi, const uint32_t* Bcolptr, const uint32_t* Browids, const uint32_t* Acolptr,
+                           const uint32_t* Arowids, uint32_t* colflop, uint32_t* colnnz) {
+    /* columns lo .. hi-1 (they are independent; full-size tests spread ranges over the host cores) */
     uint32_t cap = 16;
     uint32_t* tab = (uint32_t*)malloc(sizeof(uint32_t) * cap);
-    for (uint32_t i = 0; i < nreads; ++i) {
+    for (uint32_t i = lo; i < hi; ++i) {
         uint32_t f = 0;
         for (uint32_t j = Bcolptr[i]; j < Bcolptr[i + 1]; ++j) {              /* overlap.hpp:177-198 */
             uint32_t c = Browids[j];
@@ -572,19 +573,27 @@ void oracle_symbolic(uint32_t nreads, const uint32_t* Bcolptr, const uint32_t* B
     free(tab);
 }
 
+void oracle_symbolic(uint32_t nreads, const uint32_t* Bcolptr, const uint32_t* Browids, const uint32_t* Acolptr,
+                     const uint32_t* Arowids, uint32_t* colflop, uint32_t* colnnz) {
+    oracle_symbolic_range(0, nreads, Bcolptr, Browids, Acolptr, Arowids, colflop, colnnz);
+}
+
 /* Phase 2: LocalSpGEMM (overlap.hpp:281-363) + what RunPairWiseAlignments reads from each value
  * (overlap.hpp:531-585: chain(), choose(), overlapop on the chosen seed).
  * colptrC = exclusive scan of colnnz (nreads+1).  out has colptrC[nreads] records, column-major, slot
  * order within a column -- exactly the order the reference writes lines in at one thread. */
-void oracle_numeric(uint32_t nreads, const uint32_t* Bcolptr, const uint32_t* Browids, const uint16_t* Bvalues,
-                    const uint32_t* Acolptr, const uint32_t* Arowids, const uint16_t* Avalues,
-                    const char* const* seqs, const uint32_t* lens, int k, int binSize, const uint32_t* colptrC,
-                    oracle_pair* out) {
+/* the columns cols[0..ncols) only (cols == NULL: the columns 0..ncols-1); column cols[x] has colnnz[x] pairs and its records go
+ * to out + outoff[x] */
+void oracle_numeric_cols(const uint32_t* cols, uint32_t ncols, const uint32_t* colnnz, const uint64_t* outoff,
+                         const uint32_t* Bcolptr, const uint32_t* Browids, const uint16_t* Bvalues,
+                         const uint32_t* Acolptr, const uint32_t* Arowids, const uint16_t* Avalues,
+                         const char* const* seqs, const uint32_t* lens, int k, int binSize, oracle_pair* out) {
     uint32_t cap = 16;
     uint32_t* hk = (uint32_t*)malloc(sizeof(uint32_t) * cap);
     oval_t* hv = (oval_t*)calloc(cap, sizeof(oval_t));
-    for (uint32_t i = 0; i < nreads; ++i) {
-        uint32_t nnzc = colptrC[i + 1] - colptrC[i];
+    for (uint32_t x = 0; x < ncols; ++x) {
+        const uint32_t i = cols ? cols[x] : x;
+        uint32_t nnzc = colnnz[x];
         uint32_t ht = pow2_at_least(16, nnzc);                                /* :291-295 */
         if (ht > cap) {
             hk = (uint32_t*)realloc(hk, sizeof(uint32_t) * ht);
@@ -610,7 +619,7 @@ void oracle_numeric(uint32_t nreads, const uint32_t* Bcolptr, const uint32_t* Br
                 }
             }
         }
-        oracle_pair* o = out + colptrC[i];
+        oracle_pair* o = out + outoff[x];
         uint32_t idx = 0;
         for (uint32_t j = 0; j < ht; ++j) {                                   /* :343-361 slot order */
             if (hk[j] == EMPTY32) continue;
@@ -631,6 +640,17 @@ void oracle_numeric(uint32_t nreads, const uint32_t* Bcolptr, const uint32_t* Br
         }
     }
     free(hk); free(hv);
+}
+
+void oracle_numeric(uint32_t nreads, const uint32_t* Bcolptr, const uint32_t* Browids, const uint16_t* Bvalues,
+                    const uint32_t* Acolptr, const uint32_t* Arowids, const uint16_t* Avalues,
+                    const char* const* seqs, const uint32_t* lens, int k, int binSize, const uint32_t* colptrC,
+                    oracle_pair* out) {
+    uint32_t* nz = (uint32_t*)malloc(sizeof(uint32_t) * (nreads ? nreads : 1));
+    uint64_t* off = (uint64_t*)malloc(sizeof(uint64_t) * (nreads ? nreads : 1));
+    for (uint32_t i = 0; i < nreads; ++i) { nz[i] = colptrC[i + 1] - colptrC[i]; off[i] = colptrC[i]; }
+    oracle_numeric_cols(NULL, nreads, nz, off, Bcolptr, Browids, Bvalues, Acolptr, Arowids, Avalues, seqs, lens, k, binSize, out);
+    free(nz); free(off);
 }
 
 /* ---------------------------------------------------------------------------------------------------

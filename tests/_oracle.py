@@ -42,6 +42,9 @@ def lib():
         L.oracle_build_B.argtypes = [C.c_uint32, C.c_uint64, u32p, u32p, u16p, u32p, u32p, u16p]
         L.oracle_transpose.argtypes = [C.c_uint32, C.c_uint32, u32p, u32p, u16p, u32p, u32p, u16p]
         L.oracle_symbolic.argtypes = [C.c_uint32, u32p, u32p, u32p, u32p, u32p, u32p]
+        L.oracle_symbolic_range.argtypes = [C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p, u32p, u32p]
+        L.oracle_numeric_cols.argtypes = [u32p, C.c_uint32, u32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS"), u32p, u32p, u16p, u32p, u32p,
+                                          u16p, C.POINTER(C.c_char_p), u32p, C.c_int, C.c_int, C.c_void_p]
         L.oracle_numeric.argtypes = [C.c_uint32, u32p, u32p, u16p, u32p, u32p, u16p, C.POINTER(C.c_char_p), u32p,
                                      C.c_int, C.c_int, u32p, C.c_void_p]
         L.oracle_xavier_align.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_int,
@@ -134,6 +137,63 @@ def spgemm(seqs, nkmers, Bc, Br, Bv, k=17, bin_size=500):
     lib().oracle_numeric(nreads, Bc, _pad(Br, np.uint32), _pad(Bv, np.uint16), Ac, _pad(Ar, np.uint32),
                          _pad(Av, np.uint16), arr, lens, k, bin_size, colptrC, out.ctypes.data)
     return flop, colptrC, pairs
+
+
+# ---- full-size helpers: the columns are independent, so ranges / samples of them can be spread over the host cores ----
+_PAR = {}
+
+
+def _sym_job(rng):
+    lo, hi = rng
+    P = _PAR
+    flop = np.zeros(P["nreads"], np.uint32)
+    nnzc = np.zeros(P["nreads"], np.uint32)
+    lib().oracle_symbolic_range(lo, hi, P["Bc"], P["Br"], P["Ac"], P["Ar"], flop, nnzc)
+    return lo, hi, flop[lo:hi].copy(), nnzc[lo:hi].copy()
+
+
+def _num_job(cols):
+    P = _PAR
+    cols = np.ascontiguousarray(cols, np.uint32)
+    nz = np.ascontiguousarray(P["nnzc"][cols], np.uint32)
+    off = np.zeros(len(cols), np.uint64)
+    np.cumsum(nz[:-1], out=off[1:])
+    out = np.zeros(max(int(nz.sum()), 1), PAIR_DT)
+    lib().oracle_numeric_cols(cols, len(cols), nz, off, P["Bc"], P["Br"], P["Bv"], P["Ac"], P["Ar"], P["Av"], P["arr"], P["lens"], P["k"],
+                              P["bin"], out.ctypes.data)
+    return out[:int(nz.sum())]
+
+
+def spgemm_parallel(seqs, nkmers, Bc, Br, Bv, sample_cols, k=17, bin_size=500, procs=None):
+    """symbolic phase on ALL columns and numeric phase on `sample_cols` only, over a fork pool.
+    returns (colflop, colnnz, {col: pairs[PAIR_DT] in slot order})"""
+    import multiprocessing as mp
+    nreads = len(seqs)
+    Ac, Ar, Av = transpose(nreads, nkmers, Bc, Br, Bv)
+    procs = procs or min(64, os.cpu_count() or 1)
+    _PAR.update(nreads=nreads, Bc=Bc, Br=_pad(Br, np.uint32), Bv=_pad(Bv, np.uint16), Ac=Ac, Ar=_pad(Ar, np.uint32), Av=_pad(Av, np.uint16), k=k,
+                bin=bin_size)
+    step = max(1, nreads // (procs * 8))
+    ranges = [(lo, min(nreads, lo + step)) for lo in range(0, nreads, step)]
+    flop = np.zeros(nreads, np.uint32)
+    nnzc = np.zeros(nreads, np.uint32)
+    with mp.get_context("fork").Pool(procs) as pool:
+        for lo, hi, f, z in pool.imap_unordered(_sym_job, ranges):
+            flop[lo:hi] = f
+            nnzc[lo:hi] = z
+    sample_cols = np.asarray(sample_cols, np.uint32)
+    _PAR.update(nnzc=nnzc, arr=(C.c_char_p * nreads)(*[bytes(s) for s in seqs]), lens=np.asarray([len(s) for s in seqs], np.uint32))
+    chunks = [sample_cols[x:x + 16] for x in range(0, len(sample_cols), 16)]
+    per_col = {}
+    with mp.get_context("fork").Pool(procs) as pool:
+        for cols, rec in zip(chunks, pool.map(_num_job, chunks)):
+            o = 0
+            for c in cols:
+                n = int(nnzc[c])
+                per_col[int(c)] = rec[o:o + n]
+                o += n
+    _PAR.clear()
+    return flop, nnzc, per_col
 
 
 def xavier_align(row: bytes, col: bytes, i: int, j: int, x: int = 7, k: int = 17):

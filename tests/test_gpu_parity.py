@@ -452,6 +452,66 @@ def test_baseline_config1_full_size_parity(eng):
     assert bad == 0, bad
 
 
+def test_baseline_config3_100k_read_set_parity(eng):
+    """BASELINE configs[3]'s read set (100k reads x 10 kb) on one GPU, the size the roofline target is quoted on and a different
+    regime from 10k reads (~500 pairs per column, 92 % of them single-product, half-size key tables, four LDS classes):
+      * every column's product count and pair count (colptrC) against the oracle's symbolic phase (all 100k columns, host cores),
+      * every record of 2,500 sampled columns (incl. the largest ones) against the oracle's numeric phase,
+      * size-independent properties of all ~50 M records,
+      * X-drop on ALL pairs, 20,000 of them (mostly chance pairs) against the oracle's scalar Xavier."""
+    import time
+    t0 = time.time()
+    rs = synth.make_reads(100000, read_len=10000, coverage=30.0, err=0.15, seed=1)
+    seqs = rs.seqs()
+    eng.set_reads(rs)
+    nk, nt, _ = eng.count_kmers(17, 2, 8)
+    tk, tr, tp = eng.get_tuples()
+    eng.assemble_counted()
+    pars = BellaPars()
+    n, flops = eng.overlap(pars)
+    pairs, ext, colptrC = eng.get_pairs()
+    assert n > 40_000_000
+    assert (pairs["rid"] > pairs["cid"]).all()
+    assert (np.diff(pairs["cid"].astype(np.int64)) >= 0).all()                       # column-major
+    key = pairs["cid"].astype(np.uint64) << np.uint64(32) | pairs["rid"].astype(np.uint64)
+    assert (np.diff(key.reshape(-1)) != 0).all() and len(np.unique(key)) == len(key)  # every pair once
+    del key
+    assert ((ext["nbins"] >= 1) & (ext["support"] >= 1)).all()
+    t1 = time.time()
+    Bc, Br, Bv = O.build_B(rs.nreads, tk, tr, tp)
+    for a_, b_ in zip(eng.get_B(), (Bc, Br, Bv)):
+        assert np.array_equal(a_, b_)
+    per_row = np.diff(colptrC.astype(np.int64))
+    big = np.argsort(per_row)[-200:]                                                 # the columns with the most pairs
+    sample = np.unique(np.concatenate([np.arange(0, rs.nreads, 43), big])).astype(np.uint32)
+    flop, nnzc, per_col = O.spgemm_parallel(seqs, nk, Bc, Br, Bv, sample, 17)
+    t2 = time.time()
+    assert flops == int(flop.astype(np.int64).sum())
+    assert np.array_equal(per_row, nnzc.astype(np.int64))
+    got_idx = np.concatenate([np.arange(int(colptrC[c]), int(colptrC[c + 1])) for c in sample])
+    exp = np.concatenate([per_col[int(c)] for c in sample])
+    check_pairs(pairs[got_idx], ext[got_idx], exp, rs.lengths, 17)
+    # configs[3] aligns: X-drop on all pairs
+    npass = eng.align_pairs(pars)
+    alns = eng.get_alignments()
+    assert 0 < npass < n
+    rng = np.random.default_rng(11)
+    pick = np.sort(rng.choice(n, size=20000, replace=False))
+    global _XSEQS
+    _XSEQS = seqs
+    import multiprocessing as mp
+    jobs = [(int(pairs["rid"][i]), int(pairs["cid"][i]), int(pairs["seedH"][i]), int(pairs["seedV"][i])) for i in pick]
+    with mp.get_context("fork").Pool(min(64, os.cpu_count() or 1)) as pool:
+        res = pool.map(_xavier_job, jobs, chunksize=64)
+    bad = 0
+    for i, e in zip(pick, res):
+        al = alns[i]
+        bad += (int(al["score"]), int(al["begH"]), int(al["endH"]), int(al["begV"]), int(al["endV"])) != e
+    assert bad == 0, bad
+    print("100k parity: %d pairs, %d sampled columns (%d records), gpu part %.0f s, oracle %.0f s, total %.0f s"
+          % (n, len(sample), len(exp), t1 - t0, t2 - t1, time.time() - t0))
+
+
 _XSEQS = None
 
 

@@ -180,3 +180,17 @@ def test_count_kmers_matches_numpy_statement():
         t = synth.count_and_tuples(rs, k, lo, up)
         assert t.nkmers == len(codes)
         assert np.array_equal(t.kmer, tk) and np.array_equal(t.read, tr) and np.array_equal(t.pos, tp)
+
+
+def test_parallel_column_helpers_equal_the_serial_oracle():
+    """oracle_symbolic_range / oracle_numeric_cols (what the full-size GPU tests spread over the host cores) == the serial phases"""
+    from bella_amd import synth
+    rs = synth.make_reads(200, read_len=2500, coverage=20.0, err=0.15, seed=9)
+    seqs = rs.seqs()
+    codes, counts, tk, tr, tp, _ = O.count_kmers(seqs, 17, 2, 8)
+    Bc, Br, Bv = O.build_B(rs.nreads, tk, tr, tp)
+    flop, colptrC, pairs = O.spgemm(seqs, len(codes), Bc, Br, Bv, 17)
+    f2, nz2, per = O.spgemm_parallel(seqs, len(codes), Bc, Br, Bv, np.arange(0, 200, 3), procs=2)
+    assert np.array_equal(flop, f2) and np.array_equal(np.diff(colptrC), nz2)
+    for c, rec in per.items():
+        assert np.array_equal(rec, pairs[colptrC[c]:colptrC[c + 1]]), c
