@@ -38,11 +38,12 @@ RB = os.path.join(ROOT, "oracle", "_ref")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def run_ref(binary, fastq, extra, cwd):
+def run_ref(binary, fastq, extra, cwd, no_aslr=False):
     with open(os.path.join(cwd, "in.txt"), "w") as f:
         f.write(fastq + "\n")  # list file must end in '\n' (kmercount.hpp:96)
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    p = subprocess.run([os.path.join(RB, binary), "-f", "in.txt", "-o", "out"] + extra, cwd=cwd, env=env,
+    pre = ["setarch", "x86_64", "-R"] if no_aslr else []      # fixed stack addresses: xavier.h:165's uninitialised maxpos reads 0-ish
+    p = subprocess.run(pre + [os.path.join(RB, binary), "-f", "in.txt", "-o", "out"] + extra, cwd=cwd, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     # exit status is meaningless (teardown abort): judge by the final stdout line
     out = p.stdout.decode(errors="replace")
@@ -56,7 +57,21 @@ def stdout_numbers(txt):
     return nums
 
 
-def make_set(name, rs, flags):
+def flagged_pairs(rs, tup, k, xdrop=7):
+    """how many candidate pairs hit the reference's uninitialised-maxpos case, by the oracle's restatement"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    seqs = rs.seqs()
+    Bc, Br, Bv = O.build_B(rs.nreads, tup.kmer, tup.read, tup.pos)
+    _, _, pairs = O.spgemm(seqs, tup.nkmers, Bc, Br, Bv, k)
+    fl = 0
+    for p in pairs:
+        e = O.xavier_align(seqs[int(p["rid"])], seqs[int(p["cid"])], int(p["seedH"]), int(p["seedV"]), xdrop, k)
+        fl += int(e["flagged"])
+    return len(pairs), fl
+
+
+def make_set(name, rs, flags, aslr_check=False):
     d = os.path.join(GOLD, name)
     os.makedirs(d, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
@@ -78,8 +93,18 @@ def make_set(name, rs, flags):
                 g.write(data)
         with open(os.path.join(d, "stdout.json"), "w") as f:
             json.dump({"align": stdout_numbers(so2), "skip": stdout_numbers(so3)}, f, indent=1)
+        meta = {"flags": flags, "nreads": rs.nreads, "threads": 1}
+        if aslr_check:
+            # the same binary with address-space randomisation off: the garbage the reference reads at xavier.h:165 changes, the
+            # output files must not (those alignments never pass the threshold)
+            _, align_r = run_ref("bella_ref", fq, flags, tmp, no_aslr=True)
+            _, paf_r = run_ref("bella_ref", fq, flags + ["--paf"], tmp, no_aslr=True)
+            assert align_r == align and paf_r == paf, "reference output depends on the uninitialised maxpos"
+            k = int(flags[flags.index("-k") + 1]) if "-k" in flags else 17
+            npairs, nflag = flagged_pairs(rs, tup, k)
+            meta.update({"aslr_off_output_identical": True, "candidate_pairs": npairs, "flagged_pairs": nflag})
         with open(os.path.join(d, "meta.json"), "w") as f:
-            json.dump({"flags": flags, "nreads": rs.nreads, "threads": 1}, f, indent=1)
+            json.dump(meta, f, indent=1)
     print(name, "reads", rs.nreads, "tuples", tup.kmer.shape[0], "nkmers", tup.nkmers, "align lines",
           align.count(b"\n"), "skip lines", skip.count(b"\n"))
 
@@ -226,10 +251,19 @@ def eval_kats(sets=("toy120", "toylen80", "toyhifi50"), min_overlaps=(300, 500, 
     return out
 
 
+def junk_rich_set():
+    """mostly unrelated reads (coverage 2) and k = 11: almost every candidate pair is a chance k-mer hit, a third of the
+    alignments start with no positive cell (the reference's uninitialised maxpos)"""
+    return synth.make_reads(220, read_len=2500, err=0.15, seed=31, coverage=2.0)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     if "--eval-only" in sys.argv:
         print(eval_kats())
+        return
+    if "--junk-only" in sys.argv:
+        make_set("toyjunk220", junk_rich_set(), ["-k", "11"], aslr_check=True)
         return
     # the reference's own 3-read sanity input is a data file (sanitytests/reversecomptest.fastq)
     rs = synth.read_fastq(os.path.join(REF, "sanitytests", "reversecomptest.fastq"))
@@ -242,6 +276,7 @@ def main():
     make_set("toysync60", synth.make_reads(60, read_len=2500, err=0.02, seed=9, mix=(1 / 3, 1 / 3, 1 / 3), coverage=7.0),
              ["-s", "-e", "0.02"])                                                 # syncmer selection
     make_set("toymin70", synth.make_reads(70, read_len=2200, err=0.06, seed=23, coverage=9.0), ["-w", "7", "-e", "0.06"])   # minimizers
+    make_set("toyjunk220", junk_rich_set(), ["-k", "11"], aslr_check=True)
     xavier_kats()
     eval_kats()
     # read intervals of the reference's E. coli sample (dataset/ecsample-truth.txt, columns 3-4): the FASTQ itself is not in

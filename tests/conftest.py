@@ -15,7 +15,7 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-GOLDEN_SETS = ["sanity3", "toy120", "toylen80", "toyhifi50", "toyrep90", "toysync60", "toymin70"]
+GOLDEN_SETS = ["sanity3", "toy120", "toylen80", "toyhifi50", "toyrep90", "toysync60", "toymin70", "toyjunk220"]
 
 
 def pytest_configure(config):
@@ -38,7 +38,7 @@ class Golden:
         self.out = {k: gzip.open(os.path.join(d, k + ".out.gz"), "rb").read() for k in ("skip", "align", "paf")}
         fl = self.meta["flags"]
         self.err = float(fl[fl.index("-e") + 1]) if "-e" in fl else 0.15
-        self.k = 17
+        self.k = int(fl[fl.index("-k") + 1]) if "-k" in fl else 17
         self.window = int(fl[fl.index("-w") + 1]) if "-w" in fl else 0             # main.cpp:165
         self.syncmer = "-s" in fl                                            # main.cpp:169
         self.lower = int(fl[fl.index("-l") + 1]) if "-l" in fl else 2          # main.cpp:91-92 defaults

@@ -42,15 +42,14 @@ def test_aligned_output_bit_exact(golden):
     Bc, Br, Bv = O.build_B(g.rs.nreads, g.tk, g.tr, g.tp)
     _, _, pairs = O.spgemm(g.seqs, g.nkmers, Bc, Br, Bv, g.k)
     got, alns, passed = O.align_lines(g.names, g.seqs, pairs, g.xdrop, g.k, g.err)
-    if got != g.out["align"]:
-        # lines may only differ where the reference read its uninitialised `maxpos`
-        exp = g.out["align"].split(b"\n")
-        gl = got.split(b"\n")
-        flagged_pairs = {(g.names[p["cid"]], g.names[p["rid"]]) for p, a in zip(pairs, alns) if a["flagged"]}
-        bad = [l for l in set(exp) ^ set(gl) if l and tuple(l.decode().split("\t")[:2]) not in flagged_pairs]
-        assert not bad, bad[:5]
-    else:
-        assert got == g.out["align"]
+    # No tolerance.  Alignments that begin with no positive cell read an uninitialised `maxpos` in the reference (xavier.h:165,
+    # SURVEY B.5(4)); the restatement uses 0 and flags them.  They never pass the threshold: the reference's file is the same
+    # with address-space randomisation on and off (oracle/make_golden.py, meta.json of toyjunk220: 12,714 of 21,915 pairs
+    # flagged), and it is this file, byte for byte.
+    assert got == g.out["align"]
+    if "flagged_pairs" in g.meta:
+        assert int(sum(int(a["flagged"]) for a in alns)) == g.meta["flagged_pairs"] and len(pairs) == g.meta["candidate_pairs"]
+        assert not any(a["flagged"] and ok for a, ok in zip(alns, passed))         # a flagged alignment is never emitted
 
 
 def test_paf_output_bit_exact(golden):
@@ -58,11 +57,7 @@ def test_paf_output_bit_exact(golden):
     Bc, Br, Bv = O.build_B(g.rs.nreads, g.tk, g.tr, g.tp)
     _, _, pairs = O.spgemm(g.seqs, g.nkmers, Bc, Br, Bv, g.k)
     got, alns, _ = O.align_lines(g.names, g.seqs, pairs, g.xdrop, g.k, g.err, paf=True)
-    if got != g.out["paf"]:
-        flagged = {(g.names[p["cid"]], g.names[p["rid"]]) for p, a in zip(pairs, alns) if a["flagged"]}
-        bad = [l for l in set(got.split(b"\n")) ^ set(g.out["paf"].split(b"\n"))
-               if l and (l.decode().split("\t")[0], l.decode().split("\t")[5]) not in flagged]
-        assert not bad, bad[:5]
+    assert got == g.out["paf"]
 
 
 def test_xavier_known_answers():
