@@ -12,10 +12,26 @@
 //   stdout: nnz(C) (overlap.hpp:686) and, when aligning, the number of lines written (overlap.hpp:771).
 //   errors: the reference returns void and prints; so does this (message on stderr, then abort(), as CSC.cpp:269 does).
 // The Kmer length is bpars.kmerSize (Kmer::set_k(bpars.kmerSize), main.cpp:183).
+//   bpars.numGPU (-g): as the reference's GPU build fans batches over the devices inside the call (loganGPU/functions.cuh:441-443,
+//       498-637; align.hpp:226-229), the call drives min(numGPU, devices) contexts from one host thread each: the host already
+//       holds all of B, so every context receives it, takes the output columns i % N == g and the results are merged back into
+//       the reference's column order (the multi-process path exchanges row-block panels with RCCL instead: bella_hip.h).
+//   bpars.totalMemory / userDefMem (-m): stage count and stage boundaries by the reference's own formula (estimateMemory,
+//       overlap.hpp:365-404; stages :682-710): ceil(1.5 * nnz(C) * (sizeof(spmatPtr_) + sizeof(uint32_t)) / free_memory), boundaries by
+//       upper_bound on colptrC.  With more than one stage the output is formed stage by stage (each pass holds its own columns
+//       only) and APPENDED -- the reference overwrites the file from offset 0 in every stage (overlap.hpp:613-636, a defect);
+//       the file written here is the single-stage one.
+// Also here, in namespace bella_hip (the reference defines functions of the same names and signatures, so these cannot be
+// overloads): bella_hip::xavierAlign -- include/align.hpp:152, same arguments, same xavierResult -- and bella_hip::alignXavier,
+// the batched form shaped like alignLogan (include/align.hpp:210-211), both forwarding to bella_hip_xdrop_batch.
 #pragma once
+#include <algorithm>
+#include <cmath>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -41,24 +57,63 @@ inline int seed_overlap(const bella_pair& p, int len1, int len2, unsigned short 
 }
 }  // namespace bella_hip_detail
 
+namespace bella_hip_detail {
+struct StageOut { std::string text; size_t lines = 0; };
+
+// one context = one GPU: B in, then per stage [lo, hi): overlap (+ alignment) and the formatted lines of ITS columns
+struct Worker {
+    bella_ctx* ctx = nullptr;
+    std::vector<uint64_t> colptr;            // colptrC of the last pass (nreads + 1)
+    std::vector<bella_pair> pairs;
+    std::vector<bella_aln> alns;
+    uint64_t nnzc = 0;
+};
+
+inline void format_column(std::stringstream& ss, size_t& lines, const Worker& w, uint32_t col, const readVector_& reads, const BELLApars& bpars) {
+    for (uint64_t n = w.colptr[col]; n < w.colptr[col + 1]; ++n) {
+        const bella_pair& q = w.pairs[n];
+        const readType_& r1 = reads[q.rid];
+        const readType_& r2 = reads[q.cid];
+        unsigned short l1 = r1.seq.length(), l2 = r2.seq.length();
+        if (bpars.skipAlignment) {                                            // overlap.hpp:577-588
+            ss << r2.nametag << '\t' << r1.nametag << '\t' << q.count << '\t'
+               << seed_overlap(q, (int)r1.seq.length(), (int)r2.seq.length(), bpars.kmerSize) << '\t' << l2 << '\t' << l1 << '\n';
+            ++lines;
+            continue;
+        }
+        const bella_aln& a = w.alns[n];                                      // PostAlignDecision, overlap.hpp:462-491
+        if (!a.passed) continue;
+        if (!bpars.outputPaf) {
+            ss << r2.nametag << '\t' << r1.nametag << '\t' << q.count << '\t' << a.score << '\t' << a.ov << '\t'
+               << (a.strand ? "c" : "n") << '\t' << a.begV << '\t' << a.endV << '\t' << l2 << '\t' << a.begH << '\t' << a.endH
+               << '\t' << l1 << '\n';
+        } else {
+            int begH = a.begH, endH = a.endH;
+            if (a.strand) { unsigned int tmp = begH; begH = l1 - endH; endH = l1 - tmp; }   // toOriginalCoordinates :149-154
+            ss << r2.nametag << '\t' << l2 << '\t' << a.begV << '\t' << a.endV << '\t' << (a.strand ? "-" : "+") << '\t'
+               << r1.nametag << '\t' << l1 << '\t' << begH << '\t' << endH << '\t' << a.score << '\t' << a.ov << '\t' << 255 << '\n';
+        }
+        ++lines;
+    }
+}
+}  // namespace bella_hip_detail
+
 template <typename MultiplyOperation, typename AddOperation>
 void HashSpGEMM(const CSC<uint32_t, unsigned short>& A, const CSC<uint32_t, unsigned short>& B, MultiplyOperation, AddOperation,
                 const readVector_& reads, spmatPtr_& getvaluetype, char* filename, const BELLApars& bpars, const double& ratiophi) {
     using namespace bella_hip_detail;
     (void)A; (void)getvaluetype; (void)ratiophi;   // ratiophi = slope(bpars.errorRate) is recomputed from bpars
-    bella_ctx* ctx = nullptr;
-    check(nullptr, bella_hip_init(0, &ctx), "bella_hip_init");
-
     const uint32_t nreads = (uint32_t)reads.size();
+    const int ndev = bella_hip_device_count();
+    if (ndev <= 0) check(nullptr, BELLA_ERR_NO_DEVICE, "bella_hip_device_count");
+    // -g: one context per requested GPU.  BELLA_HIP_SHIM_OVERSUBSCRIBE=1 (tests on a one-GPU box) lets contexts share a device.
+    int N = bpars.numGPU > 1 ? (int)bpars.numGPU : 1;
+    if (N > ndev && !std::getenv("BELLA_HIP_SHIM_OVERSUBSCRIBE")) N = ndev;
     std::vector<uint64_t> offs(nreads + 1, 0);
     for (uint32_t r = 0; r < nreads; ++r) offs[r + 1] = offs[r] + reads[r].seq.size();
     std::string flat;
     flat.reserve(offs[nreads]);
     for (uint32_t r = 0; r < nreads; ++r) flat += reads[r].seq;
-    check(ctx, bella_hip_set_reads(ctx, (const uint8_t*)flat.data(), offs.data(), nreads), "bella_hip_set_reads");
-    std::string().swap(flat);
-    check(ctx, bella_hip_set_B(ctx, bpars.kmerSize, (uint32_t)B.rows, B.colptr, B.rowids, B.values), "bella_hip_set_B");
-
     bella_params p;
     p.kmer_size = bpars.kmerSize;
     p.bin_size = bpars.binSize;
@@ -66,51 +121,154 @@ void HashSpGEMM(const CSC<uint32_t, unsigned short>& A, const CSC<uint32_t, unsi
     p.skip_alignment = bpars.skipAlignment;
     p.error_rate = bpars.errorRate;
     p.delta_chernoff = bpars.deltaChernoff;
-    uint64_t nnzc = 0, flops = 0;
-    check(ctx, bella_hip_overlap(ctx, &p, &nnzc, &flops), "bella_hip_overlap");
-    std::cout << nnzc << std::endl;                                           // overlap.hpp:686
-    std::vector<bella_pair> pairs(nnzc);
-    check(ctx, bella_hip_get_pairs(ctx, pairs.data(), nullptr, nullptr), "bella_hip_get_pairs");
 
-    std::stringstream ss;
-    size_t outputted = 0;
-    if (bpars.skipAlignment) {                                                // overlap.hpp:577-588
-        for (const bella_pair& q : pairs) {
-            const readType_& r1 = reads[q.rid];
-            const readType_& r2 = reads[q.cid];
-            unsigned short l1 = r1.seq.length(), l2 = r2.seq.length();
-            ss << r2.nametag << '\t' << r1.nametag << '\t' << q.count << '\t'
-               << seed_overlap(q, (int)r1.seq.length(), (int)r2.seq.length(), bpars.kmerSize) << '\t' << l2 << '\t' << l1 << '\n';
-            ++outputted;
-        }
-    } else {
-        uint64_t npass = 0;
-        check(ctx, bella_hip_align_pairs(ctx, &p, &npass), "bella_hip_align_pairs");
-        std::vector<bella_aln> al(nnzc);
-        if (nnzc) check(ctx, bella_hip_get_alignments(ctx, al.data()), "bella_hip_get_alignments");
-        for (size_t n = 0; n < pairs.size(); ++n) {                            // PostAlignDecision, overlap.hpp:462-491
-            const bella_aln& a = al[n];
-            if (!a.passed) continue;
-            const readType_& r1 = reads[pairs[n].rid];
-            const readType_& r2 = reads[pairs[n].cid];
-            unsigned short l1 = r1.seq.length(), l2 = r2.seq.length();
-            if (!bpars.outputPaf) {
-                ss << r2.nametag << '\t' << r1.nametag << '\t' << pairs[n].count << '\t' << a.score << '\t' << a.ov << '\t'
-                   << (a.strand ? "c" : "n") << '\t' << a.begV << '\t' << a.endV << '\t' << l2 << '\t' << a.begH << '\t' << a.endH
-                   << '\t' << l1 << '\n';
-            } else {
-                int begH = a.begH, endH = a.endH;
-                if (a.strand) { unsigned int tmp = begH; begH = l1 - endH; endH = l1 - tmp; }   // toOriginalCoordinates :149-154
-                ss << r2.nametag << '\t' << l2 << '\t' << a.begV << '\t' << a.endV << '\t' << (a.strand ? "-" : "+") << '\t'
-                   << r1.nametag << '\t' << l1 << '\t' << begH << '\t' << endH << '\t' << a.score << '\t' << a.ov << '\t' << 255 << '\n';
+    std::vector<Worker> W((size_t)N);
+    auto on_all = [&](const std::function<void(int)>& fn) {                  // one host thread per context
+        if (N == 1) { fn(0); return; }
+        std::vector<std::thread> th;
+        for (int g = 0; g < N; ++g) th.emplace_back(fn, g);
+        for (auto& t : th) t.join();
+    };
+    on_all([&](int g) {
+        Worker& w = W[(size_t)g];
+        check(nullptr, bella_hip_init(g % ndev, &w.ctx), "bella_hip_init");
+        check(w.ctx, bella_hip_set_reads(w.ctx, (const uint8_t*)flat.data(), offs.data(), nreads), "bella_hip_set_reads");
+        check(w.ctx, bella_hip_set_B(w.ctx, bpars.kmerSize, (uint32_t)B.rows, B.colptr, B.rowids, B.values), "bella_hip_set_B");
+        check(w.ctx, bella_hip_set_partition(w.ctx, (uint32_t)g, (uint32_t)N), "bella_hip_set_partition");
+    });
+    std::string().swap(flat);
+    auto do_overlap = [&](uint32_t lo, uint32_t hi) {                        // columns [lo, hi) on every context; colptrC only
+        on_all([&](int g) {
+            Worker& w = W[(size_t)g];
+            check(w.ctx, bella_hip_set_column_range(w.ctx, lo, hi - lo), "bella_hip_set_column_range");
+            uint64_t flops = 0;
+            check(w.ctx, bella_hip_overlap(w.ctx, &p, &w.nnzc, &flops), "bella_hip_overlap");
+            w.colptr.assign((size_t)nreads + 1, 0);
+            check(w.ctx, bella_hip_get_pairs(w.ctx, nullptr, nullptr, w.colptr.data()), "bella_hip_get_pairs");
+        });
+    };
+    auto fetch = [&]() {                                                     // the records of the last pass (+ their alignments)
+        on_all([&](int g) {
+            Worker& w = W[(size_t)g];
+            w.pairs.resize(w.nnzc);
+            check(w.ctx, bella_hip_get_pairs(w.ctx, w.pairs.data(), nullptr, nullptr), "bella_hip_get_pairs");
+            if (!bpars.skipAlignment) {
+                uint64_t npass = 0;
+                check(w.ctx, bella_hip_align_pairs(w.ctx, &p, &npass), "bella_hip_align_pairs");
+                w.alns.resize(w.nnzc);
+                if (w.nnzc) check(w.ctx, bella_hip_get_alignments(w.ctx, w.alns.data()), "bella_hip_get_alignments");
             }
-            ++outputted;
-        }
-        std::cout << outputted << std::endl;                                  // overlap.hpp:771
+        });
+    };
+    // first pass over all columns: nnz(C) and colptrC (what estimateNNZ_Hash + prefixsum give the reference, overlap.hpp:674-679)
+    const double free_memory = bpars.totalMemory * 1024 * 1024;               // estimateMemory, overlap.hpp:365-404 (no LINUX/OSX define)
+    do_overlap(0, nreads);
+    uint64_t nnzc = 0;
+    std::vector<uint64_t> colptrC((size_t)nreads + 1, 0);                    // merged over the contexts: column i lives on context i % N
+    for (uint32_t i = 0; i < nreads; ++i) {
+        const Worker& w = W[(size_t)(i % (uint32_t)N)];
+        colptrC[i + 1] = colptrC[i] + (w.colptr[i + 1] - w.colptr[i]);
     }
+    nnzc = colptrC[nreads];
+    std::cout << nnzc << std::endl;                                           // overlap.hpp:686
+    const double safety_net = 1.5;                                            // overlap.hpp:92
+    const uint64_t required_memory = (uint64_t)(safety_net * nnzc * (sizeof(spmatPtr_) + sizeof(uint32_t)));
+    int stages = (int)std::ceil((double)required_memory / free_memory);       // overlap.hpp:683
+    if (stages < 1) stages = 1;
+    const uint64_t nnzcperstage = (uint64_t)(free_memory / (safety_net * (sizeof(spmatPtr_) + sizeof(uint32_t))));
+    std::vector<uint32_t> colStart((size_t)stages + 1, 0);
+    for (int i = 1; i < stages; ++i) {                                        // overlap.hpp:704-710
+        auto upper = std::upper_bound(colptrC.begin(), colptrC.end(), (uint64_t)i * nnzcperstage);
+        colStart[(size_t)i] = (uint32_t)(upper - colptrC.begin() - 1);
+    }
+    colStart[(size_t)stages] = nreads;
+
     std::ofstream ofs(filename, std::ios::binary | std::ios::app);            // overlap.hpp:613
-    const std::string text = ss.str();
-    ofs.write(text.data(), (std::streamsize)text.size());
+    for (int b = 0; b < stages; ++b) {
+        const uint32_t lo = colStart[(size_t)b], hi = colStart[(size_t)b + 1];
+        if (stages > 1) do_overlap(lo, hi);                                   // a single stage reuses the first pass
+        fetch();
+        std::stringstream ss;
+        size_t outputted = 0;
+        for (uint32_t i = lo; i < hi; ++i) format_column(ss, outputted, W[(size_t)(i % (uint32_t)N)], i, reads, bpars);
+        if (!bpars.skipAlignment) std::cout << outputted << std::endl;        // overlap.hpp:771 (per stage)
+        const std::string text = ss.str();
+        ofs.write(text.data(), (std::streamsize)text.size());
+    }
     ofs.close();
-    bella_hip_destroy(ctx);
+    for (auto& w : W) bella_hip_destroy(w.ctx);
 }
+
+// ---- the align.hpp call surface ---------------------------------------------------------------------------------------------
+namespace bella_hip {
+
+namespace detail {
+struct ThreadCtx {                            // xavierAlign is called concurrently from the reference's OpenMP pair loop (overlap.hpp:565)
+    bella_ctx* ctx = nullptr;
+    ~ThreadCtx() { if (ctx) bella_hip_destroy(ctx); }
+};
+inline bella_ctx* thread_context() {
+    static thread_local ThreadCtx t;
+    if (!t.ctx) bella_hip_detail::check(nullptr, bella_hip_init(0, &t.ctx), "bella_hip_init");
+    return t.ctx;
+}
+}  // namespace detail
+
+// alignLogan-shaped batch (include/align.hpp:210-211): target[n] ("row", read H), query[n] ("col", read V) and seeds[n] in
+// (beginPositionH/V = the seed k-mer's start on target / query, as SeedX(i, j, kmerSize) sets them, align.hpp:166);
+// out[n] = what xavierAlign(target[n], query[n], target[n].size(), i, j, bpars.xDrop, bpars.kmerSize) returns, index-aligned.
+inline void alignXavier(const std::vector<std::string>& target, const std::vector<std::string>& query, const std::vector<SeedX>& seeds,
+                        const BELLApars& bpars, std::vector<xavierResult>& out) {
+    using bella_hip_detail::check;
+    const size_t n = seeds.size();
+    out.resize(n);
+    if (!n) return;
+    bella_ctx* ctx = detail::thread_context();
+    std::vector<uint64_t> offs(2 * n + 1, 0);
+    std::string flat;
+    for (size_t t = 0; t < n; ++t) {
+        offs[2 * t + 1] = offs[2 * t] + target[t].size();
+        offs[2 * t + 2] = offs[2 * t + 1] + query[t].size();
+        flat += target[t];
+        flat += query[t];
+    }
+    check(ctx, bella_hip_set_reads(ctx, (const uint8_t*)flat.data(), offs.data(), (uint32_t)(2 * n)), "bella_hip_set_reads");
+    std::vector<bella_seed> sd(n);
+    for (size_t t = 0; t < n; ++t) {
+        sd[t].rid = (uint32_t)(2 * t);
+        sd[t].cid = (uint32_t)(2 * t + 1);
+        sd[t].seedH = (uint16_t)seeds[t].beginPositionH;
+        sd[t].seedV = (uint16_t)seeds[t].beginPositionV;
+    }
+    bella_params p;
+    p.kmer_size = bpars.kmerSize;
+    p.bin_size = bpars.binSize;
+    p.xdrop = bpars.xDrop;
+    p.skip_alignment = 0;
+    p.error_rate = bpars.errorRate;
+    p.delta_chernoff = bpars.deltaChernoff;
+    std::vector<bella_aln> al(n);
+    check(ctx, bella_hip_xdrop_batch(ctx, sd.data(), n, &p, al.data()), "bella_hip_xdrop_batch");
+    for (size_t t = 0; t < n; ++t) {
+        out[t].score = al[t].score;
+        out[t].strand = al[t].strand ? "c" : "n";
+        out[t].seed.beginPositionH = al[t].begH;
+        out[t].seed.beginPositionV = al[t].begV;
+        out[t].seed.endPositionH = al[t].endH;
+        out[t].seed.endPositionV = al[t].endV;
+    }
+}
+
+// include/align.hpp:152
+inline xavierResult xavierAlign(const std::string& row, const std::string& col, int rowLen, int i, int j, int xDrop, int kmerSize) {
+    (void)rowLen;                                                              // == row.size() at the reference's call site (overlap.hpp:565)
+    BELLApars bp;
+    bp.kmerSize = (unsigned short)kmerSize;
+    bp.xDrop = (unsigned short)xDrop;
+    bp.errorRate = 0.15;
+    std::vector<xavierResult> out;
+    alignXavier({row}, {col}, {SeedX(i, j, kmerSize)}, bp, out);
+    return out[0];
+}
+
+}  // namespace bella_hip

@@ -57,18 +57,19 @@
 
 typedef uint32_t KIDX;
 
-extern "C" int bella_dropin_hashspgemm(uint32_t nreads, uint32_t nkmers, uint64_t ntuples, const uint32_t* t_kmer,
-                                       const uint32_t* t_read, const uint16_t* t_pos, const char* const* seqs,
-                                       const char* const* names, int kmerSize, int binSize, int xDrop, int skipAlignment,
-                                       int outputPaf, double errorRate, double deltaChernoff, const char* outfile,
-                                       char* stdout_log, size_t stdout_cap) {
+// numGPU = BELLApars::numGPU (-g), totalMemoryMB = BELLApars::totalMemory (-m): the shim derives contexts and stages from them
+extern "C" int bella_dropin_hashspgemm2(uint32_t nreads, uint32_t nkmers, uint64_t ntuples, const uint32_t* t_kmer,
+                                        const uint32_t* t_read, const uint16_t* t_pos, const char* const* seqs,
+                                        const char* const* names, int kmerSize, int binSize, int xDrop, int skipAlignment,
+                                        int outputPaf, double errorRate, double deltaChernoff, int numGPU, double totalMemoryMB,
+                                        const char* outfile, char* stdout_log, size_t stdout_cap) {
     std::stringstream sc;
     std::streambuf* oc = std::cout.rdbuf(sc.rdbuf());
     BELLApars bpars;
     bpars.kmerSize = kmerSize; bpars.binSize = binSize; bpars.xDrop = xDrop;
     bpars.skipAlignment = skipAlignment != 0; bpars.outputPaf = outputPaf != 0;
     bpars.errorRate = errorRate; bpars.deltaChernoff = deltaChernoff;
-    bpars.totalMemory = 400000.0; bpars.userDefMem = true;
+    bpars.totalMemory = totalMemoryMB; bpars.userDefMem = true; bpars.numGPU = (unsigned short)numGPU;
     double ratiophi = slope(bpars.errorRate);
     readVector_ reads(nreads);
     for (uint32_t r = 0; r < nreads; ++r) { reads[r].nametag = names[r]; reads[r].seq = seqs[r]; reads[r].readid = r; }
@@ -102,5 +103,41 @@ extern "C" int bella_dropin_hashspgemm(uint32_t nreads, uint32_t nkmers, uint64_
     std::cout.rdbuf(oc);
     std::string s = sc.str();
     if (stdout_log && stdout_cap) { size_t n = std::min(stdout_cap - 1, s.size()); memcpy(stdout_log, s.data(), n); stdout_log[n] = 0; }
+    return 0;
+}
+
+extern "C" int bella_dropin_hashspgemm(uint32_t nreads, uint32_t nkmers, uint64_t ntuples, const uint32_t* t_kmer,
+                                       const uint32_t* t_read, const uint16_t* t_pos, const char* const* seqs,
+                                       const char* const* names, int kmerSize, int binSize, int xDrop, int skipAlignment,
+                                       int outputPaf, double errorRate, double deltaChernoff, const char* outfile,
+                                       char* stdout_log, size_t stdout_cap) {
+    return bella_dropin_hashspgemm2(nreads, nkmers, ntuples, t_kmer, t_read, t_pos, seqs, names, kmerSize, binSize, xDrop, skipAlignment,
+                                    outputPaf, errorRate, deltaChernoff, 1, 400000.0, outfile, stdout_log, stdout_cap);
+}
+
+// the align.hpp call surface through the shim: out = {score, begH, endH, begV, endV}, strand = "n" / "c"
+extern "C" int bella_dropin_xavier_align(const char* row, const char* col, int i, int j, int xDrop, int kmerSize, int* out, char* strand) {
+    const std::string r(row), c(col);
+    xavierResult res = bella_hip::xavierAlign(r, c, (int)r.size(), i, j, xDrop, kmerSize);
+    out[0] = res.score; out[1] = res.seed.beginPositionH; out[2] = res.seed.endPositionH; out[3] = res.seed.beginPositionV; out[4] = res.seed.endPositionV;
+    strand[0] = res.strand[0]; strand[1] = 0;
+    return 0;
+}
+
+// the batched form (alignLogan's shape, align.hpp:210-211): n pairs at once
+extern "C" int bella_dropin_align_batch(int n, const char* const* rows, const char* const* cols, const int* is, const int* js, int xDrop,
+                                        int kmerSize, int* out, char* strands) {
+    std::vector<std::string> target, query;
+    std::vector<SeedX> seeds;
+    for (int t = 0; t < n; ++t) { target.emplace_back(rows[t]); query.emplace_back(cols[t]); seeds.emplace_back(is[t], js[t], kmerSize); }
+    BELLApars bp;
+    bp.kmerSize = (unsigned short)kmerSize; bp.xDrop = (unsigned short)xDrop; bp.errorRate = 0.15;
+    std::vector<xavierResult> res;
+    bella_hip::alignXavier(target, query, seeds, bp, res);
+    for (int t = 0; t < n; ++t) {
+        out[5 * t] = res[t].score; out[5 * t + 1] = res[t].seed.beginPositionH; out[5 * t + 2] = res[t].seed.endPositionH;
+        out[5 * t + 3] = res[t].seed.beginPositionV; out[5 * t + 4] = res[t].seed.endPositionV;
+        strands[t] = res[t].strand[0];
+    }
     return 0;
 }

@@ -9,7 +9,7 @@ import pytest
 import _oracle as O
 from bella_amd import BellaPars, Engine, api, synth
 from bella_amd.api import BellaHipError
-from conftest import GOLD, load_golden
+from conftest import GOLD, ROOT, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -294,6 +294,75 @@ def test_dropin_shim_from_reference_call_site(eng, tmp_path):
             nums = so.value.decode().split()
             assert nums[:3] == g.stdout[key][:3]            # nkmer, nnz(A) after merge, nnz(C): the stdout protocol
             assert open(f, "rb").read() == g.out[key]       # the reference's file, byte for byte (no tolerance)
+
+
+def test_dropin_shim_stages_and_gpus_from_bellapars(eng, tmp_path, monkeypatch):
+    """BELLApars::totalMemory (-m) -> the reference's stage count and boundaries (overlap.hpp:365-404,682-710); BELLApars::numGPU
+    (-g) -> that many contexts (here sharing the one GPU): the file stays the reference's single-stage file, byte for byte"""
+    import ctypes as C
+    path = os.path.join(ROOT, "oracle", "_ref", "libbella_dropin.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libbella_dropin.so not built")
+    monkeypatch.setenv("BELLA_HIP_SHIM_OVERSUBSCRIBE", "1")
+    lib = C.CDLL(path)
+    u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+    u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+    lib.bella_dropin_hashspgemm2.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, u32p, u32p, u16p, C.POINTER(C.c_char_p),
+                                             C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                             C.c_double, C.c_int, C.c_double, C.c_char_p, C.c_char_p, C.c_size_t]
+    g = load_golden("toy120")
+    n = g.rs.nreads
+    sarr = (C.c_char_p * n)(*g.seqs)
+    narr = (C.c_char_p * n)(*[x.encode() for x in g.names])
+    nnzc = int(g.stdout["skip"][2])
+    for ngpu, stages in ((1, 1), (1, 3), (2, 1), (3, 4)):
+        # required = 1.5 * nnzc * (16 + 4) bytes (overlap.hpp:682); a budget of required / (stages - 0.5) gives `stages` stages
+        mem_mb = 400000.0 if stages == 1 else 1.5 * nnzc * 20 / (stages - 0.5) / (1024 * 1024)
+        for skip, key in ((1, "skip"), (0, "align")):
+            so = C.create_string_buffer(4096)
+            f = str(tmp_path / ("g%d_s%d_%s.out" % (ngpu, stages, key)))
+            lib.bella_dropin_hashspgemm2(n, g.nkmers, len(g.tk), g.tk, g.tr, g.tp, sarr, narr, g.k, 500, 7, skip, 0, g.err, 0.1, ngpu, mem_mb,
+                                         f.encode(), so, len(so))
+            nums = so.value.decode().split()
+            assert nums[:3] == g.stdout[key][:3]
+            assert open(f, "rb").read() == g.out[key], (ngpu, stages, key)
+            if not skip:
+                assert len(nums) == 3 + stages and sum(int(x) for x in nums[3:]) == int(g.stdout["align"][3])   # outputted per stage (:771)
+
+
+def test_dropin_shim_align_call_surface(eng):
+    """bella_hip::xavierAlign (align.hpp:152) and the alignLogan-shaped batch (align.hpp:210-211) of the shim, compiled against
+    the reference's headers, on the reference's known answers"""
+    import ctypes as C
+    path = os.path.join(ROOT, "oracle", "_ref", "libbella_dropin.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libbella_dropin.so not built")
+    lib = C.CDLL(path)
+    kats = [k for k in json.load(open(os.path.join(ROOT, "tests", "golden", "xavier_kat.json"))) if k["kind"] == "align"]
+    assert len(kats) >= 10
+    oracle_flag = [int(O.xavier_align(k["row"].encode(), k["col"].encode(), k["i"], k["j"], k["x"], k["k"])["flagged"]) for k in kats]
+    for kat, fl in zip(kats[:6], oracle_flag):                         # one call per pair
+        out = (C.c_int * 5)()
+        st = C.create_string_buffer(2)
+        lib.bella_dropin_xavier_align(kat["row"].encode(), kat["col"].encode(), kat["i"], kat["j"], kat["x"], kat["k"], out, st)
+        if not fl:
+            assert list(out) == kat["expect"] and st.value.decode() == kat["strand"], kat["name"]
+    same = [k for k in kats if (k["x"], k["k"]) == (kats[0]["x"], kats[0]["k"])]
+    n = len(same)
+    rows = (C.c_char_p * n)(*[k["row"].encode() for k in same])
+    cols = (C.c_char_p * n)(*[k["col"].encode() for k in same])
+    is_ = (C.c_int * n)(*[k["i"] for k in same])
+    js_ = (C.c_int * n)(*[k["j"] for k in same])
+    out = (C.c_int * (5 * n))()
+    st = C.create_string_buffer(n + 1)
+    lib.bella_dropin_align_batch(n, rows, cols, is_, js_, same[0]["x"], same[0]["k"], out, st)
+    checked = 0
+    for t, kat in enumerate(same):
+        if O.xavier_align(kat["row"].encode(), kat["col"].encode(), kat["i"], kat["j"], kat["x"], kat["k"])["flagged"]:
+            continue
+        assert list(out[5 * t:5 * t + 5]) == kat["expect"] and st.raw[t:t + 1].decode() == kat["strand"], kat["name"]
+        checked += 1
+    assert checked >= 8
 
 
 def _run_constructed(eng, lens, per_read, nkmers, k=17, seed=0):
