@@ -36,13 +36,18 @@ struct Buf {
 // half-size key tables of pair-rich inputs); tiers whose workgroups need the same share of a CU's 160 KB (1/4, 1/3, 1/2, all of
 // it) form one LDS class = ONE launch that walks its tiers' lists from the largest columns down.  Last: the global-workspace
 // tier.  BELLA_HIP_TIERS=a,b,c (read once per context; tuning aid / tests) overrides the LDS caps.
-constexpr uint32_t kNumTiers = 12;  // at most
-constexpr uint32_t kDefaultTiers = 10;
-const uint32_t kTierCapsDefault[kNumTiers] = {768, 1280, 2048, 2752, 3712, 4600, 5568, 8192, 11008, 65535};
-const uint32_t kTierCapsHalf[kNumTiers] = {768, 1280, 2105, 2789, 3500, 4096, 6144, 8192, 11008, 65535};
+constexpr uint32_t kNumTiers = 15;  // at most
+constexpr uint32_t kDefaultTiers = 14;
+const uint32_t kTierCapsDefault[kNumTiers] = {384, 689, 1000, 1394, 2048, 2752, 3712, 4600, 5568, 8192, 11008, 65535, 65535, 65535};
+const uint32_t kTierCapsHalf[kNumTiers] = {300, 526, 800, 1064, 1600, 2105, 2789, 3500, 4096, 6144, 8192, 11008, 65535, 65535};
 constexpr uint32_t kHalfTableMaxCap = 4096;              // above: quarter-size key tables on any input
-constexpr uint32_t kNumClasses = 4;
-const size_t kClassLds[kNumClasses] = {40160, 54608, 81920, 163840};   // 4, 3, 2, 1 workgroups per CU
+// LDS classes: the share of a CU's 160 KB a column's workgroup needs, and the workgroup size that goes with it.  A column costs
+// a fixed ~18 us of latency (three dependent memory round trips, ~16 barriers) plus time per product: small columns get small
+// workgroups so that 16 or 8 of them share a CU; where only one or two columns fit a CU they get 1024 threads -- every class
+// keeps the CU's 32 wavefront slots filled.
+constexpr uint32_t kNumClasses = 6;
+const size_t kClassLds[kNumClasses] = {10240, 20480, 40160, 54608, 81920, 163840};   // 16, 8, 4, 3, 2, 1 workgroups per CU
+const int kClassBlock[kNumClasses] = {128, 256, 256, 512, 1024, 1024};   // measured: tools/ notes in DESIGN.md 4.1
 constexpr uint32_t kGlobalGrid = 1024;      // persistent workgroups of the global path: latency-bound, four per CU
 constexpr uint32_t kAsmGrid = 1024;
 
@@ -109,13 +114,13 @@ struct bella_ctx {
     Buf comm_meta;
     bool pass_known = false;             // tier lengths and product total of the last pass (valid for pass_sig)
     uint64_t pass_sig[6] = {};
-    uint32_t pass_tcnt[16] = {};
+    uint32_t pass_tcnt[20] = {};
     uint64_t pass_products = 0;
     uint32_t pass_retry = 0, pass_overflow = 0;
     uint32_t tier_caps[kNumTiers] = {};  // ascending LDS caps, last = 65535 (global-workspace tier); per context
     uint32_t ntiers = 0;
     bool tiers_from_env = false;
-    size_t lds_attr[12] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
+    size_t lds_attr[16] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
     hipStream_t side[kNumTiers + 1]{};   // independent tier launches / fold instances run concurrently
     hipEvent_t fork = nullptr, join[kNumTiers + 1]{};
 };
@@ -347,8 +352,8 @@ int bella_hip_init(int device, bella_ctx** out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BELLA_ERR_NO_DEVICE;
     bella_ctx* c = new bella_ctx();
     c->device = device;
-    for (uint32_t t = 0; t < kDefaultTiers; ++t) c->tier_caps[t] = kTierCapsDefault[t];
-    c->ntiers = kDefaultTiers;
+    c->ntiers = 0;
+    for (uint32_t t = 0; t < kNumTiers; ++t) { c->tier_caps[t] = kTierCapsDefault[t]; c->ntiers = t + 1; if (kTierCapsDefault[t] == 65535) break; }
     if (const char* tv = getenv("BELLA_HIP_TIERS")) {             // tuning aid / tests: ascending LDS caps, each <= 11008
         uint32_t n = 0;
         uint32_t caps[kNumTiers];
@@ -1243,7 +1248,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     uint32_t caps[kNumTiers] = {};
     const bool half_tables = !(c->pair_ratio1024 * 5 < 1024);
     const uint32_t* tier_caps = (half_tables && !c->tiers_from_env) ? kTierCapsHalf : c->tier_caps;
-    const uint32_t g_ntiers = c->ntiers;
+    uint32_t g_ntiers = c->ntiers;
+    if (!c->tiers_from_env)
+        for (g_ntiers = 1; tier_caps[g_ntiers - 1] != 65535; ++g_ntiers) {}
     for (uint32_t t = 0; t < g_ntiers; ++t) caps[t] = force_global && t + 1 < g_ntiers ? 0 : tier_caps[t];
     const int want_state = (force_global ? 2 : 1) + (half_tables ? 2 : 0);
     if (c->caps_state != want_state) {                         // the tier caps only change with the operands or the debug switch
@@ -1344,7 +1351,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         const bool half = (half_tables || (c->debug & 16u)) && cap <= kHalfTableMaxCap;     // debug bit 4: tests
         return half ? cap / 2 : cap / 4;
     };
-    struct Launch { int lo, hi; size_t lds; uint32_t rows; };
+    struct Launch { int lo, hi; size_t lds; uint32_t rows; int cls; };
     Launch ln[kNumTiers];
     int nl = 0;
     {
@@ -1354,7 +1361,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
             int cls = (int)kNumClasses - 1;
             for (int k2 = 0; k2 < (int)kNumClasses; ++k2)
                 if (lds <= kClassLds[k2]) { cls = k2; break; }
-            if (cls != cls_prev || nl == 0) { ln[nl++] = Launch{t, t, lds, 0}; cls_prev = cls; }
+            if (cls != cls_prev || nl == 0) { ln[nl++] = Launch{t, t, lds, 0, cls}; cls_prev = cls; }
             ln[nl - 1].hi = t;
             ln[nl - 1].lds = lds;                                 // the class is carved for its largest tier
             ln[nl - 1].rows += tcnt[t];
@@ -1381,7 +1388,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
     auto launch_class = [&](int l, bool on_main) -> int {
         hipStream_t sst = c->stream;
         if (!on_main) {
-            const int which = nside < 1 ? 0 : 1;
+            const int which = nside;                              // 0, 1, 2: one class each
             int r2 = side_stream(which);
             if (r2) return r2;
             sst = c->side[which];
@@ -1397,18 +1404,26 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         a.dcap = dcap_of(a.cap);
         const size_t lds = ln[l].lds;
         const bool ga = gaux_in_t2(a.cap, a.dcap, true);
-        // classes with one or two columns per CU: 1024 threads per column, so that the CU's 32 wavefront slots stay filled
-        const bool big_block = lds > kClassLds[1] && !(c->debug & 8u);
+        const int blk = (c->debug & 8u) ? 512 : kClassBlock[ln[l].cls];     // debug bit 3: tests, 512 threads everywhere
         int ki;
         void (*kern)(SpgemmArgs);
-        if (!big_block) {
+        if (blk == 512) {
             ki = a.cap <= 8 * 512 ? (ga ? 0 : 1) : a.cap <= 16 * 512 ? (ga ? 2 : 3) : 4;
             kern = ki == 0 ? k_spgemm_rows_lds<8, true, 512> : ki == 1 ? k_spgemm_rows_lds<8, false, 512>
                  : ki == 2 ? k_spgemm_rows_lds<16, true, 512> : ki == 3 ? k_spgemm_rows_lds<16, false, 512> : k_spgemm_rows_lds<22, false, 512>;
-        } else {
+        } else if (blk == 1024) {
             ki = a.cap <= 4 * 1024 ? (ga ? 5 : 6) : a.cap <= 8 * 1024 ? (ga ? 7 : 8) : 9;
             kern = ki == 5 ? k_spgemm_rows_lds<4, true, 1024> : ki == 6 ? k_spgemm_rows_lds<4, false, 1024>
                  : ki == 7 ? k_spgemm_rows_lds<8, true, 1024> : ki == 8 ? k_spgemm_rows_lds<8, false, 1024> : k_spgemm_rows_lds<11, false, 1024>;
+        } else if (blk == 256 && a.cap <= 6 * 256) {              // cap <= 1394 <= 6 * 256
+            ki = ga ? 10 : 11;
+            kern = ga ? k_spgemm_rows_lds<6, true, 256> : k_spgemm_rows_lds<6, false, 256>;
+        } else if (blk == 256) {                                  // cap <= 2752 <= 11 * 256
+            ki = ga ? 14 : 15;
+            kern = ga ? k_spgemm_rows_lds<11, true, 256> : k_spgemm_rows_lds<11, false, 256>;
+        } else {                                                  // cap <= 689 <= 6 * 128
+            ki = ga ? 12 : 13;
+            kern = ga ? k_spgemm_rows_lds<6, true, 128> : k_spgemm_rows_lds<6, false, 128>;
         }
         if (lds > c->lds_attr[ki]) {                             // once per kernel and size, not per launch
             HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1417,7 +1432,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
 #ifdef BELLA_DEV_PROF
         a.prof = (unsigned long long*)c->prof.p + 10 * l;
 #endif
-        kern<<<ln[l].rows, big_block ? 1024 : 512, lds, sst>>>(a);
+        kern<<<ln[l].rows, blk, lds, sst>>>(a);
 #ifdef BELLA_DEV_PROF
         a.prof = nullptr;
 #endif
@@ -1430,7 +1445,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         if (ln[l].rows && whole_cu(l) && l != main_l) { rc = launch_class(l, true); if (rc) return rc; }
     if (global_tier) {                                            // the columns above the LDS tiers (or all of them: debug bit 0)
         hipStream_t sst = c->stream;
-        if (main_l >= 0) { rc = side_stream(2); if (rc) return rc; sst = c->side[2]; }
+        if (main_l >= 0) { rc = side_stream(2); if (rc) return rc; sst = c->side[2]; }      // (launch_class uses sides 0, 1 then)
         a.rowdesc = ptr<uint4>(c->rowlists) + (size_t)(g_ntiers - 1) * nr;
         a.nrows = tcnt[g_ntiers - 1];
         a.cap = tier_caps[g_ntiers - 1];
@@ -1440,8 +1455,19 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out)
         KCHK(c);
         launches++;
     }
-    for (int l = nl - 1; l >= 0; --l)
-        if (ln[l].rows && (!whole_cu(l) || l == main_l)) { rc = launch_class(l, l == main_l); if (rc) return rc; }
+    {   // the three largest remaining classes each get a side stream; what is left (the classes of the smallest columns) runs on
+        // the main stream, larger class first
+        int side_left = global_tier ? 2 : 3;
+        for (int l = nl - 1; l >= 0; --l) {
+            if (!ln[l].rows || (whole_cu(l) && l != main_l)) continue;
+            int later = 0;                                        // non-empty classes below this one
+            for (int m2 = 0; m2 < l; ++m2) later += ln[m2].rows ? 1 : 0;
+            const bool on_main = l == main_l || side_left == 0 || later == 0;
+            if (!on_main) side_left--;
+            rc = launch_class(l, on_main);
+            if (rc) return rc;
+        }
+    }
     for (int w = 0; w < 3; ++w)
         if (used[w]) {
             HIPCHK(c, hipEventRecord(c->join[w], c->side[w]));

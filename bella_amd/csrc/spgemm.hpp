@@ -54,8 +54,8 @@ constexpr uint32_t kCtlOverflow = 17;     // overflow list length
 constexpr uint32_t kCtlWork2 = 18;        // k_fold_overflow counter
 constexpr uint32_t kCtlStatus = 19;       // bit0: a pair ended with > 16 bins and no scratch was given
 constexpr uint32_t kCtlRetry = 21;        // columns whose key table overflowed in an LDS tier (rerun on the global path)
-constexpr uint32_t kCtlTierCnt = 32;      // [14] columns per tier, last used entry = wide columns
-constexpr uint32_t kCtlTotals = 46;       // u64[2]: nnz(C), products (8-byte aligned)
+constexpr uint32_t kCtlTierCnt = 32;      // [16] columns per tier, last used entry = wide columns
+constexpr uint32_t kCtlTotals = 48;       // u64[2]: nnz(C), products (8-byte aligned)
 constexpr uint32_t kCtlWords = 64;
 
 struct SpgemmArgs {
@@ -566,7 +566,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 // LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap, dcap); NX * 512 >= cap (8: the tiers up to 4096 products,
 // 16: the two big tiers that keep HiFi-like columns with long lists off the global path)
 template <uint32_t NX, bool GALIAS, int BLK = BELLA_ROW_BLOCK>
-__global__ __launch_bounds__(BLK, (BLK == 1024 ? (NX <= 4 ? 8 : 4) : (NX <= 8 ? 6 : 2))) void k_spgemm_rows_lds(SpgemmArgs a) {
+__global__ __launch_bounds__(BLK, (BLK == 1024 ? (NX <= 4 ? 8 : 4) : BLK <= 256 ? 8 : (NX <= 8 ? 6 : 2))) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // the launch covers the tiers of one LDS class, largest columns first: workgroup x -> (tier, place in the tier's list)
     const uint32_t* tc = a.ctl + kCtlTierCnt;
