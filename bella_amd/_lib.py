@@ -60,6 +60,8 @@ SIGNATURES = [
     ("bella_hip_comm_init", C.c_int, [vp, C.c_int, C.c_int, vp]),
     ("bella_hip_comm_destroy", C.c_int, [vp]),
     ("bella_hip_allgather_panels", C.c_int, [vp]),
+    ("bella_hip_count_kmers_dist", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("bella_hip_panel_device_ptrs", C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(vp),
                                                C.POINTER(vp), C.POINTER(vp)]),
     ("bella_hip_set_B_device", C.c_int, [vp, C.c_uint16, C.c_uint32, vp, vp, vp, C.c_uint64]),

@@ -181,6 +181,15 @@ class Engine:
     def comm_destroy(self):
         self._chk(self.lib.bella_hip_comm_destroy(self.h))
 
+    def count_kmers_dist(self, first_read, nreads_block, k=17, lower=2, upper=8, syncmer=False, window=0):
+        """collective (needs comm_init): the dictionary is counted across the ranks, tuples only for this rank's read block"""
+        nk, nt, nd = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+        sel = 1 if syncmer else (2 if window else 0)
+        self._chk(self.lib.bella_hip_count_kmers_dist(self.h, k, lower, upper, sel, window, first_read, nreads_block, C.byref(nk), C.byref(nt),
+                                                      C.byref(nd)))
+        self.nkmers_counted, self.ntuples_counted = nk.value, nt.value
+        return nk.value, nt.value, nd.value
+
     def allgather_panels(self):
         """collective: every rank's row block of B -> the whole matrix on every rank, device layout built"""
         self._chk(self.lib.bella_hip_allgather_panels(self.h))

@@ -246,8 +246,9 @@ __global__ __launch_bounds__(kBlock) void k_lookup_ids(const uint32_t* packed, c
 }
 
 // tuple pass 2: (id, read, position) in the reference's generation order -- read by read, positions ascending
+// (read_base: the reads handed in are the block read_base .. read_base + nreads - 1 of the read set; t_read holds absolute ids)
 __global__ __launch_bounds__(kBlock) void k_write_tuples(const uint32_t* ids, const uint32_t* nk, const uint64_t* koff, const uint64_t* tstart,
-                                                         uint32_t nreads, uint32_t* t_kmer, uint32_t* t_read, uint16_t* t_pos) {
+                                                         uint32_t nreads, uint32_t read_base, uint32_t* t_kmer, uint32_t* t_read, uint16_t* t_pos) {
     __shared__ uint32_t scr[kWaves];
     for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
         const uint64_t o = koff[r];
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void k_write_tuples(const uint32_t* ids, co
             const uint32_t f = id != 0xFFFFFFFFu ? 1u : 0u;
             uint32_t tot;
             const uint32_t ex = block_excl_scan<kWaves>(f, scr, &tot);
-            if (f) { t_kmer[w + ex] = id; t_read[w + ex] = r; t_pos[w + ex] = (uint16_t)j; }
+            if (f) { t_kmer[w + ex] = id; t_read[w + ex] = read_base + r; t_pos[w + ex] = (uint16_t)j; }
             w += tot;
         }
     }

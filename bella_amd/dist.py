@@ -87,26 +87,45 @@ def allgather_panels(rowcnt, rowids, values, group=None):
     return colptr, ids, val
 
 
-def exchange_panels(eng, device_index: int, backend: str = "nccl", k: int = 17):
-    """All ranks call after Engine.assemble_*_panel: gives every rank the whole matrix.  Preferred path: the library's own
-    RCCL communicator (bella_hip_comm_init + bella_hip_allgather_panels: one grouped point-to-point exchange straight between
-    the device arrays); the 128-byte communicator id travels over torch.distributed.  Falls back to torch.distributed's
-    all_gather (also RCCL with the "nccl" backend; the only path with "gloo").  Returns the name of the path taken."""
+def init_comm(eng, device_index: int, backend: str = "nccl") -> bool:
+    """All ranks call once: creates the library's own RCCL communicator (bella_hip_comm_init); the 128-byte id travels over
+    torch.distributed.  Returns False (and leaves the context without a communicator) when that is not possible -- "gloo"
+    backend in CPU-rendezvous tests, or librccl missing: the callers then use the torch.distributed paths."""
     import torch
     import torch.distributed as dist
+    if backend != "nccl":
+        return False
     world, rank = dist.get_world_size(), dist.get_rank()
-    if backend == "nccl":
+    try:
+        dev = torch.device("cuda", device_index)
+        raw = eng.comm_id() if rank == 0 else bytes(128)
+        t = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0)
+        eng.comm_init(world, rank, bytes(t.cpu().tolist()))
+        ok = 1
+    except Exception as e:
+        import sys
+        print("[bella_amd.dist] library communicator unavailable (%r); using torch.distributed" % (e,), file=sys.stderr)
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", device_index))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # all ranks take the same path
+    if int(flag.item()) == 0:
         try:
-            dev = torch.device("cuda", device_index)
-            raw = eng.comm_id() if rank == 0 else bytes(128)
-            t = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
-            dist.broadcast(t, src=0)
-            eng.comm_init(world, rank, bytes(t.cpu().tolist()))
-            eng.allgather_panels()
-            return "bella_hip_allgather_panels (RCCL send/recv group)"
-        except Exception as e:                              # reported in the bench line
-            import sys
-            print("[bella_amd.dist] C++ RCCL path failed (%r); using torch.distributed" % (e,), file=sys.stderr)
+            eng.comm_destroy()
+        except Exception:
+            pass
+        return False
+    return True
+
+
+def exchange_panels(eng, device_index: int, backend: str = "nccl", k: int = 17, have_comm: bool = False):
+    """All ranks call after Engine.assemble_*_panel: gives every rank the whole matrix.  With the library's communicator
+    (init_comm): bella_hip_allgather_panels, one grouped point-to-point exchange straight between the device arrays.  Otherwise
+    torch.distributed's all_gather (RCCL too with the "nccl" backend; the only path with "gloo").  Returns the path's name."""
+    import torch
+    if have_comm:
+        eng.allgather_panels()
+        return "bella_hip_allgather_panels (RCCL send/recv group)"
     pc, pr, pv = eng.panel_tensors(device_index)
     if backend != "nccl":
         pc, pr, pv = pc.cpu(), pr.cpu(), pv.cpu()

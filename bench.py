@@ -187,8 +187,17 @@ def main():
         t1 = time.time()
         eng = Engine(local)
         eng.set_reads(rs)                                   # reads are replicated (2 bit/base)
-        nk, nt, ndistinct = eng.count_kmers(17, 2, 8)
-        info = {"rs": rs, "nk": nk, "kcount_ms": eng.timings().kcount_ms, "xchg_ms": None, "xchg_path": None}
+        have_comm = False
+        if world > 1:
+            from bella_amd import dist as bd
+            have_comm = bd.init_comm(eng, local, backend)   # the library's own RCCL communicator (include/bella_hip.h)
+            lo, npanel = bd.block_range(rank, world, nreads)
+        if have_comm:                                       # the dictionary is counted ACROSS the ranks, tuples for the own read block
+            nk, nt, ndistinct = eng.count_kmers_dist(lo, npanel, 17, 2, 8)
+        else:
+            nk, nt, ndistinct = eng.count_kmers(17, 2, 8)
+        info = {"rs": rs, "nk": nk, "kcount_ms": eng.timings().kcount_ms, "xchg_ms": None, "xchg_path": None,
+                "kcount_path": "bella_hip_count_kmers_dist (code space split over the ranks)" if have_comm else "bella_hip_count_kmers (every rank, all reads)"}
         info["tup"] = synth.Tuples(*eng.get_tuples(), nk) if want_host_tuples else None
         if rank == 0:
             log("[bench] reads %d (%.1f s), distinct k-mers %d, reliable %d, tuples %d (device: %.1f ms)"
@@ -197,13 +206,11 @@ def main():
             eng.assemble_counted()
             info["asm_ms"] = eng.timings().assemble_ms
         else:
-            from bella_amd import dist as bd
-            lo, npanel = bd.block_range(rank, world, nreads)
             eng.assemble_counted_panel(lo, npanel)             # from the device-resident tuples of this rank's read block
             info["asm_ms"] = eng.timings().assemble_ms
             sync()
             tx = time.perf_counter()
-            info["xchg_path"] = bd.exchange_panels(eng, local, backend)     # C++ RCCL entry of the library, or torch.distributed
+            info["xchg_path"] = bd.exchange_panels(eng, local, backend, have_comm=have_comm)
             sync()
             info["xchg_ms"] = (time.perf_counter() - tx) * 1e3
             info["asm_ms"] += eng.timings().assemble_ms
@@ -333,7 +340,7 @@ def main():
                    "partition": "columns i %% %d == rank" % n_gpus},
         "roofline": roofline_of(acc, nnz / n_gpus, copy_gbps, "none"),
         "phases_ms_per_step": phases_of(acc),
-        "kcount_ms_max": float(mx[4]), "assemble_ms_max": float(mx[5]), "panel_allgather_ms": info["xchg_ms"], "panel_allgather_path": info["xchg_path"],
+        "kcount_ms_max": float(mx[4]), "assemble_ms_max": float(mx[5]), "panel_allgather_ms": info["xchg_ms"], "panel_allgather_path": info["xchg_path"], "kcount_path": info["kcount_path"],
         "single_gpu_same_workload": single,
         "speedup_vs_single_gpu": (single["ms_per_step"] / (elapsed * 1e3 / a.steps)) if single else None,
         "pairs_match_single_gpu": (single["pairs"] == int(tot_pairs)) if single else None,

@@ -221,6 +221,12 @@ int bella_hip_comm_init(bella_ctx* ctx, int nranks, int rank, const uint8_t id[B
 int bella_hip_comm_destroy(bella_ctx* ctx);
 /* collective: needs a panel (rank r: rows [first_r, first_r + rows_r), the blocks in rank order covering all reads) */
 int bella_hip_allgather_panels(bella_ctx* ctx);
+/* collective k-mer counting (kmercount.hpp:467-677 + main.cpp:393-416 across the ranks; the reference's relative is --split-count,
+ * kmercount.hpp:534, which partitions the k-mer space into sequential passes): rank r counts the canonical k-mers of ITS range of
+ * the code space over all reads, the partial dictionaries are exchanged once, tuples are made for the reads of the rank's own
+ * block only (the block it will pass to bella_hip_assemble_counted_panel).  selector: 0 all k-mers, 1 syncmers (-s), 2 minimizers (-w). */
+int bella_hip_count_kmers_dist(bella_ctx* ctx, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t selector, uint32_t window,
+                               uint32_t first_read, uint32_t nreads_block, uint32_t* nkmers, uint64_t* ntuples, uint64_t* ndistinct);
 
 /* ---- measurement --------------------------------------------------------------------------------- */
 int bella_hip_get_timings(bella_ctx* ctx, bella_timings* t);

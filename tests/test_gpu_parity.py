@@ -859,6 +859,20 @@ def test_library_communicator_allgather_single_rank(eng):
     eng.overlap(BellaPars(skipAlignment=True))
     for a, b in zip(p1, eng.get_pairs()):
         assert np.array_equal(a, b)
+    # distributed counting on the 1-rank communicator: the whole code space here, tuples for a read block only
+    nk2, nt2, nd2 = eng.count_kmers_dist(40, 70, 17, 2, 8)
+    assert nk2 == nk
+    tk, tr, tp = eng.get_tuples()
+    eng.count_kmers(17, 2, 8)
+    fk, fr, fp = eng.get_tuples()
+    keep = (fr >= 40) & (fr < 110)
+    assert nt2 == int(keep.sum()) and np.array_equal(tk, fk[keep]) and np.array_equal(tr, fr[keep]) and np.array_equal(tp, fp[keep])
+    eng.count_kmers_dist(40, 70, 17, 2, 8)
+    with pytest.raises(BellaHipError):
+        eng.assemble_counted()                     # the tuples cover a block only
+    with pytest.raises(BellaHipError):
+        eng.assemble_counted_panel(30, 20)         # outside the block
+    eng.assemble_counted_panel(40, 70)
     eng.comm_destroy()
 
 

@@ -1,46 +1,48 @@
 #!/usr/bin/env bash
-# HBM traffic of the SpGEMM kernels from the PMC counters (MI355X_MICROARCH.md "HBM"): FETCH_SIZE and WRITE_SIZE in SEPARATE
-# passes, each with --kernel-trace only.  Run on the GPU box:  bash tools/collect_traffic.sh  (writes gpurun_out/traffic/)
+# HBM traffic of the SpGEMM row kernels from the PMC counters (MI355X_MICROARCH.md "HBM"): FETCH_SIZE and WRITE_SIZE in SEPARATE
+# passes, each with --kernel-trace only.  Run on the GPU box:  bash tools/collect_traffic.sh <key> [bench args]
+# (writes gpurun_out/traffic/<key>.json; key = "10k" | "100k")
 set -euo pipefail
+KEY=${1:-10k}; shift || true
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/traffic
-rm -rf "$OUT"; mkdir -p "$OUT"
+mkdir -p "$OUT"; rm -rf "$OUT/$KEY"_*
+STEPS=4
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -o t -- python "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/bench_$C.json" 2> "$OUT/bench_$C.err" || true
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/${KEY}_$C" -o t -- python "$R/bench.py" --steps $STEPS --warmup 1 --no-cpu-baseline --no-100k --no-xdrop "$@" > "$OUT/${KEY}_bench_$C.json" 2> "$OUT/${KEY}_bench_$C.err" || true
 done
 python - <<PY
 import csv, collections, json, glob
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob("$OUT/%s/*counter_collection.csv" % c)
+    f = glob.glob("$OUT/${KEY}_%s/*counter_collection.csv" % c)
     if not f: continue
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f[0])):
         if r["Counter_Name"] != c: continue
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].split("(")[0].split("<")[0]
         agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     out[c] = {k: {"sum_kb": v[0], "dispatches": v[1]} for k, v in agg.items() if "bella::" in k}
-json.dump(out, open("$OUT/traffic_raw.json", "w"), indent=1)
-bench = json.loads([l for l in open("$OUT/bench_FETCH_SIZE.json") if l.startswith("{")][-1])
-steps = 5
+bench = json.loads([l for l in open("$OUT/${KEY}_bench_FETCH_SIZE.json") if l.startswith("{")][-1])
+passes = $STEPS + 1
 def tot(c, pred):
-    return sum(v["sum_kb"] for k, v in out.get(c, {}).items() if pred(k)) * 1024 / steps
+    return sum(v["sum_kb"] for k, v in out.get(c, {}).items() if pred(k)) * 1024 / passes
 sp = lambda k: "k_spgemm_rows" in k or "k_fold" in k
 fetch, write = tot("FETCH_SIZE", sp), tot("WRITE_SIZE", sp)
 # calibration of FETCH_SIZE on our own coalesced stream: k_row_flops reads 2 B per nonzero of B' (the compact count array)
 nnz = bench["config"]["nnzA"]
 rf = tot("FETCH_SIZE", lambda k: "k_row_flops" in k)
-ratio = rf / (2.0 * nnz)
 summary = {
- "workload": "configs[1] %d reads, 1 GPU" % bench["config"]["reads"],
- "kernels": "k_spgemm_rows_* + k_fold_overflow", "per": "step (= one launch set)",
+ "workload": "%d reads, 1 GPU" % bench["config"]["reads"],
+ "kernels": "k_spgemm_rows_lds (all LDS classes) + k_fold_overflow", "per": "step (= one launch set)",
  "FETCH_SIZE_raw_bytes": fetch, "WRITE_SIZE_raw_bytes": write,
- "fetch_calibration": {"kernel": "k_row_flops", "expected_bytes": 2 * nnz, "ratio_measured_over_expected": ratio,
-                       "note": "FETCH_SIZE reads 1/2 of the streamed bytes on gfx950 (MI355X_MICROARCH.md, HBM); checked on our own coalesced stream (u16 per lane here; 0.539 on the 8-byte stream of the earlier layout)"},
+ "fetch_calibration": {"kernel": "k_row_flops", "expected_bytes": 2 * nnz, "ratio_measured_over_expected": rf / (2.0 * nnz),
+                       "note": "FETCH_SIZE reads 1/2 of the streamed bytes on gfx950 (MI355X_MICROARCH.md, HBM); checked on our own coalesced u16 stream"},
  "hbm_bytes_corrected": 2.0 * fetch + write,
  "algorithmic_bytes": bench["roofline"]["algorithmic_bytes_per_step"],
+ "raw": out,
 }
-json.dump(summary, open("$OUT/hbm_traffic.json", "w"), indent=1)
-print(json.dumps(summary))
+json.dump(summary, open("$OUT/$KEY.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in summary.items() if k != "raw"}))
 PY

@@ -1,17 +1,29 @@
 #!/usr/bin/env bash
-# Regenerates the judged artefacts of a round on the GPU box: bench line, rocprofv3 kernel stats of the same command, HBM traffic.
-# usage: bash tools/refresh_profiles.sh r01_c      (outputs under gpurun_out/refresh/, copy into profiles/)
+# Regenerates the judged artefacts of a round on the GPU box: the bench line, rocprofv3 kernel stats + the step timeline of the
+# same commands (10k and 100k reads), HBM traffic (PMC) and SQ counters.  usage: bash tools/refresh_profiles.sh r02
+# (outputs under gpurun_out/refresh/; copy into profiles/)
 set -uo pipefail
-TAG=${1:-r01_x}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/refresh; rm -rf $OUT; mkdir -p $OUT
 cd $R
 python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o s -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null )
-python tools/summarize_rocprof.py $OUT/prof/s_kernel_stats.csv 30 > $OUT/${TAG}_kernel_stats.txt
-cp $OUT/prof/s_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
-bash tools/collect_traffic.sh > $OUT/traffic.log 2>&1
-cp $R/gpurun_out/traffic/hbm_traffic.json $OUT/r01_hbm_traffic.json
-cp $R/gpurun_out/traffic/traffic_raw.json $OUT/r01_hbm_traffic_raw.json
-rm -rf $OUT/prof
-tail -3 $OUT/traffic.log; cat $OUT/${TAG}_bench.json; head -12 $OUT/${TAG}_kernel_stats.txt
+for KEY in 10k 100k; do
+  if [ $KEY = 10k ]; then ARGS="--steps 20 --warmup 3"; else ARGS="--reads 100000 --steps 5 --warmup 2"; fi
+  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$KEY -o s -- python $R/bench.py $ARGS --no-cpu-baseline --no-100k --no-xdrop > $OUT/${TAG}_bench_under_rocprof_$KEY.json 2>/dev/null )
+  python tools/summarize_rocprof.py $OUT/prof_$KEY/s_kernel_stats.csv 30 > $OUT/${TAG}_kernel_stats_$KEY.txt
+  cp $OUT/prof_$KEY/s_kernel_stats.csv $OUT/${TAG}_kernel_stats_$KEY.csv
+  python tools/timeline.py $OUT/prof_$KEY/s_kernel_trace.csv > $OUT/${TAG}_step_timeline_$KEY.txt
+  rm -rf $OUT/prof_$KEY
+done
+bash tools/collect_traffic.sh 10k > $OUT/traffic_10k.log 2>&1
+bash tools/collect_traffic.sh 100k --reads 100000 > $OUT/traffic_100k.log 2>&1
+python - <<PY
+import json
+d = {k: json.load(open("$R/gpurun_out/traffic/%s.json" % k)) for k in ("10k", "100k")}
+json.dump(d, open("$OUT/${TAG}_hbm_traffic.json", "w"), indent=1)
+PY
+bash tools/collect_sq.sh > $OUT/${TAG}_sq_counters_10k.txt 2>/dev/null
+BENCH_ARGS="--reads 100000" bash tools/collect_sq.sh > $OUT/${TAG}_sq_counters_100k.txt 2>/dev/null
+bash tools/collect_sq_xdrop.sh > $OUT/${TAG}_xdrop_sq.txt 2>/dev/null
+tail -2 $OUT/traffic_10k.log $OUT/traffic_100k.log; cat $OUT/${TAG}_bench.json | cut -c1-600; cat $OUT/${TAG}_step_timeline_10k.txt | tail -3
