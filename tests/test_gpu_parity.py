@@ -782,6 +782,44 @@ def test_wide_columns_bit_exact(eng, monkeypatch, budget):
     assert (ext["nbins"] > 1).any()
 
 
+def test_hifi_syncmer_medium_set_parity(eng):
+    """BASELINE configs[4]'s regime at medium size: 1,200 HiFi-like reads (15 kb, 0.5 % error, 30x), syncmer selection (-s) with
+    -u 40: ~30,000 products per column (the columns of the 11k-65k global-workspace path and of the >= 65,536 wide path), pairs
+    with hundreds to thousands of products (long fold walks).  Every column's product and pair count against the oracle's symbolic
+    phase, every record of 150 sampled columns against its numeric phase, X-drop on 3,000 sampled pairs."""
+    rs = synth.make_reads(1200, read_len=15000, coverage=30.0, err=0.005, seed=2, mix=(1 / 3, 1 / 3, 1 / 3))
+    seqs = rs.seqs()
+    eng.set_reads(rs)
+    nk, nt, _ = eng.count_kmers(17, 2, 40, syncmer=True)
+    tk, tr, tp = eng.get_tuples()
+    eng.assemble_counted()
+    pars = BellaPars(errorRate=0.005)
+    n, flops = eng.overlap(pars)
+    pairs, ext, colptrC = eng.get_pairs()
+    Bc, Br, Bv = O.build_B(rs.nreads, tk, tr, tp)
+    per_row = np.diff(colptrC.astype(np.int64))
+    sample = np.unique(np.concatenate([np.arange(0, rs.nreads, 9), np.argsort(per_row)[-20:]])).astype(np.uint32)
+    flop, nnzc, per_col = O.spgemm_parallel(seqs, nk, Bc, Br, Bv, sample, 17)
+    assert flops == int(flop.astype(np.int64).sum()) and int(flop.max()) > 11008          # beyond the LDS tiers
+    assert flops / max(n, 1) > 200                                                         # long product lists
+    assert np.array_equal(per_row, nnzc.astype(np.int64))
+    got_idx = np.concatenate([np.arange(int(colptrC[c]), int(colptrC[c + 1])) for c in sample])
+    exp = np.concatenate([per_col[int(c)] for c in sample])
+    check_pairs(pairs[got_idx], ext[got_idx], exp, rs.lengths, 17)
+    eng.align_pairs(pars)
+    alns = eng.get_alignments()
+    pick = np.sort(np.random.default_rng(5).choice(n, size=min(3000, n), replace=False))
+    global _XSEQS
+    _XSEQS = seqs
+    import multiprocessing as mp
+    jobs = [(int(pairs["rid"][i]), int(pairs["cid"][i]), int(pairs["seedH"][i]), int(pairs["seedV"][i])) for i in pick]
+    with mp.get_context("fork").Pool(min(64, os.cpu_count() or 1)) as pool:
+        res = pool.map(_xavier_job, jobs, chunksize=16)
+    bad = sum((int(alns[i]["score"]), int(alns[i]["begH"]), int(alns[i]["endH"]), int(alns[i]["begV"]), int(alns[i]["endV"])) != e
+              for i, e in zip(pick, res))
+    assert bad == 0, bad
+
+
 @pytest.mark.parametrize("tier", ["8192", "11008"])
 def test_big_lds_tiers_bit_exact(monkeypatch, tier):
     """every column through the 8192-product LDS tier (the 16-positions-per-thread instance of the row kernel)"""
