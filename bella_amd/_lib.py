@@ -73,6 +73,8 @@ SIGNATURES = [
     ("bella_hip_align_pairs", C.c_int, [vp, C.POINTER(Params), C.POINTER(C.c_uint64)]),
     ("bella_hip_get_alignments", C.c_int, [vp, vp]),
     ("bella_hip_xdrop_batch", C.c_int, [vp, vp, C.c_uint64, C.POINTER(Params), vp]),
+    ("bella_hip_align_pairs_exact", C.c_int, [vp, C.POINTER(Params), C.POINTER(C.c_uint64)]),
+    ("bella_hip_xdrop_batch_exact", C.c_int, [vp, vp, C.c_uint64, C.POINTER(Params), vp]),
     ("bella_hip_get_timings", C.c_int, [vp, C.POINTER(Timings)]),
     ("bella_hip_set_debug", C.c_int, [vp, C.c_uint32]),
 ]

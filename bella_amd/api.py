@@ -234,10 +234,12 @@ class Engine:
         return pairs, ex, colptrC
 
     # ---- RunPairWiseAlignments ----
-    def align_pairs(self, pars: BellaPars):
+    def align_pairs(self, pars: BellaPars, exact: bool = False):
+        """exact=True: the growing-band gapped X-drop of the reference's CUDA build (LOGAN / SeqAn extendSeed) instead of Xavier"""
         n = C.c_uint64(0)
         cp = pars.c()
-        self._chk(self.lib.bella_hip_align_pairs(self.h, C.byref(cp), C.byref(n)))
+        fn = self.lib.bella_hip_align_pairs_exact if exact else self.lib.bella_hip_align_pairs
+        self._chk(fn(self.h, C.byref(cp), C.byref(n)))
         return n.value
 
     def get_alignments(self):
@@ -246,11 +248,12 @@ class Engine:
             self._chk(self.lib.bella_hip_get_alignments(self.h, out.ctypes.data))
         return out
 
-    def xdrop_batch(self, seeds: np.ndarray, pars: BellaPars):
+    def xdrop_batch(self, seeds: np.ndarray, pars: BellaPars, exact: bool = False):
         seeds = np.ascontiguousarray(seeds, SEED_DT)
         out = np.zeros(len(seeds), ALN_DT)
         cp = pars.c()
-        self._chk(self.lib.bella_hip_xdrop_batch(self.h, _p(seeds), len(seeds), C.byref(cp), _p(out)))
+        fn = self.lib.bella_hip_xdrop_batch_exact if exact else self.lib.bella_hip_xdrop_batch
+        self._chk(fn(self.h, _p(seeds), len(seeds), C.byref(cp), _p(out)))
         return out
 
     def timings(self) -> Timings:

@@ -17,6 +17,7 @@
 #include "core.hpp"
 #include "fastq.hpp"
 #include "kcount.hpp"
+#include "logan.hpp"
 #include "spgemm.hpp"
 #include "util.hpp"
 #include "wide.hpp"
@@ -105,7 +106,7 @@ struct bella_ctx {
     uint32_t n_overflow = 0;
     // alignment
     uint64_t nalns = 0;
-    Buf alns, seeds, xest, xest2, xids, xorder, xres;
+    Buf alns, seeds, xest, xest2, xids, xorder, xres, lg_res, lg_redo, lg_scratch;
     bella_timings tm{};
     hipEvent_t ev[10]{};
     uint32_t* pinned = nullptr;          // 128 host words the per-pass read backs land in
@@ -411,7 +412,7 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
                   &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx, &c->w_idx2, &c->w_hv, &c->w_ovfl,
                   &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
-                  &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres};
+                  &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->lg_res, &c->lg_redo, &c->lg_scratch};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& st : c->side) (void)hipStreamDestroy(st);
@@ -1706,6 +1707,50 @@ int bella_hip_get_pairs(bella_ctx* c, bella_pair* pairs, bella_pair_ext* ext, ui
     return 0;
 }
 
+// the exact gapped X-drop of the reference's CUDA build (logan.hpp): one wavefront per extension, LDS rings; the rare extension
+// whose band outgrows them is redone on rings in HBM
+static int run_logan(bella_ctx* c, const bella_params* p, const bella_seed* d_seeds, const bella_pair* d_pairs, uint64_t n, bella_aln* d_out) {
+    if (2 * n >= 0x7FFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "too many pairs for one batch (2^30)");
+    LoganArgs a;
+    a.seeds = d_seeds; a.pairs = d_pairs; a.n = n;
+    a.packed = ptr<uint32_t>(c->packed); a.roff = ptr<uint64_t>(c->roff);
+    a.k = p->kmer_size; a.xdrop = p->xdrop;
+    const double p_mat = pow(1 - p->error_rate, 2), p_mis = 1 - p_mat;
+    a.ratiophi = 1.0 * p_mat - 1.0 * p_mis;
+    a.delta = p->delta_chernoff;
+    a.out = d_out;
+    ENSURE(c, c->lg_res, 16 * (2 * n + 1));
+    ENSURE(c, c->lg_redo, 4 * (2 * n + 2));
+    a.res = ptr<int4>(c->lg_res);
+    a.redo = ptr<uint32_t>(c->lg_redo) + 1;
+    a.nredo = ptr<uint32_t>(c->lg_redo);
+    a.scratch = nullptr; a.scratch_cap = 0;
+    HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
+    if (n) {
+        HIPCHK(c, hipMemsetAsync(a.nredo, 0, 4, c->stream));
+        k_logan_lds<<<(unsigned)(2 * n), 64, 0, c->stream>>>(a);
+        KCHK(c);
+        uint32_t nredo = 0;
+        HIPCHK(c, hipMemcpyAsync(&nredo, a.nredo, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (nredo) {
+            const uint32_t cap = 65536 + 8;                       // reads are < 65536 bases
+            const unsigned grid = nredo < 256u ? nredo : 256u;
+            ENSURE(c, c->lg_scratch, (size_t)grid * 3 * cap * 2);
+            a.scratch = ptr<int16_t>(c->lg_scratch);
+            a.scratch_cap = cap;
+            k_logan_hbm<<<grid, 64, 0, c->stream>>>(a);
+            KCHK(c);
+        }
+        k_logan_finish<<<nblk(n), 256, 0, c->stream>>>(a);
+        KCHK(c);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[9]));
+    c->tm.xdrop_ms = ev_ms(c->ev[8], c->ev[9]);
+    return 0;
+}
+
 static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_seeds, const bella_pair* d_pairs, uint64_t n,
                      bella_aln* d_out) {
     XdropArgs a;
@@ -1765,14 +1810,19 @@ static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_se
     return 0;
 }
 
-int bella_hip_align_pairs(bella_ctx* c, const bella_params* p, uint64_t* npassed) {
+static int align_pairs_impl(bella_ctx* c, const bella_params* p, uint64_t* npassed, bool exact);
+int bella_hip_align_pairs(bella_ctx* c, const bella_params* p, uint64_t* npassed) { return align_pairs_impl(c, p, npassed, false); }
+int bella_hip_align_pairs_exact(bella_ctx* c, const bella_params* p, uint64_t* npassed) { return align_pairs_impl(c, p, npassed, true); }
+
+static int align_pairs_impl(bella_ctx* c, const bella_params* p, uint64_t* npassed, bool exact) {
     if (!c) return BELLA_ERR_BAD_ARG;
     if (!c->have_pairs) return fail(c, BELLA_ERR_STATE, "overlap first");
     int rc = check_params(c, p);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     ENSURE(c, c->alns, sizeof(bella_aln) * c->npairs);
-    rc = run_xdrop(c, p, nullptr, ptr<bella_pair>(c->pairs), c->npairs, ptr<bella_aln>(c->alns));
+    rc = exact ? run_logan(c, p, nullptr, ptr<bella_pair>(c->pairs), c->npairs, ptr<bella_aln>(c->alns))
+               : run_xdrop(c, p, nullptr, ptr<bella_pair>(c->pairs), c->npairs, ptr<bella_aln>(c->alns));
     if (rc) return rc;
     c->nalns = c->npairs;
     c->have_alns = true;
@@ -1802,7 +1852,15 @@ int bella_hip_get_alignments(bella_ctx* c, bella_aln* out) {
     return 0;
 }
 
+static int xdrop_batch_impl(bella_ctx* c, const bella_seed* seeds, uint64_t n, const bella_params* p, bella_aln* out, bool exact);
 int bella_hip_xdrop_batch(bella_ctx* c, const bella_seed* seeds, uint64_t n, const bella_params* p, bella_aln* out) {
+    return xdrop_batch_impl(c, seeds, n, p, out, false);
+}
+int bella_hip_xdrop_batch_exact(bella_ctx* c, const bella_seed* seeds, uint64_t n, const bella_params* p, bella_aln* out) {
+    return xdrop_batch_impl(c, seeds, n, p, out, true);
+}
+
+static int xdrop_batch_impl(bella_ctx* c, const bella_seed* seeds, uint64_t n, const bella_params* p, bella_aln* out, bool exact) {
     if (!c || !p || (n && (!seeds || !out))) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
     if (!c->have_reads) return fail(c, BELLA_ERR_STATE, "set_reads first");
     if (p->kmer_size < 1 || p->kmer_size > 32) return fail(c, BELLA_ERR_BAD_ARG, "k must be in [1,32]");
@@ -1824,7 +1882,8 @@ int bella_hip_xdrop_batch(bella_ctx* c, const bella_seed* seeds, uint64_t n, con
     hipError_t e = hipSuccess;
     if (n) e = hipMemcpyAsync(c->seeds.p, seeds, sizeof(bella_seed) * n, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        rc = run_xdrop(c, p, ptr<bella_seed>(c->seeds), nullptr, n, ptr<bella_aln>(dalns));
+        rc = exact ? run_logan(c, p, ptr<bella_seed>(c->seeds), nullptr, n, ptr<bella_aln>(dalns))
+                   : run_xdrop(c, p, ptr<bella_seed>(c->seeds), nullptr, n, ptr<bella_aln>(dalns));
         if (rc == 0 && n) e = hipMemcpyAsync(out, dalns.p, sizeof(bella_aln) * n, hipMemcpyDeviceToHost, c->stream);
         if (rc == 0 && e == hipSuccess) e = hipStreamSynchronize(c->stream);
     }

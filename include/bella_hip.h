@@ -207,6 +207,13 @@ int bella_hip_get_alignments(bella_ctx* ctx, bella_aln* out);
 int bella_hip_xdrop_batch(bella_ctx* ctx, const bella_seed* seeds, uint64_t n, const bella_params* p,
                           bella_aln* out);
 
+/* The exact (growing band) gapped X-drop of the reference's CUDA build instead of Xavier's 32-cell adaptive band: the scores and
+ * seed positions of loganGPU/functions.cuh:223-408,505-547,680-682 (= SeqAn's extendSeed(GappedXDrop), include/align.hpp:93-139)
+ * and the pass test of PostAlignDecisionGPU (include/overlap.hpp:797-871).  Same inputs and outputs as the two calls above;
+ * bella_aln::steps = anti-diagonals computed, flagged = 0. */
+int bella_hip_align_pairs_exact(bella_ctx* ctx, const bella_params* p, uint64_t* npassed);
+int bella_hip_xdrop_batch_exact(bella_ctx* ctx, const bella_seed* seeds, uint64_t n, const bella_params* p, bella_aln* out);
+
 /* ---- multi-GPU: one context per GPU, RCCL over xGMI ------------------------------------------------
  * The reference's multi-GPU path hands alignment batches to the devices inside one call (loganGPU/functions.cuh:441-443,
  * 498-637; include/align.hpp:226-229) and has no collective.  Here reads are 1D row-block partitioned: context r assembles the

@@ -863,6 +863,130 @@ int oracle_post_align(int score, int begV, int endV, int begH, int endH, uint32_
     return (float)score >= thr;                                               /* :457 */
 }
 
+/* ---------------------------------------------------------------------------------------------------
+ * LOGAN: the exact (growing band) gapped X-drop of the reference's CUDA build (loganGPU/functions.cuh), linear gap, +1/-1/-1.
+ * Pinned on SeqAn's extendSeed(GappedXDrop) compiled from the reference (oracle/_ref: bella_ref_seqan_align), the CPU algorithm
+ * the CUDA kernel ports line by line.  Where the two differ the CPU function decides (one place: an empty prefix / suffix, where
+ * the CUDA kernel returns without writing its result, functions.cuh:270-271, and SeqAn returns 0).
+ * ------------------------------------------------------------------------------------------------- */
+#define LG_UNDEF (-32767)                                                     /* functions.cuh:18 */
+#define LG_GAP (-1)                                                           /* functions.cuh:16 */
+
+/* functions.cuh:223-408 extendSeedLGappedXDropOneDirectionGlobal: query read forward, database read BACKWARD
+ * (dbPos = col + rows - antiDiagNo - 1, :119-120).  Returns the extension score; *extCol / *extRow = bases of query / database
+ * covered (updateExtendedSeedL :67-100 adds / subtracts them). */
+int oracle_logan_one_direction(const char* q, int qlen, const char* db, int dlen, int xdrop, int* extCol, int* extRow, int* steps) {
+    const int cols = qlen + 1, rows = dlen + 1;                               /* :260-267 */
+    *extCol = 0; *extRow = 0;
+    if (rows == 1 || cols == 1) return 0;                                     /* :270 (SeqAn: return 0) */
+    const int cap = (qlen < dlen ? qlen : dlen) + 4;
+    int* b0 = (int*)malloc(sizeof(int) * cap);
+    int* b1 = (int*)malloc(sizeof(int) * cap);
+    int* b2 = (int*)malloc(sizeof(int) * cap);
+    int *ad1 = b0, *ad2 = b1, *ad3 = b2;
+    int a1size = 0, a2size = 0, a3size = 0;
+    int minCol = 1, maxCol = 2;                                               /* :275-276 */
+    int offset1 = 0, offset2 = 0, offset3 = 0;
+    a2size = 1; ad2[0] = 0;                                                   /* initAntiDiags :186-216 */
+    a3size = 2; ad3[0] = LG_GAP; ad3[1] = LG_GAP;
+    int antiDiagNo = 1, best = 0;                                             /* :283-285 */
+    while (minCol < maxCol) {                                                 /* :290 */
+        ++antiDiagNo;
+        int* t = ad1; ad1 = ad2; ad2 = ad3; ad3 = t;                          /* :299-311 */
+        int tl = a1size; a1size = a2size; a2size = a3size; a3size = tl;
+        offset1 = offset2; offset2 = offset3; offset3 = minCol - 1;
+        a3size = maxCol + 1 - offset3;                                        /* initAntiDiag3 :160-184 */
+        ad3[0] = LG_UNDEF;
+        ad3[maxCol - offset3] = LG_UNDEF;
+        if (antiDiagNo * LG_GAP > best - xdrop) {
+            if (offset3 == 0) ad3[0] = antiDiagNo * LG_GAP;
+            if (antiDiagNo - maxCol == 0) ad3[maxCol - offset3] = antiDiagNo * LG_GAP;
+        }
+        for (int col = minCol; col < maxCol; ++col) {                         /* computeAntidiag :102-148 */
+            const int queryPos = col - 1, dbPos = col + rows - antiDiagNo - 1;
+            int a = ad2[col - offset2], b = ad2[col - offset2 - 1];
+            int tmp = (a > b ? a : b) + LG_GAP;
+            const int sc = (q[queryPos] == db[dbPos]) ? 1 : -1;
+            const int dg = ad1[col - offset1 - 1] + sc;
+            if (dg > tmp) tmp = dg;
+            ad3[col - minCol + 1] = (tmp < best - xdrop) ? LG_UNDEF : tmp;
+        }
+        int adb = LG_UNDEF;                                                   /* :318-333 */
+        for (int x = 0; x < a3size; ++x) if (ad3[x] > adb) adb = ad3[x];
+        if (adb > best) best = adb;
+        while (minCol - offset3 < a3size && ad3[minCol - offset3] == LG_UNDEF &&          /* :339-343 */
+               minCol - offset2 - 1 < a2size && ad2[minCol - offset2 - 1] == LG_UNDEF)
+            ++minCol;
+        while (maxCol - offset3 > 0 && ad3[maxCol - offset3 - 1] == LG_UNDEF && ad2[maxCol - offset2 - 1] == LG_UNDEF)   /* :346-350 */
+            --maxCol;
+        ++maxCol;
+        if (minCol < antiDiagNo + 2 - rows) minCol = antiDiagNo + 2 - rows;   /* :358 end of the database segment */
+        if (maxCol > cols) maxCol = cols;                                     /* :360 end of the query segment */
+    }
+    if (steps) *steps = antiDiagNo - 1;
+    int lcol = a3size + offset3 - 2;                                          /* :364-366 */
+    int lrow = antiDiagNo - lcol;
+    int lscore = ad3[lcol - offset3];
+    if (lscore == LG_UNDEF) {
+        if (ad2[a2size - 2] != LG_UNDEF) {                                    /* :370-376 reached the end of the query segment */
+            lcol = a2size + offset2 - 2; lrow = antiDiagNo - 1 - lcol; lscore = ad2[lcol - offset2];
+        } else if (a2size > 2 && ad2[a2size - 3] != LG_UNDEF) {               /* :378-384 end of the database segment */
+            lcol = a2size + offset2 - 3; lrow = antiDiagNo - 1 - lcol; lscore = ad2[lcol - offset2];
+        }
+    }
+    if (lscore == LG_UNDEF)                                                   /* :389-401 general case */
+        for (int x = 0; x < a1size; ++x)
+            if (ad1[x] > lscore) { lscore = ad1[x]; lcol = x + offset1; lrow = antiDiagNo - 2 - lcol; }
+    if (lscore != LG_UNDEF) { *extCol = lcol; *extRow = lrow; }               /* :403-404 */
+    free(b0); free(b1); free(b2);
+    return lscore;
+}
+
+/* The pair as RunPairWiseAlignmentsGPU prepares it (include/overlap.hpp:918-944: strand test, reverse complement of the H read,
+ * seed remap) and extendSeedL runs it (functions.cuh:505-547 prefixes / suffixes, :680-682 score = left + right + k and the end
+ * positions; the begin positions come back with the left kernel's seeds :631).  row = H read (rid), col = V read (cid). */
+void oracle_logan_align(const char* row, uint32_t rowLen, const char* col, uint32_t colLen, int i, int j, int X, int k, oracle_aln* out) {
+    int rc = 1;
+    for (int t = 0; t < k; ++t) if (comp(row[i + k - 1 - t]) != col[j + t]) { rc = 0; break; }
+    char* h = (char*)malloc(rowLen + 1);
+    if (rc) { for (uint32_t t = 0; t < rowLen; ++t) h[t] = comp(row[rowLen - 1 - t]); i = (int)rowLen - i - k; }
+    else memcpy(h, row, rowLen);
+    const int begH = i, begV = j, endH = i + k, endV = j + k;
+    /* left: query prefix reversed (reverse_copy :539), target prefix as is (memcpy :541; the kernel reads it backward) */
+    char* pq = (char*)malloc(begV + 1);
+    for (int t = 0; t < begV; ++t) pq[t] = col[begV - 1 - t];
+    int lc = 0, lr = 0, st1 = 0, st2 = 0;
+    const int left = oracle_logan_one_direction(pq, begV, h, begH, X, &lc, &lr, &st1);
+    /* right: query suffix as is (memcpy :542), target suffix reversed (reverse_copy :543; read backward = forward) */
+    const int sl = (int)rowLen - endH;
+    char* st = (char*)malloc(sl + 1);
+    for (int t = 0; t < sl; ++t) st[t] = h[rowLen - 1 - t];
+    int rcol = 0, rrow = 0;
+    const int right = oracle_logan_one_direction(col + endV, (int)colLen - endV, st, sl, X, &rcol, &rrow, &st2);
+    out->score = left + right + k;                                            /* :680 */
+    out->begH = begH - lr; out->begV = begV - lc;                             /* updateExtendedSeedL :81-83 */
+    out->endH = endH + rrow; out->endV = endV + rcol;                         /* :96-97 */
+    out->strand = rc;
+    out->flagged = 0;
+    out->steps = st1 + st2;
+    free(h); free(pq); free(st);
+}
+
+/* include/overlap.hpp:797-871 PostAlignDecisionGPU (fixedThreshold == -1): as PostAlignDecision, but the threshold test is made
+ * in double (:826-827), not in float */
+int oracle_post_align_gpu(int score, int begV, int endV, int begH, int endH, uint32_t len1_H, uint32_t len2_V,
+                          double ratiophi, double delta, uint16_t* ov_out) {
+    uint16_t read1len = (uint16_t)len1_H, read2len = (uint16_t)len2_V;        /* :814-815 */
+    uint16_t overlapLenV = (uint16_t)(endV - begV), overlapLenH = (uint16_t)(endH - begH);   /* :818-819 */
+    uint16_t minLeft = (uint16_t)(begV < begH ? begV : begH);                 /* :821 */
+    int r2 = read2len - endV, r1 = read1len - endH;
+    uint16_t minRight = (uint16_t)(r2 < r1 ? r2 : r1);                        /* :822 */
+    uint16_t ov = (uint16_t)(minLeft + minRight + (overlapLenV + overlapLenH) / 2);   /* :823 */
+    double thr = (1 - delta) * (ratiophi * (double)ov);                       /* :830 */
+    *ov_out = ov;
+    return (double)score >= thr;                                              /* :831 */
+}
+
 /* overlap.hpp:149-154 toOriginalCoordinates (PAF, "-" strand) */
 void oracle_to_original(int* begpH, int* endpH, int lenH) {
     unsigned int tmp = (unsigned int)*begpH;

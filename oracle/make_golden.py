@@ -220,6 +220,60 @@ def xavier_kats():
     print("xavier KATs:", len(kats), "demo ->", kats[0]["expect"], kats[0]["exit_score"])
 
 
+def logan_kats():
+    """known answers of alignSeqAn (include/align.hpp:93: SeqAn's gapped X-drop extendSeed, the CPU algorithm the reference's CUDA
+    kernel loganGPU/functions.cuh:223-408 ports) computed by the reference through oracle/_ref/libbella_ref.so"""
+    lib = ctypes.CDLL(os.path.join(RB, "libbella_ref.so"))
+    lib.bella_ref_seqan_align.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.POINTER(ctypes.c_int), ctypes.c_char_p]
+    rng = np.random.default_rng(77)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+
+    def rnd(n):
+        return bytes(synth.BASES[rng.integers(0, 4, size=n, dtype=np.uint8)])
+
+    def mutate(s, e):
+        o = bytearray()
+        for ch in s:
+            u = rng.random()
+            if u < e * 0.3:
+                continue
+            if u < e * 0.4:
+                ch = b"ACGT"[(b"ACGT".index(ch) + int(rng.integers(1, 4))) & 3]
+            o.append(ch)
+            if e * 0.4 <= u < e:
+                o.append(b"ACGT"[int(rng.integers(0, 4))])
+        return bytes(o)
+
+    kats = []
+    for trial in range(48):
+        L = int(rng.integers(80, 1400))
+        base = rnd(L)
+        e = [0.0, 0.02, 0.15, 0.15, 0.3][trial % 5]
+        a, b = mutate(base, e), mutate(base, e)
+        if trial % 6 == 5:
+            b = rnd(len(b))                                # unrelated sequences sharing only the planted k-mer
+        k = 17
+        x = [7, 7, 3, 15, 50][trial % 5]
+        i = int(rng.integers(0, len(a) - k))
+        j = int(rng.integers(0, len(b) - k))
+        if trial % 8 == 0:
+            i = 0                                          # empty left prefix on H
+        if trial % 8 == 1:
+            j = len(b) - k                                 # empty right suffix on V
+        b = b[:j] + a[i:i + k] + b[j + k:]
+        if trial % 2:                                      # the H read on the other strand
+            a, i = a[::-1].translate(comp), len(a) - i - k
+        o = (ctypes.c_int * 5)()
+        st = ctypes.create_string_buffer(2)
+        lib.bella_ref_seqan_align(a, b, len(a), i, j, x, k, o, st)
+        kats.append({"name": "t%d_e%g_x%d" % (trial, e, x), "row": a.decode(), "col": b.decode(), "i": i, "j": j, "k": k, "x": x,
+                     "expect": list(o), "strand": st.value.decode()[:1]})
+    with open(os.path.join(GOLD, "logan_kat.json"), "w") as f:
+        json.dump(kats, f, indent=0)
+    print("logan KATs:", len(kats))
+
+
 def eval_kats(sets=("toy120", "toylen80", "toyhifi50"), min_overlaps=(300, 500, 1000)):
     """known answers of the reference's quality evaluator (benchmark/evaluation.cpp built as oracle/_ref/bella_eval): recall,
     precision, F1 of each golden aligned output against the truth its read names encode (r<idx>_<start>_<len>_<strand>)"""
@@ -262,6 +316,9 @@ def main():
     if "--eval-only" in sys.argv:
         print(eval_kats())
         return
+    if "--logan-only" in sys.argv:
+        logan_kats()
+        return
     if "--junk-only" in sys.argv:
         make_set("toyjunk220", junk_rich_set(), ["-k", "11"], aslr_check=True)
         return
@@ -278,6 +335,7 @@ def main():
     make_set("toymin70", synth.make_reads(70, read_len=2200, err=0.06, seed=23, coverage=9.0), ["-w", "7", "-e", "0.06"])   # minimizers
     make_set("toyjunk220", junk_rich_set(), ["-k", "11"], aslr_check=True)
     xavier_kats()
+    logan_kats()
     eval_kats()
     # read intervals of the reference's E. coli sample (dataset/ecsample-truth.txt, columns 3-4): the FASTQ itself is not in
     # the reference snapshot; the intervals shape the "ecsample-like" synthetic set of BASELINE configs[0]

@@ -9,6 +9,7 @@
 //   bella_ref_build_B       CSC tuple ctor + MergeDuplicates, as main.cpp:476-480 -> CSC.cpp:422-479,301-420
 //   bella_ref_hashspgemm    main.cpp:476-525: CSC(tuples) -> Transpose -> HashSpGEMM(...) (overlap.hpp:650)
 //   bella_ref_xavier_align  align.hpp:152 xavierAlign
+//   bella_ref_seqan_align   align.hpp:93 alignSeqAn (SeqAn extendSeed, GappedXDrop)
 //   bella_ref_slope         align.hpp:72
 #include <iostream>
 #include <cstdio>
@@ -210,6 +211,20 @@ int bella_ref_xavier_xdrop(const char* target, const char* query, int begH, int 
     out[3] = getBeginPositionV(seed);
     out[4] = getEndPositionV(seed);
     out[5] = r.second;
+    return 0;
+}
+
+// include/align.hpp:93 alignSeqAn = SeqAn's gapped X-drop extendSeed (seqan/seeds/seeds_extension.h:789-848), the CPU algorithm that
+// loganGPU/functions.cuh:223-408 ports to CUDA: the pin of the oracle's LOGAN restatement.  out = {score, begH, endH, begV, endV}
+int bella_ref_seqan_align(const char* row, const char* col, int rowLen, int i, int j, int xDrop, int kmerSize, int* out, char* strand) {
+    std::string r(row), c(col);
+    seqAnResult res = alignSeqAn(r, c, rowLen, i, j, xDrop, kmerSize, false, false, false);
+    out[0] = res.score;
+    out[1] = (int)beginPositionH(res.seed);
+    out[2] = (int)endPositionH(res.seed);
+    out[3] = (int)beginPositionV(res.seed);
+    out[4] = (int)endPositionV(res.seed);
+    *strand = res.strand[0];
     return 0;
 }
 

@@ -49,6 +49,7 @@ def lib():
                                      C.c_int, C.c_int, u32p, C.c_void_p]
         L.oracle_xavier_align.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_void_p]
+        L.oracle_logan_align.argtypes = L.oracle_xavier_align.argtypes
         L.oracle_xavier_xdrop.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_void_p]
         L.oracle_post_align.restype = C.c_int
@@ -208,6 +209,23 @@ def xavier_xdrop(target: bytes, query: bytes, begH: int, begV: int, k: int, x: i
     return out[0]
 
 
+def logan_align(row: bytes, col: bytes, i: int, j: int, x: int = 7, k: int = 17):
+    """the exact gapped X-drop of the reference's CUDA build (loganGPU/functions.cuh), pair prepared as overlap.hpp:918-944 does"""
+    out = np.zeros(1, ALN_DT)
+    lib().oracle_logan_align(row, len(row), col, len(col), i, j, x, k, out.ctypes.data)
+    return out[0]
+
+
+def post_align_gpu(score, begV, endV, begH, endH, lenH, lenV, ratiophi, delta=0.1):
+    """PostAlignDecisionGPU (overlap.hpp:797-871): the threshold test in double"""
+    ov = C.c_uint16(0)
+    L = lib()
+    L.oracle_post_align_gpu.argtypes = L.oracle_post_align.argtypes
+    ok = L.oracle_post_align_gpu(int(score), int(begV), int(endV), int(begH), int(endH), int(lenH), int(lenV), float(ratiophi), float(delta),
+                                 C.byref(ov))
+    return bool(ok), int(ov.value)
+
+
 def post_align(score, begV, endV, begH, endH, lenH, lenV, ratiophi, delta=0.1):
     ov = C.c_uint16(0)
     ok = lib().oracle_post_align(int(score), int(begV), int(endV), int(begH), int(endH), int(lenH), int(lenV),
@@ -279,6 +297,7 @@ def ref():
                                            C.c_char_p, C.c_size_t]
         R.bella_ref_xavier_align.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.POINTER(C.c_int), C.c_char_p]
+        R.bella_ref_seqan_align.argtypes = R.bella_ref_xavier_align.argtypes
         R.bella_ref_slope.restype = C.c_double
         R.bella_ref_slope.argtypes = [C.c_double]
     return _ref
@@ -307,6 +326,14 @@ def ref_hashspgemm(seqs, names, nkmers, tk, tr, tp, outfile, k=17, bin_size=500,
                                outfile.encode(), so, len(so), se, len(se))
     data = open(outfile, "rb").read() if os.path.exists(outfile) else b""
     return data, so.value.decode(), se.value.decode()
+
+
+def ref_seqan_align(row: bytes, col: bytes, i, j, x=7, k=17):
+    """alignSeqAn (align.hpp:93) = SeqAn's gapped X-drop extendSeed from the reference tree"""
+    o = (C.c_int * 5)()
+    st = C.create_string_buffer(2)
+    ref().bella_ref_seqan_align(row, col, len(row), i, j, x, k, o, st)
+    return list(o), st.value.decode()[:1]
 
 
 def ref_xavier_align(row: bytes, col: bytes, i, j, x=7, k=17):

@@ -146,6 +146,46 @@ def test_xavier_known_answers_on_gpu(eng):
             assert ("c" if a["strand"] else "n") == kat["strand"]
 
 
+def test_exact_xdrop_mode_matches_logan_oracle_and_seqan_answers(eng):
+    """the LOGAN-equivalent scoring kernel (logan.hpp): the reference's alignSeqAn known answers, and a golden read set's candidate
+    pairs (Xavier's seeds) field by field against the oracle's restatement of loganGPU/functions.cuh + PostAlignDecisionGPU"""
+    kats = json.load(open(os.path.join(GOLD, "logan_kat.json")))
+    seqs, seeds = [], []
+    for kat in kats:
+        seqs += [kat["row"].encode(), kat["col"].encode()]
+        seeds.append((len(seqs) - 2, len(seqs) - 1, kat["i"], kat["j"]))
+    eng.set_reads(synth.readset_from_seqs(seqs))
+    for (rid, cid, i, j), kat in zip(seeds, kats):
+        sd = np.zeros(1, api.SEED_DT)
+        sd[0] = (rid, cid, i, j)
+        a = eng.xdrop_batch(sd, BellaPars(kmerSize=kat["k"], xDrop=kat["x"]), exact=True)[0]
+        assert [int(a["score"]), int(a["begH"]), int(a["endH"]), int(a["begV"]), int(a["endV"])] == kat["expect"], kat["name"]
+        assert ("c" if a["strand"] else "n") == kat["strand"]
+    for name in ("toy120", "toyjunk220"):
+        g = load_golden(name)
+        eng.set_reads(g.rs)
+        eng.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
+        pars = BellaPars(errorRate=g.err, kmerSize=g.k)
+        n, _ = eng.overlap(pars)
+        pairs, _, _ = eng.get_pairs(ext=False)
+        npass = eng.align_pairs(pars, exact=True)
+        alns = eng.get_alignments()
+        phi = O.slope(g.err)
+        step = max(1, n // 3000)
+        ok_cnt = 0
+        for t in range(0, n, step):
+            p, a = pairs[t], alns[t]
+            rid, cid = int(p["rid"]), int(p["cid"])
+            e = O.logan_align(g.seqs[rid], g.seqs[cid], int(p["seedH"]), int(p["seedV"]), g.xdrop, g.k)
+            ok, ov = O.post_align_gpu(e["score"], e["begV"], e["endV"], e["begH"], e["endH"], len(g.seqs[rid]), len(g.seqs[cid]), phi)
+            assert (int(a["score"]), int(a["begH"]), int(a["endH"]), int(a["begV"]), int(a["endV"]), int(a["ov"]), int(a["passed"]), int(a["strand"]),
+                    int(a["steps"])) == (int(e["score"]), int(e["begH"]), int(e["endH"]), int(e["begV"]), int(e["endV"]), ov, int(ok),
+                                         int(e["strand"]), int(e["steps"])), (name, t)
+            ok_cnt += int(ok)
+        assert npass == int(alns["passed"].sum()) and (step > 1 or ok_cnt == npass)
+        assert not alns["flagged"].any()
+
+
 def test_partition_union_equals_whole(eng):
     g = load_golden("toy120")
     eng.set_reads(g.rs)

@@ -189,3 +189,49 @@ def test_parallel_column_helpers_equal_the_serial_oracle():
     assert np.array_equal(flop, f2) and np.array_equal(np.diff(colptrC), nz2)
     for c, rec in per.items():
         assert np.array_equal(rec, pairs[colptrC[c]:colptrC[c + 1]]), c
+
+
+def test_logan_restatement_matches_seqan_known_answers():
+    """oracle_logan_align (loganGPU/functions.cuh restated) == alignSeqAn of the reference (SeqAn extendSeed, GappedXDrop) on the
+    committed known answers: score, the four seed positions, strand"""
+    kats = json.load(open(os.path.join(GOLD, "logan_kat.json")))
+    assert len(kats) >= 40
+    for k in kats:
+        o = O.logan_align(k["row"].encode(), k["col"].encode(), k["i"], k["j"], k["x"], k["k"])
+        got = [int(o["score"]), int(o["begH"]), int(o["endH"]), int(o["begV"]), int(o["endV"])]
+        assert got == k["expect"] and ("c" if o["strand"] else "n") == k["strand"], k["name"]
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_logan_restatement_matches_seqan_in_process():
+    """fresh random pairs (true overlaps at several error rates, unrelated pairs, both strands, seeds at the sequence ends, X from
+    3 to 50) through the reference's own alignSeqAn"""
+    from bella_amd import synth
+    rng = np.random.default_rng(123)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    n = 0
+    for trial in range(150):
+        L = int(rng.integers(60, 2500))
+        a = bytes(synth.BASES[rng.integers(0, 4, size=L, dtype=np.uint8)])
+        e = float(rng.choice([0.0, 0.05, 0.15, 0.3]))
+        keep = rng.random(L) >= e * 0.5
+        b = bytearray(np.frombuffer(a, np.uint8)[keep].tobytes())
+        for t in np.nonzero(rng.random(len(b)) < e * 0.5)[0]:
+            b[t] = b"ACGT"[int(rng.integers(0, 4))]
+        b = bytes(b) if trial % 5 else bytes(synth.BASES[rng.integers(0, 4, size=L, dtype=np.uint8)])
+        k, x = 17, int(rng.choice([3, 7, 15, 50]))
+        if len(b) < k + 2:
+            continue
+        i, j = int(rng.integers(0, len(a) - k)), int(rng.integers(0, len(b) - k))
+        if trial % 7 == 0:
+            i = 0
+        if trial % 11 == 0:
+            j = len(b) - k
+        b = b[:j] + a[i:i + k] + b[j + k:]
+        if trial % 2:
+            a, i = a[::-1].translate(comp), len(a) - i - k
+        ref, st = O.ref_seqan_align(a, b, i, j, x, k)
+        o = O.logan_align(a, b, i, j, x, k)
+        assert [int(o["score"]), int(o["begH"]), int(o["endH"]), int(o["begV"]), int(o["endV"])] == ref and ("c" if o["strand"] else "n") == st, trial
+        n += 1
+    assert n > 100
