@@ -42,6 +42,9 @@ def _p(a):
     return a.ctypes.data if a is not None and a.size else None
 
 
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
 class Engine:
     def __init__(self, device: int = 0):
         self.lib = _lib.load()
@@ -67,8 +70,7 @@ class Engine:
 
     # ---- reads (readVector_) ----
     def set_reads(self, rs):
-        from .synth import BASES
-        asc = np.ascontiguousarray(BASES[rs.codes])
+        asc = np.ascontiguousarray(_ACGT[rs.codes])       # the C ABI takes ASCII bases, as the reference's readVector_ holds them
         offs = np.ascontiguousarray(rs.offsets, dtype=np.uint64)
         self._chk(self.lib.bella_hip_set_reads(self.h, _p(asc), offs.ctypes.data, rs.nreads))
         self.nreads = rs.nreads

@@ -1354,6 +1354,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     int rc = 0;
     uint32_t* const ctl_host = c->pinned + 32;
 #define EVREC(i) HIPCHK(c, hipEventRecord(c->ev[i], c->stream))
+    struct Launch { int lo, hi; size_t lds; uint32_t rows; int cls; };
+    Launch ln[kNumTiers];
+    int nl = 0;
     auto enqueue = [&]() -> int {
     EVREC(2);
     if (c->caps_state != want_state) {                         // the tier caps only change with the operands or the debug switch
@@ -1448,9 +1451,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         const bool half = (half_tables || (c->debug & 16u)) && cap <= kHalfTableMaxCap;     // debug bit 4: tests
         return half ? cap / 2 : cap / 4;
     };
-    struct Launch { int lo, hi; size_t lds; uint32_t rows; int cls; };
-    Launch ln[kNumTiers];
-    int nl = 0;
+    nl = 0;
     {
         int cls_prev = -1;
         for (int t = 0; t + 1 < (int)g_ntiers; ++t) {

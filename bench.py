@@ -46,7 +46,7 @@ def cpu_baseline_child(npz, threads):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import re
     import _oracle as O
-    from bella_amd import synth
+    from bella_testkit import synth
     z = np.load(npz, allow_pickle=False)
     rs = synth.ReadSet(z["codes"], z["offsets"], ["r%d" % i for i in range(len(z["offsets"]) - 1)])
     seqs = rs.seqs()
@@ -155,8 +155,9 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from bella_amd import BellaPars, Engine, synth
+    from bella_amd import BellaPars, Engine
 
+    from bella_testkit import synth
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -31,7 +31,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bella_amd import synth  # noqa: E402
+from bella_testkit import synth  # noqa: E402
 
 REF = os.environ.get("BELLA_REFERENCE", "/root/reference")
 RB = os.path.join(ROOT, "oracle", "_ref")

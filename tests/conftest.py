@@ -24,7 +24,7 @@ def pytest_configure(config):
 
 class Golden:
     def __init__(self, name):
-        from bella_amd import synth
+        from bella_testkit import synth
         d = os.path.join(GOLD, name)
         self.name = name
         self.rs = synth.read_fastq(os.path.join(d, "reads.fastq.gz"))

@@ -6,7 +6,9 @@ import re
 import numpy as np
 import pytest
 
-from bella_amd import _lib, api, synth
+from bella_amd import _lib, api
+
+from bella_testkit import synth
 from conftest import ROOT, load_golden
 import _oracle as O
 
@@ -43,6 +45,7 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hpp", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "_oracle" not in txt and "liboracle" not in txt and "bella_ref" not in txt, f
+                assert "bella_testkit" not in txt, f               # host-side numpy helpers are test tooling, not product
 
 
 def test_host_writers_against_golden(golden):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import _oracle as O
-from bella_amd import packing, synth
+from bella_testkit import packing, synth
 from conftest import ROOT, load_golden
 
 HSRC = os.path.join(ROOT, "tests", "harness", "core_harness.cpp")

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 import _oracle as O
-from bella_amd import BellaPars, Engine, api, synth
+from bella_amd import BellaPars, Engine, api
+from bella_testkit import synth
 from bella_amd.api import BellaHipError
 from conftest import GOLD, ROOT, load_golden
 

@@ -125,7 +125,7 @@ def test_build_B_matches_reference_code(golden):
 def test_hashspgemm_matches_reference_code_on_fresh_input(tmp_path):
     """Fresh synthetic input (not a committed fixture), our own k-mer ids: the reference's HashSpGEMM run
     in-process through the shim vs the oracle, byte for byte, skip-alignment and aligned."""
-    from bella_amd import synth
+    from bella_testkit import synth
     rs = synth.make_reads(60, read_len=1500, err=0.15, seed=123)
     t = synth.count_and_tuples(rs, 17, 2, 8)
     seqs = rs.seqs()
@@ -168,7 +168,7 @@ def test_count_kmers_matches_reference_tuples(golden):
 
 
 def test_count_kmers_matches_numpy_statement():
-    from bella_amd import synth
+    from bella_testkit import synth
     rs = synth.make_reads(60, read_len=900, coverage=12.0, err=0.1, seed=5)
     for k, lo, up in ((17, 2, 8), (11, 2, 4), (32, 2, 8), (5, 3, 60000)):
         codes, counts, tk, tr, tp, _ = O.count_kmers(rs.seqs(), k, lo, up)
@@ -179,7 +179,7 @@ def test_count_kmers_matches_numpy_statement():
 
 def test_parallel_column_helpers_equal_the_serial_oracle():
     """oracle_symbolic_range / oracle_numeric_cols (what the full-size GPU tests spread over the host cores) == the serial phases"""
-    from bella_amd import synth
+    from bella_testkit import synth
     rs = synth.make_reads(200, read_len=2500, coverage=20.0, err=0.15, seed=9)
     seqs = rs.seqs()
     codes, counts, tk, tr, tp, _ = O.count_kmers(seqs, 17, 2, 8)
@@ -206,7 +206,7 @@ def test_logan_restatement_matches_seqan_known_answers():
 def test_logan_restatement_matches_seqan_in_process():
     """fresh random pairs (true overlaps at several error rates, unrelated pairs, both strands, seeds at the sequence ends, X from
     3 to 50) through the reference's own alignSeqAn"""
-    from bella_amd import synth
+    from bella_testkit import synth
     rng = np.random.default_rng(123)
     comp = bytes.maketrans(b"ACGT", b"TGCA")
     n = 0

@@ -1,7 +1,8 @@
 """Development aid: HiFi-like set (long product lists, wide columns with a raised -u) through the device pipeline."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bella_amd import BellaPars, Engine, synth
+from bella_amd import BellaPars, Engine
+from bella_testkit import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 upper = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 rs = synth.make_reads(n, read_len=15000, coverage=30.0, err=0.005, seed=2, mix=(1 / 3, 1 / 3, 1 / 3))

@@ -1,7 +1,8 @@
 import os, sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np
-from bella_amd import BellaPars, Engine, synth
+from bella_amd import BellaPars, Engine
+from bella_testkit import synth
 n = int(sys.argv[1]); upper = int(sys.argv[2]); sync = int(sys.argv[3])
 rs = synth.make_reads(n, read_len=15000, coverage=30.0, err=0.005, seed=2, mix=(1 / 3, 1 / 3, 1 / 3))
 eng = Engine(0)

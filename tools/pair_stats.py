@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from bella_amd import synth
+from bella_testkit import synth
 from bella_amd.api import Engine, BellaPars
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000

@@ -7,8 +7,9 @@ import tempfile
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bella_amd import BellaPars, Engine, evaluate as ev, hash_spgemm, synth
+from bella_amd import BellaPars, Engine, evaluate as ev, hash_spgemm
 
+from bella_testkit import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 rs = synth.make_reads(n, read_len=10000, coverage=30.0, err=0.15, seed=1)
 eng = Engine(0)

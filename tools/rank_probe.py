@@ -1,7 +1,8 @@
 """Development aid: what ONE rank of an N-GPU weak-scaling run computes (N x 10k reads, columns i % N == r), on one GPU."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bella_amd import BellaPars, Engine, synth
+from bella_amd import BellaPars, Engine
+from bella_testkit import synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rs = synth.make_reads(10000 * N, read_len=10000, coverage=30.0, err=0.15, seed=1)
 eng = Engine(0)

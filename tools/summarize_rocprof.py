@@ -7,7 +7,9 @@ import sys
 
 def short(n):
     n = re.sub(r"\(.*", "", n)
-    n = re.sub(r"<.*", "<...>", n)
+    if "bella::" not in n:
+        n = re.sub(r"<.*", "<...>", n)                       # library kernels: template arguments are noise
+    n = n.replace("void ", "").replace("bella::", "")
     return n[-90:]
 
 
