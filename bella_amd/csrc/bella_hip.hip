@@ -1443,6 +1443,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     ENSURE(c, c->prof, 8 * 10 * kNumTiers);
     HIPCHK(c, hipMemsetAsync(c->prof.p, 0, 8 * 10 * kNumTiers, c->stream));
     a.prof = nullptr;
+    a.stop_phase = getenv("BELLA_DEV_STOP") ? atoi(getenv("BELLA_DEV_STOP")) : -1;
 #endif
     // LDS classes: consecutive tiers whose workgroups take the same share of a CU; one launch per class (largest class first, on
     // side streams so that the classes overlap; the class of the smallest columns, which finishes last, on the main stream), and

@@ -88,6 +88,7 @@ struct SpgemmArgs {
     int binSize;
 #ifdef BELLA_DEV_PROF
     unsigned long long* prof;    // development builds only: 10 counters per launch (phase cycles of wavefront 0, columns)
+    int stop_phase;              // development builds only: leave the column after this phase (instruction counts per phase)
 #endif
     int inject_unordered;        // tests: pretend every fifth column's lists came out of order in phase S (exercises the fallback)
 };
@@ -152,7 +153,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     const uint32_t tid = threadIdx.x;
 #ifdef BELLA_DEV_PROF                                          // development builds only (tools/prof_build.sh): wavefront 0's clock per phase
     long long tc_ = clock64();
-#define BELLA_BPROF(n) { const long long t2_ = clock64(); if (tid == 0 && a.prof) atomicAdd(a.prof + (n), (unsigned long long)(t2_ - tc_)); tc_ = clock64(); }
+#define BELLA_BPROF(n) { const long long t2_ = clock64(); if (tid == 0 && a.prof) atomicAdd(a.prof + (n), (unsigned long long)(t2_ - tc_)); \
+                         if (a.stop_phase == (n)) { if (tid == 0) a.nnzC[i] = 0; return true; } tc_ = clock64(); }
 #else
 #define BELLA_BPROF(n)
 #endif
@@ -174,7 +176,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // ---- X: expand products in reference order, group keys --------------------------------------------
     // X1/X2: each thread owns a CONTIGUOUS run of B' entries (so one block scan orders all products); it only records,
     // per product, where its A' entry lives and the B' side word -- LDS writes, no dependent global loads.
-    constexpr uint32_t RMAX = 8;
+    constexpr uint32_t RMAX = kRowBlock >= 1024 ? 4 : 8;      // B' entries per thread and round (registers: 1024-thread workgroups run at 64 VGPRs)
     uint32_t running = 0;
     for (uint32_t jb = 0; jb < n; jb += RMAX * kRowBlock) {
         const uint32_t nn = n - jb < RMAX * kRowBlock ? n - jb : RMAX * kRowBlock;
@@ -315,23 +317,44 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // atomics of one wavefront execute in program order), so a list is ordered ACROSS 64-product chunks and only
     // chunk-mates can be swapped; phase R repairs that.  (T2 is dead: its memory becomes S_p.) -----------------------
     uint16_t* S_p = (uint16_t*)m.T2;
-    if (GALIAS && wave_id() != 0) {                           // the other wavefronts: Gaux, which shares T2's memory (T2 is dead)
-        for (uint32_t s = tid - 64; s < H1; s += kRowBlock - 64) m.Gaux[s] = 0;
+    if (GALIAS) {                                             // Gaux shares T2's memory (T2 is dead), above S_p
+        for (uint32_t s = tid; s < H1; s += kRowBlock) m.Gaux[s] = 0;
     }
-    if (wave_id() == 0) {
-        for (uint32_t base = 0; base < F; base += kSU * kScatterChunk) {
-            uint32_t g[kSU], old[kSU];
+    {
+        // the first kSW wavefronts each own the key slots g with g % kSW == their number and scan ALL products for them, kSA chunks
+        // of 64 in flight per stage: a key's products are appended by ONE wavefront, in product order (program order across
+        // chunks; inside a chunk the same-address atomics of one instruction -- see phase R).
+        constexpr uint32_t kSA = kRowBlock == 1024 ? 4 : 8;
+        constexpr uint32_t kSW = kRowWaves < 4 ? kRowWaves : 4;
+        const uint32_t w = wave_id(), lane = lane_id();
+        if (w < kSW) {
+            for (uint32_t base = 0; base < F; base += kSA * kScatterChunk) {
+                uint32_t g[kSA], old[kSA];
+                bool mine[kSA];
 #pragma unroll
-            for (uint32_t u = 0; u < kSU; ++u) {
-                const uint32_t p = base + u * kScatterChunk + tid;
-                g[u] = p < F ? ((m.A_gov[p] >> 16) & GMASK) : 0xFFFFFFFFu;
+                for (uint32_t u = 0; u < kSA; ++u) {
+                    const uint32_t p = base + u * kScatterChunk + lane;
+                    g[u] = m.A_gov[p < F ? p : F - 1];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kSA; ++u) {
+                    const uint32_t p = base + u * kScatterChunk + lane;
+                    g[u] = (g[u] >> 16) & GMASK;
+                    mine[u] = p < F && (g[u] & (kSW - 1)) == w;
+                }
+                // (old stays unset for the other lanes on purpose: with a default value the compiler folds the first use into the
+                // predicated block and waits there; the list end is a 16-bit load for the same reason)
+#pragma unroll
+                for (uint32_t u = 0; u < kSA; ++u)
+                    if (mine[u]) old[u] = atomicAdd(&m.T1cnt[g[u]], 0x10000u);
+#pragma unroll
+                for (uint32_t u = 0; u < kSA; ++u)
+                    if (mine[u]) g[u] = ((const uint16_t*)m.T1first)[2u * g[u]];   // END of the key's list (low half)
+#pragma unroll
+                for (uint32_t u = 0; u < kSA; ++u)
+                    if (mine[u] && (old[u] & 0xFFFFu) != 1u)          // single-product pairs have no list
+                        S_p[g[u] - (old[u] & 0xFFFFu) + (old[u] >> 16)] = (uint16_t)(base + u * kScatterChunk + lane);
             }
-#pragma unroll
-            for (uint32_t u = 0; u < kSU; ++u) old[u] = g[u] != 0xFFFFFFFFu ? atomicAdd(&m.T1cnt[g[u]], 0x10000u) : 0u;
-#pragma unroll
-            for (uint32_t u = 0; u < kSU; ++u)
-                if (g[u] != 0xFFFFFFFFu && (old[u] & 0xFFFFu) != 1u)      // single-product pairs have no list
-                    S_p[(m.T1first[g[u]] & 0xFFFFu) - (old[u] & 0xFFFFu) + (old[u] >> 16)] = (uint16_t)(base + u * kScatterChunk + tid);
         }
     }
     __syncthreads();
@@ -340,7 +363,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // ---- R: exact rank of every product inside its pair's list (global path: list position corrected by the chunk-mates on
     // the wrong side; LDS tiers: checked) and the lists in rank order: L_hv / L_gov. -------------------------------------------------------------
     // NX = list positions per thread in the LDS tiers (cap <= NX * kRowBlock)
-    uint32_t dstv[NX], hvv[NX], govv[NX];
+    uint32_t hvv[NX], govv[NX];
     auto rank_one = [&](uint32_t x, uint32_t& dst, uint32_t& hvq, uint32_t& govq, uint32_t& flq) {
         const uint32_t p = S_p[x];
         const uint32_t gov = m.A_gov[p];
@@ -375,19 +398,49 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     };
     if (OVERLAY) {
+        // LDS tiers: verify instead of repair (see rank_one), in straight-line stages over groups of four of the thread's NX list
+        // positions.  A list ends where the next position's product belongs to another key slot.
+        constexpr uint32_t kRB = 4;
 #pragma unroll
-        for (uint32_t u = 0; u < NX; ++u) {
-            const uint32_t x = tid + u * kRowBlock;
-            uint32_t flq;
-            dstv[u] = 0xFFFFFFFFu; hvv[u] = 0; govv[u] = 0;
-            if (x < Fm) rank_one(x, dstv[u], hvv[u], govv[u], flq);
+        for (uint32_t u0 = 0; u0 < NX; u0 += kRB) {
+            uint32_t pv[kRB], pn[kRB], gn[kRB];
+            bool bad[kRB];
+#pragma unroll
+            for (uint32_t v = 0; v < kRB; ++v) {
+                const uint32_t x = tid + (u0 + v) * kRowBlock;
+                const bool ok = u0 + v < NX && x < Fm;
+                const uint32_t xc = ok ? x : 0u, xn = ok && x + 1 < Fm ? x + 1 : xc;
+                pv[v] = S_p[xc]; pn[v] = S_p[xn];
+            }
+#pragma unroll
+            for (uint32_t v = 0; v < kRB; ++v) {
+                const uint32_t x = tid + (u0 + v) * kRowBlock;
+                const bool ok = u0 + v < NX && x < Fm;
+                pv[v] = ok ? pv[v] : 0u; pn[v] = ok ? pn[v] : 0u;
+                bad[v] = pn[v] < pv[v];
+            }
+#pragma unroll
+            for (uint32_t v = 0; v < kRB; ++v)
+                if (u0 + v < NX) { govv[u0 + v] = m.A_gov[pv[v]]; hvv[u0 + v] = m.A_hv[pv[v]]; gn[v] = m.A_gov[pn[v]]; }
+#pragma unroll
+            for (uint32_t v = 0; v < kRB; ++v) {
+                if (u0 + v >= NX) continue;
+                const uint32_t x = tid + (u0 + v) * kRowBlock;
+                if (x < Fm) {
+                    const bool last = x + 1 == Fm || ((gn[v] >> 16) & GMASK) != ((govv[u0 + v] >> 16) & GMASK);
+                    if (!last && bad[v]) *s_fail = 1;
+                    if (last) govv[u0 + v] |= kLastBit;
+                }
+            }
         }
         if (a.inject_unordered && i % 5u == 2u && tid == 0) *s_fail = 1;
         __syncthreads();                                      // every A_hv / A_gov read is done: reuse them as L_hv / L_gov
         if (*s_fail) return false;                            // a list out of order (see above): nothing irreversible happened
 #pragma unroll
-        for (uint32_t u = 0; u < NX; ++u)
-            if (dstv[u] != 0xFFFFFFFFu) { m.L_hv[dstv[u]] = hvv[u]; m.L_gov[dstv[u]] = govv[u]; }
+        for (uint32_t u = 0; u < NX; ++u) {
+            const uint32_t x = tid + u * kRowBlock;
+            if (x < Fm) { m.L_hv[x] = hvv[u]; m.L_gov[x] = govv[u]; }
+        }
     } else {
         for (uint32_t x = tid; x < Fm; x += kRowBlock) {
             uint32_t dst, hvq, govq, flq;
