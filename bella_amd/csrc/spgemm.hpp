@@ -508,12 +508,13 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             // plain chain: the position is compared with every later product until one is within k of it.
             // within k  <=>  (x + k - q) mod 2^16 <= 2k  in either half (k-mer starts are <= 65535 - k): eight products per test
             const us2 xk = __builtin_bit_cast(us2, x) + kk2;
-            const uint32_t farq = x ^ 0x80008000u;            // a product 32768 away in both coordinates: never within k
+            // The last group of a list reads up to W - 1 words beyond its end (the next list, or the words behind the lists: always
+            // inside the column's arrays); a "hit" found there lies at or beyond the end and is cut off below -- no masked tail.
             uint32_t t = s + 1;
             constexpr uint32_t W = BELLA_WALK_W;              // products per test
             uint32_t q[W];
             bool hit = false;
-            while (t + W <= mm) {
+            while (t < mm) {
                 us2 acc = lim2;
 #pragma unroll
                 for (uint32_t u = 0; u < W; ++u) {
@@ -522,18 +523,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
                 }
                 if (__builtin_bit_cast(uint32_t, acc) != lim) { hit = true; break; }
                 t += W;
-            }
-            if (!hit && t < mm) {                             // the last, partial group: one more round trip, masked
-                us2 acc = lim2;
-#pragma unroll
-                for (uint32_t u = 0; u < W; ++u) {
-                    const uint32_t idx = t + u;
-                    const uint32_t v = lst[idx < mm ? idx : mm - 1];
-                    q[u] = idx < mm ? v : farq;
-                    acc = __builtin_elementwise_min(acc, (us2)(xk - __builtin_bit_cast(us2, q[u])));
-                }
-                if (__builtin_bit_cast(uint32_t, acc) != lim) hit = true;
-                else t = mm;
             }
             if (hit) {                                        // first product of the group that is within k
                 uint32_t f = W - 1;
@@ -544,6 +533,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
                 }
                 t += f;
             }
+            t = t < mm ? t : mm;                              // ran off the end, or the first product within k lies beyond it
             const uint32_t contrib = t - s - 1;
             if (contrib) atomicAdd(&m.T1cnt[g], (contrib & 0xFFFFu) << 16);   // the cursor half already holds m
             if (a.tmp_ext && t == mm) atomicAdd(&m.Gaux[g], 1u);

@@ -191,14 +191,31 @@ def main():
         have_comm = False
         if world > 1:
             from bella_amd import dist as bd
-            have_comm = bd.init_comm(eng, local, backend)   # the library's own RCCL communicator (include/bella_hip.h)
+            # the library's own RCCL communicator (include/bella_hip.h); BELLA_BENCH_NO_LIBCOMM=1: torch.distributed paths only
+            have_comm = False if os.environ.get("BELLA_BENCH_NO_LIBCOMM") else bd.init_comm(eng, local, backend)
             lo, npanel = bd.block_range(rank, world, nreads)
+        def all_ok(flag):                                   # every rank takes the same path
+            if world == 1:
+                return bool(flag)
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
+        counted = False
         if have_comm:                                       # the dictionary is counted ACROSS the ranks, tuples for the own read block
-            nk, nt, ndistinct = eng.count_kmers_dist(lo, npanel, 17, 2, 8)
-        else:
+            try:
+                nk, nt, ndistinct = eng.count_kmers_dist(lo, npanel, 17, 2, 8)
+                counted = True
+            except Exception as e:                          # reported, then every rank counts all reads itself
+                log("[bench] rank %d: bella_hip_count_kmers_dist failed (%r)" % (rank, e))
+            counted = all_ok(counted)
+        if not counted:
+            have_dist_count = False
             nk, nt, ndistinct = eng.count_kmers(17, 2, 8)
+        else:
+            have_dist_count = True
         info = {"rs": rs, "nk": nk, "kcount_ms": eng.timings().kcount_ms, "xchg_ms": None, "xchg_path": None,
-                "kcount_path": "bella_hip_count_kmers_dist (code space split over the ranks)" if have_comm else "bella_hip_count_kmers (every rank, all reads)"}
+                "kcount_path": "bella_hip_count_kmers_dist (code space split over the ranks)" if have_dist_count else "bella_hip_count_kmers (every rank, all reads)"}
         info["tup"] = synth.Tuples(*eng.get_tuples(), nk) if want_host_tuples else None
         if rank == 0:
             log("[bench] reads %d (%.1f s), distinct k-mers %d, reliable %d, tuples %d (device: %.1f ms)"
@@ -211,7 +228,16 @@ def main():
             info["asm_ms"] = eng.timings().assemble_ms
             sync()
             tx = time.perf_counter()
-            info["xchg_path"] = bd.exchange_panels(eng, local, backend, have_comm=have_comm)
+            xok = False
+            if have_comm:
+                try:
+                    info["xchg_path"] = bd.exchange_panels(eng, local, backend, have_comm=True)
+                    xok = True
+                except Exception as e:
+                    log("[bench] rank %d: bella_hip_allgather_panels failed (%r)" % (rank, e))
+                xok = all_ok(xok)
+            if not xok:
+                info["xchg_path"] = bd.exchange_panels(eng, local, backend, have_comm=False)
             sync()
             info["xchg_ms"] = (time.perf_counter() - tx) * 1e3
             info["asm_ms"] += eng.timings().assemble_ms
