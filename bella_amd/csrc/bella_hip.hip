@@ -48,7 +48,10 @@ constexpr uint32_t kHalfTableMaxCap = 4096;              // above: quarter-size 
 // keeps the CU's 32 wavefront slots filled.
 constexpr uint32_t kNumClasses = 6;
 const size_t kClassLds[kNumClasses] = {10240, 20480, 40160, 54608, 81920, 163840};   // 16, 8, 4, 3, 2, 1 workgroups per CU
-const int kClassBlock[kNumClasses] = {128, 256, 256, 512, 1024, 1024};   // measured: tools/ notes in DESIGN.md 4.1
+#ifndef BELLA_CLASS_BLOCKS
+#define BELLA_CLASS_BLOCKS {128, 256, 512, 512, 1024, 1024}
+#endif
+const int kClassBlock[kNumClasses] = BELLA_CLASS_BLOCKS;   // measured (tools/ab_blocks.sh): DESIGN.md 4.1
 constexpr uint32_t kGlobalGrid = 1024;      // persistent workgroups of the global path: latency-bound, four per CU
 constexpr uint32_t kAsmGrid = 1024;
 
