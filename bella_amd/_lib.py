@@ -27,7 +27,7 @@ class Params(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("assemble_ms", C.c_float), ("symbolic_ms", C.c_float), ("spgemm_ms", C.c_float), ("fold_ms", C.c_float),
                 ("compact_ms", C.c_float), ("xdrop_ms", C.c_float), ("overlap_total_ms", C.c_float), ("spgemm_launches", C.c_uint32),
-                ("kcount_ms", C.c_float)]
+                ("kcount_ms", C.c_float), ("retry_columns", C.c_uint32), ("overflow_pairs", C.c_uint32)]
 
 
 # every symbol include/bella_hip.h declares: (name, restype, argtypes)

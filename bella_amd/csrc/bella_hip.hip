@@ -1660,6 +1660,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     c->tm.compact_ms = ev_ms(c->ev[6], c->ev[7]);
     c->tm.overlap_total_ms = ev_ms(c->ev[2], c->ev[7]);
     c->tm.spgemm_launches = launches;
+    c->tm.retry_columns = c->n_retry;
+    c->tm.overflow_pairs = c->n_overflow;
 #ifdef BELLA_DEV_PROF
     {
         unsigned long long ph[10 * kNumTiers];

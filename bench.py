@@ -105,6 +105,7 @@ def timed_passes(eng, pars, steps, warmup, sync):
         acc["sym"] += tm.symbolic_ms
         acc["comp"] += tm.compact_ms
         acc["launches"] += tm.spgemm_launches
+        acc["retry"] = max(acc.get("retry", 0), int(tm.retry_columns))
     sync()
     acc["elapsed"] = time.perf_counter() - ts
     acc["npairs"], acc["flops"], acc["steps"] = npairs, flops, steps
@@ -118,6 +119,7 @@ def roofline_of(acc, nnz_share, copy_gbps, traffic_key):
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
          "kernel": "SpGEMM = k_spgemm_rows_lds (one launch set = the concurrent LDS-class launches of a pass) + k_fold_overflow",
          "kernel_ms_per_step": k_ms, "launches_per_step": acc["launches"] / acc["steps"], "algorithmic_bytes_per_step": alg_bytes,
+         "columns_redone_on_global_path": acc.get("retry", 0),
          "measured_copy_ceiling_GBps": copy_gbps}
     # HBM traffic of the same kernels from the PMC counters (tools/collect_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes,
     # gfx950 FETCH_SIZE x2 correction calibrated on our own stream): a profiling run, so read from the committed summary

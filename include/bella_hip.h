@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define BELLA_HIP_ABI_VERSION 2
+#define BELLA_HIP_ABI_VERSION 3
 
 enum {
     BELLA_OK = 0,
@@ -102,6 +102,10 @@ typedef struct {
     float overlap_total_ms;   /* bella_hip_overlap, stream time start to end                */
     uint32_t spgemm_launches; /* row-kernel launches (one per non-empty LDS tier)            */
     float kcount_ms;          /* bella_hip_count_kmers: counting + dictionary + tuples      */
+    uint32_t retry_columns;   /* last pass: columns an LDS tier handed to the global-workspace path (key table too small for
+                                 the column's pairs, or a product list out of order -- see DESIGN 4.1, phase S).  Normally 0 or a
+                                 handful; a large value is a performance cliff worth reporting                              */
+    uint32_t overflow_pairs;  /* last pass: pairs that ended with > 16 bins (serial fold with libstdc++'s sort order)       */
 } bella_timings;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */

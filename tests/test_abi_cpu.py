@@ -21,13 +21,13 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == {s[0] for s in _lib.SIGNATURES}
-    assert lib.bella_hip_abi_version() == 2
+    assert lib.bella_hip_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
     assert _lib.PAIR_DT.itemsize == 16 and _lib.EXT_DT.itemsize == 8 and _lib.ALN_DT.itemsize == 32 and _lib.SEED_DT.itemsize == 12
     import ctypes
-    assert ctypes.sizeof(_lib.Params) == 24 and ctypes.sizeof(_lib.Timings) == 36
+    assert ctypes.sizeof(_lib.Params) == 24 and ctypes.sizeof(_lib.Timings) == 44
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -982,6 +982,10 @@ def test_out_of_order_lists_fall_back_to_the_repairing_path(eng):
         _, flop, ecol, exp = oracle_pairs(g.rs, g.seqs, g.nkmers, g.tk, g.tr, g.tp, g.k)
         assert n == len(exp)
         check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
+        assert eng.timings().retry_columns >= 5                          # the redone columns are counted and reported
+        eng.set_debug(0)
+        eng.overlap(BellaPars(skipAlignment=True))
+        assert eng.timings().retry_columns == 0                         # gfx950 keeps product order: nothing is redone
     finally:
         eng.set_debug(0)
 
