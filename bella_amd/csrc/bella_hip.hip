@@ -1369,7 +1369,6 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     }
     // one control block per pass (counters, tier lengths, status, totals): one fill, one read back
     uint32_t* d_ctl = ptr<uint32_t>(c->ctl);
-    HIPCHK(c, hipMemsetAsync(d_ctl, 0, 4 * kCtlWords, c->stream));
     // the columns of this context: i0 + j * stride, j < nown.  The symbolic kernels only visit those; the entries of all other
     // columns in flops / nnzC are zero from the one clear made when the operands, the partition or the stage changed.
     const uint32_t hi = c->range_hi < nr ? c->range_hi : nr;
@@ -1385,10 +1384,13 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
             std::memcpy(c->sym_sig, sig, sizeof(sig));
         }
     }
+    // (the control block is cleared by the first kernel of the pass)
     if (nown) {
         k_row_flops<<<nblk(nown, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint16_t>(c->Bcnt), i0, c->part_stride, nown,
-                                                                  ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC));
+                                                                  ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC), d_ctl);
         KCHK(c);
+    } else {
+        HIPCHK(c, hipMemsetAsync(d_ctl, 0, 4 * kCtlWords, c->stream));
     }
     k_tier_lists<<<nblk(nown ? nown : 1), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, i0, c->part_stride, nown, ptr<uint32_t>(c->tiercaps), g_ntiers,
                                                   ptr<uint32_t>(c->Bptr), ptr<uint64_t>(c->roff), ptr<uint4>(c->rowlists),
@@ -1596,8 +1598,13 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         return 0;
     };
     auto finish = [&]() -> int {                                  // colptrC, compaction, the pass's host round trip
-        int r2 = scan_u32_to_u64(c, ptr<uint32_t>(c->nnzC), ptr<uint64_t>(c->colptrC), (uint64_t)nr + 1);
-        if (r2) return r2;
+        if ((uint64_t)nr + 1 <= kScanSingleMax) {
+            k_scan_counts<<<1, 1024, 0, c->stream>>>(ptr<uint32_t>(c->nnzC), ptr<uint64_t>(c->colptrC), nr + 1);
+            KCHK(c);
+        } else {
+            int r2 = scan_u32_to_u64(c, ptr<uint32_t>(c->nnzC), ptr<uint64_t>(c->colptrC), (uint64_t)nr + 1);
+            if (r2) return r2;
+        }
         EVREC(6);
         if (nr) {
             k_compact_pairs<<<nblk(nown ? nown : 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint64_t>(c->flopptr), ptr<uint64_t>(c->colptrC),

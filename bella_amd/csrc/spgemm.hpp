@@ -730,7 +730,8 @@ __global__ __launch_bounds__(kBlock) void k_sample_pair_ratio(const uint32_t* Bp
 // One wavefront per column of this context (partition i % stride == first, stage [lo, hi)): column j is i0 + j * stride.  The
 // entries of the other columns are zero: the host clears the arrays when the operands, the partition or the stage change.
 __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, const uint16_t* Bcnt, uint32_t i0, uint32_t stride, uint32_t nown,
-                                                      uint32_t* flops, uint32_t* nnzC) {
+                                                      uint32_t* flops, uint32_t* nnzC, uint32_t* ctl) {
+    if (blockIdx.x == 0 && threadIdx.x < kCtlWords) ctl[threadIdx.x] = 0;   // the pass's control block (first kernel of the pass)
     const uint32_t j = blockIdx.x * kWaves + wave_id();       // the j-th column of this context: i0 + j * stride
     if (j >= nown) return;
     const uint32_t i = i0 + j * stride;
@@ -800,6 +801,30 @@ __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, ui
         if (tier < ntiers) desc[(uint64_t)tier * nreads + o] = ds;
         else widelist[o] = i;
     }
+}
+
+// colptrC = exclusive prefix sums (u64) of the nreads + 1 pair counts: ONE launch of one 1024-thread workgroup, every thread a
+// contiguous chunk (the counts were just written: L2 resident).  Above kScanSingleMax entries the
+// library scan (two launches, many workgroups) takes over: one workgroup walking 10^5 counts takes 0.2 ms.
+constexpr uint32_t kScanSingleMax = 1u << 15;
+__global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* in, uint64_t* out, uint32_t n) {
+    __shared__ unsigned long long s_w[16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
+    unsigned long long sum = 0;
+    for (uint32_t x = lo; x < hi; ++x) sum += in[x];
+    unsigned long long inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long t = __shfl_up(inc, d, 64);
+        if ((int)lane_id() >= d) inc += t;
+    }
+    if (lane_id() == 63) s_w[wave_id()] = inc;
+    __syncthreads();
+    unsigned long long run = inc - sum;
+    for (uint32_t w = 0; w < wave_id(); ++w) run += s_w[w];
+    for (uint32_t x = lo; x < hi; ++x) { out[x] = run; run += in[x]; }
 }
 
 __global__ __launch_bounds__(kBlock) void k_compact_pairs(const uint64_t* flopptr, const uint64_t* colptrC,
