@@ -182,19 +182,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def prepare(nreads, want_host_tuples):
+    def prepare(nreads, want_host_tuples, use_lib=False, rs=None):
         """reads -> reliable k-mer dictionary + tuples on the device (bella_hip_count_kmers: the reference's SplitCount + tuple
-        loop) -> B (N = 1: whole; N > 1: this rank's row-block panel, then the all-gather) -> device layout"""
+        loop) -> B (N = 1: whole; N > 1: this rank's row-block panel, then the all-gather) -> device layout.
+        use_lib (N > 1): the library's own RCCL communicator does the counting exchange and the panel all-gather
+        (bella_hip_count_kmers_dist, bella_hip_allgather_panels); otherwise every rank counts all reads and the panels travel
+        through torch.distributed's all_gather."""
         t0 = time.time()
-        rs = synth.make_reads(nreads, read_len=a.read_len, coverage=30.0, err=0.15, seed=1)
+        if rs is None:
+            rs = synth.make_reads(nreads, read_len=a.read_len, coverage=30.0, err=0.15, seed=1)
         t1 = time.time()
         eng = Engine(local)
         eng.set_reads(rs)                                   # reads are replicated (2 bit/base; SURVEY 8e)
         have_comm = False
         if world > 1:
             from bella_amd import dist as bd
-            # the library's own RCCL communicator (include/bella_hip.h); BELLA_BENCH_NO_LIBCOMM=1: torch.distributed paths only
-            have_comm = False if os.environ.get("BELLA_BENCH_NO_LIBCOMM") else bd.init_comm(eng, local, backend)
+            have_comm = bd.init_comm(eng, local, backend) if use_lib else False   # the library's own RCCL communicator (include/bella_hip.h)
             lo, npanel = bd.block_range(rank, world, nreads)
         def all_ok(flag):                                   # every rank takes the same path
             if world == 1:
@@ -216,7 +219,7 @@ def main():
             nk, nt, ndistinct = eng.count_kmers(17, 2, 8)
         else:
             have_dist_count = True
-        info = {"rs": rs, "nk": nk, "kcount_ms": eng.timings().kcount_ms, "xchg_ms": None, "xchg_path": None,
+        info = {"rs": rs, "nk": nk, "kcount_ms": eng.timings().kcount_ms, "xchg_ms": None, "xchg_path": None, "have_comm": have_comm,
                 "kcount_path": "bella_hip_count_kmers_dist (code space split over the ranks)" if have_dist_count else "bella_hip_count_kmers (every rank, all reads)"}
         info["tup"] = synth.Tuples(*eng.get_tuples(), nk) if want_host_tuples else None
         if rank == 0:
@@ -354,9 +357,40 @@ def main():
         acc1 = timed_passes(eng, pars, 3, 1, torch.cuda.synchronize)
         single = {"ms_per_step": acc1["elapsed"] * 1e3 / 3, "value": acc1["npairs"] / (acc1["elapsed"] / 3), "pairs": int(acc1["npairs"])}
     dist.barrier()
-    if rank != 0:
-        dist.destroy_process_group()
-        return
+    import threading
+    printed = threading.Lock()
+    out_box = {}
+
+    def emit(o):
+        if printed.acquire(blocking=False):
+            print(json.dumps(o), flush=True)
+
+    lib = {"status": "not run"}
+    if (backend == "nccl" or os.environ.get("BELLA_BENCH_FORCE_LIB_PROBE")) and not os.environ.get("BELLA_BENCH_NO_LIBCOMM"):
+        def fire():                                          # watchdog: the measured line goes out without the library-path record
+            if rank == 0 and "out" in out_box:
+                o = dict(out_box["out"])
+                o["library_rccl_path"] = {"status": "timed out after %d s" % WATCHDOG_S}
+                emit(o)
+            os._exit(0)
+        WATCHDOG_S = int(os.environ.get("BELLA_BENCH_LIB_TIMEOUT", "240"))
+        lib["status"] = "pending"
+    else:
+        fire = None
+    def library_path_probe():
+        eng2, info2 = prepare(nreads, False, use_lib=True, rs=info["rs"])
+        if not info2["have_comm"]:
+            eng2.close()
+            return {"status": "communicator unavailable"}
+        eng2.set_partition(rank, n_gpus)
+        eng2.set_debug(2)
+        np2, fl2 = eng2.overlap(pars)
+        t2 = torch.tensor([float(np2), info2["kcount_ms"], info2["xchg_ms"] or 0.0], dtype=torch.float64, device=tdev)
+        s2 = t2.clone(); dist.all_reduce(s2, op=dist.ReduceOp.SUM)
+        m2 = t2.clone(); dist.all_reduce(m2, op=dist.ReduceOp.MAX)
+        eng2.close()
+        return {"status": "ok", "kcount_path": info2["kcount_path"], "kcount_ms_max": float(m2[1]), "panel_allgather_path": info2["xchg_path"],
+                "panel_allgather_ms": float(m2[2]), "pairs_match": int(s2[0]) == int(tot_pairs)}
     colptr, _, _ = eng.get_B()
     nnz = int(colptr[-1])
     out = {
@@ -374,7 +408,24 @@ def main():
         "speedup_vs_single_gpu": (single["ms_per_step"] / (elapsed * 1e3 / a.steps)) if single else None,
         "pairs_match_single_gpu": (single["pairs"] == int(tot_pairs)) if single else None,
     }
-    print(json.dumps(out))
+    out_box["out"] = out
+    if fire is not None:
+        timer = threading.Timer(WATCHDOG_S, fire)
+        timer.daemon = True
+        timer.start()
+        try:
+            lib = library_path_probe()
+        except Exception as e:
+            lib = {"status": "failed: %r" % (e,)}
+        timer.cancel()
+    out["library_rccl_path"] = lib
+    if rank != 0:
+        dist.destroy_process_group()
+        return
+    # The same set-up once more through the library's own RCCL communicator (C ABI: bella_hip_comm_init, bella_hip_count_kmers_dist,
+    # bella_hip_allgather_panels), checked against the result above.  It runs AFTER the measurement and under a watchdog: should that
+    # path stall on this box, the line above is printed without it.
+    emit(out)
     dist.destroy_process_group()
 
 

@@ -520,10 +520,16 @@ def test_baseline_config1_full_size_parity(eng):
     """BASELINE configs[1] at full size (10k reads x 10 kb, the bench workload): every pair record vs the oracle, plus
     size-independent properties (strict lower triangle, unique pairs, count==1 <=> single shared k-mer record)."""
     rs = synth.make_reads(10000, read_len=10000, coverage=30.0, err=0.15, seed=1)
-    t = synth.count_and_tuples(rs, 17, 2, 8, device="cuda:0")
     seqs = rs.seqs()
     eng.set_reads(rs)
-    eng.assemble_tuples(17, t.nkmers, t.kmer, t.read, t.pos)
+    # the bench's own pipeline: the engine counts the k-mers, builds the dictionary and the tuples, and assembles from them; the
+    # test kit's independent (torch) counter must agree with it tuple for tuple (ids = ranks of the canonical k-mers)
+    nk, nt, _ = eng.count_kmers(17, 2, 8)
+    t = synth.Tuples(*eng.get_tuples(), nk)
+    t2 = synth.count_and_tuples(rs, 17, 2, 8, device="cuda:0")
+    assert nk == t2.nkmers and np.array_equal(t.kmer, t2.kmer) and np.array_equal(t.read, t2.read) and np.array_equal(t.pos, t2.pos)
+    del t2
+    eng.assemble_counted()
     n, flops = eng.overlap(BellaPars(skipAlignment=True))
     pairs, ext, colptrC = eng.get_pairs()
     assert (pairs["rid"] > pairs["cid"]).all()
