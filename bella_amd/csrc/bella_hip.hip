@@ -52,7 +52,8 @@ const size_t kClassLds[kNumClasses] = {10240, 20480, 40160, 54608, 81920, 163840
 #define BELLA_CLASS_BLOCKS {128, 256, 512, 512, 1024, 1024}
 #endif
 const int kClassBlock[kNumClasses] = BELLA_CLASS_BLOCKS;   // measured (tools/ab_blocks.sh): DESIGN.md 4.1
-constexpr uint32_t kGlobalGrid = 1024;      // persistent workgroups of the global path: latency-bound, four per CU
+constexpr uint32_t kMidToWideMin = 16;      // columns above the LDS tiers in one pass from which on they take the sort-based path
+constexpr uint32_t kGlobalGrid = 1024;      // persistent workgroups of the global path (1024 threads each: latency-bound, two resident per CU)
 constexpr uint32_t kAsmGrid = 1024;
 
 struct CastU64 {
@@ -102,7 +103,7 @@ struct bella_ctx {
 #endif
     Buf flopsr, flopptr, nnzC, colptrC, rowlists, tiercaps, tmp_pairs, tmp_ext, pairs, ext, sortscr, ws,
         status, cubtmp, plist_hv, overflow, ctl, retry;
-    Buf w_f, w_off, w_key, w_key2, w_idx, w_idx2, w_hv, w_ovfl, w_plist, w_scr, w_rlen, w_rstart, w_rrank, w_segfirst,
+    Buf w_f, w_off, w_key, w_key2, w_idx, w_idx2, w_hv, w_ovfl, w_plist, w_scr, w_rlen, w_rstart, w_rrank, w_redo, w_segfirst,
         w_toff, w_table, w_nruns;
     uint32_t n_wide = 0;
     uint32_t n_retry = 0;
@@ -370,7 +371,7 @@ int bella_hip_init(int device, bella_ctx** out) {
         uint32_t caps[kNumTiers];
         for (const char* q = tv; *q && n + 1 < kNumTiers;) {
             const uint32_t v = (uint32_t)strtoul(q, nullptr, 10);
-            if (v >= 16 && v <= 11008 && (n == 0 || v > caps[n - 1])) caps[n++] = v;
+            if (v >= 64 && v <= 11008 && (n == 0 || v > caps[n - 1])) caps[n++] = v;   // (>= 64: the slot-order table of a tier holds >= 16 slots)
             while (*q && *q != ',') ++q;
             if (*q == ',') ++q;
         }
@@ -414,7 +415,7 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->fill, &c->ori, &c->w, &c->wscan, &c->Atmp, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC,
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
                   &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx, &c->w_idx2, &c->w_hv, &c->w_ovfl,
-                  &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
+                  &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_redo, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
                   &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->lg_res, &c->lg_redo, &c->lg_scratch};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -1288,6 +1289,12 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     k_wide_ranks<<<nw < 1024u ? nw : 1024u, kBlock, 0, c->stream>>>(a);
     KCHK(c);
     if (np) {
+        // one workgroup per pair (closed-form fold); what it leaves over (lists of >= 32768 products, > 16 bins) to the serial fold
+        ENSURE(c, c->w_redo, 4 * ((size_t)np + 1));
+        a.redo = ptr<uint32_t>(c->w_redo);
+        HIPCHK(c, hipMemsetAsync(a.redo + np, 0, 4, c->stream));
+        k_wide_fold_wg<<<np < 16384u ? np : 16384u, kWideFoldBlock, 0, c->stream>>>(a);
+        KCHK(c);
         k_wide_fold<<<nblk(np, 64), 64, 0, c->stream>>>(a);
         KCHK(c);
     }
@@ -1477,7 +1484,12 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     // the global-workspace tier to side stream 2, and the class of the smallest columns (it finishes last) stays on the main stream.
     int main_l = -1;
     for (int l = 0; l < nl; ++l) if (ln[l].rows) { main_l = l; break; }
-    const bool global_tier = tcnt[g_ntiers - 1] != 0;
+    // The columns above the LDS tiers (<= 65,535 products): a handful runs on the global-workspace path next to the LDS classes; when
+    // a pass has many of them (HiFi-like inputs, deep coverage) they join the wide columns on the sort-based path of wide.hpp, which
+    // works at HBM speed instead of L2 latency (debug bit 5: tests, any number of them).
+    const uint32_t n_mid = tcnt[g_ntiers - 1];
+    const bool mid_to_wide = !force_global && n_mid != 0 && (n_mid >= kMidToWideMin || (c->debug & 32u));
+    const bool global_tier = n_mid != 0 && !mid_to_wide;
     bool used[3] = {};
     bool forked = false;
     auto side_stream = [&](int which) -> int {                    // first use: make the stream wait for what the main stream did so far
@@ -1555,7 +1567,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         a.cap = tier_caps[g_ntiers - 1];
         a.dcap = a.cap;
         const unsigned grid = a.nrows < kGlobalGrid ? a.nrows : kGlobalGrid;
-        k_spgemm_rows_global<<<grid, kRowBlock, 0, sst>>>(a);
+        k_spgemm_rows_global<<<grid, kGlobalBlock, 0, sst>>>(a);
         KCHK(c);
         launches++;
     }
@@ -1593,7 +1605,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         a.rowlist = ptr<uint32_t>(c->retry);
         a.rowdesc = nullptr;
         a.nrows_dev = ptr<uint32_t>(c->ctl) + kCtlRetry;
-        k_spgemm_rows_global<<<kGlobalGrid, kRowBlock, 0, c->stream>>>(a);
+        k_spgemm_rows_global<<<kGlobalGrid, kGlobalBlock, 0, c->stream>>>(a);
         KCHK(c);
         return 0;
     };
@@ -1621,9 +1633,14 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         return 0;
     };
     if (!skip_rare) { rc = rerun_columns(); if (rc) return rc; }
-    c->n_wide = tcnt[g_ntiers];
-    if (c->n_wide) {                                              // columns with >= 65536 products (wide.hpp); rare, host-driven
-        rc = run_wide(c, a, c->n_wide, (const uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr));
+    c->n_wide = tcnt[g_ntiers] + (mid_to_wide ? n_mid : 0);
+    if (c->n_wide) {                                              // columns with >= 65536 products, and the mid-size ones (wide.hpp); host-driven
+        uint32_t* const widelist = (uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr);
+        if (mid_to_wide) {
+            k_desc_cols<<<nblk(n_mid), 256, 0, c->stream>>>(ptr<uint4>(c->rowlists) + (size_t)(g_ntiers - 1) * nr, n_mid, widelist + tcnt[g_ntiers]);
+            KCHK(c);
+        }
+        rc = run_wide(c, a, c->n_wide, widelist);
         if (rc) return rc;
     }
     EVREC(5);
@@ -1660,7 +1677,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
                     (unsigned long long)F, (unsigned long long)Fub);
     }
     c->pass_known = true;
-    c->pass_rare_free = c->n_retry == 0 && c->n_overflow == 0 && tcnt[g_ntiers] == 0;
+    c->pass_rare_free = c->n_retry == 0 && c->n_overflow == 0 && c->n_wide == 0;
     c->tm.symbolic_ms = ev_ms(c->ev[2], c->ev[3]);
     c->tm.spgemm_ms = ev_ms(c->ev[3], c->ev[5]);
     c->tm.fold_ms = skip_rare ? 0.f : ev_ms(c->ev[5], c->ev[8]);

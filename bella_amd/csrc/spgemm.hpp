@@ -44,6 +44,9 @@ constexpr uint32_t kScatterChunk = 64;                    // phase S appends one
 #ifndef BELLA_WALK_W
 #define BELLA_WALK_W 8
 #endif
+#ifndef BELLA_WALK_W_GLOBAL
+#define BELLA_WALK_W_GLOBAL 32
+#endif
 #ifndef BELLA_ROW_BLOCK
 #define BELLA_ROW_BLOCK 512
 #endif
@@ -511,7 +514,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             // The last group of a list reads up to W - 1 words beyond its end (the next list, or the words behind the lists: always
             // inside the column's arrays); a "hit" found there lies at or beyond the end and is cut off below -- no masked tail.
             uint32_t t = s + 1;
-            constexpr uint32_t W = BELLA_WALK_W;              // products per test
+            constexpr uint32_t W = OVERLAY ? BELLA_WALK_W : BELLA_WALK_W_GLOBAL;   // products per test (global path: latency per round trip, not issue, is what counts)
             uint32_t q[W];
             bool hit = false;
             while (t < mm) {
@@ -624,7 +627,11 @@ __global__ __launch_bounds__(BLK, (BLK == 1024 ? (NX <= 4 ? 8 : 4) : BLK <= 256 
 
 // Global-workspace path: columns with more products than the largest LDS tier (< 65536), and -- second launch, list and
 // length produced on the device -- columns whose key table overflowed in an LDS tier.  Persistent workgroups.
-__global__ __launch_bounds__(kRowBlock) void k_spgemm_rows_global(SpgemmArgs a) {
+#ifndef BELLA_GLOBAL_BLOCK
+#define BELLA_GLOBAL_BLOCK 1024
+#endif
+constexpr int kGlobalBlock = BELLA_GLOBAL_BLOCK;          // threads per column on the global-workspace path
+__global__ __launch_bounds__(kGlobalBlock) void k_spgemm_rows_global(SpgemmArgs a) {
     uint8_t* ws = a.ws + (uint64_t)blockIdx.x * a.ws_stride;
     const uint32_t nrows = a.nrows_dev ? *a.nrows_dev : a.nrows;
     for (uint32_t x = blockIdx.x; x < nrows; x += gridDim.x) {
@@ -633,7 +640,7 @@ __global__ __launch_bounds__(kRowBlock) void k_spgemm_rows_global(SpgemmArgs a) 
         if (f < 16u) f = 16u;                             // T2 needs >= 16 slots
         const RowMem m = carve<false>(ws, f, f, false);
         const uint32_t b0 = a.Bptr[i];
-        (void)process_row<false, 8, false>(a, i, b0, a.Bptr[i + 1] - b0, (uint32_t)(a.roff[i + 1] - a.roff[i]), m);
+        (void)process_row<false, 8, false, kGlobalBlock>(a, i, b0, a.Bptr[i + 1] - b0, (uint32_t)(a.roff[i + 1] - a.roff[i]), m);
         __syncthreads();
     }
 }

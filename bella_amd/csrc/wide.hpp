@@ -3,9 +3,11 @@
 // Same computation as spgemm.hpp (overlap.hpp:281-363 LocalSpGEMM + chain.hpp:74-150), arranged for columns of any size:
 // expand the column's products to HBM, radix-sort them by (column, partner read) -- stable, so a pair's products stay in
 // product order --, run-length encode into pairs, reproduce the reference's hash-slot order per column with the same
-// atomicMin insertion as phase O of the row kernel (64-bit items), fold every pair with the serial statement of the
-// semiring (core.hpp:fold_pair, one lane per pair) and write the records at the column's ranks.  Rare by construction
-// (HiFi sets with a raised -u, repeats): clarity over speed.
+// atomicMin insertion as phase O of the row kernel (64-bit items), fold every pair -- one workgroup per pair with the closed
+// form of the row kernel's phase P (parents + independent walks) on the pair's list in HBM; the serial statement of the
+// semiring (core.hpp:fold_pair, one lane per pair) only for lists of >= 32768 products and pairs that end with > 16 bins --
+// and write the records at the column's ranks.  Also the path of the columns above the LDS tiers (11,009 ... 65,535 products)
+// when a pass has more than a handful of them (HiFi sets with a raised -u, repeats, deep coverage).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -50,6 +52,7 @@ struct WideArgs {
     bella_pair_ext* tmp_ext;
     uint32_t* nnzC;
     uint32_t* status;            // ctl word: bit0 = > 16 bins without scratch (never here)
+    uint32_t* redo;              // [npairs] pairs left to the serial fold (k_wide_fold) by k_wide_fold_wg; redo[npairs] = their number
 };
 
 // products of the wide columns in the reference's order (B' entry order, then the k-mer's read list)
@@ -146,19 +149,9 @@ __global__ __launch_bounds__(kBlock) void k_wide_ranks(WideArgs a) {
     }
 }
 
-// the fold: one lane per pair, serial statement of the semiring on the pair's own list (in place)
-__global__ __launch_bounds__(64) void k_wide_fold(WideArgs a) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.npairs) return;
+__device__ __forceinline__ void wide_write_pair(const WideArgs& a, uint32_t r, const FoldResult& fr) {
     const uint32_t seg = (uint32_t)(a.R_key[r] >> 32), key = (uint32_t)a.R_key[r];
     const uint32_t cid = a.cols[seg];
-    const uint64_t lo = a.R_start[r];
-    const uint32_t mm = a.R_len[r];
-    uint32_t* w = (uint32_t*)(a.plist + lo);
-    for (uint32_t t = 0; t < mm; ++t) w[2 * t + 1] &= 0xFFFFu;       // drop the flag bits: the fold recomputes them from the reads
-    struct S2 { uint32_t* base; __device__ uint32_t& operator[](uint32_t e) const { return base[2u * e]; } };
-    FoldResult fr;
-    fold_pair(S2{w}, S2{w + 1}, mm, a.k, a.binSize, a.sort_scratch + lo, fr);
     const uint32_t k = (uint32_t)a.k;
     const uint32_t seedH = fr.seed & 0xFFFFu, seedV = fr.seed >> 16;
     const uint64_t leH = kmer_le(a.packed, a.roff[key] + seedH, k);
@@ -173,6 +166,153 @@ __global__ __launch_bounds__(64) void k_wide_fold(WideArgs a) {
         ex.nbins = fr.nbins; ex.support = fr.support; ex.binov = fr.binov; ex.pad = 0;
         a.tmp_ext[o] = ex;
     }
+}
+
+// The fold of one pair by one workgroup: the closed form of the row kernel's phase P (spgemm.hpp) on the pair's own list in HBM
+// (uint2 {posH | posV << 16, overlap estimate | flags << 16}, product order):
+//   parent(l) = first later product whose overlap estimate is within binSize of l's (none: a final bin, a "root");
+//   a position walks its ancestor path and is dropped at the first ancestor within k of it in either coordinate; count = m + the
+//   ancestors passed alive (mod 2^16); support(root) = positions that reach it; the winner is the first maximum among the roots in
+//   descending product order (std::sort's insertion-sort regime, <= 16 bins).
+// The upper half of a product's second word (the flags, which the record recomputes from the reads) serves as its support counter,
+// a.sort_scratch as the parent links (u16: lists of >= 32768 products, and pairs with > 16 bins, go to the serial fold).
+constexpr int kWideFoldBlock = 256;
+__global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
+    __shared__ uint32_t s_flag, s_contrib, s_surv, s_roots;
+    __shared__ unsigned long long s_best;
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t kRoot = 0x8000u;
+    for (uint32_t r = blockIdx.x; r < a.npairs; r += gridDim.x) {
+        const uint32_t mm = a.R_len[r];
+        const uint64_t lo = a.R_start[r];
+        uint2* w = a.plist + lo;
+        if (mm >= kRoot) {                                         // parent links are u16
+            if (tid == 0) a.redo[atomicAdd(&a.redo[a.npairs], 1u)] = r;
+            continue;
+        }
+        uint16_t* Par = a.sort_scratch + lo;
+        if (tid == 0) { s_flag = 0; s_contrib = 0; s_surv = 0; s_roots = 0; s_best = 0; }
+        __syncthreads();
+        // parents; the flag halves become the support counters
+        for (uint32_t y = tid; y < mm; y += kWideFoldBlock) {
+            const uint32_t ovw = w[y].y & 0xFFFFu;
+            w[y].y = ovw;
+            uint32_t par = kRoot;
+            for (uint32_t t = y + 1; t < mm; ++t)
+                if (iabs_((int)(w[t].y & 0xFFFFu) - (int)ovw) < a.binSize) { par = t; break; }
+            if (y + 1 < mm && par != y + 1) s_flag = 1;
+            if (par == kRoot) atomicAdd(&s_roots, 1u);
+            Par[y] = (uint16_t)par;
+        }
+        __syncthreads();
+        const bool plain = s_flag == 0;
+        uint32_t contrib = 0, surv = 0;
+        if (plain) {
+            // plain chain: every position is compared with the later products until one is within k of it (16 per round trip)
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            const us2 kk2 = {(unsigned short)a.k, (unsigned short)a.k};
+            const us2 lim2 = {(unsigned short)(2 * a.k + 1), (unsigned short)(2 * a.k + 1)};
+            const uint32_t lim = __builtin_bit_cast(uint32_t, lim2);
+            constexpr uint32_t W = 16;
+            for (uint32_t y = tid; y + 1 < mm; y += kWideFoldBlock) {
+                const us2 xk = __builtin_bit_cast(us2, w[y].x) + kk2;
+                uint32_t t = y + 1;
+                uint32_t q[W];
+                bool hit = false;
+                while (t < mm) {
+                    us2 acc = lim2;
+#pragma unroll
+                    for (uint32_t u = 0; u < W; ++u) {
+                        const uint32_t idx = t + u < mm ? t + u : mm - 1;      // (copies of the last product: a hit there is the last one's)
+                        q[u] = w[idx].x;
+                        acc = __builtin_elementwise_min(acc, (us2)(xk - __builtin_bit_cast(us2, q[u])));
+                    }
+                    if (__builtin_bit_cast(uint32_t, acc) != lim) { hit = true; break; }
+                    t += W;
+                }
+                if (hit) {
+                    uint32_t f = W - 1;
+#pragma unroll
+                    for (int u = (int)W - 2; u >= 0; --u) {
+                        const us2 dd = __builtin_elementwise_min(lim2, (us2)(xk - __builtin_bit_cast(us2, q[u])));
+                        f = __builtin_bit_cast(uint32_t, dd) != lim ? (uint32_t)u : f;
+                    }
+                    t += f;
+                }
+                t = t < mm ? t : mm;
+                contrib += t - y - 1;
+                surv += t == mm ? 1u : 0u;
+            }
+        } else {
+            for (uint32_t y = tid; y + 1 < mm; y += kWideFoldBlock) {
+                const uint32_t x = w[y].x;
+                uint32_t root = y, t = Par[y];
+                bool dead = false;
+                while (!(t & kRoot)) {
+                    if (!far_apart(x, w[t].x, a.k)) { dead = true; break; }
+                    contrib++; root = t; t = Par[t];
+                }
+                if (!dead) atomicAdd(&w[root].y, 0x10000u);
+            }
+        }
+        if (contrib) atomicAdd(&s_contrib, contrib);
+        if (surv) atomicAdd(&s_surv, surv);
+        __syncthreads();
+        FoldResult fr;
+        fr.many_bins = 0;
+        fr.count = (uint16_t)(mm + s_contrib);
+        uint32_t win = mm - 1;
+        if (plain) {
+            fr.nbins = 1; fr.support = (uint16_t)(s_surv + 1);
+        } else {
+            const uint32_t nroots = s_roots;
+            if (nroots > 16) {                                     // std::sort leaves the insertion-sort regime (common.h:145)
+                if (tid == 0) a.redo[atomicAdd(&a.redo[a.npairs], 1u)] = r;
+                __syncthreads();
+                continue;
+            }
+            // first maximum in descending product order = the largest (support, product index)
+            unsigned long long best = 0;
+            for (uint32_t l = tid; l < mm; l += kWideFoldBlock) {
+                if (!(Par[l] & kRoot)) continue;
+                const uint32_t cnt = (w[l].y >> 16) + (l + 1 == mm ? 1u : 0u);   // the last product counts itself
+                const unsigned long long key = ((unsigned long long)cnt << 32) | l;
+                best = key > best ? key : best;
+            }
+            if (best) atomicMax(&s_best, best);
+            __syncthreads();
+            win = (uint32_t)s_best;
+            fr.nbins = (uint16_t)nroots; fr.support = (uint16_t)(s_best >> 32);
+        }
+        if (tid == 0) {
+            const uint2 e = w[win];
+            fr.seed = e.x; fr.binov = (uint16_t)(e.y & 0xFFFFu);
+            wide_write_pair(a, r, fr);
+        }
+        __syncthreads();
+    }
+}
+
+// the serial fold of the pairs k_wide_fold_wg left over: one lane per pair, serial statement of the semiring on the pair's own
+// list (in place), libstdc++'s sort order for > 16 bins
+__global__ __launch_bounds__(64) void k_wide_fold(WideArgs a) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= a.redo[a.npairs]) return;
+    const uint32_t r = a.redo[x];
+    const uint64_t lo = a.R_start[r];
+    const uint32_t mm = a.R_len[r];
+    uint32_t* w = (uint32_t*)(a.plist + lo);
+    for (uint32_t t = 0; t < mm; ++t) w[2 * t + 1] &= 0xFFFFu;       // drop the flag / support halves
+    struct S2 { uint32_t* base; __device__ uint32_t& operator[](uint32_t e) const { return base[2u * e]; } };
+    FoldResult fr;
+    fold_pair(S2{w}, S2{w + 1}, mm, a.k, a.binSize, a.sort_scratch + lo, fr);
+    wide_write_pair(a, r, fr);
+}
+
+// column ids of a tier's descriptor list (the columns above the LDS tiers join the wide columns)
+__global__ void k_desc_cols(const uint4* desc, uint32_t n, uint32_t* out) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n) out[x] = desc[x].x;
 }
 
 }  // namespace bella

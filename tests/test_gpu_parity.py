@@ -867,6 +867,40 @@ def test_hifi_syncmer_medium_set_parity(eng):
     assert bad == 0, bad
 
 
+@pytest.mark.parametrize("name", ["toy120", "toyrep90", "toyhifi50", "toysync60"])
+def test_columns_above_the_lds_tiers_on_the_sort_based_path(monkeypatch, name):
+    """the path of the columns with more products than the largest LDS tier when a pass has many of them (wide.hpp: expand, radix
+    sort, slot order, one workgroup per pair with the closed-form fold): with a 64-product LDS tier and debug bit 5 most
+    columns of a golden set take it -- single- and multi-bin pairs, long lists, both strands; then the many-bins set (serial
+    fold for > 16 bins)"""
+    g = load_golden(name)
+    try:
+        monkeypatch.setenv("BELLA_HIP_TIERS", "64")
+        e = Engine(0)
+        e.set_debug(32)
+        e.set_reads(g.rs)
+        e.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
+        n, flops = e.overlap(BellaPars(skipAlignment=True, kmerSize=g.k))
+        pairs, ext, colptrC = e.get_pairs()
+        _, flop, ecol, exp = oracle_pairs(g.rs, g.seqs, g.nkmers, g.tk, g.tr, g.tp, g.k)
+        assert flops == int(flop.sum()) and n == len(exp) and int((flop > 64).sum()) > 10
+        assert np.array_equal(colptrC, ecol.astype(np.uint64))
+        check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
+        if name == "toyrep90":
+            assert (ext["nbins"] > 1).any()
+            a = [(t, 600 * t + 200) for t in range(40)]
+            b = sorted([(t, 100 + 19 * t) for t in range(40)], key=lambda x: x[1])
+            c = [(100 + t, 50 + 40 * t) for t in range(120)]
+            d = [(100 + t, 60 + 40 * t) for t in range(120)]
+            exp2 = _run_constructed(e, [30000, 30000, 6000, 6000], [a, b, c, d], 300)
+            by = {(int(p["rid"]), int(p["cid"])): p for p in exp2}
+            assert by[(1, 0)]["nbins"] > 16 and by[(3, 2)]["support"] > 64
+        e.close()
+    finally:
+        monkeypatch.setenv("BELLA_HIP_TIERS", "768,1280,2048,3072,4096,6144,8192,11008")
+        Engine(0).close()
+
+
 @pytest.mark.parametrize("tier", ["8192", "11008"])
 def test_big_lds_tiers_bit_exact(monkeypatch, tier):
     """every column through the 8192-product LDS tier (the 16-positions-per-thread instance of the row kernel)"""
