@@ -1239,7 +1239,7 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     a.W_key = ptr<uint64_t>(c->w_key); a.W_idx = ptr<uint32_t>(c->w_idx); a.W_hv = ptr<uint32_t>(c->w_hv); a.W_ovfl = ptr<uint32_t>(c->w_ovfl);
     a.plist = ptr<uint2>(c->w_plist); a.sort_scratch = ptr<uint16_t>(c->w_scr);
     a.tmp_pairs = sa.tmp_pairs; a.tmp_ext = sa.tmp_ext; a.nnzC = sa.nnzC; a.status = sa.ctl + kCtlStatus;
-    k_wide_expand<<<nw < 1024u ? nw : 1024u, kBlock, 0, c->stream>>>(a);
+    k_wide_expand<<<nw < 2048u ? nw : 2048u, kWideExpandBlock, 0, c->stream>>>(a);
     KCHK(c);
     int seg_bits = 1;
     while ((1u << seg_bits) < nw) ++seg_bits;

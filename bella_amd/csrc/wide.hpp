@@ -56,24 +56,31 @@ struct WideArgs {
 };
 
 // products of the wide columns in the reference's order (B' entry order, then the k-mer's read list)
-__global__ __launch_bounds__(kBlock) void k_wide_expand(WideArgs a) {
-    __shared__ uint32_t scr[kWaves];
+constexpr int kWideExpandBlock = 1024;                     // one workgroup per column: its entries in rounds of 1024
+__global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
+    __shared__ uint32_t scr[kWideExpandBlock / 64];
     for (uint32_t s = blockIdx.x; s < a.nw; s += gridDim.x) {
         const uint32_t i = a.cols[s];
         const uint32_t b0 = a.Bptr[i], n = a.Bptr[i + 1] - b0;
         const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
         const uint64_t o = a.woff[s];
         uint32_t running = 0;
-        for (uint32_t jb = 0; jb < n; jb += kBlock) {
+        for (uint32_t jb = 0; jb < n; jb += kWideExpandBlock) {
             const uint32_t j = jb + threadIdx.x;
             uint2 be = make_uint2(0u, 0u);
             if (j < n) be = a.Bent[b0 + j];
             const uint32_t cnt = (be.y >> 16) & 0x3FFFu;
             uint32_t tot;
-            uint32_t p = running + block_excl_scan<kWaves>(cnt, scr, &tot);
+            uint32_t p = running + block_excl_scan<kWideExpandBlock / 64>(cnt, scr, &tot);
             const uint32_t posV = be.y & 0xFFFFu, pal = (be.y >> 30) & 1u;
-            for (uint32_t t = 0; t < cnt; ++t, ++p) {
-                const uint2 ae = a.Aent[(uint64_t)be.x + t];
+            for (uint32_t t0 = 0; t0 < cnt; t0 += 8) {          // eight independent A' loads in flight
+            uint2 aeb[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) aeb[u] = a.Aent[(uint64_t)be.x + (t0 + u < cnt ? t0 + u : cnt - 1)];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                if (t0 + u >= cnt) break;
+                const uint2 ae = aeb[u];
                 const uint32_t key = ae.x & 0x7FFFFFFFu;
                 const uint32_t posH = ae.y & 0xFFFFu, lenH = ae.y >> 16;
                 const bool oriented = (ae.x >> 31) == (be.y >> 31);
@@ -83,6 +90,8 @@ __global__ __launch_bounds__(kBlock) void k_wide_expand(WideArgs a) {
                 a.W_idx[o + p] = (uint32_t)(o + p);
                 a.W_hv[o + p] = posH | (posV << 16);
                 a.W_ovfl[o + p] = ov | (fl << 16);
+                ++p;
+            }
             }
             running += tot;
         }
@@ -176,10 +185,18 @@ __device__ __forceinline__ void wide_write_pair(const WideArgs& a, uint32_t r, c
 //   descending product order (std::sort's insertion-sort regime, <= 16 bins).
 // The upper half of a product's second word (the flags, which the record recomputes from the reads) serves as its support counter,
 // a.sort_scratch as the parent links (u16: lists of >= 32768 products, and pairs with > 16 bins, go to the serial fold).
-constexpr int kWideFoldBlock = 256;
+#ifndef BELLA_WIDE_FOLD_BLOCK
+#define BELLA_WIDE_FOLD_BLOCK 256
+#endif
+#ifndef BELLA_WIDE_FOLD_W
+#define BELLA_WIDE_FOLD_W 16
+#endif
+constexpr int kWideFoldBlock = BELLA_WIDE_FOLD_BLOCK;
+constexpr uint32_t kWideFoldLds = 8192;                    // positions of a list staged in LDS for the walks (32 KB: five workgroups per CU)
 __global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
     __shared__ uint32_t s_flag, s_contrib, s_surv, s_roots;
     __shared__ unsigned long long s_best;
+    __shared__ uint32_t s_hv[kWideFoldLds + 16];
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t kRoot = 0x8000u;
     for (uint32_t r = blockIdx.x; r < a.npairs; r += gridDim.x) {
@@ -192,10 +209,13 @@ __global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
         }
         uint16_t* Par = a.sort_scratch + lo;
         if (tid == 0) { s_flag = 0; s_contrib = 0; s_surv = 0; s_roots = 0; s_best = 0; }
+        const bool staged = mm <= kWideFoldLds;
         __syncthreads();
-        // parents; the flag halves become the support counters
+        // parents; the flag halves become the support counters; the positions of a list that fits go to LDS for the walks
         for (uint32_t y = tid; y < mm; y += kWideFoldBlock) {
-            const uint32_t ovw = w[y].y & 0xFFFFu;
+            const uint2 e0 = w[y];
+            const uint32_t ovw = e0.y & 0xFFFFu;
+            if (staged) s_hv[y] = e0.x;
             w[y].y = ovw;
             uint32_t par = kRoot;
             for (uint32_t t = y + 1; t < mm; ++t)
@@ -213,9 +233,9 @@ __global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
             const us2 kk2 = {(unsigned short)a.k, (unsigned short)a.k};
             const us2 lim2 = {(unsigned short)(2 * a.k + 1), (unsigned short)(2 * a.k + 1)};
             const uint32_t lim = __builtin_bit_cast(uint32_t, lim2);
-            constexpr uint32_t W = 16;
+            constexpr uint32_t W = BELLA_WIDE_FOLD_W;
             for (uint32_t y = tid; y + 1 < mm; y += kWideFoldBlock) {
-                const us2 xk = __builtin_bit_cast(us2, w[y].x) + kk2;
+                const us2 xk = __builtin_bit_cast(us2, staged ? s_hv[y] : w[y].x) + kk2;
                 uint32_t t = y + 1;
                 uint32_t q[W];
                 bool hit = false;
@@ -224,7 +244,7 @@ __global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
 #pragma unroll
                     for (uint32_t u = 0; u < W; ++u) {
                         const uint32_t idx = t + u < mm ? t + u : mm - 1;      // (copies of the last product: a hit there is the last one's)
-                        q[u] = w[idx].x;
+                        q[u] = staged ? s_hv[idx] : w[idx].x;
                         acc = __builtin_elementwise_min(acc, (us2)(xk - __builtin_bit_cast(us2, q[u])));
                     }
                     if (__builtin_bit_cast(uint32_t, acc) != lim) { hit = true; break; }
@@ -245,11 +265,11 @@ __global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
             }
         } else {
             for (uint32_t y = tid; y + 1 < mm; y += kWideFoldBlock) {
-                const uint32_t x = w[y].x;
+                const uint32_t x = staged ? s_hv[y] : w[y].x;
                 uint32_t root = y, t = Par[y];
                 bool dead = false;
                 while (!(t & kRoot)) {
-                    if (!far_apart(x, w[t].x, a.k)) { dead = true; break; }
+                    if (!far_apart(x, staged ? s_hv[t] : w[t].x, a.k)) { dead = true; break; }
                     contrib++; root = t; t = Par[t];
                 }
                 if (!dead) atomicAdd(&w[root].y, 0x10000u);
