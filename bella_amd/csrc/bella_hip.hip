@@ -1239,6 +1239,9 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     a.W_key = ptr<uint64_t>(c->w_key); a.W_idx = ptr<uint32_t>(c->w_idx); a.W_hv = ptr<uint32_t>(c->w_hv); a.W_ovfl = ptr<uint32_t>(c->w_ovfl);
     a.plist = ptr<uint2>(c->w_plist); a.sort_scratch = ptr<uint16_t>(c->w_scr);
     a.tmp_pairs = sa.tmp_pairs; a.tmp_ext = sa.tmp_ext; a.nnzC = sa.nnzC; a.status = sa.ctl + kCtlStatus;
+    int rbits = 1;
+    while ((1ull << rbits) < (uint64_t)c->nreads) ++rbits;       // a partner read id fits rbits bits
+    a.rbits = (uint32_t)rbits;
     k_wide_expand<<<nw < 2048u ? nw : 2048u, kWideExpandBlock, 0, c->stream>>>(a);
     KCHK(c);
     int seg_bits = 1;
@@ -1246,9 +1249,9 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     hipcub::DoubleBuffer<uint64_t> dk(ptr<uint64_t>(c->w_key), ptr<uint64_t>(c->w_key2));
     hipcub::DoubleBuffer<uint32_t> dv(ptr<uint32_t>(c->w_idx), ptr<uint32_t>(c->w_idx2));
     size_t tb = 0;
-    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (int)T, 0, 32 + seg_bits, c->stream));
+    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (int)T, 0, rbits + seg_bits, c->stream));
     ENSURE(c, c->cubtmp, tb);
-    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb, dk, dv, (int)T, 0, 32 + seg_bits, c->stream));
+    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb, dk, dv, (int)T, 0, rbits + seg_bits, c->stream));
     a.S_key = dk.Current(); a.S_idx = dv.Current();
     uint64_t* rkey = dk.Current() == ptr<uint64_t>(c->w_key) ? ptr<uint64_t>(c->w_key2) : ptr<uint64_t>(c->w_key);
     size_t tb2 = 0;

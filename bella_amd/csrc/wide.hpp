@@ -30,7 +30,8 @@ struct WideArgs {
     int k;
     int binSize;
     // products, product order
-    uint64_t* W_key;             // segment << 32 | partner read
+    uint64_t* W_key;             // segment << rbits | partner read (rbits = bits of a read id: the sort runs over rbits + segment bits only)
+    uint32_t rbits;
     uint32_t* W_idx;             // global product index (woff[seg] + p)
     uint32_t* W_hv;              // posH | posV << 16
     uint32_t* W_ovfl;            // overlap estimate | flags << 16
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
                 const bool oriented = (ae.x >> 31) == (be.y >> 31);
                 const uint32_t ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, (uint32_t)a.k) & 0xFFFFu;
                 const uint32_t fl = (oriented ? 1u : 0u) | (pal << 1);
-                a.W_key[o + p] = ((uint64_t)s << 32) | key;
+                a.W_key[o + p] = ((uint64_t)s << a.rbits) | key;
                 a.W_idx[o + p] = (uint32_t)(o + p);
                 a.W_hv[o + p] = posH | (posV << 16);
                 a.W_ovfl[o + p] = ov | (fl << 16);
@@ -108,8 +109,8 @@ __global__ void k_wide_gather(WideArgs a, uint64_t totalF) {
 __global__ void k_wide_segments(WideArgs a) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r > a.npairs) return;
-    const uint32_t seg = r < a.npairs ? (uint32_t)(a.R_key[r] >> 32) : a.nw;
-    const uint32_t prev = r == 0 ? 0xFFFFFFFFu : (uint32_t)(a.R_key[r - 1] >> 32);
+    const uint32_t seg = r < a.npairs ? (uint32_t)(a.R_key[r] >> a.rbits) : a.nw;
+    const uint32_t prev = r == 0 ? 0xFFFFFFFFu : (uint32_t)(a.R_key[r - 1] >> a.rbits);
     if (r == 0) { for (uint32_t s = 0; s <= seg && s <= a.nw; ++s) a.seg_first[s] = 0; }
     else if (seg != prev) { for (uint32_t s = prev + 1; s <= seg && s <= a.nw; ++s) a.seg_first[s] = r; }
 }
@@ -123,8 +124,8 @@ __global__ void k_wide_table_fill(uint64_t* table, uint64_t n) {
 __global__ void k_wide_insert(WideArgs a) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.npairs) return;
-    const uint32_t seg = (uint32_t)(a.R_key[r] >> 32);
-    const uint32_t key = (uint32_t)a.R_key[r];
+    const uint32_t seg = (uint32_t)(a.R_key[r] >> a.rbits);
+    const uint32_t key = (uint32_t)(a.R_key[r] & ((1ull << a.rbits) - 1ull));
     const uint64_t ht = a.toff[seg + 1] - a.toff[seg];
     unsigned long long* T = (unsigned long long*)(a.table + a.toff[seg]);
     const uint32_t first = a.S_idx[a.R_start[r]] - (uint32_t)a.woff[seg];    // product index inside the column
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void k_wide_ranks(WideArgs a) {
 }
 
 __device__ __forceinline__ void wide_write_pair(const WideArgs& a, uint32_t r, const FoldResult& fr) {
-    const uint32_t seg = (uint32_t)(a.R_key[r] >> 32), key = (uint32_t)a.R_key[r];
+    const uint32_t seg = (uint32_t)(a.R_key[r] >> a.rbits), key = (uint32_t)(a.R_key[r] & ((1ull << a.rbits) - 1ull));
     const uint32_t cid = a.cols[seg];
     const uint32_t k = (uint32_t)a.k;
     const uint32_t seedH = fr.seed & 0xFFFFu, seedV = fr.seed >> 16;
@@ -186,17 +187,24 @@ __device__ __forceinline__ void wide_write_pair(const WideArgs& a, uint32_t r, c
 // The upper half of a product's second word (the flags, which the record recomputes from the reads) serves as its support counter,
 // a.sort_scratch as the parent links (u16: lists of >= 32768 products, and pairs with > 16 bins, go to the serial fold).
 #ifndef BELLA_WIDE_FOLD_BLOCK
-#define BELLA_WIDE_FOLD_BLOCK 256
+#define BELLA_WIDE_FOLD_BLOCK 512
 #endif
 #ifndef BELLA_WIDE_FOLD_W
 #define BELLA_WIDE_FOLD_W 16
 #endif
 constexpr int kWideFoldBlock = BELLA_WIDE_FOLD_BLOCK;
-constexpr uint32_t kWideFoldLds = 8192;                    // positions of a list staged in LDS for the walks (32 KB: five workgroups per CU)
+constexpr uint32_t kGridSlots = 2048, kGridMax = 4096, kGridMin = 96;   // lists of kGridMin < m <= kGridMax products use the grid
+constexpr uint32_t kWideFoldLds = 6144;                    // products of a list staged in LDS (positions + overlap estimates, 36 KB; with the grid 68 KB: two workgroups per CU)
 __global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
     __shared__ uint32_t s_flag, s_contrib, s_surv, s_roots;
     __shared__ unsigned long long s_best;
     __shared__ uint32_t s_hv[kWideFoldLds + 16];
+    __shared__ uint16_t s_ov[kWideFoldLds + 16];
+    // position grid of a long plain-chain list: per coordinate, chains of list positions by bucket floor(pos / 2^sh) (2^sh > k), heads
+    // hashed into kGridSlots slots.  Two positions within k of each other sit in the same or in adjacent buckets, so "the first later
+    // product within k" is a look at three chains per coordinate instead of a walk over all later products (quadratic in the list).
+    __shared__ uint32_t s_head[2][kGridSlots];
+    __shared__ uint16_t s_next[2][kGridMax];
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t kRoot = 0x8000u;
     for (uint32_t r = blockIdx.x; r < a.npairs; r += gridDim.x) {
@@ -211,23 +219,71 @@ __global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
         if (tid == 0) { s_flag = 0; s_contrib = 0; s_surv = 0; s_roots = 0; s_best = 0; }
         const bool staged = mm <= kWideFoldLds;
         __syncthreads();
-        // parents; the flag halves become the support counters; the positions of a list that fits go to LDS for the walks
-        for (uint32_t y = tid; y < mm; y += kWideFoldBlock) {
-            const uint2 e0 = w[y];
-            const uint32_t ovw = e0.y & 0xFFFFu;
-            if (staged) s_hv[y] = e0.x;
-            w[y].y = ovw;
-            uint32_t par = kRoot;
-            for (uint32_t t = y + 1; t < mm; ++t)
-                if (iabs_((int)(w[t].y & 0xFFFFu) - (int)ovw) < a.binSize) { par = t; break; }
-            if (y + 1 < mm && par != y + 1) s_flag = 1;
-            if (par == kRoot) atomicAdd(&s_roots, 1u);
-            Par[y] = (uint16_t)par;
+        // a list that fits is staged in LDS (positions and overlap estimates): one streaming read of the pair's list
+        if (staged) {
+            for (uint32_t y = tid; y < mm; y += kWideFoldBlock) {
+                const uint2 e0 = w[y];
+                s_hv[y] = e0.x; s_ov[y] = (uint16_t)e0.y;
+            }
+            __syncthreads();
+        }
+        // is it a plain chain (every product's parent is its successor)?  Only otherwise the parent links are stored and the flag
+        // halves of the list words cleared (they become the support counters)
+        for (uint32_t y = tid; y + 1 < mm; y += kWideFoldBlock) {
+            const int ov0 = staged ? (int)s_ov[y] : (int)(w[y].y & 0xFFFFu), ov1 = staged ? (int)s_ov[y + 1] : (int)(w[y + 1].y & 0xFFFFu);
+            if (!(iabs_(ov1 - ov0) < a.binSize)) s_flag = 1;
         }
         __syncthreads();
+        if (s_flag) {
+            for (uint32_t y = tid; y < mm; y += kWideFoldBlock) {
+                const uint32_t ovw = staged ? (uint32_t)s_ov[y] : w[y].y & 0xFFFFu;
+                w[y].y = ovw;
+                uint32_t par = kRoot;
+                for (uint32_t t = y + 1; t < mm; ++t)
+                    if (iabs_((int)(staged ? (uint32_t)s_ov[t] : w[t].y & 0xFFFFu) - (int)ovw) < a.binSize) { par = t; break; }
+                if (par == kRoot) atomicAdd(&s_roots, 1u);
+                Par[y] = (uint16_t)par;
+            }
+            __syncthreads();
+        }
         const bool plain = s_flag == 0;
         uint32_t contrib = 0, surv = 0;
-        if (plain) {
+        if (plain && mm > kGridMin && mm <= kGridMax) {
+            const uint32_t sh = a.k < 32 ? 5u : 6u;                // bucket width > k
+            uint32_t T = 64;
+            while (T < mm && T < kGridSlots) T <<= 1;
+            for (uint32_t x = tid; x < T; x += kWideFoldBlock) { s_head[0][x] = 0xFFFFu; s_head[1][x] = 0xFFFFu; }
+            __syncthreads();
+            for (uint32_t y = tid; y < mm; y += kWideFoldBlock) {
+                const uint32_t hv = s_hv[y];
+                s_next[0][y] = (uint16_t)atomicExch(&s_head[0][((hv & 0xFFFFu) >> sh) & (T - 1)], y);
+                s_next[1][y] = (uint16_t)atomicExch(&s_head[1][((hv >> 16) >> sh) & (T - 1)], y);
+            }
+            __syncthreads();
+            const uint32_t kk = (uint32_t)a.k;
+            for (uint32_t y = tid; y + 1 < mm; y += kWideFoldBlock) {
+                const uint32_t hv = s_hv[y];
+                uint32_t t = mm;                                   // the first later product within k in either coordinate
+#pragma unroll
+                for (uint32_t cdn = 0; cdn < 2; ++cdn) {
+                    const uint32_t pos = cdn ? hv >> 16 : hv & 0xFFFFu;
+                    const uint32_t b = pos >> sh;
+                    for (uint32_t db = 0; db < 3; ++db) {
+                        if (db == 0 && b == 0) continue;           // bucket -1
+                        uint32_t e = s_head[cdn][(b + db - 1) & (T - 1)];
+                        while (e != 0xFFFFu) {
+                            const uint32_t q = s_hv[e];
+                            const uint32_t qp = cdn ? q >> 16 : q & 0xFFFFu;
+                            const uint32_t dlt = qp > pos ? qp - pos : pos - qp;
+                            if (e > y && e < t && dlt <= kk) t = e;
+                            e = s_next[cdn][e];
+                        }
+                    }
+                }
+                contrib += t - y - 1;
+                surv += t == mm ? 1u : 0u;
+            }
+        } else if (plain) {
             // plain chain: every position is compared with the later products until one is within k of it (16 per round trip)
             typedef unsigned short us2 __attribute__((ext_vector_type(2)));
             const us2 kk2 = {(unsigned short)a.k, (unsigned short)a.k};
