@@ -26,4 +26,7 @@ PY
 bash tools/collect_sq.sh > $OUT/${TAG}_sq_counters_10k.txt 2>/dev/null
 BENCH_ARGS="--reads 100000" bash tools/collect_sq.sh > $OUT/${TAG}_sq_counters_100k.txt 2>/dev/null
 bash tools/collect_sq_xdrop.sh > $OUT/${TAG}_xdrop_sq.txt 2>/dev/null
-tail -2 $OUT/traffic_10k.log $OUT/traffic_100k.log; cat $OUT/${TAG}_bench.json | cut -c1-600; cat $OUT/${TAG}_step_timeline_10k.txt | tail -3
+# the HiFi-like probe (columns above the LDS tiers on the sort-based path) and one rank's share of the strong-scaling run
+( python tools/hifi_probe2.py 3000 40 1 2>&1 | tail -1; bash tools/hifi_trace.sh 3000 40 1 2>&1 | tail -18 ) > $OUT/${TAG}_hifi_probe.txt
+python tools/rank_probe.py 2 4 8 2>&1 | tail -8 > $OUT/${TAG}_rank_probe_100k.txt
+tail -n 2 $OUT/traffic_10k.log; tail -n 2 $OUT/traffic_100k.log; cat $OUT/${TAG}_bench.json | cut -c1-600; cat $OUT/${TAG}_step_timeline_10k.txt | tail -3

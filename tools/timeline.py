@@ -5,7 +5,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "k_row_flops" in r["Kernel_Name"]]
-first = idx[-1] - 1
+first = idx[-1]                                              # k_row_flops is the first kernel of a pass (it clears the control block)
 t0 = int(rows[first]["Start_Timestamp"])
 rs, re_, end = None, None, None
 for r in rows[first:]:
@@ -19,4 +19,4 @@ for r in rows[first:]:
     if "copyBuffer" in k and rs is not None:
         end = e
         break
-print("row kernels span (first start -> last end): %.1f us ; pass span (fill -> control block copy): %.1f us" % ((re_ - rs) / 1e3, (end - t0) / 1e3))
+print("row kernels span (first start -> last end): %.1f us ; pass span (k_row_flops -> control block copy): %.1f us" % ((re_ - rs) / 1e3, (end - t0) / 1e3))
