@@ -53,6 +53,7 @@ const size_t kClassLds[kNumClasses] = {10240, 20480, 40160, 54608, 81920, 163840
 #endif
 const int kClassBlock[kNumClasses] = BELLA_CLASS_BLOCKS;   // measured (tools/ab_blocks.sh): DESIGN.md 4.1
 constexpr uint32_t kMidToWideMin = 16;      // columns above the LDS tiers in one pass from which on they take the sort-based path
+constexpr uint32_t kRerunGrid = 256;        // persistent workgroups of the rerun launch (columns an LDS tier handed over)
 constexpr uint32_t kGlobalGrid = 1024;      // persistent workgroups of the global path (1024 threads each: latency-bound, two resident per CU)
 constexpr uint32_t kAsmGrid = 1024;
 
@@ -1482,9 +1483,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         }
     }
     // Streams: at most four run concurrently on this device (hardware queues), and a workgroup of the whole-CU class only starts
-    // on an EMPTY CU: next to the small classes it starves until they are done.  So the whole-CU class (few columns, if any) runs
-    // first, alone, on the main stream; then the half-CU class goes to side stream 0, the third-of-a-CU class to side stream 1,
-    // the global-workspace tier to side stream 2, and the class of the smallest columns (it finishes last) stays on the main stream.
+    // on an EMPTY CU.  So the whole-CU class (few columns, if any) is launched first, on side stream 0, and takes its CUs before the
+    // others arrive; then the next classes go to the remaining side streams, the global-workspace tier to side stream 2, and the
+    // class of the smallest columns (it finishes last) stays on the main stream.
     int main_l = -1;
     for (int l = 0; l < nl; ++l) if (ln[l].rows) { main_l = l; break; }
     // The columns above the LDS tiers (<= 65,535 products): a handful runs on the global-workspace path next to the LDS classes; when
@@ -1560,8 +1561,12 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         return 0;
     };
     auto whole_cu = [&](int l) { return 2 * ln[l].lds > kClassLds[kNumClasses - 1]; };
+    // the whole-CU class (few columns, if any) goes FIRST, on a side stream of its own: its workgroups take their CUs before the other
+    // classes' workgroups arrive, and those fill the rest of the chip next to it instead of waiting behind it
+    int nwhole = 0;
     for (int l = nl - 1; l >= 0; --l)
-        if (ln[l].rows && whole_cu(l) && l != main_l) { rc = launch_class(l, true); if (rc) return rc; }
+        if (ln[l].rows && whole_cu(l) && l != main_l && nwhole == 0) { rc = launch_class(l, false); if (rc) return rc; nwhole++; }
+        else if (ln[l].rows && whole_cu(l) && l != main_l) { rc = launch_class(l, true); if (rc) return rc; }
     if (global_tier) {                                            // the columns above the LDS tiers (or all of them: debug bit 0)
         hipStream_t sst = c->stream;
         if (main_l >= 0) { rc = side_stream(2); if (rc) return rc; sst = c->side[2]; }      // (launch_class uses sides 0, 1 then)
@@ -1576,7 +1581,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     }
     {   // the three largest remaining classes each get a side stream; what is left (the classes of the smallest columns) runs on
         // the main stream, larger class first
-        int side_left = global_tier ? 2 : 3;
+        int side_left = 3 - nwhole - (global_tier ? 1 : 0);
         for (int l = nl - 1; l >= 0; --l) {
             if (!ln[l].rows || (whole_cu(l) && l != main_l)) continue;
             int later = 0;                                        // non-empty classes below this one
@@ -1608,7 +1613,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         a.rowlist = ptr<uint32_t>(c->retry);
         a.rowdesc = nullptr;
         a.nrows_dev = ptr<uint32_t>(c->ctl) + kCtlRetry;
-        k_spgemm_rows_global<<<kGlobalGrid, kGlobalBlock, 0, c->stream>>>(a);
+        k_spgemm_rows_global<<<kRerunGrid, kGlobalBlock, 0, c->stream>>>(a);   // (the list is usually empty or a handful of columns)
         KCHK(c);
         return 0;
     };
