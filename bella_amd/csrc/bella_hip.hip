@@ -1495,10 +1495,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     const bool mid_to_wide = !force_global && n_mid != 0 && (n_mid >= kMidToWideMin || (c->debug & 32u));
     const bool global_tier = n_mid != 0 && !mid_to_wide;
     bool used[3] = {};
-    bool forked = false;
     auto side_stream = [&](int which) -> int {                    // first use: make the stream wait for what the main stream did so far
-        if (!forked) { HIPCHK(c, hipEventRecord(c->fork, c->stream)); forked = true; }
-        if (!used[which]) { HIPCHK(c, hipStreamWaitEvent(c->side[which], c->fork, 0)); used[which] = true; }
+        // (the fork point is ev[3], recorded on the main stream right after the symbolic kernels: no event of its own)
+        if (!used[which]) { HIPCHK(c, hipStreamWaitEvent(c->side[which], c->ev[3], 0)); used[which] = true; }
         return 0;
     };
     a.rowlist = nullptr;
