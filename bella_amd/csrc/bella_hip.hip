@@ -41,6 +41,7 @@ constexpr uint32_t kNumTiers = 15;  // at most
 constexpr uint32_t kDefaultTiers = 14;
 const uint32_t kTierCapsDefault[kNumTiers] = {384, 689, 1000, 1394, 2048, 2752, 3712, 4600, 5568, 8192, 11008, 65535, 65535, 65535};
 const uint32_t kTierCapsHalf[kNumTiers] = {300, 526, 800, 1064, 1600, 2105, 2789, 3500, 4096, 6144, 8192, 11008, 65535, 65535};
+constexpr uint32_t kFullTableMaxCap = 300;               // pair-rich inputs: the smallest tier holds as many pairs as products
 constexpr uint32_t kHalfTableMaxCap = 4096;              // above: quarter-size key tables on any input
 // LDS classes: the share of a CU's 160 KB a column's workgroup needs, and the workgroup size that goes with it.  A column costs
 // a fixed ~18 us of latency (three dependent memory round trips, ~16 barriers) plus time per product: small columns get small
@@ -1466,6 +1467,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     // the global-workspace tier.
     auto dcap_of = [&](uint32_t cap) -> uint32_t {
         const bool half = (half_tables || (c->debug & 16u)) && cap <= kHalfTableMaxCap;     // debug bit 4: tests
+        // pair-rich inputs: the smallest columns are almost all chance pairs (one product each): their tier gets a full-size table
+        if (half_tables && cap <= kFullTableMaxCap) return cap;
         return half ? cap / 2 : cap / 4;
     };
     nl = 0;
