@@ -745,9 +745,20 @@ __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, cons
     if (lane_id() == 0) nnzC[i] = 0;                          // this pass's pair counts start from zero
     uint32_t s = 0;
     const uint32_t b0 = Bptr[i], b1 = Bptr[i + 1];
-    uint32_t e = b0 + lane_id();
-    for (; e + 192 < b1; e += 256) s += (uint32_t)Bcnt[e] + Bcnt[e + 64] + Bcnt[e + 128] + Bcnt[e + 192];   // four loads in flight
-    for (; e < b1; e += 64) s += Bcnt[e];
+    // head up to an 8-byte boundary, body four counts per lane and load (two loads in flight), tail
+    const uint32_t head0 = (4u - (b0 & 3u)) & 3u, head = head0 < b1 - b0 ? head0 : b1 - b0;
+    if (lane_id() < head) s += Bcnt[b0 + lane_id()];
+    const uint32_t e0 = b0 + head;
+    const uint2* B4 = (const uint2*)(Bcnt + e0);
+    const uint32_t ng = (b1 - e0) >> 2;
+    uint32_t g = lane_id();
+    for (; g + 64 < ng; g += 128) {
+        const uint2 v = B4[g], v2 = B4[g + 64];
+        s += (v.x & 0xFFFFu) + (v.x >> 16) + (v.y & 0xFFFFu) + (v.y >> 16) + (v2.x & 0xFFFFu) + (v2.x >> 16) + (v2.y & 0xFFFFu) + (v2.y >> 16);
+    }
+    for (; g < ng; g += 64) { const uint2 v = B4[g]; s += (v.x & 0xFFFFu) + (v.x >> 16) + (v.y & 0xFFFFu) + (v.y >> 16); }
+    const uint32_t e1 = e0 + (ng << 2);
+    if (e1 + lane_id() < b1) s += Bcnt[e1 + lane_id()];
 #pragma unroll
     for (int dlt = 32; dlt > 0; dlt >>= 1) s += __shfl_xor(s, dlt, 64);
     if (lane_id() == 0) flops[i] = s;
