@@ -164,6 +164,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     const uint32_t H1 = m.dcap;
     uint32_t* s_d = m.scr + 48;
     uint32_t* s_fail = m.scr + 49;
+    uint32_t* s_np = m.scr + 50;                              // LDS tiers: some pair of the column is not a plain chain
     const uint32_t k = (uint32_t)a.k;
     constexpr uint32_t GMASK = OVERLAY ? 0x1FFFu : 0xFFFFu;   // LDS tiers (<= 2048 slots): flags and the LAST mark ride on top of the T1 slot
     constexpr uint32_t kLastBit = 1u << 29;                   // L_gov (LDS tiers) / bit 2 of L_fl (global path): last product of its pair's list
@@ -173,7 +174,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         m.T2[s] = kEmpty; m.T2[s + H1] = kEmpty;             // the slot-order table of phase O (<= 2 * dcap slots), untouched until then
         if (!GALIAS) m.Gaux[s] = 0;
     }
-    if (tid == 0) { *s_d = 0; *s_fail = 0; }
+    if (tid == 0) { *s_d = 0; *s_fail = 0; *s_np = 0; }
     __syncthreads();
 
     // ---- X: expand products in reference order, group keys --------------------------------------------
@@ -432,6 +433,9 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
                 if (x < Fm) {
                     const bool last = x + 1 == Fm || ((gn[v] >> 16) & GMASK) != ((govv[u0 + v] >> 16) & GMASK);
                     if (!last && bad[v]) *s_fail = 1;
+                    // the successor's overlap estimate is at hand: is it this product's parent (phase P)?  If that holds for every
+                    // product of the column, all its pairs are plain chains and the parent phase is left out
+                    if (!last && !(iabs_((int)(gn[v] & 0xFFFFu) - (int)(govv[u0 + v] & 0xFFFFu)) < a.binSize)) *s_np = 1;
                     if (last) govv[u0 + v] |= kLastBit;
                 }
             }
@@ -474,6 +478,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     par_t* Par = (par_t*)m.T2;                                // S_p is dead
     // (Par holds ABSOLUTE list positions; a list ends at the entry carrying the LAST mark: no per-pair look-up on the fast path)
     auto is_last = [&](uint32_t y, uint32_t gov) -> bool { return OVERLAY ? (gov & kLastBit) != 0 : (m.L_fl[y] & 4u) != 0; };
+    const bool need_parents = !OVERLAY || *s_np != 0;         // (wave-uniform: read after the barrier that follows phase R)
+    if (need_parents)
     for (uint32_t y = tid; y < Fm; y += kRowBlock) {
         const uint32_t gov = m.L_gov[y];
         uint32_t gt = y + 1 < Fm ? m.L_gov[y + 1] : 0u;       // the usual parent: in flight together with the entry itself
@@ -493,7 +499,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
         Par[y] = (par_t)par;
     }
-    __syncthreads();
+    if (need_parents) __syncthreads();
     BELLA_BPROF(6)
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     const us2 kk2 = {(unsigned short)a.k, (unsigned short)a.k};
