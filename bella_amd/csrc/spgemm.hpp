@@ -44,6 +44,9 @@ constexpr uint32_t kScatterChunk = 64;                    // phase S appends one
 #ifndef BELLA_WALK_W
 #define BELLA_WALK_W 8
 #endif
+#ifndef BELLA_SCATTER_WAVES
+#define BELLA_SCATTER_WAVES 1
+#endif
 #ifndef BELLA_WALK_W_GLOBAL
 #define BELLA_WALK_W_GLOBAL 32
 #endif
@@ -325,11 +328,12 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         for (uint32_t s = tid; s < H1; s += kRowBlock) m.Gaux[s] = 0;
     }
     {
-        // the first kSW wavefronts each own the key slots g with g % kSW == their number and scan ALL products for them, kSA chunks
-        // of 64 in flight per stage: a key's products are appended by ONE wavefront, in product order (program order across
-        // chunks; inside a chunk the same-address atomics of one instruction -- see phase R).
-        constexpr uint32_t kSA = kRowBlock == 1024 ? 4 : 8;
-        constexpr uint32_t kSW = kRowWaves < 4 ? kRowWaves : 4;
+        // kSW wavefronts each own the key slots g with g % kSW == their number and scan ALL products for them, kSA chunks of 64 in
+        // flight per stage: a key's products are appended by ONE wavefront, in product order (program order across chunks; inside
+        // a chunk the same-address atomics of one instruction -- see phase R).  Measured (tools/ab_blocks.sh): one wavefront beats
+        // 2, 4 and 8 -- every further wavefront scans all products again and the kernel is issue-bound.
+        constexpr uint32_t kSA = 8;
+        constexpr uint32_t kSW = kRowWaves < BELLA_SCATTER_WAVES ? kRowWaves : BELLA_SCATTER_WAVES;
         const uint32_t w = wave_id(), lane = lane_id();
         if (w < kSW) {
             for (uint32_t base = 0; base < F; base += kSA * kScatterChunk) {
@@ -513,7 +517,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         const uint32_t mm = m.T1first[g] & 0xFFFFu;           // END of the list: the walk runs on absolute positions s = y .. mm
         const uint32_t* lst = m.L_hv;
         const uint32_t s = y;
-        if (!(m.T1key[g] >> 31)) {
+        if (!need_parents || !(m.T1key[g] >> 31)) {           // (all-plain column: no look-up)
             // plain chain: the position is compared with every later product until one is within k of it.
             // within k  <=>  (x + k - q) mod 2^16 <= 2k  in either half (k-mer starts are <= 65535 - k): eight products per test
             const us2 xk = __builtin_bit_cast(us2, x) + kk2;
