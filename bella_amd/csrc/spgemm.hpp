@@ -274,8 +274,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     }
     __syncthreads();
     BELLA_BPROF(2)
-    // Single-product pairs (multiop only: count 1, one bin, seed = the k-mer; 47 % of the pairs at 10k reads, 92 % at 100k) are
-    // finished right here, at their rank, from the product-order arrays; only the other pairs get a list.
+    // Every pair gets its output rank; the multi-product pairs get a list.  (The records of the single-product pairs are written
+    // during phase S by the wavefronts that have no part in the ordered scatter.)
     const uint64_t obase = a.flopptr[i];
     uint32_t Fm;                                              // products of the multi-product pairs = total list length
     {
@@ -297,23 +297,9 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             const uint32_t g = it & 0xFFFFu;
             const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
             m.G[rank] = (uint16_t)g;
-            m.T1first[g] = (st + (mm > 1 ? mm : 0u)) | (rank << 16);   // END of the pair's list: every later phase works from it
-            if (mm == 1) {
-                const uint32_t p = it >> 16;                  // the pair's only product
-                const uint32_t hv = m.A_hv[p], gov = m.A_gov[p];
-                const uint32_t fl = OVERLAY ? gov >> 30 : (uint32_t)m.A_fl[p];
-                bella_pair pr;
-                pr.rid = m.T1key[g]; pr.cid = i; pr.count = 1; pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
-                pr.flags = (uint16_t)((fl & 1u) | ((((fl & 1u) ^ 1u) | (fl >> 1)) << 1));   // bit1: revcomp(seedH)==seedV
-                a.tmp_pairs[obase + rank] = pr;
-                if (a.tmp_ext) {
-                    bella_pair_ext ex2;
-                    ex2.nbins = 1; ex2.support = 1; ex2.binov = (uint16_t)(gov & 0xFFFFu); ex2.pad = 0;
-                    a.tmp_ext[obase + rank] = ex2;
-                }
-            } else {
-                st += mm;
-            }
+            // low half: END of the pair's list (every later phase works from it); a single-product pair has no list: its product
+            m.T1first[g] = (mm > 1 ? st + mm : it >> 16) | (rank << 16);
+            if (mm > 1) st += mm;
             rank++;
         }
     }
@@ -335,7 +321,27 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         constexpr uint32_t kSA = 8;
         constexpr uint32_t kSW = kRowWaves < BELLA_SCATTER_WAVES ? kRowWaves : BELLA_SCATTER_WAVES;
         const uint32_t w = wave_id(), lane = lane_id();
-        if (w < kSW) {
+        if (w >= kSW) {
+            // the other wavefronts meanwhile: the records of the single-product pairs (multiop only: count 1, one bin, seed = the k-mer;
+            // 47 % of the pairs at 10k reads, 92 % at 100k), at their ranks, straight from the product-order arrays
+            constexpr uint32_t kOthers = kRowBlock - 64 * kSW;
+            for (uint32_t r = tid - 64 * kSW; r < d; r += kOthers) {
+                const uint32_t g = m.G[r];
+                if ((m.T1cnt[g] & 0xFFFFu) != 1u) continue;     // (wavefront 0 only touches the cursor half of the word)
+                const uint32_t p = m.T1first[g] & 0xFFFFu;      // the pair's only product
+                const uint32_t hv = m.A_hv[p], gov = m.A_gov[p];
+                const uint32_t fl = OVERLAY ? gov >> 30 : (uint32_t)m.A_fl[p];
+                bella_pair pr;
+                pr.rid = m.T1key[g]; pr.cid = i; pr.count = 1; pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
+                pr.flags = (uint16_t)((fl & 1u) | ((((fl & 1u) ^ 1u) | (fl >> 1)) << 1));   // bit1: revcomp(seedH)==seedV
+                a.tmp_pairs[obase + r] = pr;
+                if (a.tmp_ext) {
+                    bella_pair_ext ex2;
+                    ex2.nbins = 1; ex2.support = 1; ex2.binov = (uint16_t)(gov & 0xFFFFu); ex2.pad = 0;
+                    a.tmp_ext[obase + r] = ex2;
+                }
+            }
+        } else {
             for (uint32_t base = 0; base < F; base += kSA * kScatterChunk) {
                 uint32_t g[kSA], old[kSA];
                 bool mine[kSA];
