@@ -44,6 +44,9 @@ constexpr uint32_t kScatterChunk = 64;                    // phase S appends one
 #ifndef BELLA_WALK_W
 #define BELLA_WALK_W 8
 #endif
+#ifndef BELLA_SCATTER_CHUNKS
+#define BELLA_SCATTER_CHUNKS 8
+#endif
 #ifndef BELLA_SCATTER_WAVES
 #define BELLA_SCATTER_WAVES 1
 #endif
@@ -318,7 +321,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         // flight per stage: a key's products are appended by ONE wavefront, in product order (program order across chunks; inside
         // a chunk the same-address atomics of one instruction -- see phase R).  Measured (tools/ab_blocks.sh): one wavefront beats
         // 2, 4 and 8 -- every further wavefront scans all products again and the kernel is issue-bound.
-        constexpr uint32_t kSA = 8;
+        constexpr uint32_t kSA = BELLA_SCATTER_CHUNKS;
         constexpr uint32_t kSW = kRowWaves < BELLA_SCATTER_WAVES ? kRowWaves : BELLA_SCATTER_WAVES;
         const uint32_t w = wave_id(), lane = lane_id();
         if (w >= kSW) {
