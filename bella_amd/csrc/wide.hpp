@@ -193,8 +193,14 @@ __device__ __forceinline__ void wide_write_pair(const WideArgs& a, uint32_t r, c
 #define BELLA_WIDE_FOLD_W 16
 #endif
 constexpr int kWideFoldBlock = BELLA_WIDE_FOLD_BLOCK;
-constexpr uint32_t kGridSlots = 2048, kGridMax = 4096, kGridMin = 96;   // lists of kGridMin < m <= kGridMax products use the grid
-constexpr uint32_t kWideFoldLds = 6144;                    // products of a list staged in LDS (positions + overlap estimates, 36 KB; with the grid 68 KB: two workgroups per CU)
+#ifndef BELLA_WIDE_GRID_SLOTS
+#define BELLA_WIDE_GRID_SLOTS 1024
+#endif
+#ifndef BELLA_WIDE_FOLD_LDS
+#define BELLA_WIDE_FOLD_LDS 4096
+#endif
+constexpr uint32_t kGridSlots = BELLA_WIDE_GRID_SLOTS, kGridMax = 4096, kGridMin = 96;   // lists of kGridMin < m <= kGridMax products use the grid
+constexpr uint32_t kWideFoldLds = BELLA_WIDE_FOLD_LDS;                    // products of a list staged in LDS (positions + overlap estimates, 24 KB; with the grid 48 KB: three workgroups per CU)
 __global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
     __shared__ uint32_t s_flag, s_contrib, s_surv, s_roots;
     __shared__ unsigned long long s_best;
