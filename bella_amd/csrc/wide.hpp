@@ -60,6 +60,8 @@ struct WideArgs {
 constexpr int kWideExpandBlock = 1024;                     // one workgroup per column: its entries in rounds of 1024
 __global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
     __shared__ uint32_t scr[kWideExpandBlock / 64];
+    __shared__ uint32_t s_off[kWideExpandBlock + 1];        // first product of each entry of the round
+    __shared__ uint2 s_be[kWideExpandBlock];
     for (uint32_t s = blockIdx.x; s < a.nw; s += gridDim.x) {
         const uint32_t i = a.cols[s];
         const uint32_t b0 = a.Bptr[i], n = a.Bptr[i + 1] - b0;
@@ -72,28 +74,34 @@ __global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
             if (j < n) be = a.Bent[b0 + j];
             const uint32_t cnt = (be.y >> 16) & 0x3FFFu;
             uint32_t tot;
-            uint32_t p = running + block_excl_scan<kWideExpandBlock / 64>(cnt, scr, &tot);
-            const uint32_t posV = be.y & 0xFFFFu, pal = (be.y >> 30) & 1u;
-            for (uint32_t t0 = 0; t0 < cnt; t0 += 8) {          // eight independent A' loads in flight
-            uint2 aeb[8];
-#pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) aeb[u] = a.Aent[(uint64_t)be.x + (t0 + u < cnt ? t0 + u : cnt - 1)];
-#pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) {
-                if (t0 + u >= cnt) break;
-                const uint2 ae = aeb[u];
+            const uint32_t ex = block_excl_scan<kWideExpandBlock / 64>(cnt, scr, &tot);
+            s_off[threadIdx.x] = ex; s_be[threadIdx.x] = be;
+            if (threadIdx.x == 0) s_off[kWideExpandBlock] = tot;
+            __syncthreads();
+            // product-parallel: product q of the round belongs to the last entry whose first product is <= q (binary search over
+            // the round's offsets); neighbouring lanes read neighbouring A' entries and write neighbouring products
+            for (uint32_t q = threadIdx.x; q < tot; q += kWideExpandBlock) {
+                uint32_t lo = 0, hi = kWideExpandBlock;        // s_off[lo] <= q < s_off[hi]
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_off[mid] <= q) lo = mid; else hi = mid;
+                }
+                const uint2 eb = s_be[lo];
+                const uint32_t t = q - s_off[lo];
+                const uint2 ae = a.Aent[(uint64_t)eb.x + t];
+                const uint32_t posV = eb.y & 0xFFFFu, pal = (eb.y >> 30) & 1u;
                 const uint32_t key = ae.x & 0x7FFFFFFFu;
                 const uint32_t posH = ae.y & 0xFFFFu, lenH = ae.y >> 16;
-                const bool oriented = (ae.x >> 31) == (be.y >> 31);
+                const bool oriented = (ae.x >> 31) == (eb.y >> 31);
                 const uint32_t ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, (uint32_t)a.k) & 0xFFFFu;
                 const uint32_t fl = (oriented ? 1u : 0u) | (pal << 1);
-                a.W_key[o + p] = ((uint64_t)s << a.rbits) | key;
-                a.W_idx[o + p] = (uint32_t)(o + p);
-                a.W_hv[o + p] = posH | (posV << 16);
-                a.W_ovfl[o + p] = ov | (fl << 16);
-                ++p;
+                const uint64_t p = o + running + q;
+                a.W_key[p] = ((uint64_t)s << a.rbits) | key;
+                a.W_idx[p] = (uint32_t)p;
+                a.W_hv[p] = posH | (posV << 16);
+                a.W_ovfl[p] = ov | (fl << 16);
             }
-            }
+            __syncthreads();
             running += tot;
         }
     }
