@@ -1229,7 +1229,7 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
                                         (unsigned long long)T);
     ENSURE(c, c->w_key, 8 * T); ENSURE(c, c->w_key2, 8 * T);
     ENSURE(c, c->w_idx, 4 * T); ENSURE(c, c->w_idx2, 4 * T);
-    ENSURE(c, c->w_hv, 4 * T); ENSURE(c, c->w_ovfl, 4 * T);
+    ENSURE(c, c->w_hv, 8 * T);
     ENSURE(c, c->w_plist, 8 * T); ENSURE(c, c->w_scr, 2 * T);
     ENSURE(c, c->w_rlen, 4 * (T + 1)); ENSURE(c, c->w_rstart, 4 * (T + 2)); ENSURE(c, c->w_rrank, 4 * T);
     ENSURE(c, c->w_segfirst, 4 * ((size_t)nw + 2));
@@ -1238,7 +1238,7 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     a.cols = d_cols; a.nw = nw; a.woff = ptr<uint64_t>(c->w_off);
     a.Bptr = sa.Bptr; a.Bent = sa.Bent; a.Aent = sa.Aent; a.roff = sa.roff; a.packed = sa.packed; a.flopptr = sa.flopptr;
     a.k = sa.k; a.binSize = sa.binSize;
-    a.W_key = ptr<uint64_t>(c->w_key); a.W_idx = ptr<uint32_t>(c->w_idx); a.W_hv = ptr<uint32_t>(c->w_hv); a.W_ovfl = ptr<uint32_t>(c->w_ovfl);
+    a.W_key = ptr<uint64_t>(c->w_key); a.W_idx = ptr<uint32_t>(c->w_idx); a.W_rec = ptr<uint2>(c->w_hv);
     a.plist = ptr<uint2>(c->w_plist); a.sort_scratch = ptr<uint16_t>(c->w_scr);
     a.tmp_pairs = sa.tmp_pairs; a.tmp_ext = sa.tmp_ext; a.nnzC = sa.nnzC; a.status = sa.ctl + kCtlStatus;
     int rbits = 1;

@@ -33,8 +33,7 @@ struct WideArgs {
     uint64_t* W_key;             // segment << rbits | partner read (rbits = bits of a read id: the sort runs over rbits + segment bits only)
     uint32_t rbits;
     uint32_t* W_idx;             // global product index (woff[seg] + p)
-    uint32_t* W_hv;              // posH | posV << 16
-    uint32_t* W_ovfl;            // overlap estimate | flags << 16
+    uint2* W_rec;                // {posH | posV << 16, overlap estimate | flags << 16}
     // sorted
     const uint64_t* S_key;
     const uint32_t* S_idx;
@@ -98,8 +97,7 @@ __global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
                 const uint64_t p = o + running + q;
                 a.W_key[p] = ((uint64_t)s << a.rbits) | key;
                 a.W_idx[p] = (uint32_t)p;
-                a.W_hv[p] = posH | (posV << 16);
-                a.W_ovfl[p] = ov | (fl << 16);
+                a.W_rec[p] = make_uint2(posH | (posV << 16), ov | (fl << 16));
             }
             __syncthreads();
             running += tot;
@@ -112,7 +110,7 @@ __global__ void k_wide_gather(WideArgs a, uint64_t totalF) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= totalF) return;
     const uint32_t src = a.S_idx[x];
-    a.plist[x] = make_uint2(a.W_hv[src], a.W_ovfl[src]);       // .y keeps the flags in its upper half until the fold
+    a.plist[x] = a.W_rec[src];                                       // .y keeps the flags in its upper half until the fold
 }
 __global__ void k_wide_segments(WideArgs a) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,20 +230,31 @@ __global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
         uint16_t* Par = a.sort_scratch + lo;
         if (tid == 0) { s_flag = 0; s_contrib = 0; s_surv = 0; s_roots = 0; s_best = 0; }
         const bool staged = mm <= kWideFoldLds;
-        __syncthreads();
+        const bool grid = mm > kGridMin && mm <= kGridMax && mm <= kWideFoldLds;    // (used if the chain turns out plain)
+        const uint32_t sh = a.k < 32 ? 5u : 6u;                    // bucket width > k
+        uint32_t T = 64;
+        while (T < mm && T < kGridSlots) T <<= 1;
+        if (grid) for (uint32_t x = tid; x < T; x += kWideFoldBlock) { s_head[0][x] = 0xFFFFu; s_head[1][x] = 0xFFFFu; }
         // a list that fits is staged in LDS (positions and overlap estimates): one streaming read of the pair's list
         if (staged) {
             for (uint32_t y = tid; y < mm; y += kWideFoldBlock) {
                 const uint2 e0 = w[y];
                 s_hv[y] = e0.x; s_ov[y] = (uint16_t)e0.y;
             }
-            __syncthreads();
         }
+        __syncthreads();
         // is it a plain chain (every product's parent is its successor)?  Only otherwise the parent links are stored and the flag
-        // halves of the list words cleared (they become the support counters)
-        for (uint32_t y = tid; y + 1 < mm; y += kWideFoldBlock) {
-            const int ov0 = staged ? (int)s_ov[y] : (int)(w[y].y & 0xFFFFu), ov1 = staged ? (int)s_ov[y + 1] : (int)(w[y + 1].y & 0xFFFFu);
-            if (!(iabs_(ov1 - ov0) < a.binSize)) s_flag = 1;
+        // halves of the list words cleared (they become the support counters).  The grid is filled in the same sweep.
+        for (uint32_t y = tid; y < mm; y += kWideFoldBlock) {
+            if (y + 1 < mm) {
+                const int ov0 = staged ? (int)s_ov[y] : (int)(w[y].y & 0xFFFFu), ov1 = staged ? (int)s_ov[y + 1] : (int)(w[y + 1].y & 0xFFFFu);
+                if (!(iabs_(ov1 - ov0) < a.binSize)) s_flag = 1;
+            }
+            if (grid) {
+                const uint32_t hv = s_hv[y];
+                s_next[0][y] = (uint16_t)atomicExch(&s_head[0][((hv & 0xFFFFu) >> sh) & (T - 1)], y);
+                s_next[1][y] = (uint16_t)atomicExch(&s_head[1][((hv >> 16) >> sh) & (T - 1)], y);
+            }
         }
         __syncthreads();
         if (s_flag) {
@@ -262,18 +271,7 @@ __global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
         }
         const bool plain = s_flag == 0;
         uint32_t contrib = 0, surv = 0;
-        if (plain && mm > kGridMin && mm <= kGridMax) {
-            const uint32_t sh = a.k < 32 ? 5u : 6u;                // bucket width > k
-            uint32_t T = 64;
-            while (T < mm && T < kGridSlots) T <<= 1;
-            for (uint32_t x = tid; x < T; x += kWideFoldBlock) { s_head[0][x] = 0xFFFFu; s_head[1][x] = 0xFFFFu; }
-            __syncthreads();
-            for (uint32_t y = tid; y < mm; y += kWideFoldBlock) {
-                const uint32_t hv = s_hv[y];
-                s_next[0][y] = (uint16_t)atomicExch(&s_head[0][((hv & 0xFFFFu) >> sh) & (T - 1)], y);
-                s_next[1][y] = (uint16_t)atomicExch(&s_head[1][((hv >> 16) >> sh) & (T - 1)], y);
-            }
-            __syncthreads();
+        if (plain && grid) {
             const uint32_t kk = (uint32_t)a.k;
             for (uint32_t y = tid; y + 1 < mm; y += kWideFoldBlock) {
                 const uint32_t hv = s_hv[y];
