@@ -300,6 +300,15 @@ def main():
                             "passed": int(npass), "ms": xms, "pairs_per_s": len(al) / (xms * 1e-3) if xms else None,
                             "antidiagonal_steps": steps_tot, "gcups": 31 * steps_tot / (xms * 1e-3) / 1e9 if xms else None,
                             "flagged": int(al["flagged"].sum()), "bound": "VALU issue (profiles/r02_xdrop_sq.txt)"}
+            try:   # VALU issue rate of k_xdrop_sorted from the committed SQ counters (a profiling run): wave-instructions per SIMD-cycle / 0.25
+                import re
+                ln = [l for l in open(os.path.join(ROOT, "profiles", "r02_xdrop_sq.txt")) if "k_xdrop_sorted" in l][0]
+                us = float(re.search(r"\| ([0-9.]+) us \|", ln).group(1))
+                valu = float(re.search(r"SQ_INSTS_VALU=([0-9.e+]+)", ln).group(1))
+                out["xdrop"]["valu_issue_frac"] = valu / (us * 1e-6 * 2.4e9 * 1024 * 0.25)
+                out["xdrop"]["valu_issue_frac_source"] = "profiles/r02_xdrop_sq.txt: SQ_INSTS_VALU / (kernel time x 2.4 GHz x 1024 SIMDs x 1/4)"
+            except Exception:
+                pass
             del al
         if not a.no_cpu_baseline:
             tup = info["tup"]
