@@ -840,28 +840,23 @@ __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, ui
     }
 }
 
-// colptrC = exclusive prefix sums (u64) of the nreads + 1 pair counts: ONE launch of one 1024-thread workgroup, every thread a
-// contiguous chunk (the counts were just written: L2 resident).  Above kScanSingleMax entries the
-// library scan (two launches, many workgroups) takes over: one workgroup walking 10^5 counts takes 0.2 ms.
-constexpr uint32_t kScanSingleMax = 1u << 15;
+// colptrC = exclusive prefix sums (u64) of the nreads + 1 pair counts: ONE launch of one 1024-thread workgroup for passes of up to
+// kScanSingleMax columns (the counts go through LDS: coalesced reads, every thread then scans a contiguous chunk; their total is
+// < 2^32 at this size).  Above, the library scan (two launches, many workgroups) takes over.
+constexpr uint32_t kScanSingleMax = 12288;
 __global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* in, uint64_t* out, uint32_t n) {
-    __shared__ unsigned long long s_w[16];
+    __shared__ uint32_t s_v[kScanSingleMax];
+    __shared__ uint32_t s_w[16];
     const uint32_t tid = threadIdx.x;
+    for (uint32_t x = tid; x < n; x += 1024) s_v[x] = in[x];
+    __syncthreads();
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
-    unsigned long long sum = 0;
-    for (uint32_t x = lo; x < hi; ++x) sum += in[x];
-    unsigned long long inc = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long t = __shfl_up(inc, d, 64);
-        if ((int)lane_id() >= d) inc += t;
-    }
-    if (lane_id() == 63) s_w[wave_id()] = inc;
-    __syncthreads();
-    unsigned long long run = inc - sum;
-    for (uint32_t w = 0; w < wave_id(); ++w) run += s_w[w];
-    for (uint32_t x = lo; x < hi; ++x) { out[x] = run; run += in[x]; }
+    uint32_t sum = 0;
+    for (uint32_t x = lo; x < hi; ++x) sum += s_v[x];
+    uint32_t tot;
+    uint64_t run = block_excl_scan<16>(sum, s_w, &tot);
+    for (uint32_t x = lo; x < hi; ++x) { out[x] = run; run += s_v[x]; }
 }
 
 __global__ __launch_bounds__(kBlock) void k_compact_pairs(const uint64_t* flopptr, const uint64_t* colptrC,
