@@ -175,6 +175,20 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     constexpr uint32_t GMASK = OVERLAY ? 0x1FFFu : 0xFFFFu;   // LDS tiers (<= 2048 slots): flags and the LAST mark ride on top of the T1 slot
     constexpr uint32_t kLastBit = 1u << 29;                   // L_gov (LDS tiers) / bit 2 of L_fl (global path): last product of its pair's list
 
+    // the B' entries of the first round travel while the tables are initialised (their load is the second of two dependent HBM
+    // round trips at the head of every column: descriptor, then entries)
+    constexpr uint32_t RMAX = kRowBlock >= 1024 ? 4 : 8;      // B' entries per thread and round (registers: 1024-thread workgroups run at 64 VGPRs)
+    uint2 be0[RMAX];
+    {
+        const uint32_t nn = n < RMAX * kRowBlock ? n : RMAX * kRowBlock;
+        const uint32_t R = (nn + kRowBlock - 1) / kRowBlock;
+        const uint32_t j0 = tid * R;
+#pragma unroll
+        for (uint32_t u = 0; u < RMAX; ++u) {
+            be0[u] = make_uint2(0u, 0u);
+            if (u < R && j0 + u < nn) be0[u] = a.Bent[b0 + j0 + u];
+        }
+    }
     for (uint32_t s = tid; s < H1; s += kRowBlock) {
         m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0;
         m.T2[s] = kEmpty; m.T2[s + H1] = kEmpty;             // the slot-order table of phase O (<= 2 * dcap slots), untouched until then
@@ -186,7 +200,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // ---- X: expand products in reference order, group keys --------------------------------------------
     // X1/X2: each thread owns a CONTIGUOUS run of B' entries (so one block scan orders all products); it only records,
     // per product, where its A' entry lives and the B' side word -- LDS writes, no dependent global loads.
-    constexpr uint32_t RMAX = kRowBlock >= 1024 ? 4 : 8;      // B' entries per thread and round (registers: 1024-thread workgroups run at 64 VGPRs)
     uint32_t running = 0;
     for (uint32_t jb = 0; jb < n; jb += RMAX * kRowBlock) {
         const uint32_t nn = n - jb < RMAX * kRowBlock ? n - jb : RMAX * kRowBlock;
@@ -196,8 +209,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         uint32_t csum = 0;
 #pragma unroll
         for (uint32_t u = 0; u < RMAX; ++u) {
-            be[u] = make_uint2(0u, 0u);
-            if (u < R && j0 + u < nn) be[u] = a.Bent[b0 + jb + j0 + u];
+            be[u] = be0[u];
+            if (jb) { be[u] = make_uint2(0u, 0u); if (u < R && j0 + u < nn) be[u] = a.Bent[b0 + jb + j0 + u]; }
             csum += (be[u].y >> 16) & 0x3FFFu;
         }
         uint32_t tot;
