@@ -44,6 +44,9 @@ constexpr uint32_t kScatterChunk = 64;                    // phase S appends one
 #ifndef BELLA_WALK_W
 #define BELLA_WALK_W 8
 #endif
+#ifndef BELLA_GATHER_BATCH
+#define BELLA_GATHER_BATCH(blk) 4u                          // (8 for the <= 512-thread classes measured 8 % slower)
+#endif
 #ifndef BELLA_SCATTER_CHUNKS
 #define BELLA_SCATTER_CHUNKS 8
 #endif
@@ -226,18 +229,19 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     __syncthreads();
     BELLA_BPROF(0)
     // X3: product-parallel gather of the A' entries (balanced: every lane has work; four independent loads in flight)
-    for (uint32_t base = 0; base < F; base += 4 * kRowBlock) {
-        uint2 ae[4];
-        uint32_t bw[4];
+    constexpr uint32_t XB = BELLA_GATHER_BATCH(kRowBlock);    // A' loads in flight per lane
+    for (uint32_t base = 0; base < F; base += XB * kRowBlock) {
+        uint2 ae[XB];
+        uint32_t bw[XB];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
+        for (uint32_t u = 0; u < XB; ++u) {
             const uint32_t p = base + u * kRowBlock + tid;
             ae[u] = make_uint2(0u, 0u);
             bw[u] = 0;
             if (p < F) { ae[u] = a.Aent[m.A_hv[p]]; bw[u] = m.A_gov[p]; }
         }
 #pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
+        for (uint32_t u = 0; u < XB; ++u) {
             const uint32_t p = base + u * kRowBlock + tid;
             if (p >= F) continue;
             const uint32_t key = ae[u].x & 0x7FFFFFFFu;
