@@ -1521,6 +1521,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         a.rowdesc = ptr<uint4>(c->rowlists);
         a.tier_lo = (uint32_t)ln[l].lo;
         a.tier_hi = (uint32_t)ln[l].hi;
+        a.tcount_valid = ln[l].hi - ln[l].lo <= 3 ? 1u : 0u;
+        for (int k2 = 0; k2 < 4; ++k2) a.tcount[k2] = ln[l].lo + k2 <= ln[l].hi ? tcnt[ln[l].lo + k2] : 0u;
         a.nrows = ln[l].rows;
         a.cap = tier_caps[ln[l].hi];
         a.dcap = dcap_of(a.cap);

@@ -76,6 +76,8 @@ struct SpgemmArgs {
                                  // one load instead of a chain of three before the first B' entry can be fetched
     uint32_t nrows;
     uint32_t tier_lo, tier_hi;   // class launches: the tiers tier_hi .. tier_lo (big columns first); their lists are nreads apart
+    uint32_t tcount[4];          // columns of the tiers tier_lo .. tier_lo + 3 (the host knows them at launch: no load before the descriptor)
+    uint32_t tcount_valid;       // 0: the class spans more than four tiers, the counts are read from the control block
     uint32_t nreads;
     const uint32_t* Bptr;
     const uint2* Bent;
@@ -651,10 +653,19 @@ template <uint32_t NX, bool GALIAS, int BLK = BELLA_ROW_BLOCK>
 __global__ __launch_bounds__(BLK, (BLK == 1024 ? (NX <= 4 ? 8 : 4) : BLK <= 256 ? 8 : (NX <= 8 ? 6 : 2))) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // the launch covers the tiers of one LDS class, largest columns first: workgroup x -> (tier, place in the tier's list)
-    const uint32_t* tc = a.ctl + kCtlTierCnt;
     uint32_t x = blockIdx.x, t = a.tier_hi;
-    while (t > a.tier_lo && x >= tc[t]) { x -= tc[t]; --t; }
-    if (x >= tc[t]) return;
+    if (a.tcount_valid) {
+#pragma unroll
+        for (int k2 = 3; k2 >= 1; --k2)
+            if (a.tier_lo + (uint32_t)k2 == t && x >= a.tcount[k2]) { x -= a.tcount[k2]; --t; }
+        const uint32_t rel = t - a.tier_lo;
+        const uint32_t ct = rel == 0 ? a.tcount[0] : rel == 1 ? a.tcount[1] : rel == 2 ? a.tcount[2] : a.tcount[3];
+        if (x >= ct) return;
+    } else {
+        const uint32_t* tc = a.ctl + kCtlTierCnt;
+        while (t > a.tier_lo && x >= tc[t]) { x -= tc[t]; --t; }
+        if (x >= tc[t]) return;
+    }
     const uint4 ds = a.rowdesc[(size_t)t * a.nreads + x];
     const uint32_t i = ds.x;
     const RowMem m = carve<GALIAS>(smem, a.cap, a.dcap, true);
