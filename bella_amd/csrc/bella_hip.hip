@@ -53,6 +53,7 @@ const size_t kClassLds[kNumClasses] = {10240, 20480, 40160, 54608, 81920, 163840
 #define BELLA_CLASS_BLOCKS {128, 256, 512, 512, 1024, 1024}
 #endif
 const int kClassBlock[kNumClasses] = BELLA_CLASS_BLOCKS;   // measured (tools/ab_blocks.sh): DESIGN.md 4.1
+constexpr uint32_t kLongListMaxCap = 2752;   // long-list inputs: LDS tiers above this many products are closed
 constexpr uint32_t kMidToWideMin = 16;      // columns above the LDS tiers in one pass from which on they take the sort-based path
 constexpr uint32_t kRerunGrid = 256;        // persistent workgroups of the rerun launch (columns an LDS tier handed over)
 constexpr uint32_t kGlobalGrid = 1024;      // persistent workgroups of the global path (1024 threads each: latency-bound, two resident per CU)
@@ -1355,8 +1356,13 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     uint32_t g_ntiers = c->ntiers;
     if (!c->tiers_from_env)
         for (g_ntiers = 1; tier_caps[g_ntiers - 1] != 65535; ++g_ntiers) {}
-    for (uint32_t t = 0; t < g_ntiers; ++t) caps[t] = force_global && t + 1 < g_ntiers ? 0 : tier_caps[t];
-    const int want_state = (force_global ? 2 : 1) + (half_tables ? 2 : 0);
+    // Long-list inputs (at most one pair in 64 products on the assembly-time sample: HiFi-like sets): the fold of a pair is
+    // quadratic in its list inside the row kernels and has a position grid on the sort-based path, so the larger LDS tiers are
+    // closed and their columns take that path with the columns above the tiers.
+    const bool long_lists = !force_global && !c->tiers_from_env && c->pair_ratio1024 < 16;
+    for (uint32_t t = 0; t < g_ntiers; ++t)
+        caps[t] = (force_global || (long_lists && tier_caps[t] > kLongListMaxCap)) && t + 1 < g_ntiers ? 0 : tier_caps[t];
+    const int want_state = (force_global ? 2 : 1) + (half_tables ? 2 : 0) + (long_lists ? 4 : 0);
     const uint64_t psig[6] = {c->layout_gen, ((uint64_t)c->part_first << 32) | c->part_stride, ((uint64_t)c->range_lo << 32) | c->range_hi, nr,
                               (uint64_t)want_state, (uint64_t)g_ntiers};
     const bool warm = c->pass_known && std::memcmp(psig, c->pass_sig, sizeof(psig)) == 0;
