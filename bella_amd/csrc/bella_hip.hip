@@ -53,7 +53,10 @@ const size_t kClassLds[kNumClasses] = {10240, 20480, 40160, 54608, 81920, 163840
 #define BELLA_CLASS_BLOCKS {128, 256, 512, 512, 1024, 1024}
 #endif
 const int kClassBlock[kNumClasses] = BELLA_CLASS_BLOCKS;   // measured (tools/ab_blocks.sh): DESIGN.md 4.1
-constexpr uint32_t kLongListMaxCap = 2752;   // long-list inputs: LDS tiers above this many products are closed
+#ifndef BELLA_LONG_LIST_MAX_CAP
+#define BELLA_LONG_LIST_MAX_CAP 2752
+#endif
+constexpr uint32_t kLongListMaxCap = BELLA_LONG_LIST_MAX_CAP;   // long-list inputs: LDS tiers above this many products are closed
 constexpr uint32_t kMidToWideMin = 16;      // columns above the LDS tiers in one pass from which on they take the sort-based path
 constexpr uint32_t kRerunGrid = 256;        // persistent workgroups of the rerun launch (columns an LDS tier handed over)
 constexpr uint32_t kGlobalGrid = 1024;      // persistent workgroups of the global path (1024 threads each: latency-bound, two resident per CU)
