@@ -1242,35 +1242,46 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     a.cols = d_cols; a.nw = nw; a.woff = ptr<uint64_t>(c->w_off);
     a.Bptr = sa.Bptr; a.Bent = sa.Bent; a.Aent = sa.Aent; a.roff = sa.roff; a.packed = sa.packed; a.flopptr = sa.flopptr;
     a.k = sa.k; a.binSize = sa.binSize;
-    a.W_key = ptr<uint64_t>(c->w_key); a.W_idx = ptr<uint32_t>(c->w_idx); a.W_rec = ptr<uint2>(c->w_hv);
+    a.W_key = c->w_key.p; a.W_idx = ptr<uint32_t>(c->w_idx); a.W_rec = ptr<uint2>(c->w_hv);
     a.plist = ptr<uint2>(c->w_plist); a.sort_scratch = ptr<uint16_t>(c->w_scr);
     a.tmp_pairs = sa.tmp_pairs; a.tmp_ext = sa.tmp_ext; a.nnzC = sa.nnzC; a.status = sa.ctl + kCtlStatus;
     int rbits = 1;
     while ((1ull << rbits) < (uint64_t)c->nreads) ++rbits;       // a partner read id fits rbits bits
     a.rbits = (uint32_t)rbits;
-    k_wide_expand<<<nw < 2048u ? nw : 2048u, kWideExpandBlock, 0, c->stream>>>(a);
-    KCHK(c);
     int seg_bits = 1;
     while ((1u << seg_bits) < nw) ++seg_bits;
-    hipcub::DoubleBuffer<uint64_t> dk(ptr<uint64_t>(c->w_key), ptr<uint64_t>(c->w_key2));
-    hipcub::DoubleBuffer<uint32_t> dv(ptr<uint32_t>(c->w_idx), ptr<uint32_t>(c->w_idx2));
-    size_t tb = 0;
-    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (int)T, 0, rbits + seg_bits, c->stream));
-    ENSURE(c, c->cubtmp, tb);
-    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb, dk, dv, (int)T, 0, rbits + seg_bits, c->stream));
-    a.S_key = dk.Current(); a.S_idx = dv.Current();
-    uint64_t* rkey = dk.Current() == ptr<uint64_t>(c->w_key) ? ptr<uint64_t>(c->w_key2) : ptr<uint64_t>(c->w_key);
-    size_t tb2 = 0;
-    HIPCHK(c, hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, a.S_key, rkey, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_nruns), (int)T, c->stream));
-    ENSURE(c, c->cubtmp, tb2);
-    HIPCHK(c, hipcub::DeviceRunLengthEncode::Encode(c->cubtmp.p, tb2, a.S_key, rkey, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_nruns), (int)T, c->stream));
+    a.key32 = rbits + seg_bits <= 32 && !(c->debug & 64u) ? 1u : 0u;   // debug bit 6: tests, 64-bit keys on any input
+    k_wide_expand<<<nw < 2048u ? nw : 2048u, kWideExpandBlock, 0, c->stream>>>(a);
+    KCHK(c);
+    // sort by (column, partner read) over the meaningful bits, run-length encode into pairs; u32 keys when they fit
+    auto sort_and_encode = [&](auto key_tag) -> int {
+        using K = decltype(key_tag);
+        hipcub::DoubleBuffer<K> dk((K*)c->w_key.p, (K*)c->w_key2.p);
+        hipcub::DoubleBuffer<uint32_t> dv(ptr<uint32_t>(c->w_idx), ptr<uint32_t>(c->w_idx2));
+        size_t tb = 0;
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (int)T, 0, rbits + seg_bits, c->stream));
+        ENSURE(c, c->cubtmp, tb);
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb, dk, dv, (int)T, 0, rbits + seg_bits, c->stream));
+        a.S_key = dk.Current(); a.S_idx = dv.Current();
+        K* rkey = dk.Current() == (K*)c->w_key.p ? (K*)c->w_key2.p : (K*)c->w_key.p;
+        size_t tb2 = 0;
+        HIPCHK(c, hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, (const K*)a.S_key, rkey, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_nruns), (int)T, c->stream));
+        ENSURE(c, c->cubtmp, tb2);
+        HIPCHK(c, hipcub::DeviceRunLengthEncode::Encode(c->cubtmp.p, tb2, (const K*)a.S_key, rkey, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_nruns), (int)T, c->stream));
+        a.R_key = rkey;
+        return 0;
+    };
+    {
+        const int rc2 = a.key32 ? sort_and_encode(uint32_t{}) : sort_and_encode(uint64_t{});
+        if (rc2) return rc2;
+    }
     uint32_t np = 0;
     HIPCHK(c, hipMemcpyAsync(&np, c->w_nruns.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->w_rlen) + np, 0, 4, c->stream));
     rc = scan_u32(c, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_rstart), (uint64_t)np + 1);
     if (rc) return rc;
-    a.R_key = rkey; a.R_len = ptr<uint32_t>(c->w_rlen); a.R_start = ptr<uint32_t>(c->w_rstart); a.npairs = np;
+    a.R_len = ptr<uint32_t>(c->w_rlen); a.R_start = ptr<uint32_t>(c->w_rstart); a.npairs = np;
     a.R_rank = ptr<uint32_t>(c->w_rrank); a.seg_first = ptr<uint32_t>(c->w_segfirst);
     k_wide_gather<<<nblk(T), 256, 0, c->stream>>>(a, T);
     KCHK(c);

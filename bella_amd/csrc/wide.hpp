@@ -30,16 +30,18 @@ struct WideArgs {
     int k;
     int binSize;
     // products, product order
-    uint64_t* W_key;             // segment << rbits | partner read (rbits = bits of a read id: the sort runs over rbits + segment bits only)
+    void* W_key;                 // segment << rbits | partner read (rbits = bits of a read id: the sort runs over rbits + segment bits only);
+                                 // u32 words when rbits + segment bits <= 32 (key32), else u64
+    uint32_t key32;
     uint32_t rbits;
     uint32_t* W_idx;             // global product index (woff[seg] + p)
     uint2* W_rec;                // {posH | posV << 16, overlap estimate | flags << 16}
     // sorted
-    const uint64_t* S_key;
+    const void* S_key;
     const uint32_t* S_idx;
     uint2* plist;                // [totalF] {hv, ov} in sorted order = per-pair lists in product order
     // pairs (runs of S_key)
-    const uint64_t* R_key;       // [npairs]
+    const void* R_key;           // [npairs]
     const uint32_t* R_len;
     const uint32_t* R_start;     // exclusive scan of R_len
     uint32_t npairs;
@@ -95,7 +97,8 @@ __global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
                 const uint32_t ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, (uint32_t)a.k) & 0xFFFFu;
                 const uint32_t fl = (oriented ? 1u : 0u) | (pal << 1);
                 const uint64_t p = o + running + q;
-                a.W_key[p] = ((uint64_t)s << a.rbits) | key;
+                if (a.key32) ((uint32_t*)a.W_key)[p] = (s << a.rbits) | key;
+                else ((uint64_t*)a.W_key)[p] = ((uint64_t)s << a.rbits) | key;
                 a.W_idx[p] = (uint32_t)p;
                 a.W_rec[p] = make_uint2(posH | (posV << 16), ov | (fl << 16));
             }
@@ -103,6 +106,10 @@ __global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
             running += tot;
         }
     }
+}
+
+__device__ __forceinline__ uint64_t wide_rkey(const WideArgs& a, uint32_t r) {
+    return a.key32 ? (uint64_t)((const uint32_t*)a.R_key)[r] : ((const uint64_t*)a.R_key)[r];
 }
 
 // per-pair lists in product order + first pair of each segment
@@ -115,8 +122,8 @@ __global__ void k_wide_gather(WideArgs a, uint64_t totalF) {
 __global__ void k_wide_segments(WideArgs a) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r > a.npairs) return;
-    const uint32_t seg = r < a.npairs ? (uint32_t)(a.R_key[r] >> a.rbits) : a.nw;
-    const uint32_t prev = r == 0 ? 0xFFFFFFFFu : (uint32_t)(a.R_key[r - 1] >> a.rbits);
+    const uint32_t seg = r < a.npairs ? (uint32_t)(wide_rkey(a, r) >> a.rbits) : a.nw;
+    const uint32_t prev = r == 0 ? 0xFFFFFFFFu : (uint32_t)(wide_rkey(a, r - 1) >> a.rbits);
     if (r == 0) { for (uint32_t s = 0; s <= seg && s <= a.nw; ++s) a.seg_first[s] = 0; }
     else if (seg != prev) { for (uint32_t s = prev + 1; s <= seg && s <= a.nw; ++s) a.seg_first[s] = r; }
 }
@@ -130,8 +137,8 @@ __global__ void k_wide_table_fill(uint64_t* table, uint64_t n) {
 __global__ void k_wide_insert(WideArgs a) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.npairs) return;
-    const uint32_t seg = (uint32_t)(a.R_key[r] >> a.rbits);
-    const uint32_t key = (uint32_t)(a.R_key[r] & ((1ull << a.rbits) - 1ull));
+    const uint32_t seg = (uint32_t)(wide_rkey(a, r) >> a.rbits);
+    const uint32_t key = (uint32_t)(wide_rkey(a, r) & ((1ull << a.rbits) - 1ull));
     const uint64_t ht = a.toff[seg + 1] - a.toff[seg];
     unsigned long long* T = (unsigned long long*)(a.table + a.toff[seg]);
     const uint32_t first = a.S_idx[a.R_start[r]] - (uint32_t)a.woff[seg];    // product index inside the column
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_wide_ranks(WideArgs a) {
 }
 
 __device__ __forceinline__ void wide_write_pair(const WideArgs& a, uint32_t r, const FoldResult& fr) {
-    const uint32_t seg = (uint32_t)(a.R_key[r] >> a.rbits), key = (uint32_t)(a.R_key[r] & ((1ull << a.rbits) - 1ull));
+    const uint32_t seg = (uint32_t)(wide_rkey(a, r) >> a.rbits), key = (uint32_t)(wide_rkey(a, r) & ((1ull << a.rbits) - 1ull));
     const uint32_t cid = a.cols[seg];
     const uint32_t k = (uint32_t)a.k;
     const uint32_t seedH = fr.seed & 0xFFFFu, seedV = fr.seed >> 16;

@@ -245,7 +245,8 @@ int bella_hip_get_timings(bella_ctx* ctx, bella_timings* t);
  * column as if its product lists had come out of order (the LDS tiers verify the order and fall back to the repairing path);
  * bit3 = tests: 512-thread workgroups in every LDS class (default: 1024 threads where a CU holds one or two columns);
  * bit4 = tests: key tables of cap/2 slots (the layout of pair-rich inputs) on any input; bit5 = tests: every column above the
- * LDS tiers takes the sort-based path of the wide columns (default: from 16 such columns in a pass on) */
+ * LDS tiers takes the sort-based path of the wide columns (default: from 16 such columns in a pass on); bit6 = tests: that path
+ * sorts on 64-bit keys on any input (default: 32-bit keys when column bits + read-id bits fit) */
 int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
 
 #ifdef __cplusplus

@@ -867,8 +867,8 @@ def test_hifi_syncmer_medium_set_parity(eng):
     assert bad == 0, bad
 
 
-@pytest.mark.parametrize("name", ["toy120", "toyrep90", "toyhifi50", "toysync60"])
-def test_columns_above_the_lds_tiers_on_the_sort_based_path(monkeypatch, name):
+@pytest.mark.parametrize("name,dbg", [("toy120", 32), ("toyrep90", 32), ("toyhifi50", 32), ("toysync60", 32), ("toyrep90", 32 | 64)])
+def test_columns_above_the_lds_tiers_on_the_sort_based_path(monkeypatch, name, dbg):
     """the path of the columns with more products than the largest LDS tier when a pass has many of them (wide.hpp: expand, radix
     sort, slot order, one workgroup per pair with the closed-form fold): with a 64-product LDS tier and debug bit 5 most
     columns of a golden set take it -- single- and multi-bin pairs, long lists, both strands; then the many-bins set (serial
@@ -877,7 +877,7 @@ def test_columns_above_the_lds_tiers_on_the_sort_based_path(monkeypatch, name):
     try:
         monkeypatch.setenv("BELLA_HIP_TIERS", "64")
         e = Engine(0)
-        e.set_debug(32)
+        e.set_debug(dbg)                                             # bit 6: 64-bit sort keys (the default here is 32-bit)
         e.set_reads(g.rs)
         e.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
         n, flops = e.overlap(BellaPars(skipAlignment=True, kmerSize=g.k))
