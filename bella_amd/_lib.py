@@ -24,10 +24,17 @@ class Params(C.Structure):
                 ("error_rate", C.c_double), ("delta_chernoff", C.c_double)]
 
 
+class WriteStats(C.Structure):
+    _fields_ = [("lines", C.c_uint64), ("bytes", C.c_uint64), ("aligned_pairs", C.c_uint64), ("aligned_bases", C.c_uint64),
+                ("total_read_len", C.c_uint64), ("bases_passed", C.c_uint64), ("bases_failed", C.c_uint64), ("seconds", C.c_double),
+                ("format_seconds", C.c_double), ("threads", C.c_uint32), ("pad", C.c_uint32)]
+
+
 class Timings(C.Structure):
     _fields_ = [("assemble_ms", C.c_float), ("symbolic_ms", C.c_float), ("spgemm_ms", C.c_float), ("fold_ms", C.c_float),
                 ("compact_ms", C.c_float), ("xdrop_ms", C.c_float), ("overlap_total_ms", C.c_float), ("spgemm_launches", C.c_uint32),
-                ("kcount_ms", C.c_float), ("retry_columns", C.c_uint32), ("overflow_pairs", C.c_uint32)]
+                ("kcount_ms", C.c_float), ("retry_columns", C.c_uint32), ("overflow_pairs", C.c_uint32), ("layout_ms", C.c_float),
+                ("rows_ms", C.c_float)]
 
 
 # every symbol include/bella_hip.h declares: (name, restype, argtypes)
@@ -75,6 +82,8 @@ SIGNATURES = [
     ("bella_hip_xdrop_batch", C.c_int, [vp, vp, C.c_uint64, C.POINTER(Params), vp]),
     ("bella_hip_align_pairs_exact", C.c_int, [vp, C.POINTER(Params), C.POINTER(C.c_uint64)]),
     ("bella_hip_xdrop_batch_exact", C.c_int, [vp, vp, C.c_uint64, C.POINTER(Params), vp]),
+    ("bella_hip_write_output", C.c_int, [C.c_char_p, C.POINTER(Params), C.c_int, C.c_uint32, vp, vp, vp, vp, C.c_uint64, C.c_int,
+                                         C.POINTER(WriteStats)]),
     ("bella_hip_get_timings", C.c_int, [vp, C.POINTER(Timings)]),
     ("bella_hip_set_debug", C.c_int, [vp, C.c_uint32]),
 ]

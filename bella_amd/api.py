@@ -14,7 +14,7 @@ import sys
 import numpy as np
 
 from . import _lib
-from ._lib import ALN_DT, EXT_DT, PAIR_DT, SEED_DT, Params, Timings
+from ._lib import ALN_DT, EXT_DT, PAIR_DT, SEED_DT, Params, Timings, WriteStats
 
 
 class BellaHipError(RuntimeError):
@@ -308,6 +308,25 @@ def format_aligned(names, lengths, pairs, alns, paf=False) -> bytes:
     return "".join(out).encode()
 
 
+def write_output(filename: str, pars: BellaPars, names, lengths, pairs, alns=None, nthreads: int = 0) -> WriteStats:
+    """bella_hip_write_output: the library's multi-threaded writer (overlap.hpp:603-642); APPENDS to `filename`."""
+    lib = _lib.load()
+    enc = [n.encode() if isinstance(n, str) else bytes(n) for n in names]
+    arr = (C.c_char_p * len(enc))(*enc)
+    lens = np.ascontiguousarray(lengths, np.uint32)
+    pairs = np.ascontiguousarray(pairs, PAIR_DT)
+    st = WriteStats()
+    cp = pars.c()
+    if alns is not None:
+        alns = np.ascontiguousarray(alns, ALN_DT)
+    rc = lib.bella_hip_write_output(filename.encode(), C.byref(cp), 1 if pars.outputPaf else 0, len(enc), C.cast(arr, C.c_void_p),
+                                    lens.ctypes.data, pairs.ctypes.data if len(pairs) else None,
+                                    alns.ctypes.data if alns is not None and len(alns) else None, len(pairs), nthreads, C.byref(st))
+    if rc:
+        raise BellaHipError(rc, "bella_hip_write_output failed")
+    return st
+
+
 def hash_spgemm(engine: Engine, pars: BellaPars, filename: str, stdout=sys.stdout, stages: int = 1):
     """HashSpGEMM-shaped driver (include/overlap.hpp:650-789): the operands and reads are already in `engine`.
     Writes `filename` and the stdout protocol lines nnz(C) (:686) and, when aligning, outputted per stage (:771).
@@ -315,7 +334,8 @@ def hash_spgemm(engine: Engine, pars: BellaPars, filename: str, stdout=sys.stdou
     (:682-789); the file is the same, every pass only holds its own columns."""
     nreads = engine.nreads
     bounds = [(nreads * b) // stages for b in range(stages + 1)]
-    chunks, outputted, total = [], [], 0
+    outputted, total = [], 0
+    open(filename, "wb").close()
     try:
         for b in range(stages):
             if stages > 1:
@@ -324,17 +344,14 @@ def hash_spgemm(engine: Engine, pars: BellaPars, filename: str, stdout=sys.stdou
             total += npairs
             pairs, _, _ = engine.get_pairs(ext=False)
             if pars.skipAlignment:
-                chunks.append(format_skip(engine.names, engine.lengths, pairs, pars.kmerSize))
+                write_output(filename, pars, engine.names, engine.lengths, pairs)
             else:
                 outputted.append(engine.align_pairs(pars))
-                chunks.append(format_aligned(engine.names, engine.lengths, pairs, engine.get_alignments(), pars.outputPaf))
+                write_output(filename, pars, engine.names, engine.lengths, pairs, engine.get_alignments())
     finally:
         if stages > 1:
             engine.set_column_range(0, 0xFFFFFFFF)
     print(total, file=stdout)
     for o in outputted:
         print(o, file=stdout)
-    with open(filename, "wb") as f:
-        for c in chunks:
-            f.write(c)
     return total

@@ -60,24 +60,33 @@ struct AsmArgs {
     uint8_t* ws;            // global tables for reads with more than kAsmLdsSlots tuples
     uint64_t ws_stride;
     uint32_t* status;
+    uint32_t ht_lo, ht_hi;  // this launch: the reads whose table size ht satisfies ht_lo < ht <= ht_hi
+    uint32_t ht_cover;      // largest table size any launch of this assembly covers (sized from the longest read)
 };
-constexpr uint32_t kAsmLdsSlots = 4096;
-constexpr size_t kAsmLdsBytes = 64 + (size_t)16 * kAsmLdsSlots;
+constexpr uint32_t kAsmLdsSlots = 8192;                    // largest table held in LDS (one 1024-thread workgroup per CU)
+constexpr uint32_t kAsmScratchBytes = 128;
+__host__ __device__ inline size_t asm_lds_bytes(uint32_t ht) { return kAsmScratchBytes + (size_t)12 * ht; }
 
 // One read: de-duplicate (keep FIRST occurrence index for the slot order, LAST occurrence's position as the
 // value: CSC.cpp:344 with main.cpp:477-480's lambda), then emulate the insertion order into the reference's
 // table of size ht = 2^n >= max(16, #tuples) (CSC.cpp:322-326) with the atomicMin displacement scheme
 // (see spgemm.hpp phase O), and emit the slots in order (CSC.cpp:358-373).
-__device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* scr, uint32_t* K, uint32_t* first,
-                                        uint32_t* last, uint32_t* T2, uint32_t ht) {
+// K[s]: k-mer id; FL[s]: first occurrence << 16 | last occurrence (tuple indices inside the read, < 65536); T2: the slot-order table.
+// One compare-and-swap per tuple: the thread that claims a slot stores FL with a plain store; a duplicate k-mer inside a read
+// (rare: repeats) only raises a flag, and a flagged read takes one more pass that folds every tuple into FL with a CAS loop.
+template <int BLK>
+__device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* scr, uint32_t* K, uint32_t* FL, uint32_t* T2, uint32_t ht) {
+    constexpr int NW = BLK / 64;
     const uint32_t tid = threadIdx.x;
     const uint64_t ts = a.tstart[r];
     const uint32_t n = (uint32_t)(a.tstart[r + 1] - ts);
-    uint32_t* s_d = scr + 8;
-    for (uint32_t s = tid; s < ht; s += kBlock) { K[s] = kEmpty; first[s] = kEmpty; last[s] = 0; T2[s] = kEmpty; }
-    if (tid == 0) *s_d = 0;
+    uint32_t* s_d = scr + 16;
+    uint32_t* s_dup = scr + 17;
+    for (uint32_t s = tid; s < ht; s += BLK) { K[s] = kEmpty; T2[s] = kEmpty; }
+    if (tid == 0) { *s_d = 0; *s_dup = 0; }
     __syncthreads();
-    for (uint32_t t = tid; t < n; t += kBlock) {
+    uint32_t mine = 0;
+    for (uint32_t t = tid; t < n; t += BLK) {
         const uint32_t key = a.t_kmer[ts + t];
         uint32_t h = (key * 107u) & (ht - 1);
         uint32_t old;
@@ -86,16 +95,33 @@ __device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* 
             if (old == kEmpty || old == key) break;
             h = (h + 1) & (ht - 1);
         }
-        if (old == kEmpty) atomicAdd(s_d, 1u);
-        atomicMin(&first[h], t);
-        atomicMax(&last[h], t);
+        if (old == kEmpty) { FL[h] = (t << 16) | t; ++mine; }
+        else *s_dup = 1;
     }
+    if (mine) atomicAdd(s_d, mine);
     __syncthreads();
+    if (*s_dup) {                                            // some k-mer occurs twice in this read: first = min, last = max over ALL tuples
+        for (uint32_t t = tid; t < n; t += BLK) {
+            const uint32_t key = a.t_kmer[ts + t];
+            uint32_t h = (key * 107u) & (ht - 1);
+            while (K[h] != key) h = (h + 1) & (ht - 1);
+            uint32_t cur = FL[h];
+            for (;;) {
+                const uint32_t f = cur >> 16, l = cur & 0xFFFFu;
+                const uint32_t want = ((t < f ? t : f) << 16) | (t > l ? t : l);
+                if (want == cur) break;
+                const uint32_t got = atomicCAS(&FL[h], cur, want);
+                if (got == cur) break;
+                cur = got;
+            }
+        }
+        __syncthreads();
+    }
     const uint32_t d = *s_d;
-    for (uint32_t s = tid; s < ht; s += kBlock) {
+    for (uint32_t s = tid; s < ht; s += BLK) {
         const uint32_t key = K[s];
         if (key == kEmpty) continue;
-        uint32_t item = (first[s] << 16) | s;
+        uint32_t item = (FL[s] & 0xFFFF0000u) | s;
         uint32_t h = (key * 107u) & (ht - 1);
         for (;;) {
             const uint32_t old = atomicMin(&T2[h], item);
@@ -105,37 +131,54 @@ __device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* 
         }
     }
     __syncthreads();
-    const uint32_t c = (ht + kBlock - 1) / kBlock;
+    const uint32_t c = (ht + BLK - 1) / BLK;
     const uint32_t lo = tid * c;
     const uint32_t hi = lo + c < ht ? lo + c : ht;
     uint32_t occ = 0;
     for (uint32_t s = lo; s < hi; ++s) occ += (T2[s] != kEmpty);
     uint32_t tot;
-    uint32_t rank = block_excl_scan(occ, scr, &tot);
+    uint32_t rank = block_excl_scan<NW>(occ, scr, &tot);
     for (uint32_t s = lo; s < hi; ++s) {
         const uint32_t it = T2[s];
         if (it == kEmpty) continue;
         const uint32_t g = it & 0xFFFFu;
         a.Bk_tmp[ts + rank] = K[g];
-        a.Bpos_tmp[ts + rank] = a.t_pos[ts + last[g]];
+        a.Bpos_tmp[ts + rank] = a.t_pos[ts + (FL[g] & 0xFFFFu)];
         rank++;
     }
     if (tid == 0) a.rowcnt[r] = d;
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kBlock) void k_asm_rows(AsmArgs a) {
+// LDS classes by table size: one workgroup per read, the workgroup size grows with the table so that a CU's wavefront slots
+// stay filled; a launch covers the reads with ht_lo < ht <= ht_hi (the others leave at once)
+template <int BLK>
+__global__ __launch_bounds__(BLK) void k_asm_rows_lds(AsmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t r = blockIdx.x;
+    const uint32_t n = (uint32_t)(a.tstart[r + 1] - a.tstart[r]);
+    if (n == 0 || n >= 65536u) {
+        if (a.ht_lo == 0 && threadIdx.x == 0) { a.rowcnt[r] = 0; if (n) atomicOr(a.status, 16u); }
+        return;
+    }
+    const uint32_t ht = pow2_at_least(16u, n);
+    if (a.ht_lo == 0 && ht > a.ht_cover && threadIdx.x == 0) atomicOr(a.status, 256u);   // more tuples than the read has bases
+    if (ht <= a.ht_lo || ht > a.ht_hi) return;
     uint32_t* scr = (uint32_t*)smem;
-    uint32_t* L = (uint32_t*)(smem + 64);
+    uint32_t* L = (uint32_t*)(smem + kAsmScratchBytes);
+    asm_row<BLK>(a, r, scr, L, L + ht, L + 2 * ht, ht);
+}
+
+// reads whose table does not fit LDS (> 8192 tuples): tables in a global workspace, persistent workgroups
+__global__ __launch_bounds__(1024) void k_asm_rows_global(AsmArgs a) {
+    __shared__ uint32_t scr[kAsmScratchBytes / 4];
     uint32_t* W = (uint32_t*)(a.ws + (uint64_t)blockIdx.x * a.ws_stride);
     for (uint32_t r = blockIdx.x; r < a.nreads; r += gridDim.x) {
         const uint32_t n = (uint32_t)(a.tstart[r + 1] - a.tstart[r]);
-        if (n == 0) { if (threadIdx.x == 0) a.rowcnt[r] = 0; continue; }
-        if (n >= 65536u) { if (threadIdx.x == 0) { atomicOr(a.status, 16u); a.rowcnt[r] = 0; } continue; }
+        if (n == 0 || n >= 65536u) continue;
         const uint32_t ht = pow2_at_least(16u, n);
-        if (ht <= kAsmLdsSlots) asm_row(a, r, scr, L, L + ht, L + 2 * ht, L + 3 * ht, ht);
-        else asm_row(a, r, scr, W, W + ht, W + 2 * ht, W + 3 * ht, ht);
+        if (ht <= a.ht_lo) continue;
+        asm_row<1024>(a, r, scr, W, W + ht, W + 2 * ht, ht);
     }
 }
 
@@ -150,83 +193,98 @@ __global__ __launch_bounds__(kBlock) void k_compact_B(const uint64_t* tstart, co
     for (uint32_t x = lane_id(); x < cnt; x += 64) { Bk[dst + x] = Bk_tmp[src + x]; Bpos[dst + x] = Bpos_tmp[src + x]; }
 }
 
-__global__ __launch_bounds__(kBlock) void k_entry_rows(const uint32_t* Bptr, uint32_t nreads, uint32_t* Brow) {
+// ---- device layout (B' / A') from the CSR of B: one stable radix sort + segmented passes ------------------------------------
+// The k-mer lists of A' are the runs of equal k-mer id in the entries of B sorted by k-mer id; the sort is stable and the entries
+// of B are grouped by ascending read, so every run comes out in ascending read order = the reference's 1-thread Transpose
+// (transpose.h:26-50).  The sort carries everything the emit pass needs per entry in a 64-bit value, so that pass gathers nothing
+// by entry index: hi = read | ori << 31 (= Aent.x), lo = pos | place in the read's row << 16.
+
+// per entry e of B (one wavefront per read row): sort key (k-mer id), sort value, validation; clears the scatter target of
+// k_layout_heads.  ori: the occurrence is not the canonical form (Kmer::rep() = min(kmer, twin), kmercode/Kmer.cpp:314-317).
+__global__ __launch_bounds__(kBlock) void k_layout_prep(const uint32_t* Bptr, const uint32_t* Bk, const uint16_t* Bpos, uint32_t nreads,
+                                                        const uint32_t* packed, const uint64_t* roff, uint32_t k, uint32_t nkmers,
+                                                        uint32_t* key, uint64_t* val, uint32_t* w, uint32_t* status) {
     const uint32_t r = blockIdx.x * kWaves + wave_id();
     if (r >= nreads) return;
-    for (uint32_t e = Bptr[r] + lane_id(); e < Bptr[r + 1]; e += 64) Brow[e] = r;
-}
-
-// per entry: degree histogram, smallest read of the k-mer, orientation bit (occurrence is not the canonical
-// form: Kmer::rep() = min(kmer, twin), kmercode/Kmer.cpp:314-317; palindromes get 0) and palindrome bit
-__global__ void k_kmer_stats(const uint32_t* Bk, const uint16_t* Bpos, const uint32_t* Brow, uint64_t nnz,
-                             const uint32_t* packed, const uint64_t* roff, uint32_t k, uint32_t nkmers, uint32_t* deg,
-                             uint32_t* minread, uint8_t* ori, uint32_t* status) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nnz) return;
-    const uint32_t km = Bk[e], r = Brow[e];
-    if (km >= nkmers) { atomicOr(status, 32u); return; }
-    if ((uint64_t)Bpos[e] + k > roff[r + 1] - roff[r]) { atomicOr(status, 128u); return; }   // the k-mer would run past the end of its read
-    const uint64_t le = kmer_le(packed, roff[r] + Bpos[e], k);
-    const uint64_t fw = kmer_fw_from_le(le, k), rc = kmer_rc_from_le(le, k);
-    ori[e] = (uint8_t)((fw > rc ? 1u : 0u) | (fw == rc ? 2u : 0u));   // bit0: not the canonical form, bit1: palindrome
-    atomicAdd(&deg[km], 1u);
-    atomicMin(&minread[km], r);
-}
-
-// weight of entry e in the "first appearance" layout of A': the owner (smallest read) reserves the whole list
-__global__ void k_first_weight(const uint32_t* Bk, const uint32_t* Brow, uint64_t nnz, uint32_t nkmers, const uint32_t* deg,
-                               const uint32_t* minread, uint32_t* w, uint32_t* status) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nnz) return;
-    const uint32_t km = Bk[e];
-    if (km >= nkmers) { w[e] = 0; return; }                     // flagged by k_kmer_stats; the host stops after this kernel
-    if (deg[km] > 16383u) atomicOr(status, 64u);                // Bent's product count field holds 14 bits
-    w[e] = (Brow[e] == minread[km]) ? deg[km] : 0u;
-}
-
-__global__ void k_col_starts(const uint32_t* Bk, const uint32_t* Brow, uint64_t nnz, const uint32_t* minread,
-                             const uint32_t* wscan, uint32_t* colstart) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nnz) return;
-    const uint32_t km = Bk[e];
-    if (Brow[e] == minread[km]) colstart[km] = wscan[e];
-}
-
-__global__ void k_fill_A(const uint32_t* Bk, const uint32_t* Brow, uint64_t nnz, const uint32_t* colstart,
-                         uint32_t* fill, uint2* Atmp) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nnz) return;
-    const uint32_t km = Bk[e];
-    const uint32_t slot = colstart[km] + atomicAdd(&fill[km], 1u);
-    Atmp[slot] = make_uint2(Brow[e], (uint32_t)e);
-}
-
-// one thread per k-mer: order its list by read id (the reference's 1-thread Transpose order,
-// transpose.h:26-50) and emit the final A' and B' entries
-__global__ void k_finalize_cols(uint32_t nkmers, const uint32_t* deg, const uint32_t* colstart, uint2* Atmp,
-                                const uint16_t* Bpos, const uint8_t* ori, const uint64_t* roff, uint2* Aent,
-                                uint2* Bent, uint16_t* Bcnt, uint32_t* status) {
-    const uint32_t km = blockIdx.x * blockDim.x + threadIdx.x;
-    if (km >= nkmers) return;
-    const uint32_t dg = deg[km];
-    if (dg == 0) return;
-    if (dg > 16383u) { atomicOr(status, 64u); return; }
-    const uint32_t cs = colstart[km];
-    for (uint32_t x = 1; x < dg; ++x) {
-        const uint2 v = Atmp[cs + x];
-        uint32_t y = x;
-        while (y > 0 && Atmp[cs + y - 1].x > v.x) { Atmp[cs + y] = Atmp[cs + y - 1]; --y; }
-        if (y != x) Atmp[cs + y] = v;
+    const uint64_t base = roff[r];
+    const uint32_t len = (uint32_t)(roff[r + 1] - base);
+    const uint32_t b0 = Bptr[r], b1 = Bptr[r + 1];
+    for (uint32_t e = b0 + lane_id(); e < b1; e += 64) {
+        const uint32_t km = Bk[e], pos = Bpos[e];
+        uint32_t ori = 0;
+        if (km >= nkmers) atomicOr(status, 32u);
+        if (pos + k > len) atomicOr(status, 128u);                       // the k-mer would run past the end of its read
+        else {
+            const uint64_t le = kmer_le(packed, base + pos, k);
+            ori = kmer_fw_from_le(le, k) > kmer_rc_from_le(le, k) ? 1u : 0u;
+        }
+        key[e] = km;
+        val[e] = ((uint64_t)(r | (ori << 31)) << 32) | (pos | ((e - b0) << 16));
+        w[e] = 0;
     }
-    for (uint32_t x = 0; x < dg; ++x) {
-        const uint2 v = Atmp[cs + x];
-        const uint32_t r = v.x, e = v.y;
-        const uint32_t o = ori[e] & 1u, pal = (ori[e] >> 1) & 1u, pos = Bpos[e];
-        const uint32_t len = (uint32_t)(roff[r + 1] - roff[r]);
-        Aent[cs + x] = make_uint2(r | (o << 31), pos | (len << 16));
-        Bent[e] = make_uint2(cs + x + 1, pos | ((dg - 1 - x) << 16) | (pal << 30) | (o << 31));
-        Bcnt[e] = (uint16_t)(dg - 1 - x);             // the products of the entry once more, compact: estimateFLOP streams 2 B per nonzero
+}
+
+// per run head of the sorted entries: its length (the k-mer's degree) lands at the entry of its first (= smallest) read; the
+// exclusive scan of that array over the entries of B is the "first appearance" layout of A': the owner row streams its lists.
+__global__ void k_layout_heads(const uint32_t* skey, const uint64_t* sval, uint64_t nnz, const uint32_t* Bptr, uint32_t* w,
+                               uint32_t* status) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nnz) return;
+    const uint32_t km = skey[x];
+    if (x && skey[x - 1] == km) return;
+    uint32_t dg = 1;
+    while (x + dg < nnz && dg <= 16384u && skey[x + dg] == km) ++dg;
+    if (dg > 16383u) { atomicOr(status, 64u); dg = 0; }                  // Bent's product count field holds 14 bits
+    const uint64_t v = sval[x];
+    w[Bptr[(uint32_t)(v >> 32) & 0x7FFFFFFFu] + ((uint32_t)v >> 16)] = dg;
+}
+
+// first / one-past-last position of the run of equal keys around x (runs are short: a few steps; long ones by bisection)
+__device__ __forceinline__ void run_bounds(const uint32_t* skey, uint64_t nnz, uint64_t x, uint64_t& lo, uint64_t& hi) {
+    const uint32_t km = skey[x];
+    uint64_t a = x;
+    uint32_t j = 0;
+    while (a > 0 && j < 16 && skey[a - 1] == km) { --a; ++j; }
+    if (j == 16 && a > 0 && skey[a - 1] == km) {                         // lower bound in [0, a)
+        uint64_t l = 0, h = a;
+        while (l < h) { const uint64_t m = (l + h) >> 1; if (skey[m] < km) l = m + 1; else h = m; }
+        a = l;
     }
+    uint64_t b = x + 1;
+    j = 0;
+    while (b < nnz && j < 16 && skey[b] == km) { ++b; ++j; }
+    if (j == 16 && b < nnz && skey[b] == km) {                           // upper bound in (b, nnz]
+        uint64_t l = b, h = nnz;
+        while (l < h) { const uint64_t m = (l + h) >> 1; if (skey[m] <= km) l = m + 1; else h = m; }
+        b = l;
+    }
+    lo = a; hi = b;
+}
+
+// per sorted entry: its place in A' and the final A' and B' entries (coalesced reads; A' written run by run, B' scattered)
+__global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64_t nnz, const uint32_t* Bptr, const uint32_t* wscan,
+                              const uint32_t* packed, const uint64_t* roff, uint32_t k, uint2* Aent, uint2* Bent) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nnz) return;
+    uint64_t lo, hi;
+    run_bounds(skey, nnz, x, lo, hi);
+    const uint32_t dg = (uint32_t)(hi - lo), rk = (uint32_t)(x - lo);
+    const uint64_t vf = sval[lo], v = sval[x];
+    const uint32_t rf = (uint32_t)(vf >> 32) & 0x7FFFFFFFu;
+    const uint32_t cs = wscan[Bptr[rf] + ((uint32_t)vf >> 16)];
+    const uint64_t le = kmer_le(packed, roff[rf] + ((uint32_t)vf & 0xFFFFu), k);   // palindrome: a property of the k-mer
+    const uint32_t pal = kmer_fw_from_le(le, k) == kmer_rc_from_le(le, k) ? 1u : 0u;
+    const uint32_t hiw = (uint32_t)(v >> 32), r = hiw & 0x7FFFFFFFu, pos = (uint32_t)v & 0xFFFFu;
+    const uint32_t ori = pal ? 0u : hiw >> 31;                            // (palindromes count as canonical)
+    const uint32_t len = (uint32_t)(roff[r + 1] - roff[r]);
+    Aent[cs + rk] = make_uint2(r | (ori << 31), pos | (len << 16));
+    Bent[Bptr[r] + ((uint32_t)v >> 16)] = make_uint2(cs + rk + 1, pos | ((dg - 1 - rk) << 16) | (pal << 30) | (ori << 31));
+}
+
+// the products of every entry once more, compact: estimateFLOP streams 2 B per nonzero
+__global__ void k_layout_bcnt(const uint2* Bent, uint64_t nnz, uint16_t* Bcnt) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz) Bcnt[e] = (uint16_t)((Bent[e].y >> 16) & 0x3FFFu);
 }
 
 }  // namespace bella

@@ -18,9 +18,11 @@
 #include "fastq.hpp"
 #include "kcount.hpp"
 #include "logan.hpp"
+#include "order.hpp"
 #include "spgemm.hpp"
 #include "util.hpp"
 #include "wide.hpp"
+#include "writer.hpp"
 #include "xdrop.hpp"
 #include "xdrop_packed.hpp"
 
@@ -60,10 +62,13 @@ constexpr uint32_t kLongListMaxCap = BELLA_LONG_LIST_MAX_CAP;   // long-list inp
 constexpr uint32_t kMidToWideMin = 16;      // columns above the LDS tiers in one pass from which on they take the sort-based path
 constexpr uint32_t kRerunGrid = 256;        // persistent workgroups of the rerun launch (columns an LDS tier handed over)
 constexpr uint32_t kGlobalGrid = 1024;      // persistent workgroups of the global path (1024 threads each: latency-bound, two resident per CU)
-constexpr uint32_t kAsmGrid = 1024;
+constexpr uint32_t kAsmGrid = 512;
 
 struct CastU64 {
     __host__ __device__ uint64_t operator()(const uint32_t& v) const { return (uint64_t)v; }
+};
+struct CountU64 {                                        // pair counts: without the "already in slot order" mark
+    __host__ __device__ uint64_t operator()(const uint32_t& v) const { return (uint64_t)(v & ~kOrderedBit); }
 };
 
 }  // namespace
@@ -100,7 +105,7 @@ struct bella_ctx {
     uint64_t panel_nnz = 0;
     // assembly temporaries
     Buf t_kmer, t_read, t_pos, tstart, Bk_tmp, Bpos_tmp, rowcnt, asm_ws;
-    Buf Brow, deg, minread, colstart, fill, ori, w, wscan, Atmp;
+    Buf lk_key, lk_key2, lk_val, lk_val2, w, wscan;
     // overlap
     uint64_t flops = 0, npairs = 0;
     uint32_t pair_ratio1024 = 1024;   // max over sampled columns of 1024 * pairs/products
@@ -108,7 +113,8 @@ struct bella_ctx {
     Buf prof;
 #endif
     Buf flopsr, flopptr, nnzC, colptrC, rowlists, tiercaps, tmp_pairs, tmp_ext, pairs, ext, sortscr, ws,
-        status, cubtmp, plist_hv, overflow, ctl, retry;
+        status, cubtmp, plist_hv, overflow, ctl, retry, orderlist, order_ws;
+    bool order_attr = false;
     Buf w_f, w_off, w_key, w_key2, w_idx, w_idx2, w_hv, w_ovfl, w_plist, w_scr, w_rlen, w_rstart, w_rrank, w_redo, w_segfirst,
         w_toff, w_table, w_nruns;
     uint32_t n_wide = 0;
@@ -120,6 +126,7 @@ struct bella_ctx {
     bella_timings tm{};
     hipEvent_t ev[10]{};
     uint32_t* pinned = nullptr;          // 128 host words the per-pass read backs land in
+    Stager stager;                       // pinned bounce buffers of the large host <-> device copies
     int caps_state = 0;
     ncclComm_t comm = nullptr;           // RCCL communicator of bella_hip_comm_init (one rank per context)
     int comm_ranks = 0, comm_rank = 0;
@@ -208,6 +215,7 @@ int status_to_error(bella_ctx* c, uint32_t st) {
     if (st & 32u) return fail(c, BELLA_ERR_BAD_ARG, "k-mer id >= nkmers");
     if (st & 64u) return fail(c, BELLA_ERR_BAD_ARG, "a k-mer occurs in more than 16383 reads");
     if (st & 128u) return fail(c, BELLA_ERR_BAD_ARG, "a tuple's position + k exceeds the length of its read");
+    if (st & 256u) return fail(c, BELLA_ERR_BAD_ARG, "a read has more tuples than bases");
     if (st & 2u) return fail(c, BELLA_ERR_ROW_TOO_LARGE, "an output column has >= 65536 products");
     return 0;
 }
@@ -229,59 +237,62 @@ int scan_u32_to_u64(bella_ctx* c, const uint32_t* in, uint64_t* out, uint64_t n)
     return 0;
 }
 
-// B (Bptr/Bk/Bpos on device) -> Bent / Aent   (see assemble.hpp)
+float ev_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms;
+}
+
+// B (Bptr/Bk/Bpos on device) -> Bent / Aent   (see assemble.hpp): one stable radix sort of the entries by k-mer id (the runs are
+// the k-mer lists of A', ascending read id) and coalesced segmented passes; 32 B of temporaries per nonzero.
 int build_layout(bella_ctx* c) {
     const uint64_t nnz = c->nnz;
     const uint32_t nk = c->nkmers;
     if (nnz >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "nnz(A) must be < 2^32 (KMERINDEX uint32, main.cpp:60)");
-    ENSURE(c, c->Brow, 4 * nnz);
-    ENSURE(c, c->deg, 4 * (size_t)nk);
-    ENSURE(c, c->minread, 4 * (size_t)nk);
-    ENSURE(c, c->colstart, 4 * (size_t)nk);
-    ENSURE(c, c->fill, 4 * (size_t)nk);
-    ENSURE(c, c->ori, nnz);
-    ENSURE(c, c->w, 4 * nnz);
-    ENSURE(c, c->wscan, 4 * nnz);
-    ENSURE(c, c->Atmp, 8 * nnz);
+    ENSURE(c, c->lk_key, 4 * nnz);
+    ENSURE(c, c->lk_key2, 4 * nnz);
+    ENSURE(c, c->lk_val, 8 * nnz);
+    ENSURE(c, c->lk_val2, 8 * nnz);
+    ENSURE(c, c->w, 4 * (nnz + 1));
+    ENSURE(c, c->wscan, 4 * (nnz + 1));
     ENSURE(c, c->Bent, 8 * nnz);
     ENSURE(c, c->Bcnt, 2 * nnz);
     ENSURE(c, c->Aent, 8 * nnz + 64);
-    HIPCHK(c, hipMemsetAsync(c->deg.p, 0, 4 * (size_t)nk, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->minread.p, 0xFF, 4 * (size_t)nk, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->fill.p, 0, 4 * (size_t)nk, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->colstart.p, 0, 4 * (size_t)nk, c->stream));
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     if (nnz) {
-        k_entry_rows<<<nblk(c->nreads, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), c->nreads, ptr<uint32_t>(c->Brow));
+        k_layout_prep<<<nblk(c->nreads, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos), c->nreads,
+                                                                        ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), c->kmer_size, nk,
+                                                                        ptr<uint32_t>(c->lk_key), ptr<uint64_t>(c->lk_val), ptr<uint32_t>(c->w),
+                                                                        ptr<uint32_t>(c->status));
         KCHK(c);
-        k_kmer_stats<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos), ptr<uint32_t>(c->Brow), nnz,
-                                                       ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), c->kmer_size, nk,
-                                                       ptr<uint32_t>(c->deg), ptr<uint32_t>(c->minread), ptr<uint8_t>(c->ori),
-                                                       ptr<uint32_t>(c->status));
-        KCHK(c);
-        k_first_weight<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bk), ptr<uint32_t>(c->Brow), nnz, nk, ptr<uint32_t>(c->deg),
-                                                         ptr<uint32_t>(c->minread), ptr<uint32_t>(c->w), ptr<uint32_t>(c->status));
-        KCHK(c);
-        // bad input (k-mer id out of range, k-mer past the end of its read, degree > 16383) stops here: the kernels below
-        // index with these values
+        // bad input (k-mer id out of range, k-mer past the end of its read) stops here: the passes below trust the keys
         uint32_t st0 = 0;
         int rc0 = read_status(c, &st0);
         if (rc0) return rc0;
         rc0 = status_to_error(c, st0);
         if (rc0) return rc0;
+        int kbits = 1;
+        while (kbits < 32 && (1ull << kbits) < (uint64_t)nk) ++kbits;
+        hipcub::DoubleBuffer<uint32_t> dk(ptr<uint32_t>(c->lk_key), ptr<uint32_t>(c->lk_key2));
+        hipcub::DoubleBuffer<uint64_t> dv(ptr<uint64_t>(c->lk_val), ptr<uint64_t>(c->lk_val2));
+        size_t tb = 0;
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (uint64_t)nnz, 0, kbits, c->stream));
+        ENSURE(c, c->cubtmp, tb);
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb, dk, dv, (uint64_t)nnz, 0, kbits, c->stream));
+        const uint32_t* skey = dk.Current();
+        const uint64_t* sval = dv.Current();
+        k_layout_heads<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->w), ptr<uint32_t>(c->status));
+        KCHK(c);
         int rc = scan_u32(c, ptr<uint32_t>(c->w), ptr<uint32_t>(c->wscan), nnz);
         if (rc) return rc;
-        k_col_starts<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bk), ptr<uint32_t>(c->Brow), nnz, ptr<uint32_t>(c->minread),
-                                                       ptr<uint32_t>(c->wscan), ptr<uint32_t>(c->colstart));
+        k_layout_emit<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->wscan), ptr<uint32_t>(c->packed),
+                                                        ptr<uint64_t>(c->roff), c->kmer_size, ptr<uint2>(c->Aent), ptr<uint2>(c->Bent));
         KCHK(c);
-        k_fill_A<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bk), ptr<uint32_t>(c->Brow), nnz, ptr<uint32_t>(c->colstart),
-                                                   ptr<uint32_t>(c->fill), ptr<uint2>(c->Atmp));
-        KCHK(c);
-        k_finalize_cols<<<nblk(nk), 256, 0, c->stream>>>(nk, ptr<uint32_t>(c->deg), ptr<uint32_t>(c->colstart), ptr<uint2>(c->Atmp),
-                                                         ptr<uint16_t>(c->Bpos), ptr<uint8_t>(c->ori), ptr<uint64_t>(c->roff),
-                                                         ptr<uint2>(c->Aent), ptr<uint2>(c->Bent), ptr<uint16_t>(c->Bcnt), ptr<uint32_t>(c->status));
+        k_layout_bcnt<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint2>(c->Bent), nnz, ptr<uint16_t>(c->Bcnt));
         KCHK(c);
     }
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     // pairs/products on a sample of columns -> key-table budget of the LDS tiers (see k_sample_pair_ratio)
     uint32_t ratio1024 = 1024;
     const size_t bitmap_bytes = 4 * (((size_t)c->nreads + 31) / 32);
@@ -302,18 +313,12 @@ int build_layout(bella_ctx* c) {
     if (rc) return rc;
     c->pair_ratio1024 = ratio1024;
     // assembly temporaries are large (tens of bytes per nonzero): give them back
-    release(c->Brow); release(c->deg); release(c->minread); release(c->colstart); release(c->fill); release(c->ori);
-    release(c->w); release(c->wscan); release(c->Atmp);
+    release(c->lk_key); release(c->lk_key2); release(c->lk_val); release(c->lk_val2); release(c->w); release(c->wscan);
+    c->tm.layout_ms = ev_ms(c->ev[4], c->ev[5]);
     c->have_matrix = true;
     c->layout_gen++;
     c->have_pairs = c->have_alns = false;
     return 0;
-}
-
-float ev_ms(hipEvent_t a, hipEvent_t b) {
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, a, b);
-    return ms;
 }
 
 int check_params(bella_ctx* c, const bella_params* p) {
@@ -417,10 +422,10 @@ void bella_hip_destroy(bella_ctx* c) {
     if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
     release(c->comm_meta);
     Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Bcnt, &c->Aent, &c->t_kmer, &c->t_read, &c->t_pos,
-                  &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->Brow, &c->deg, &c->minread, &c->colstart,
-                  &c->fill, &c->ori, &c->w, &c->wscan, &c->Atmp, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC,
+                  &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->lk_key, &c->lk_key2, &c->lk_val, &c->lk_val2,
+                  &c->w, &c->wscan, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC,
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
-                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx, &c->w_idx2, &c->w_hv, &c->w_ovfl,
+                  &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->orderlist, &c->order_ws, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx, &c->w_idx2, &c->w_hv, &c->w_ovfl,
                   &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_redo, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
                   &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->lg_res, &c->lg_redo, &c->lg_scratch};
     for (Buf* b : all) release(*b);
@@ -430,6 +435,7 @@ void bella_hip_destroy(bella_ctx* c) {
     for (auto& e : c->join) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    c->stager.destroy();
     delete c;
 }
 
@@ -471,7 +477,7 @@ int bella_hip_set_reads(bella_ctx* c, const uint8_t* bases, const uint64_t* offs
     Buf raw;
     int rc = ensure_bytes(c, raw, total);
     if (rc) return rc;
-    hipError_t e = hipMemcpyAsync(raw.p, bases, total, hipMemcpyHostToDevice, c->stream);
+    hipError_t e = c->stager.h2d(raw.p, bases, total, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->roff.p, offsets, 8 * ((size_t)nreads + 1), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->packed.p, 0, 4 * (nwords + 16), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->status.p, 0, 4, c->stream);
@@ -561,8 +567,8 @@ int bella_hip_set_B(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, const uin
     ENSURE(c, c->Bpos, 2 * nnz);
     HIPCHK(c, hipMemcpyAsync(c->Bptr.p, colptr, 4 * ((size_t)c->nreads + 1), hipMemcpyHostToDevice, c->stream));
     if (nnz) {
-        HIPCHK(c, hipMemcpyAsync(c->Bk.p, rowids, 4 * nnz, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->Bpos.p, values, 2 * nnz, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, c->stager.h2d(c->Bk.p, rowids, 4 * nnz, c->stream));
+        HIPCHK(c, c->stager.h2d(c->Bpos.p, values, 2 * nnz, c->stream));
     }
     c->nkmers = nkmers;
     c->nnz = nnz;
@@ -589,12 +595,17 @@ static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint6
     ENSURE(c, c->Bpos_tmp, 2 * ntuples);
     ENSURE(c, c->rowcnt, 4 * ((size_t)nr + 2));
     ENSURE(c, c->Bptr, 4 * ((size_t)nr + 2));
-    const uint64_t ws_stride = (uint64_t)16 * 65536;
-    ENSURE(c, c->asm_ws, ws_stride * kAsmGrid);
+    const uint64_t ws_stride = (uint64_t)12 * 65536;
+    // the longest row decides which table classes run (known on the host for tuples that came through the ABI; device-resident
+    // tuples: the longest read bounds it)
+    uint32_t maxrow = 0;
+    for (uint32_t r = first; r < first + nr && r < c->host_lens.size(); ++r) maxrow = c->host_lens[r] > maxrow ? c->host_lens[r] : maxrow;
+    if (maxrow > 65535u) maxrow = 65535u;
+    ENSURE(c, c->asm_ws, maxrow > kAsmLdsSlots ? ws_stride * kAsmGrid : 16);
     if (ntuples && t_kmer) {                          // nullptr: the tuples are already there (bella_hip_count_kmers)
-        HIPCHK(c, hipMemcpyAsync(c->t_kmer.p, t_kmer, 4 * ntuples, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->t_read.p, t_read, 4 * ntuples, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->t_pos.p, t_pos, 2 * ntuples, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, c->stager.h2d(c->t_kmer.p, t_kmer, 4 * ntuples, c->stream));
+        HIPCHK(c, c->stager.h2d(c->t_read.p, t_read, 4 * ntuples, c->stream));
+        HIPCHK(c, c->stager.h2d(c->t_pos.p, t_pos, 2 * ntuples, c->stream));
     }
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
@@ -618,11 +629,26 @@ static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint6
     a.ws = ptr<uint8_t>(c->asm_ws);
     a.ws_stride = ws_stride;
     a.status = ptr<uint32_t>(c->status);
+    a.ht_cover = 16;
+    while (a.ht_cover < maxrow) a.ht_cover <<= 1;
     if (nr) {
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_asm_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAsmLdsBytes));
-        const unsigned grid = nr < kAsmGrid ? nr : kAsmGrid;
-        k_asm_rows<<<grid, kBlock, kAsmLdsBytes, c->stream>>>(a);
-        KCHK(c);
+        // one launch per LDS class (table sizes <= 1024, 2048, 4096, 8192 slots: 256, 256, 512, 1024 threads), then the global tables
+        struct Cls { uint32_t lo, hi; int blk; void (*kern)(AsmArgs); };
+        const Cls cls[4] = {{0u, 1024u, 256, k_asm_rows_lds<256>}, {1024u, 2048u, 256, k_asm_rows_lds<256>},
+                            {2048u, 4096u, 512, k_asm_rows_lds<512>}, {4096u, 8192u, 1024, k_asm_rows_lds<1024>}};
+        for (const Cls& k2 : cls) {
+            if (maxrow <= k2.lo && k2.lo) continue;           // no read needs this class
+            const size_t lds = asm_lds_bytes(k2.hi);
+            HIPCHK(c, hipFuncSetAttribute((const void*)k2.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asm_lds_bytes(kAsmLdsSlots)));
+            a.ht_lo = k2.lo; a.ht_hi = k2.hi;
+            k2.kern<<<nr, k2.blk, lds, c->stream>>>(a);
+            KCHK(c);
+        }
+        if (maxrow > kAsmLdsSlots) {
+            a.ht_lo = kAsmLdsSlots; a.ht_hi = 65536u;
+            k_asm_rows_global<<<kAsmGrid, 1024, 0, c->stream>>>(a);
+            KCHK(c);
+        }
     }
     rc = scan_u32(c, ptr<uint32_t>(c->rowcnt), ptr<uint32_t>(c->Bptr), (uint64_t)nr + 1);
     if (rc) return rc;
@@ -641,6 +667,7 @@ static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint6
                                                                 ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos));
         KCHK(c);
     }
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));            // rows_ms = ev[0] .. ev[6]
     *nnz_out = nnz;
     return 0;
 }
@@ -666,6 +693,7 @@ int bella_hip_assemble_tuples(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers,
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev[1]));
     c->tm.assemble_ms = ev_ms(c->ev[0], c->ev[1]);
+    c->tm.rows_ms = ev_ms(c->ev[0], c->ev[6]);
     release(c->t_kmer); release(c->t_read); release(c->t_pos); release(c->Bk_tmp); release(c->Bpos_tmp); release(c->asm_ws);
     return 0;
 }
@@ -983,6 +1011,7 @@ int bella_hip_assemble_counted(bella_ctx* c) {
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev[1]));
     c->tm.assemble_ms = ev_ms(c->ev[0], c->ev[1]);
+    c->tm.rows_ms = ev_ms(c->ev[0], c->ev[6]);
     release(c->Bk_tmp); release(c->Bpos_tmp); release(c->asm_ws);
     return 0;
 }
@@ -1004,6 +1033,7 @@ int bella_hip_assemble_panel(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, 
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev[1]));
     c->tm.assemble_ms = ev_ms(c->ev[0], c->ev[1]);
+    c->tm.rows_ms = ev_ms(c->ev[0], c->ev[6]);
     release(c->t_kmer); release(c->t_read); release(c->t_pos); release(c->Bk_tmp); release(c->Bpos_tmp); release(c->asm_ws);
     c->nkmers = nkmers;
     c->kmer_size = kmer_size;
@@ -1034,6 +1064,7 @@ int bella_hip_assemble_counted_panel(bella_ctx* c, uint32_t first_read, uint32_t
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev[1]));
     c->tm.assemble_ms = ev_ms(c->ev[0], c->ev[1]);
+    c->tm.rows_ms = ev_ms(c->ev[0], c->ev[6]);
     release(c->Bk_tmp); release(c->Bpos_tmp); release(c->asm_ws);
     c->nkmers = c->kc_nkmers;
     c->kmer_size = (uint16_t)c->kc_k;
@@ -1357,9 +1388,15 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     ENSURE(c, c->ctl, 4 * kCtlWords);
     ENSURE(c, c->ws, ws_stride * kGlobalGrid);
     ENSURE(c, c->retry, 4 * ((size_t)nr + 1));
+    ENSURE(c, c->orderlist, 4 * ((size_t)nr + 1));
+    ENSURE(c, c->order_ws, kOrderWsBytes * kOrderBigGrid);
+    if (!c->order_attr) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_order_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)6 * kOrderLdsHt)));
+        c->order_attr = true;
+    }
     {   // temp storage of the pass's one scan (colptrC), so that nothing is allocated between the kernels
         size_t tb1 = 0;
-        hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> it(ptr<uint32_t>(c->nnzC), CastU64());
+        hipcub::TransformInputIterator<uint64_t, CountU64, const uint32_t*> it(ptr<uint32_t>(c->nnzC), CountU64());
         HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, it, ptr<uint64_t>(c->colptrC), (int)nr + 1, c->stream));
         ENSURE(c, c->cubtmp, tb1 + 256);
     }
@@ -1547,27 +1584,24 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         a.cap = tier_caps[ln[l].hi];
         a.dcap = dcap_of(a.cap);
         const size_t lds = ln[l].lds;
-        const bool ga = gaux_in_t2(a.cap, a.dcap, true);
         const int blk = (c->debug & 8u) ? 512 : kClassBlock[ln[l].cls];     // debug bit 3: tests, 512 threads everywhere
         int ki;
         void (*kern)(SpgemmArgs);
         if (blk == 512) {
-            ki = a.cap <= 8 * 512 ? (ga ? 0 : 1) : a.cap <= 16 * 512 ? (ga ? 2 : 3) : 4;
-            kern = ki == 0 ? k_spgemm_rows_lds<8, true, 512> : ki == 1 ? k_spgemm_rows_lds<8, false, 512>
-                 : ki == 2 ? k_spgemm_rows_lds<16, true, 512> : ki == 3 ? k_spgemm_rows_lds<16, false, 512> : k_spgemm_rows_lds<22, false, 512>;
+            ki = a.cap <= 8 * 512 ? 0 : a.cap <= 16 * 512 ? 1 : 2;
+            kern = ki == 0 ? k_spgemm_rows_lds<8, 512> : ki == 1 ? k_spgemm_rows_lds<16, 512> : k_spgemm_rows_lds<22, 512>;
         } else if (blk == 1024) {
-            ki = a.cap <= 4 * 1024 ? (ga ? 5 : 6) : a.cap <= 8 * 1024 ? (ga ? 7 : 8) : 9;
-            kern = ki == 5 ? k_spgemm_rows_lds<4, true, 1024> : ki == 6 ? k_spgemm_rows_lds<4, false, 1024>
-                 : ki == 7 ? k_spgemm_rows_lds<8, true, 1024> : ki == 8 ? k_spgemm_rows_lds<8, false, 1024> : k_spgemm_rows_lds<11, false, 1024>;
+            ki = a.cap <= 4 * 1024 ? 3 : a.cap <= 8 * 1024 ? 4 : 5;
+            kern = ki == 3 ? k_spgemm_rows_lds<4, 1024> : ki == 4 ? k_spgemm_rows_lds<8, 1024> : k_spgemm_rows_lds<11, 1024>;
         } else if (blk == 256 && a.cap <= 6 * 256) {              // cap <= 1394 <= 6 * 256
-            ki = ga ? 10 : 11;
-            kern = ga ? k_spgemm_rows_lds<6, true, 256> : k_spgemm_rows_lds<6, false, 256>;
+            ki = 6;
+            kern = k_spgemm_rows_lds<6, 256>;
         } else if (blk == 256) {                                  // cap <= 2752 <= 11 * 256
-            ki = ga ? 14 : 15;
-            kern = ga ? k_spgemm_rows_lds<11, true, 256> : k_spgemm_rows_lds<11, false, 256>;
+            ki = 7;
+            kern = k_spgemm_rows_lds<11, 256>;
         } else {                                                  // cap <= 689 <= 6 * 128
-            ki = ga ? 12 : 13;
-            kern = ga ? k_spgemm_rows_lds<6, true, 128> : k_spgemm_rows_lds<6, false, 128>;
+            ki = 8;
+            kern = k_spgemm_rows_lds<6, 128>;
         }
         if (lds > c->lds_attr[ki]) {                             // once per kernel and size, not per launch
             HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1641,23 +1675,27 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         KCHK(c);
         return 0;
     };
-    auto finish = [&]() -> int {                                  // colptrC, compaction, the pass's host round trip
+    auto finish = [&]() -> int {                                  // colptrC, slot order + move to the final place, the pass's host round trip
         if ((uint64_t)nr + 1 <= kScanSingleMax) {
             k_scan_counts<<<1, 1024, 0, c->stream>>>(ptr<uint32_t>(c->nnzC), ptr<uint64_t>(c->colptrC), nr + 1);
             KCHK(c);
         } else {
-            int r2 = scan_u32_to_u64(c, ptr<uint32_t>(c->nnzC), ptr<uint64_t>(c->colptrC), (uint64_t)nr + 1);
-            if (r2) return r2;
+            hipcub::TransformInputIterator<uint64_t, CountU64, const uint32_t*> it(ptr<uint32_t>(c->nnzC), CountU64());
+            size_t tb = c->cubtmp.cap;
+            HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cubtmp.p, tb, it, ptr<uint64_t>(c->colptrC), (int)nr + 1, c->stream));
         }
         EVREC(6);
         if (nr) {
-            k_compact_pairs<<<nblk(nown ? nown : 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint64_t>(c->flopptr), ptr<uint64_t>(c->colptrC),
-                                                                        ptr<uint32_t>(c->nnzC), nr, i0, c->part_stride, nown,
-                                                                        ptr<bella_pair>(c->tmp_pairs),
-                                                                        want_ext ? ptr<bella_pair_ext>(c->tmp_ext) : nullptr,
-                                                                        ptr<bella_pair>(c->pairs),
-                                                                        want_ext ? ptr<bella_pair_ext>(c->ext) : nullptr,
-                                                                        (uint64_t*)(d_ctl + kCtlTotals));
+            OrderArgs oa;
+            oa.flopptr = ptr<uint64_t>(c->flopptr); oa.colptrC = ptr<uint64_t>(c->colptrC); oa.nnzC = ptr<uint32_t>(c->nnzC);
+            oa.nreads = nr; oa.i0 = i0; oa.stride = c->part_stride; oa.nown = nown;
+            oa.tmp_pairs = ptr<bella_pair>(c->tmp_pairs); oa.tmp_ext = want_ext ? ptr<bella_pair_ext>(c->tmp_ext) : nullptr;
+            oa.pairs = ptr<bella_pair>(c->pairs); oa.ext = want_ext ? ptr<bella_pair_ext>(c->ext) : nullptr;
+            oa.totals = (uint64_t*)(d_ctl + kCtlTotals);
+            oa.nbig = d_ctl + kCtlOrderBig; oa.biglist = ptr<uint32_t>(c->orderlist); oa.ws = ptr<uint8_t>(c->order_ws);
+            k_order_wave<<<nblk(nown ? nown : 1, kOrderBlock / 64), kOrderBlock, 0, c->stream>>>(oa);
+            KCHK(c);
+            k_order_block<<<kOrderBigGrid, kOrderBlock, (size_t)6 * kOrderLdsHt, c->stream>>>(oa);
             KCHK(c);
         }
         EVREC(7);
@@ -1722,7 +1760,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     {
         unsigned long long ph[10 * kNumTiers];
         HIPCHK(c, hipMemcpy(ph, c->prof.p, sizeof(ph), hipMemcpyDeviceToHost));
-        static const char* nm[9] = {"expand", "gather+insert", "slot-order", "ranks+singles", "scatter", "rank/overlay", "parents", "walks", "emit"};
+        static const char* nm[9] = {"expand", "gather+insert", "count-scan", "scatter+singles", "rank/overlay", "parents", "walks", "emit", "-"};
         for (int l = 0; l < nl; ++l) {
             const unsigned long long* q = ph + 10 * l;
             if (!q[9]) continue;
@@ -1759,10 +1797,10 @@ int bella_hip_get_pairs(bella_ctx* c, bella_pair* pairs, bella_pair_ext* ext, ui
     if (!c->have_pairs) return fail(c, BELLA_ERR_STATE, "overlap first");
     HIPCHK(c, hipSetDevice(c->device));
     if (pairs && c->npairs)
-        HIPCHK(c, hipMemcpyAsync(pairs, c->pairs.p, sizeof(bella_pair) * c->npairs, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, c->stager.d2h(pairs, c->pairs.p, sizeof(bella_pair) * c->npairs, c->stream));
     if (ext && c->npairs) {
         if (c->debug & 2u) return fail(c, BELLA_ERR_STATE, "pair_ext output disabled by debug flag");
-        HIPCHK(c, hipMemcpyAsync(ext, c->ext.p, sizeof(bella_pair_ext) * c->npairs, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, c->stager.d2h(ext, c->ext.p, sizeof(bella_pair_ext) * c->npairs, c->stream));
     }
     if (colptrC)
         HIPCHK(c, hipMemcpyAsync(colptrC, c->colptrC.p, 8 * ((size_t)c->nreads + 1), hipMemcpyDeviceToHost, c->stream));
@@ -1910,7 +1948,7 @@ int bella_hip_get_alignments(bella_ctx* c, bella_aln* out) {
     if (!c || !out) return BELLA_ERR_BAD_ARG;
     if (!c->have_alns) return fail(c, BELLA_ERR_STATE, "align_pairs first");
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->nalns) HIPCHK(c, hipMemcpyAsync(out, c->alns.p, sizeof(bella_aln) * c->nalns, hipMemcpyDeviceToHost, c->stream));
+    if (c->nalns) HIPCHK(c, c->stager.d2h(out, c->alns.p, sizeof(bella_aln) * c->nalns, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1954,6 +1992,14 @@ static int xdrop_batch_impl(bella_ctx* c, const bella_seed* seeds, uint64_t n, c
     if (rc) return rc;
     if (e != hipSuccess) return fail(c, BELLA_ERR_HIP, "xdrop_batch: %s", hipGetErrorString(e));
     return 0;
+}
+
+int bella_hip_write_output(const char* path, const bella_params* p, int paf, uint32_t nreads, const char* const* names, const uint32_t* lens,
+                           const bella_pair* pairs, const bella_aln* alns, uint64_t npairs, int nthreads, bella_write_stats* stats) {
+    std::string err;
+    const int rc = write_output_impl(path, p, paf, nreads, names, lens, pairs, alns, npairs, nthreads, stats, err);
+    if (rc) fprintf(stderr, "bella_hip_write_output: %s\n", err.c_str());
+    return rc;
 }
 
 int bella_hip_get_timings(bella_ctx* c, bella_timings* t) {

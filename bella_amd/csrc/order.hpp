@@ -1,0 +1,152 @@
+// order.hpp -- the reference's output order inside a column, for many columns at a time (gfx950).
+//
+// LocalSpGEMM emits a column's pairs in the SLOT ORDER of its per-column open-addressing table (include/overlap.hpp:289-304
+// table of 2^n >= max(16, nnz) slots, :321-333 hash key*107 with linear probing, :343-361 compaction in slot order).  That order is
+// a function of (key, first product index) of the column's pairs alone: keys enter the table in the order of their first
+// products.  The row kernels (spgemm.hpp) therefore leave their records in the order of THEIR grouping table with the first product
+// index in the cid field, and the kernels here compute the slot order and move every record to its final place -- the pass over
+// the records that used to be a plain compaction (the reference's "combine step", overlap.hpp:732-745).
+//
+// The order is reproduced with parallel atomicMin insertion of (first product << 16 | record index): an entry with an earlier
+// first product displaces a later one, which resumes probing; the fixed point is exactly the layout sequential insertion produces
+// (tests/test_core_host.py proves it under random interleavings).  The insertion cascades are chains of dependent LDS round trips:
+// one WAVEFRONT per column (tables of up to 1,024 slots) keeps 24 independent columns in flight on a CU, which is what hides them;
+// larger columns take a workgroup each.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/bella_hip.h"
+#include "core.hpp"
+#include "util.hpp"
+
+namespace bella {
+
+constexpr uint32_t kOrderWaveHt = 1024;                    // largest table a single wavefront orders (4 KB + 2 KB of LDS)
+constexpr uint32_t kOrderLdsHt = 16384;                    // largest table a workgroup holds in LDS (64 KB + 32 KB)
+constexpr uint32_t kOrderBlock = 256;
+constexpr uint32_t kOrderBigGrid = 512;                    // persistent workgroups of k_order_block
+constexpr uint64_t kOrderWsBytes = (uint64_t)6 * 65536;    // global tables of one workgroup for columns with more than 16,384 pairs
+
+struct OrderArgs {
+    const uint64_t* flopptr;     // where a column's records stand in tmp_pairs
+    const uint64_t* colptrC;     // ... and where they go
+    const uint32_t* nnzC;        // pairs per column (| kOrderedBit: already in slot order, cid already the column)
+    uint32_t nreads, i0, stride, nown;
+    const bella_pair* tmp_pairs;
+    const bella_pair_ext* tmp_ext;
+    bella_pair* pairs;
+    bella_pair_ext* ext;
+    uint64_t* totals;            // totals[0] = nnz(C)
+    uint32_t* nbig;              // columns left to k_order_block
+    uint32_t* biglist;
+    uint8_t* ws;                 // kOrderWsBytes per workgroup of k_order_block
+};
+
+__device__ __forceinline__ void order_copy_record(const OrderArgs& a, uint64_t from, uint64_t to, uint32_t cid) {
+    uint4 rec = *(const uint4*)(a.tmp_pairs + from);
+    rec.y = cid;
+    *(uint4*)(a.pairs + to) = rec;
+    if (a.ext) a.ext[to] = a.tmp_ext[from];
+}
+
+// one wavefront per column: tables of up to kOrderWaveHt slots
+__global__ __launch_bounds__(kOrderBlock) void k_order_wave(OrderArgs a) {
+    __shared__ uint32_t s_T2[kOrderBlock / 64][kOrderWaveHt];
+    __shared__ uint16_t s_ord[kOrderBlock / 64][kOrderWaveHt];
+    const uint32_t j0 = blockIdx.x * (kOrderBlock / 64) + wave_id();
+    const uint32_t lane = lane_id();
+    if (j0 == 0 && lane == 0) a.totals[0] = a.colptrC[a.nreads];   // nnz(C): read back once with the control block
+    if (j0 >= a.nown) return;
+    const uint32_t i = a.i0 + j0 * a.stride;
+    const uint32_t nz = a.nnzC[i];
+    const uint32_t d = nz & ~kOrderedBit;
+    if (!d) return;
+    const uint64_t src = a.flopptr[i], dst = a.colptrC[i];
+    if (nz & kOrderedBit) {
+        for (uint32_t r = lane; r < d; r += 64) order_copy_record(a, src + r, dst + r, i);
+        return;
+    }
+    const uint32_t ht = pow2_at_least(16u, d);
+    if (ht > kOrderWaveHt) {
+        if (lane == 0) a.biglist[atomicAdd(a.nbig, 1u)] = i;
+        return;
+    }
+    uint32_t* T2 = s_T2[wave_id()];
+    uint16_t* ord = s_ord[wave_id()];
+    for (uint32_t s = lane; s < ht; s += 64) T2[s] = kEmpty;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // (one wavefront: its LDS operations execute in order; this keeps the compiler's order)
+    for (uint32_t j = lane; j < d; j += 64) {
+        const uint2 kf = *(const uint2*)(a.tmp_pairs + src + j);          // {key, first product}
+        uint32_t item = (kf.y << 16) | j;
+        uint32_t h = (kf.x * 107u) & (ht - 1);
+        for (;;) {
+            const uint32_t old = atomicMin(&T2[h], item);
+            if (old == kEmpty) break;
+            if (old > item) item = old;                       // we took the slot; the displaced entry resumes probing
+            h = (h + 1) & (ht - 1);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    {
+        const uint32_t c = ht >= 64 ? ht / 64 : 1u;
+        const uint32_t lo = lane * c < ht ? lane * c : ht, hi = lo + c < ht ? lo + c : ht;
+        uint32_t occ = 0;
+        for (uint32_t s = lo; s < hi; ++s) occ += T2[s] != kEmpty ? 1u : 0u;
+        uint32_t rank = wave_incl_scan(occ) - occ;
+        for (uint32_t s = lo; s < hi; ++s) {
+            const uint32_t it = T2[s];
+            if (it != kEmpty) ord[rank++] = (uint16_t)(it & 0xFFFFu);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    for (uint32_t r = lane; r < d; r += 64) order_copy_record(a, src + ord[r], dst + r, i);
+}
+
+// one workgroup per column (persistent): the columns k_order_wave listed
+__global__ __launch_bounds__(kOrderBlock) void k_order_block(OrderArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t scr[16];
+    const uint32_t nbig = *a.nbig;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t x = blockIdx.x; x < nbig; x += gridDim.x) {
+        const uint32_t i = a.biglist[x];
+        const uint32_t d = a.nnzC[i] & ~kOrderedBit;
+        const uint64_t src = a.flopptr[i], dst = a.colptrC[i];
+        const uint32_t ht = pow2_at_least(16u, d);
+        uint32_t* T2;
+        uint16_t* ord;
+        if (ht <= kOrderLdsHt) { T2 = (uint32_t*)smem; ord = (uint16_t*)(smem + (size_t)4 * kOrderLdsHt); }
+        else { uint8_t* w = a.ws + (uint64_t)blockIdx.x * kOrderWsBytes; T2 = (uint32_t*)w; ord = (uint16_t*)(w + (size_t)4 * 65536); }
+        for (uint32_t s = tid; s < ht; s += kOrderBlock) T2[s] = kEmpty;
+        __syncthreads();
+        for (uint32_t j = tid; j < d; j += kOrderBlock) {
+            const uint2 kf = *(const uint2*)(a.tmp_pairs + src + j);
+            uint32_t item = (kf.y << 16) | j;
+            uint32_t h = (kf.x * 107u) & (ht - 1);
+            for (;;) {
+                const uint32_t old = atomicMin(&T2[h], item);
+                if (old == kEmpty) break;
+                if (old > item) item = old;
+                h = (h + 1) & (ht - 1);
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t c = (ht + kOrderBlock - 1) / kOrderBlock;
+            const uint32_t lo = tid * c < ht ? tid * c : ht, hi = lo + c < ht ? lo + c : ht;
+            uint32_t occ = 0;
+            for (uint32_t s = lo; s < hi; ++s) occ += T2[s] != kEmpty ? 1u : 0u;
+            uint32_t tot;
+            uint32_t rank = block_excl_scan<kOrderBlock / 64>(occ, scr, &tot);
+            for (uint32_t s = lo; s < hi; ++s) {
+                const uint32_t it = T2[s];
+                if (it != kEmpty) ord[rank++] = (uint16_t)(it & 0xFFFFu);
+            }
+        }
+        __syncthreads();
+        for (uint32_t r = tid; r < d; r += kOrderBlock) order_copy_record(a, src + ord[r], dst + r, i);
+        __syncthreads();
+    }
+}
+
+}  // namespace bella

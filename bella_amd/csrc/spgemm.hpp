@@ -66,6 +66,7 @@ constexpr uint32_t kCtlOverflow = 17;     // overflow list length
 constexpr uint32_t kCtlWork2 = 18;        // k_fold_overflow counter
 constexpr uint32_t kCtlStatus = 19;       // bit0: a pair ended with > 16 bins and no scratch was given
 constexpr uint32_t kCtlRetry = 21;        // columns whose key table overflowed in an LDS tier (rerun on the global path)
+constexpr uint32_t kCtlOrderBig = 22;     // columns with more than 1,024 pairs, left to k_order_block (order.hpp)
 constexpr uint32_t kCtlTierCnt = 32;      // [16] columns per tier, last used entry = wide columns
 constexpr uint32_t kCtlTotals = 48;       // u64[2]: nnz(C), products (8-byte aligned)
 constexpr uint32_t kCtlWords = 64;
@@ -107,29 +108,26 @@ struct SpgemmArgs {
     int inject_unordered;        // tests: pretend every fifth column's lists came out of order in phase S (exercises the fallback)
 };
 
-constexpr uint32_t kRowScratchBytes = 256;                   // block scan scratch, counters, bucket histogram
-// cap = products held, dcap = distinct keys (pairs) held.  LDS tiers budget dcap = cap/2: a column with more pairs than
-// that (never seen on PacBio-like sets: pairs/products is 0.03 at 10k reads, 0.28 at 100k) is rerun on the global path.
+constexpr uint32_t kRowScratchBytes = 256;                   // block scan scratch, counters
+// cap = products held, dcap = distinct keys (pairs) held.  LDS tiers budget dcap = cap/2 or cap/4: a column with more pairs than
+// that is rerun on the global path.
 // overlay: the product-order arrays (A_hv, A_gov) are reused for the rank-order lists (LDS tiers: the values travel through
 // registers between two barriers); without it (global path, any size) the lists get their own 8*cap bytes.
-// With the half-size key tables (dcap >= cap/2) the slot-order table T2 is twice as large as the u16[cap] arrays that reuse it
-// after phase O, and Gaux (first touched in phase P) lives in its upper half: 19 instead of 21 bytes of LDS per product.
-__host__ __device__ inline bool gaux_in_t2(uint32_t cap, uint32_t dcap, bool overlay) { return overlay && 2 * dcap >= (cap + 1) / 2 + dcap; }
 __host__ __device__ inline size_t row_mem_bytes(uint32_t cap, uint32_t dcap, bool overlay) {
-    return kRowScratchBytes + (size_t)8 * cap + (size_t)(gaux_in_t2(cap, dcap, overlay) ? 20 : 24) * dcap + 2 * (size_t)((dcap + 1) & ~1u) +
+    return kRowScratchBytes + (size_t)8 * cap + (size_t)16 * dcap + (overlay ? 2 : 4) * (size_t)((cap + 3) & ~3u) + 2 * (size_t)((dcap + 1) & ~1u) +
            (overlay ? 0 : (size_t)8 * cap + 2 * (size_t)((cap + 3) & ~3u));
 }
 
 struct RowMem {
-    uint32_t* scr;      // 64 words: [0..15] scan, [16..31] bucket counts, [32..47] bucket bases, [48] distinct keys
+    uint32_t* scr;      // 64 words: [0..15] scan, [48] chunk counter of the single-product sweep, [49] fail, [50] not-plain
     uint32_t* A_hv;     // [cap]  posH | posV << 16, product order
-    uint32_t* A_gov;    // [cap]  T1 slot << 16 | overlap estimate ; LDS tiers (T1 slot < 2^14): flags << 30 on top
+    uint32_t* A_gov;    // [cap]  T1 slot << 16 | overlap estimate ; LDS tiers (T1 slot < 2^13): flags << 30 on top
     uint32_t* T1key;    // [dcap]
-    uint32_t* T1first;  // [dcap]  first product index ; after phase O: list start | rank << 16
-    uint32_t* T1cnt;    // [dcap]  products | scatter cursor << 16
-    uint32_t* T2;       // [2*dcap] slot-order table ; after phase O reused: S_p (u16 [cap]) product index lists (dcap >= cap/4)
-    uint32_t* Gaux;     // [dcap]  plain-chain pair: surviving positions (diagnostics) ; else (bins - 1) << 16
-    uint16_t* G;        // [dcap]  rank -> T1 slot
+    uint32_t* T1cnt;    // [dcap]  X: products of the key in product ranges 0 | 1 << 16 ; C..S: their scatter cursors ; then products | count << 16
+    uint32_t* T1first;  // [dcap]  X: products in ranges 2 | 3 << 16 ; C..S: their scatter cursors ; then END of the pair's list | output index << 16
+    uint32_t* Gaux;     // [dcap]  C..S: products | output index << 16 ; then plain chain: surviving positions (diagnostics), else (bins - 1) << 16
+    uint16_t* S_p;      // [cap]   per-pair lists of product indices ; from phase P on: Par (u16 [cap]; global path u32 [cap])
+    uint16_t* G;        // [dcap]  first product of a multi-product pair (its slot-order priority, k_order_*)
     uint8_t* A_fl;      // [cap]  flags: bit0 oriented (checkstrand), bit1 palindromic k-mer   (global path only)
     uint8_t* L_fl;      // [cap]  the same in rank order                                        (global path only)
     uint32_t* L_hv;     // [cap]  rank-order lists: posH | posV << 16           (== A_hv when overlaid)
@@ -137,7 +135,6 @@ struct RowMem {
     uint32_t cap, dcap;
 };
 
-template <bool GALIAS>
 __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dcap, bool overlay) {
     RowMem m;
     m.scr = (uint32_t*)base;
@@ -145,11 +142,10 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dc
     m.A_hv = w;            w += cap;
     m.A_gov = w;           w += cap;
     m.T1key = w;           w += dcap;
-    m.T1first = w;         w += dcap;
     m.T1cnt = w;           w += dcap;
-    m.T2 = w;              w += 2 * dcap;
-    if (GALIAS) m.Gaux = m.T2 + (cap + 1) / 2;             // zeroed in phase S, not at the start
-    else { m.Gaux = w; w += dcap; }
+    m.T1first = w;         w += dcap;
+    m.Gaux = w;            w += dcap;
+    m.S_p = (uint16_t*)w;  w += (overlay ? 1 : 2) * (((cap + 3) & ~3u) / 2);
     m.G = (uint16_t*)w;    w += (dcap + 1) / 2;
     if (overlay) { m.L_hv = m.A_hv; m.L_gov = m.A_gov; m.A_fl = nullptr; m.L_fl = nullptr; }
     else { m.L_hv = w; w += cap; m.L_gov = w; w += cap; m.A_fl = (uint8_t*)w; w += (cap + 3) / 4; m.L_fl = (uint8_t*)w; }
@@ -158,8 +154,12 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dc
     return m;
 }
 
-// returns false if the key table overflowed (no global side effect happened yet; the caller queues the column again)
-template <bool OVERLAY, uint32_t NX, bool GALIAS, int BLK = BELLA_ROW_BLOCK>
+// One output column.  The records leave in the order of the grouping table's slots with the pair's first product index in the cid
+// field: the reference's slot order is a function of (key, first product) alone and is produced afterwards by k_order_* for many
+// columns at a time (the insertion cascades are chains of dependent LDS round trips: in here they would hold a whole workgroup).
+// Returns false if the key table overflowed or a list came out of order (no global side effect happened yet; the caller queues
+// the column again).
+template <bool OVERLAY, uint32_t NX, int BLK = BELLA_ROW_BLOCK>
 __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t i, const uint32_t b0, const uint32_t n, const uint32_t lenV,
                                             const RowMem& m) {
     constexpr int kRowBlock = BLK;                            // threads of this workgroup
@@ -173,11 +173,11 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 #define BELLA_BPROF(n)
 #endif
     const uint32_t H1 = m.dcap;
-    uint32_t* s_d = m.scr + 48;
+    uint32_t* s_chunk = m.scr + 48;
     uint32_t* s_fail = m.scr + 49;
     uint32_t* s_np = m.scr + 50;                              // LDS tiers: some pair of the column is not a plain chain
     const uint32_t k = (uint32_t)a.k;
-    constexpr uint32_t GMASK = OVERLAY ? 0x1FFFu : 0xFFFFu;   // LDS tiers (<= 2048 slots): flags and the LAST mark ride on top of the T1 slot
+    constexpr uint32_t GMASK = OVERLAY ? 0x1FFFu : 0xFFFFu;   // LDS tiers (<= 2752 slots): flags and the LAST mark ride on top of the T1 slot
     constexpr uint32_t kLastBit = 1u << 29;                   // L_gov (LDS tiers) / bit 2 of L_fl (global path): last product of its pair's list
 
     // the B' entries of the first round travel while the tables are initialised (their load is the second of two dependent HBM
@@ -194,12 +194,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             if (u < R && j0 + u < nn) be0[u] = a.Bent[b0 + j0 + u];
         }
     }
-    for (uint32_t s = tid; s < H1; s += kRowBlock) {
-        m.T1key[s] = kEmpty; m.T1first[s] = kEmpty; m.T1cnt[s] = 0;
-        m.T2[s] = kEmpty; m.T2[s + H1] = kEmpty;             // the slot-order table of phase O (<= 2 * dcap slots), untouched until then
-        if (!GALIAS) m.Gaux[s] = 0;
-    }
-    if (tid == 0) { *s_d = 0; *s_fail = 0; *s_np = 0; }
+    for (uint32_t s = tid; s < H1; s += kRowBlock) { m.T1key[s] = kEmpty; m.T1first[s] = 0; m.T1cnt[s] = 0; }
+    if (tid == 0) { *s_chunk = 0; *s_fail = 0; *s_np = 0; }
     __syncthreads();
 
     // ---- X: expand products in reference order, group keys --------------------------------------------
@@ -228,9 +224,13 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         running += tot;
     }
     const uint32_t F = running;
+    // The products are cut into four ranges of whole 64-product chunks: a key counts its products per range (four u16 fields in
+    // T1cnt / T1first), so that in phase S four wavefronts append to the per-pair lists independently, each in product order.
+    const uint32_t RB = ((F + 255u) >> 8) << 6;
     __syncthreads();
     BELLA_BPROF(0)
-    // X3: product-parallel gather of the A' entries (balanced: every lane has work; four independent loads in flight)
+    // X3: product-parallel gather of the A' entries (balanced: every lane has work; four independent loads in flight).  Per
+    // product ONE compare-and-swap (claim or find the key's slot) and one add (the key's count in the product's range).
     constexpr uint32_t XB = BELLA_GATHER_BATCH(kRowBlock);    // A' loads in flight per lane
     for (uint32_t base = 0; base < F; base += XB * kRowBlock) {
         uint2 ae[XB];
@@ -260,12 +260,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
                 h = (h + 1 == H1) ? 0 : h + 1;
             }
             if (probes == H1) { *s_fail = 1; continue; }     // more pairs than this tier's key table holds
-            if (old == kEmpty) {
-                const uint32_t idx = atomicAdd(s_d, 1u);
-                if (GALIAS) m.G[idx] = (uint16_t)h;          // pair-rich layout: the occupied slots, densely (G is rewritten in phase O)
-            }
-            atomicMin(&m.T1first[h], p);
-            atomicAdd(&m.T1cnt[h], 1u);
+            const uint32_t q = (p >= RB ? 1u : 0u) + (p >= 2u * RB ? 1u : 0u) + (p >= 3u * RB ? 1u : 0u);
+            atomicAdd((q & 2u) ? &m.T1first[h] : &m.T1cnt[h], (q & 1u) ? 0x10000u : 1u);
             m.A_hv[p] = posH | (posV << 16);
             const uint32_t fl = (oriented ? 1u : 0u) | (pal << 1);
             if (OVERLAY) m.A_gov[p] = (fl << 30) | (h << 16) | ov;
@@ -275,129 +271,143 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     __syncthreads();
     BELLA_BPROF(1)
     if (*s_fail) return false;
-    const uint32_t d = *s_d;
 
-    // ---- O: the reference's slot order (overlap.hpp:289-361) -----------------------------------------
-    const uint32_t ht = pow2_at_least(16u, d);
-    uint32_t* T2 = m.T2;
-    // (pair-rich layout: one lane per pair from the dense slot list; otherwise a sweep over the -- small -- key table)
-    for (uint32_t r = tid; r < (GALIAS ? d : H1); r += kRowBlock) {
-        const uint32_t s = GALIAS ? (uint32_t)m.G[r] : r;
-        const uint32_t key = m.T1key[s];
-        if (key == kEmpty) continue;
-        uint32_t item = (m.T1first[s] << 16) | s;
-        uint32_t h = (key * 107u) & (ht - 1);
-        for (;;) {
-            const uint32_t old = atomicMin(&T2[h], item);
-            if (old == kEmpty) break;
-            if (old > item) item = old;          // we took the slot; the displaced entry resumes probing
-            h = (h + 1) & (ht - 1);
-        }
-    }
-    __syncthreads();
-    BELLA_BPROF(2)
-    // Every pair gets its output rank; the multi-product pairs get a list.  (The records of the single-product pairs are written
-    // during phase S by the wavefronts that have no part in the ordered scatter.)
+    // ---- C: every pair gets its output index (table-slot order), the multi-product pairs their list and four scatter cursors ----
     const uint64_t obase = a.flopptr[i];
-    uint32_t Fm;                                              // products of the multi-product pairs = total list length
+    uint32_t Fm, d;                                           // products of the multi-product pairs = total list length; pairs
     {
-        const uint32_t c = (ht + kRowBlock - 1) / kRowBlock;
-        const uint32_t lo = tid * c;
-        const uint32_t hi = lo + c < ht ? lo + c : ht;
+        const uint32_t c = (H1 + kRowBlock - 1) / kRowBlock;
+        const uint32_t lo = tid * c < H1 ? tid * c : H1;
+        const uint32_t hi = lo + c < H1 ? lo + c : H1;
         uint32_t occ = 0, csum = 0;
         for (uint32_t s = lo; s < hi; ++s) {
-            const uint32_t it = T2[s];
-            if (it != kEmpty) { occ++; const uint32_t mm = m.T1cnt[it & 0xFFFFu] & 0xFFFFu; csum += mm > 1 ? mm : 0u; }
+            const uint32_t w0 = m.T1cnt[s], w1 = m.T1first[s];
+            const uint32_t mm = (w0 & 0xFFFFu) + (w0 >> 16) + (w1 & 0xFFFFu) + (w1 >> 16);
+            occ += mm ? 1u : 0u;
+            csum += mm > 1 ? mm : 0u;
         }
         uint32_t tot;
         const uint32_t ex = block_excl_scan<kRowWaves>((occ << 16) | csum, m.scr, &tot);
         Fm = tot & 0xFFFFu;
+        d = tot >> 16;
         uint32_t rank = ex >> 16, st = ex & 0xFFFFu;
         for (uint32_t s = lo; s < hi; ++s) {
-            const uint32_t it = T2[s];
-            if (it == kEmpty) continue;
-            const uint32_t g = it & 0xFFFFu;
-            const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
-            m.G[rank] = (uint16_t)g;
-            // low half: END of the pair's list (every later phase works from it); a single-product pair has no list: its product
-            m.T1first[g] = (mm > 1 ? st + mm : it >> 16) | (rank << 16);
-            if (mm > 1) st += mm;
+            const uint32_t w0 = m.T1cnt[s], w1 = m.T1first[s];
+            const uint32_t c0 = w0 & 0xFFFFu, c1 = w0 >> 16, c2 = w1 & 0xFFFFu, c3 = w1 >> 16;
+            const uint32_t mm = c0 + c1 + c2 + c3;
+            if (!mm) continue;
+            m.Gaux[s] = mm | (rank << 16);
+            if (mm > 1) {
+                m.T1cnt[s] = st | ((st + c0) << 16);
+                m.T1first[s] = (st + c0 + c1) | ((st + c0 + c1 + c2) << 16);
+                st += mm;
+            }
             rank++;
+        }
+    }
+    __syncthreads();
+    BELLA_BPROF(2)
+
+    // ---- S: product indices into per-pair lists.  Range q is appended by ONE wavefront, 64 products at a time in product order
+    // (LDS atomics of one wavefront execute in program order; within one instruction the same-address atomics are applied in lane
+    // order -- observed, not promised: phase R verifies), from the cursor C gave the key for that range: a list is in product
+    // order.  Meanwhile the other wavefronts (all of them, once the scatter is done) sweep the products for the pairs with a single
+    // product and write their records (multiop only: count 1, one bin, seed = the k-mer; 47 % of the pairs at 10k reads, 92 % at 100k).
+    uint16_t* S_p = m.S_p;
+    {
+        constexpr uint32_t kSA = BELLA_SCATTER_CHUNKS;
+        constexpr uint32_t kOwners = kRowWaves < 4 ? kRowWaves : 4;
+        const uint32_t w = wave_id(), lane = lane_id();
+        if (w < kOwners && Fm) {
+            for (uint32_t q = w; q < 4; q += kOwners) {
+                const uint32_t p0 = q * RB, p1 = (q + 1) * RB < F ? (q + 1) * RB : F;
+                uint32_t* const curs = (q & 2u) ? m.T1first : m.T1cnt;
+                const uint32_t inc = (q & 1u) ? 0x10000u : 1u, sh = (q & 1u) * 16u;
+                for (uint32_t base = p0; base < p1; base += kSA * kScatterChunk) {
+                    uint32_t g[kSA], old[kSA];
+                    bool mine[kSA];
+#pragma unroll
+                    for (uint32_t u = 0; u < kSA; ++u) {
+                        const uint32_t p = base + u * kScatterChunk + lane;
+                        g[u] = m.A_gov[p < p1 ? p : p1 - 1];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < kSA; ++u) g[u] = (g[u] >> 16) & GMASK;
+#pragma unroll
+                    for (uint32_t u = 0; u < kSA; ++u) {
+                        const uint32_t p = base + u * kScatterChunk + lane;
+                        mine[u] = p < p1 && ((const uint16_t*)m.Gaux)[2u * g[u]] != 1u;   // single-product pairs have no list
+                    }
+                    // (old stays unset for the other lanes on purpose: with a default value the compiler folds the first use into the
+                    // predicated block and waits there)
+#pragma unroll
+                    for (uint32_t u = 0; u < kSA; ++u)
+                        if (mine[u]) old[u] = atomicAdd(&curs[g[u]], inc);
+#pragma unroll
+                    for (uint32_t u = 0; u < kSA; ++u)
+                        if (mine[u]) S_p[(old[u] >> sh) & 0xFFFFu] = (uint16_t)(base + u * kScatterChunk + lane);
+                }
+            }
+        }
+        {
+            constexpr uint32_t kSweep = 4 * 64;               // products per grab
+            for (;;) {
+                uint32_t c0 = 0;
+                if (lane == 0) c0 = atomicAdd(s_chunk, kSweep);
+                c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
+                if (c0 >= F) break;
+#pragma unroll
+                for (uint32_t u = 0; u < kSweep / 64; ++u) {
+                    const uint32_t p = c0 + u * 64 + lane;
+                    if (p >= F) continue;
+                    const uint32_t gov = m.A_gov[p];
+                    const uint32_t g = (gov >> 16) & GMASK;
+                    const uint32_t ga = m.Gaux[g];
+                    if ((ga & 0xFFFFu) != 1u) continue;
+                    const uint32_t hv = m.A_hv[p];
+                    const uint32_t fl = OVERLAY ? gov >> 30 : (uint32_t)m.A_fl[p];
+                    bella_pair pr;
+                    pr.rid = m.T1key[g]; pr.cid = p; pr.count = 1; pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
+                    pr.flags = (uint16_t)((fl & 1u) | ((((fl & 1u) ^ 1u) | (fl >> 1)) << 1));   // bit1: revcomp(seedH)==seedV
+                    a.tmp_pairs[obase + (ga >> 16)] = pr;
+                    if (a.tmp_ext) {
+                        bella_pair_ext ex2;
+                        ex2.nbins = 1; ex2.support = 1; ex2.binov = (uint16_t)(gov & 0xFFFFu); ex2.pad = 0;
+                        a.tmp_ext[obase + (ga >> 16)] = ex2;
+                    }
+                }
+            }
         }
     }
     __syncthreads();
     BELLA_BPROF(3)
 
-    // ---- S: product indices into per-pair lists.  Wavefront 0 appends 64 products at a time in product order (LDS
-    // atomics of one wavefront execute in program order), so a list is ordered ACROSS 64-product chunks and only
-    // chunk-mates can be swapped; phase R repairs that.  (T2 is dead: its memory becomes S_p.) -----------------------
-    uint16_t* S_p = (uint16_t*)m.T2;
-    if (GALIAS) {                                             // Gaux shares T2's memory (T2 is dead), above S_p
-        for (uint32_t s = tid; s < H1; s += kRowBlock) m.Gaux[s] = 0;
-    }
-    {
-        // kSW wavefronts each own the key slots g with g % kSW == their number and scan ALL products for them, kSA chunks of 64 in
-        // flight per stage: a key's products are appended by ONE wavefront, in product order (program order across chunks; inside
-        // a chunk the same-address atomics of one instruction -- see phase R).  Measured (tools/ab_blocks.sh): one wavefront beats
-        // 2, 4 and 8 -- every further wavefront scans all products again and the kernel is issue-bound.
-        constexpr uint32_t kSA = BELLA_SCATTER_CHUNKS;
-        constexpr uint32_t kSW = kRowWaves < BELLA_SCATTER_WAVES ? kRowWaves : BELLA_SCATTER_WAVES;
-        const uint32_t w = wave_id(), lane = lane_id();
-        if (w >= kSW) {
-            // the other wavefronts meanwhile: the records of the single-product pairs (multiop only: count 1, one bin, seed = the k-mer;
-            // 47 % of the pairs at 10k reads, 92 % at 100k), at their ranks, straight from the product-order arrays
-            constexpr uint32_t kOthers = kRowBlock - 64 * kSW;
-            for (uint32_t r = tid - 64 * kSW; r < d; r += kOthers) {
-                const uint32_t g = m.G[r];
-                if ((m.T1cnt[g] & 0xFFFFu) != 1u) continue;     // (wavefront 0 only touches the cursor half of the word)
-                const uint32_t p = m.T1first[g] & 0xFFFFu;      // the pair's only product
-                const uint32_t hv = m.A_hv[p], gov = m.A_gov[p];
-                const uint32_t fl = OVERLAY ? gov >> 30 : (uint32_t)m.A_fl[p];
-                bella_pair pr;
-                pr.rid = m.T1key[g]; pr.cid = i; pr.count = 1; pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
-                pr.flags = (uint16_t)((fl & 1u) | ((((fl & 1u) ^ 1u) | (fl >> 1)) << 1));   // bit1: revcomp(seedH)==seedV
-                a.tmp_pairs[obase + r] = pr;
-                if (a.tmp_ext) {
-                    bella_pair_ext ex2;
-                    ex2.nbins = 1; ex2.support = 1; ex2.binov = (uint16_t)(gov & 0xFFFFu); ex2.pad = 0;
-                    a.tmp_ext[obase + r] = ex2;
+    // ---- C2 + R: the per-pair words take their final meaning (END of list | output index, products | count, first product); every
+    // product's exact rank inside its pair's list (global path: list position corrected by the chunk-mates on the wrong side; LDS
+    // tiers: checked) and the lists in rank order: L_hv / L_gov. -------------------------------------------------------------
+    for (uint32_t s = tid; s < H1; s += kRowBlock) {
+        if (m.T1key[s] == kEmpty) continue;
+        const uint32_t ga = m.Gaux[s];
+        const uint32_t mm = ga & 0xFFFFu;
+        uint32_t end = 0;
+        if (mm > 1) {
+            end = m.T1first[s] >> 16;                         // range 3's cursor ran to the end of the list
+            uint32_t fp = S_p[end - mm];
+            if (!OVERLAY) {                                   // chunk-mates may be swapped here (phase R repairs): the smallest of the first chunk
+                const uint32_t ch = fp / kScatterChunk;
+                for (uint32_t y = end - mm + 1; y < end; ++y) {
+                    const uint32_t o = S_p[y];
+                    if (o / kScatterChunk != ch) break;
+                    fp = o < fp ? o : fp;
                 }
             }
-        } else {
-            for (uint32_t base = 0; base < F; base += kSA * kScatterChunk) {
-                uint32_t g[kSA], old[kSA];
-                bool mine[kSA];
-#pragma unroll
-                for (uint32_t u = 0; u < kSA; ++u) {
-                    const uint32_t p = base + u * kScatterChunk + lane;
-                    g[u] = m.A_gov[p < F ? p : F - 1];
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < kSA; ++u) {
-                    const uint32_t p = base + u * kScatterChunk + lane;
-                    g[u] = (g[u] >> 16) & GMASK;
-                    mine[u] = p < F && (g[u] & (kSW - 1)) == w;
-                }
-                // (old stays unset for the other lanes on purpose: with a default value the compiler folds the first use into the
-                // predicated block and waits there; the list end is a 16-bit load for the same reason)
-#pragma unroll
-                for (uint32_t u = 0; u < kSA; ++u)
-                    if (mine[u]) old[u] = atomicAdd(&m.T1cnt[g[u]], 0x10000u);
-#pragma unroll
-                for (uint32_t u = 0; u < kSA; ++u)
-                    if (mine[u]) g[u] = ((const uint16_t*)m.T1first)[2u * g[u]];   // END of the key's list (low half)
-#pragma unroll
-                for (uint32_t u = 0; u < kSA; ++u)
-                    if (mine[u] && (old[u] & 0xFFFFu) != 1u)          // single-product pairs have no list
-                        S_p[g[u] - (old[u] & 0xFFFFu) + (old[u] >> 16)] = (uint16_t)(base + u * kScatterChunk + lane);
-            }
+            m.G[s] = (uint16_t)fp;
         }
+        m.T1first[s] = end | (ga & 0xFFFF0000u);
+        m.T1cnt[s] = mm | (mm << 16);
+        m.Gaux[s] = 0;
     }
-    __syncthreads();
-    BELLA_BPROF(4)
-
-    // ---- R: exact rank of every product inside its pair's list (global path: list position corrected by the chunk-mates on
-    // the wrong side; LDS tiers: checked) and the lists in rank order: L_hv / L_gov. -------------------------------------------------------------
+    if (!OVERLAY) __syncthreads();
     // NX = list positions per thread in the LDS tiers (cap <= NX * kRowBlock)
     uint32_t hvv[NX], govv[NX];
     auto rank_one = [&](uint32_t x, uint32_t& dst, uint32_t& hvq, uint32_t& govq, uint32_t& flq) {
@@ -406,36 +416,29 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         const uint32_t g = (gov >> 16) & GMASK;
         const uint32_t end = m.T1first[g] & 0xFFFFu;
         const uint32_t hv = m.A_hv[p];
-        uint32_t fl = OVERLAY ? gov >> 30 : (uint32_t)m.A_fl[p];
-        if (OVERLAY) {
-            // LDS tiers: verify instead of repair.  On gfx950 the same-address LDS atomics of one wavefront instruction are
-            // applied in lane order (0 of 1.2e7 products ever needed the repair below), but that is not an architectural promise:
-            // a list is in product order iff every entry is below its right neighbour; if one is not, the column is redone
-            // on the global path, which repairs.
-            const bool last = x + 1 == end;
-            if (!last && S_p[x + 1] < p) *s_fail = 1;
-            dst = x; hvq = hv; govq = last ? (gov | kLastBit) : gov; flq = fl;
-        } else {
-            const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
-            const uint32_t st = end - mm;
-            const uint32_t ch = p / kScatterChunk;
-            uint32_t rk = x - st;
-            for (uint32_t y = x; y > st; --y) {               // chunk-mates on the left that belong after p
-                const uint32_t o = S_p[y - 1];
-                if (o / kScatterChunk != ch) break;
-                rk -= (o > p);
-            }
-            for (uint32_t y = x + 1; y < end; ++y) {          // chunk-mates on the right that belong before p
-                const uint32_t o = S_p[y];
-                if (o / kScatterChunk != ch) break;
-                rk += (o < p);
-            }
-            dst = st + rk; hvq = hv; govq = gov; flq = fl | (dst + 1 == end ? 4u : 0u);
+        uint32_t fl = (uint32_t)m.A_fl[p];
+        const uint32_t mm = m.T1cnt[g] & 0xFFFFu;
+        const uint32_t st = end - mm;
+        const uint32_t ch = p / kScatterChunk;
+        uint32_t rk = x - st;
+        for (uint32_t y = x; y > st; --y) {                   // chunk-mates on the left that belong after p
+            const uint32_t o = S_p[y - 1];
+            if (o / kScatterChunk != ch) break;
+            rk -= (o > p);
         }
+        for (uint32_t y = x + 1; y < end; ++y) {              // chunk-mates on the right that belong before p
+            const uint32_t o = S_p[y];
+            if (o / kScatterChunk != ch) break;
+            rk += (o < p);
+        }
+        dst = st + rk; hvq = hv; govq = gov; flq = fl | (dst + 1 == end ? 4u : 0u);
     };
     if (OVERLAY) {
-        // LDS tiers: verify instead of repair (see rank_one), in straight-line stages over groups of four of the thread's NX list
-        // positions.  A list ends where the next position's product belongs to another key slot.
+        // LDS tiers: verify instead of repair.  On gfx950 the same-address LDS atomics of one wavefront instruction are applied in
+        // lane order (0 of 1.2e7 products ever needed the repair), but that is not an architectural promise: a list is in product
+        // order iff every entry is below its right neighbour; if one is not, the column is redone on the global path, which repairs.
+        // Straight-line stages over groups of four of the thread's NX list positions.  A list ends where the next position's
+        // product belongs to another key slot.
         constexpr uint32_t kRB = 4;
 #pragma unroll
         for (uint32_t u0 = 0; u0 < NX; u0 += kRB) {
@@ -474,7 +477,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
         if (a.inject_unordered && i % 5u == 2u && tid == 0) *s_fail = 1;
         __syncthreads();                                      // every A_hv / A_gov read is done: reuse them as L_hv / L_gov
-        if (*s_fail) return false;                            // a list out of order (see above): nothing irreversible happened
+        if (*s_fail) return false;                            // a list out of order (see above): only single-product records were written
 #pragma unroll
         for (uint32_t u = 0; u < NX; ++u) {
             const uint32_t x = tid + u * kRowBlock;
@@ -488,7 +491,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
-    BELLA_BPROF(5)
+    BELLA_BPROF(4)
 
     // ---- P: the fold, in parallel.  chainop (chain.hpp:100-150) on a pair's products in order has a closed form:
     //  * every product t opens a bin with overlap ov_t and itself as first position; a bin lives, unchanged, until the first
@@ -507,7 +510,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // Par[y]: parent of position y (index inside its pair's list) or kRoot | support.  LDS tiers: u16 (lists <= 4096 long)
     typedef typename std::conditional<OVERLAY, uint16_t, uint32_t>::type par_t;
     constexpr uint32_t kRoot = OVERLAY ? 0x8000u : 0x80000000u;
-    par_t* Par = (par_t*)m.T2;                                // S_p is dead
+    par_t* Par = (par_t*)m.S_p;                               // S_p is dead
     // (Par holds ABSOLUTE list positions; a list ends at the entry carrying the LAST mark: no per-pair look-up on the fast path)
     auto is_last = [&](uint32_t y, uint32_t gov) -> bool { return OVERLAY ? (gov & kLastBit) != 0 : (m.L_fl[y] & 4u) != 0; };
     const bool need_parents = !OVERLAY || *s_np != 0;         // (wave-uniform: read after the barrier that follows phase R)
@@ -532,7 +535,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         Par[y] = (par_t)par;
     }
     if (need_parents) __syncthreads();
-    BELLA_BPROF(6)
+    BELLA_BPROF(5)
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     const us2 kk2 = {(unsigned short)a.k, (unsigned short)a.k};
     const us2 lim2 = {(unsigned short)(2 * a.k + 1), (unsigned short)(2 * a.k + 1)};
@@ -594,25 +597,28 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     __syncthreads();
-    BELLA_BPROF(7)
+    BELLA_BPROF(6)
 
-    // ---- E: one record per pair --------------------------------------------------------------------------------------
-    for (uint32_t r = tid; r < d; r += kRowBlock) {
-        const uint32_t g = m.G[r];
+    // ---- E: one record per multi-product pair, at the pair's output index (the single-product pairs left in phase S) -------------
+    for (uint32_t g = tid; g < H1; g += kRowBlock) {
         const uint32_t cw = m.T1cnt[g];
         const uint32_t mm = cw & 0xFFFFu;
         if (mm < 2) continue;
         const uint32_t aux = m.Gaux[g];
-        const uint32_t st = (m.T1first[g] & 0xFFFFu) - mm;
+        const uint32_t tf = m.T1first[g];
+        const uint32_t r = tf >> 16;                          // output index
+        const uint32_t st = (tf & 0xFFFFu) - mm;
         const uint32_t keyw = m.T1key[g];
+        const uint32_t firstp = m.G[g];
         // plain chain: one bin, headed by the last product (which phase P skips: it always survives)
         uint32_t win = mm - 1, sup = (aux & 0xFFFFu) + 1, nroots = 1;
         if (keyw >> 31) {
             nroots = (aux >> 16) + 1;
             if (nroots > 16) {
                 // std::sort is not stable past 16 elements (common.h:145): hand the pair's list to the serial fold, which
-                // reproduces libstdc++'s order exactly
+                // reproduces libstdc++'s order exactly (it keeps the cid field: the first product index)
                 for (uint32_t t = 0; t < mm; ++t) a.plist[obase + st + t] = make_uint2(m.L_hv[st + t], m.L_gov[st + t] & 0xFFFFu);
+                a.tmp_pairs[obase + r].cid = firstp;
                 a.overflow[atomicAdd(&a.ctl[kCtlOverflow], 1u)] = make_uint4(i, keyw & 0x7FFFFFFFu, st | (mm << 16), r);
                 continue;
             }
@@ -629,7 +635,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         const uint32_t hv = m.L_hv[st + win];
         const uint32_t fl = OVERLAY ? m.L_gov[st + win] >> 30 : (uint32_t)m.L_fl[st + win] & 3u;
         bella_pair pr;
-        pr.rid = keyw & 0x7FFFFFFFu; pr.cid = i; pr.count = (uint16_t)(cw >> 16); pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
+        pr.rid = keyw & 0x7FFFFFFFu; pr.cid = firstp; pr.count = (uint16_t)(cw >> 16); pr.seedH = (uint16_t)(hv & 0xFFFFu); pr.seedV = (uint16_t)(hv >> 16);
         pr.flags = (uint16_t)((fl & 1u) | ((((fl & 1u) ^ 1u) | (fl >> 1)) << 1));
         a.tmp_pairs[obase + r] = pr;
         if (a.tmp_ext) {
@@ -639,7 +645,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     if (tid == 0) a.nnzC[i] = d;
-    BELLA_BPROF(8)
+    BELLA_BPROF(7)
 #ifdef BELLA_DEV_PROF
     if (tid == 0 && a.prof) atomicAdd(a.prof + 9, 1ull);
 #endif
@@ -649,7 +655,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 
 // LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap, dcap); NX * 512 >= cap (8: the tiers up to 4096 products,
 // 16: the two big tiers that keep HiFi-like columns with long lists off the global path)
-template <uint32_t NX, bool GALIAS, int BLK = BELLA_ROW_BLOCK>
+template <uint32_t NX, int BLK = BELLA_ROW_BLOCK>
 __global__ __launch_bounds__(BLK, (BLK == 1024 ? (NX <= 4 ? 8 : 4) : BLK <= 256 ? 8 : (NX <= 8 ? 6 : 2))) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // the launch covers the tiers of one LDS class, largest columns first: workgroup x -> (tier, place in the tier's list)
@@ -668,8 +674,8 @@ __global__ __launch_bounds__(BLK, (BLK == 1024 ? (NX <= 4 ? 8 : 4) : BLK <= 256 
     }
     const uint4 ds = a.rowdesc[(size_t)t * a.nreads + x];
     const uint32_t i = ds.x;
-    const RowMem m = carve<GALIAS>(smem, a.cap, a.dcap, true);
-    if (!process_row<true, NX, GALIAS, BLK>(a, i, ds.y, ds.z & 0xFFFFu, ds.z >> 16, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
+    const RowMem m = carve(smem, a.cap, a.dcap, true);
+    if (!process_row<true, NX, BLK>(a, i, ds.y, ds.z & 0xFFFFu, ds.z >> 16, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
 }
 
 // Global-workspace path: columns with more products than the largest LDS tier (< 65536), and -- second launch, list and
@@ -684,10 +690,10 @@ __global__ __launch_bounds__(kGlobalBlock) void k_spgemm_rows_global(SpgemmArgs 
     for (uint32_t x = blockIdx.x; x < nrows; x += gridDim.x) {
         const uint32_t i = a.rowdesc ? a.rowdesc[x].x : a.rowlist[x];
         uint32_t f = a.flops[i];
-        if (f < 16u) f = 16u;                             // T2 needs >= 16 slots
-        const RowMem m = carve<false>(ws, f, f, false);
+        if (f < 16u) f = 16u;
+        const RowMem m = carve(ws, f, f, false);
         const uint32_t b0 = a.Bptr[i];
-        (void)process_row<false, 8, false, kGlobalBlock>(a, i, b0, a.Bptr[i + 1] - b0, (uint32_t)(a.roff[i + 1] - a.roff[i]), m);
+        (void)process_row<false, 8, kGlobalBlock>(a, i, b0, a.Bptr[i + 1] - b0, (uint32_t)(a.roff[i + 1] - a.roff[i]), m);
         __syncthreads();
     }
 }
@@ -721,7 +727,7 @@ __device__ __forceinline__ void write_pair(const FoldArgs& a, const uint4 ds, co
     const uint32_t flags = (leH == leV ? 1u : 0u) | (kmer_rc_from_le(leH, k) == kmer_fw_from_le(leV, k) ? 2u : 0u);
     const uint64_t o = a.flopptr[cid] + ds.w;
     bella_pair pr;
-    pr.rid = key; pr.cid = cid; pr.count = fr.count; pr.seedH = (uint16_t)seedH; pr.seedV = (uint16_t)seedV;
+    pr.rid = key; pr.cid = a.tmp_pairs[o].cid; pr.count = fr.count; pr.seedH = (uint16_t)seedH; pr.seedV = (uint16_t)seedV;   // (cid: the first product index, for k_order_*)
     pr.flags = (uint16_t)flags;
     a.tmp_pairs[o] = pr;
     if (a.tmp_ext) {
@@ -876,7 +882,7 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* in, uint64
     __shared__ uint32_t s_v[kScanSingleMax];
     __shared__ uint32_t s_w[16];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t x = tid; x < n; x += 1024) s_v[x] = in[x];
+    for (uint32_t x = tid; x < n; x += 1024) s_v[x] = in[x] & ~kOrderedBit;
     __syncthreads();
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
@@ -885,22 +891,6 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* in, uint64
     uint32_t tot;
     uint64_t run = block_excl_scan<16>(sum, s_w, &tot);
     for (uint32_t x = lo; x < hi; ++x) { out[x] = run; run += s_v[x]; }
-}
-
-__global__ __launch_bounds__(kBlock) void k_compact_pairs(const uint64_t* flopptr, const uint64_t* colptrC,
-                                                          const uint32_t* nnzC, uint32_t nreads, uint32_t i0, uint32_t stride, uint32_t nown,
-                                                          const bella_pair* tmp_pairs, const bella_pair_ext* tmp_ext,
-                                                          bella_pair* pairs, bella_pair_ext* ext, uint64_t* totals) {
-    const uint32_t j = blockIdx.x * kWaves + wave_id();       // the j-th column of this context (the others are empty)
-    if (j == 0 && lane_id() == 0) totals[0] = colptrC[nreads];   // nnz(C): read back once with the control block (totals[1] = products, k_tier_lists)
-    if (j >= nown) return;
-    const uint32_t i = i0 + j * stride;
-    const uint32_t cnt = nnzC[i];
-    const uint64_t src = flopptr[i], dst = colptrC[i];
-    for (uint32_t r = lane_id(); r < cnt; r += 64) {
-        pairs[dst + r] = tmp_pairs[src + r];
-        if (ext) ext[dst + r] = tmp_ext[src + r];
-    }
 }
 
 }  // namespace bella

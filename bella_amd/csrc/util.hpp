@@ -7,6 +7,7 @@ namespace bella {
 
 constexpr int kBlock = 256;        // 4 wavefronts
 constexpr int kWaves = kBlock / 64;
+constexpr uint32_t kOrderedBit = 0x80000000u;   // nnzC[i]: the column's records already stand in the reference's slot order (wide.hpp)
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }

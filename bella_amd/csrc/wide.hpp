@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_wide_ranks(WideArgs a) {
             if (occ) a.R_rank[(uint32_t)it] = running + ex;
             running += tot;
         }
-        if (threadIdx.x == 0) a.nnzC[a.cols[s]] = running;
+        if (threadIdx.x == 0) a.nnzC[a.cols[s]] = running | kOrderedBit;   // (records at their ranks, cid = the column: k_order_* only moves them)
     }
 }
 

@@ -26,14 +26,13 @@
 // the batched form shaped like alignLogan (include/align.hpp:210-211), both forwarding to bella_hip_xdrop_batch.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
-#include <fstream>
 #include <functional>
 #include <iostream>
-#include <sstream>
 #include <string>
 #include <vector>
 
@@ -46,21 +45,10 @@ inline void check(bella_ctx* c, int rc, const char* what) {
               << std::endl;
     std::abort();
 }
-// chain.hpp:47-71 overlapop on the chosen seed, with the strand test delivered in bella_pair::flags bit0
-inline int seed_overlap(const bella_pair& p, int len1, int len2, unsigned short k) {
-    unsigned short begpH = p.seedH, begpV = p.seedV;
-    if (!(p.flags & 1)) begpH = (unsigned short)(len1 - begpH - k);
-    unsigned short endpH = begpH + k, endpV = begpV + k;
-    int margin1 = std::min(begpH, begpV);
-    int margin2 = std::min(len1 - endpH, len2 - endpV);
-    return margin1 + margin2 + k;
-}
 }  // namespace bella_hip_detail
 
 namespace bella_hip_detail {
-struct StageOut { std::string text; size_t lines = 0; };
-
-// one context = one GPU: B in, then per stage [lo, hi): overlap (+ alignment) and the formatted lines of ITS columns
+// one context = one GPU: B in, then per stage [lo, hi): overlap (+ alignment) and the records of ITS columns
 struct Worker {
     bella_ctx* ctx = nullptr;
     std::vector<uint64_t> colptr;            // colptrC of the last pass (nreads + 1)
@@ -68,34 +56,8 @@ struct Worker {
     std::vector<bella_aln> alns;
     uint64_t nnzc = 0;
 };
-
-inline void format_column(std::stringstream& ss, size_t& lines, const Worker& w, uint32_t col, const readVector_& reads, const BELLApars& bpars) {
-    for (uint64_t n = w.colptr[col]; n < w.colptr[col + 1]; ++n) {
-        const bella_pair& q = w.pairs[n];
-        const readType_& r1 = reads[q.rid];
-        const readType_& r2 = reads[q.cid];
-        unsigned short l1 = r1.seq.length(), l2 = r2.seq.length();
-        if (bpars.skipAlignment) {                                            // overlap.hpp:577-588
-            ss << r2.nametag << '\t' << r1.nametag << '\t' << q.count << '\t'
-               << seed_overlap(q, (int)r1.seq.length(), (int)r2.seq.length(), bpars.kmerSize) << '\t' << l2 << '\t' << l1 << '\n';
-            ++lines;
-            continue;
-        }
-        const bella_aln& a = w.alns[n];                                      // PostAlignDecision, overlap.hpp:462-491
-        if (!a.passed) continue;
-        if (!bpars.outputPaf) {
-            ss << r2.nametag << '\t' << r1.nametag << '\t' << q.count << '\t' << a.score << '\t' << a.ov << '\t'
-               << (a.strand ? "c" : "n") << '\t' << a.begV << '\t' << a.endV << '\t' << l2 << '\t' << a.begH << '\t' << a.endH
-               << '\t' << l1 << '\n';
-        } else {
-            int begH = a.begH, endH = a.endH;
-            if (a.strand) { unsigned int tmp = begH; begH = l1 - endH; endH = l1 - tmp; }   // toOriginalCoordinates :149-154
-            ss << r2.nametag << '\t' << l2 << '\t' << a.begV << '\t' << a.endV << '\t' << (a.strand ? "-" : "+") << '\t'
-               << r1.nametag << '\t' << l1 << '\t' << begH << '\t' << endH << '\t' << a.score << '\t' << a.ov << '\t' << 255 << '\n';
-        }
-        ++lines;
-    }
-}
+// the reference's printLog (include/common/common.h:40-44): "INFO:\tfile(line)\tname = value" on stderr
+#define BELLA_HIP_LOG(var) do { std::cerr << "INFO:\t" << "bella_hip_shim.hpp" << "(" << __LINE__ << ")\t" << #var << " = " << (var) << std::endl; } while (0)
 }  // namespace bella_hip_detail
 
 template <typename MultiplyOperation, typename AddOperation>
@@ -183,19 +145,56 @@ void HashSpGEMM(const CSC<uint32_t, unsigned short>& A, const CSC<uint32_t, unsi
     }
     colStart[(size_t)stages] = nreads;
 
-    std::ofstream ofs(filename, std::ios::binary | std::ios::app);            // overlap.hpp:613
+    // names and lengths once; the writer (bella_hip_write_output: per-thread buffers, offset writes, overlap.hpp:603-642) appends
+    std::vector<const char*> names(nreads);
+    std::vector<uint32_t> lens(nreads);
+    for (uint32_t r = 0; r < nreads; ++r) { names[r] = reads[r].nametag.c_str(); lens[r] = (uint32_t)reads[r].seq.length(); }
     for (int b = 0; b < stages; ++b) {
         const uint32_t lo = colStart[(size_t)b], hi = colStart[(size_t)b + 1];
+        const auto t_stage = std::chrono::steady_clock::now();
         if (stages > 1) do_overlap(lo, hi);                                   // a single stage reuses the first pass
         fetch();
-        std::stringstream ss;
-        size_t outputted = 0;
-        for (uint32_t i = lo; i < hi; ++i) format_column(ss, outputted, W[(size_t)(i % (uint32_t)N)], i, reads, bpars);
-        if (!bpars.skipAlignment) std::cout << outputted << std::endl;        // overlap.hpp:771 (per stage)
-        const std::string text = ss.str();
-        ofs.write(text.data(), (std::streamsize)text.size());
+        const double aligntime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage).count();
+        // the stage's records in the reference's column order (N contexts: column i lives on context i % N)
+        const bella_pair* pp = W[0].pairs.data();
+        const bella_aln* aa = W[0].alns.data();
+        uint64_t np = W[0].nnzc;
+        std::vector<bella_pair> mp;
+        std::vector<bella_aln> ma;
+        if (N > 1) {
+            for (uint32_t i = lo; i < hi; ++i) {
+                const Worker& w = W[(size_t)(i % (uint32_t)N)];
+                mp.insert(mp.end(), w.pairs.begin() + (std::ptrdiff_t)w.colptr[i], w.pairs.begin() + (std::ptrdiff_t)w.colptr[i + 1]);
+                if (!bpars.skipAlignment) ma.insert(ma.end(), w.alns.begin() + (std::ptrdiff_t)w.colptr[i], w.alns.begin() + (std::ptrdiff_t)w.colptr[i + 1]);
+            }
+            pp = mp.data(); aa = ma.data(); np = mp.size();
+        }
+        bella_write_stats ws;
+        const int wrc = bella_hip_write_output(filename, &p, bpars.outputPaf ? 1 : 0, nreads, names.data(), lens.data(), pp, bpars.skipAlignment ? nullptr : aa, np, 0, &ws);
+        if (wrc) check(nullptr, wrc, "bella_hip_write_output");
+        const std::string ColumnsRange = "[" + std::to_string(lo) + " - " + std::to_string(hi) + "]";
+        BELLA_HIP_LOG(ColumnsRange);
+        if (!bpars.skipAlignment) {                                           // the per-stage statistics of overlap.hpp:750-777
+            const std::string AlignmentTime = std::to_string(aligntime) + " seconds";
+            BELLA_HIP_LOG(AlignmentTime);
+            const std::string AlignmentRate = std::to_string((long long)((double)ws.aligned_bases / aligntime)) + " bases/second";
+            BELLA_HIP_LOG(AlignmentRate);
+            const std::string AverageReadLength = std::to_string(ws.aligned_pairs ? (long long)((double)ws.total_read_len / (2.0 * (double)ws.aligned_pairs)) : 0LL);
+            BELLA_HIP_LOG(AverageReadLength);
+            const std::string PairsAligned = std::to_string(ws.aligned_pairs);
+            BELLA_HIP_LOG(PairsAligned);
+            std::cout << ws.lines << std::endl;                               // overlap.hpp:771 (per stage)
+            const std::string AverageLengthSuccessfulAlignment = std::to_string(ws.lines ? (long long)((double)ws.bases_passed / (double)ws.lines) : 0LL) + " bps";
+            BELLA_HIP_LOG(AverageLengthSuccessfulAlignment);
+            const uint64_t nfail = ws.aligned_pairs - ws.lines;
+            const std::string AverageLengthFailedAlignment = std::to_string(nfail ? (long long)((double)ws.bases_failed / (double)nfail) : 0LL) + " bps";
+            BELLA_HIP_LOG(AverageLengthFailedAlignment);
+        }
+        const uint64_t LinesOutputted = ws.lines;
+        BELLA_HIP_LOG(LinesOutputted);
+        const std::string OutputtingTime = std::to_string(ws.seconds) + " seconds";
+        BELLA_HIP_LOG(OutputtingTime);
     }
-    ofs.close();
     for (auto& w : W) bella_hip_destroy(w.ctx);
 }
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define BELLA_HIP_ABI_VERSION 3
+#define BELLA_HIP_ABI_VERSION 4
 
 enum {
     BELLA_OK = 0,
@@ -106,6 +106,8 @@ typedef struct {
                                  the column's pairs, or a product list out of order -- see DESIGN 4.1, phase S).  Normally 0 or a
                                  handful; a large value is a performance cliff worth reporting                              */
     uint32_t overflow_pairs;  /* last pass: pairs that ended with > 16 bins (serial fold with libstdc++'s sort order)       */
+    float layout_ms;          /* part of assemble_ms: CSR of B -> device layout B' / A' (sort + segmented passes)           */
+    float rows_ms;            /* part of assemble_ms: tuples -> rows of B in MergeDuplicates slot order (CSC.cpp:301-420)    */
 } bella_timings;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */
@@ -210,6 +212,29 @@ int bella_hip_get_alignments(bella_ctx* ctx, bella_aln* out);
 /* xavierAlign (align.hpp:152) on explicit seeds; out[n] index-aligned with seeds[n]. */
 int bella_hip_xdrop_batch(bella_ctx* ctx, const bella_seed* seeds, uint64_t n, const bella_params* p,
                           bella_aln* out);
+
+/* ---- output writer (overlap.hpp:531-590 formatting, :603-642 per-thread buffers + offset writes) -------------------------
+ * Formats pairs[npairs] (in the reference's order, as bella_hip_get_pairs delivers them) -- 6-column lines when
+ * p->skip_alignment (overlap.hpp:577-588), else the passed alignments as BELLA's 12 columns (:472-473) or PAF (paf != 0,
+ * :476-489) -- and APPENDS the text to `path` (the reference opens its file in append mode, :613).  names[nreads]: NUL-terminated
+ * read names (readType_::nametag); lens[nreads]: read lengths; alns may be NULL when p->skip_alignment.  nthreads host threads
+ * (0 = all hardware threads) each format a contiguous share into their own buffer and write it at its offset of the file.
+ * Plain host code: no context, usable from any thread.  stats (nullable): what RunPairWiseAlignments returns (:644) + timings. */
+typedef struct {
+    uint64_t lines;            /* outputted                                                       */
+    uint64_t bytes;
+    uint64_t aligned_pairs;    /* numAlignmentsThread (overlap.hpp:544)                           */
+    uint64_t aligned_bases;    /* sum of endV - begV (:569)                                       */
+    uint64_t total_read_len;   /* sum of both read lengths (:545)                                 */
+    uint64_t bases_passed;     /* numBasesAlignedTrue (:491)                                      */
+    uint64_t bases_failed;     /* numBasesAlignedFalse (:495)                                     */
+    double seconds;            /* formatting + file write                                          */
+    double format_seconds;
+    uint32_t threads;
+    uint32_t pad;
+} bella_write_stats;
+int bella_hip_write_output(const char* path, const bella_params* p, int paf, uint32_t nreads, const char* const* names, const uint32_t* lens,
+                           const bella_pair* pairs, const bella_aln* alns, uint64_t npairs, int nthreads, bella_write_stats* stats);
 
 /* The exact (growing band) gapped X-drop of the reference's CUDA build instead of Xavier's 32-cell adaptive band: the scores and
  * seed positions of loganGPU/functions.cuh:223-408,505-547,680-682 (= SeqAn's extendSeed(GappedXDrop), include/align.hpp:93-139)

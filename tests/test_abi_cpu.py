@@ -21,13 +21,13 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == {s[0] for s in _lib.SIGNATURES}
-    assert lib.bella_hip_abi_version() == 3
+    assert lib.bella_hip_abi_version() == 4
 
 
 def test_struct_layouts_match_header():
     assert _lib.PAIR_DT.itemsize == 16 and _lib.EXT_DT.itemsize == 8 and _lib.ALN_DT.itemsize == 32 and _lib.SEED_DT.itemsize == 12
     import ctypes
-    assert ctypes.sizeof(_lib.Params) == 24 and ctypes.sizeof(_lib.Timings) == 44
+    assert ctypes.sizeof(_lib.Params) == 24 and ctypes.sizeof(_lib.Timings) == 52 and ctypes.sizeof(_lib.WriteStats) == 80
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -48,8 +48,9 @@ def test_product_never_imports_the_oracle():
                 assert "bella_testkit" not in txt, f               # host-side numpy helpers are test tooling, not product
 
 
-def test_host_writers_against_golden(golden):
-    """the product's output formatting (api.format_*) fed with ORACLE results reproduces the golden files"""
+def test_host_writers_against_golden(golden, tmp_path):
+    """the product's output formatting (api.format_* and the library's multi-threaded writer bella_hip_write_output, plain host
+    code) fed with ORACLE results reproduces the golden files"""
     g = golden
     Bc, Br, Bv = O.build_B(g.rs.nreads, g.tk, g.tr, g.tp)
     _, _, op = O.spgemm(g.seqs, g.nkmers, Bc, Br, Bv, g.k)
@@ -60,6 +61,11 @@ def test_host_writers_against_golden(golden):
         a, b = g.seqs[p["rid"]], g.seqs[p["cid"]]
         pairs["flags"][n] = int(a[p["seedH"]:p["seedH"] + g.k] == b[p["seedV"]:p["seedV"] + g.k])
     assert api.format_skip(g.names, g.rs.lengths, pairs, g.k) == g.out["skip"]
+    f = str(tmp_path / "o.out")
+    for nt in (1, 3, 0):
+        open(f, "wb").close()
+        st = api.write_output(f, api.BellaPars(skipAlignment=True, kmerSize=g.k), g.names, g.rs.lengths, pairs, nthreads=nt)
+        assert open(f, "rb").read() == g.out["skip"] and st.lines == len(pairs) and st.bytes == len(g.out["skip"])
     txt, oal, passed = O.align_lines(g.names, g.seqs, op, g.xdrop, g.k, g.err)
     alns = np.zeros(len(op), _lib.ALN_DT)
     phi = O.slope(g.err)
@@ -69,6 +75,12 @@ def test_host_writers_against_golden(golden):
     assert api.format_aligned(g.names, g.rs.lengths, pairs, alns) == txt
     ptxt, _, _ = O.align_lines(g.names, g.seqs, op, g.xdrop, g.k, g.err, paf=True)
     assert api.format_aligned(g.names, g.rs.lengths, pairs, alns, paf=True) == ptxt
+    for paf, want in ((False, txt), (True, ptxt)):
+        open(f, "wb").write(b"head\n")                                     # the writer appends (overlap.hpp:613)
+        st = api.write_output(f, api.BellaPars(kmerSize=g.k, errorRate=g.err, outputPaf=paf), g.names, g.rs.lengths, pairs, alns, nthreads=5)
+        assert open(f, "rb").read() == b"head\n" + want
+        assert st.lines == int(alns["passed"].sum()) and st.aligned_pairs == len(pairs)
+        assert (st.bases_passed + st.bases_failed) % 2 ** 64 == st.aligned_bases      # (size_t sums of int differences, as in the reference)
 
 
 def test_synth_dictionary_matches_reference_counts():
