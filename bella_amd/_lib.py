@@ -34,7 +34,7 @@ class Timings(C.Structure):
     _fields_ = [("assemble_ms", C.c_float), ("symbolic_ms", C.c_float), ("spgemm_ms", C.c_float), ("fold_ms", C.c_float),
                 ("compact_ms", C.c_float), ("xdrop_ms", C.c_float), ("overlap_total_ms", C.c_float), ("spgemm_launches", C.c_uint32),
                 ("kcount_ms", C.c_float), ("retry_columns", C.c_uint32), ("overflow_pairs", C.c_uint32), ("layout_ms", C.c_float),
-                ("rows_ms", C.c_float)]
+                ("rows_ms", C.c_float), ("lane_order", C.c_uint32)]
 
 
 # every symbol include/bella_hip.h declares: (name, restype, argtypes)
@@ -66,6 +66,9 @@ SIGNATURES = [
     ("bella_hip_comm_id", C.c_int, [vp]),
     ("bella_hip_comm_init", C.c_int, [vp, C.c_int, C.c_int, vp]),
     ("bella_hip_comm_destroy", C.c_int, [vp]),
+    ("bella_hip_comm_available", C.c_int, []),
+    ("bella_hip_comm_id_local", C.c_int, [vp]),
+    ("bella_hip_comm_init_local", C.c_int, [vp, C.c_int, C.c_int, vp]),
     ("bella_hip_allgather_panels", C.c_int, [vp]),
     ("bella_hip_count_kmers_dist", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -86,6 +89,7 @@ SIGNATURES = [
                                          C.POINTER(WriteStats)]),
     ("bella_hip_get_timings", C.c_int, [vp, C.POINTER(Timings)]),
     ("bella_hip_set_debug", C.c_int, [vp, C.c_uint32]),
+    ("bella_hip_set_tuning", C.c_int, [vp, C.c_uint32, vp, C.c_uint32]),
 ]
 
 _lib = None

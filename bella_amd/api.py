@@ -169,16 +169,21 @@ class Engine:
                 t(pv.value, nnz.value, "<i2", torch.int16))
 
     # ---- multi-GPU: the library's own RCCL communicator (include/bella_hip.h) ----
-    def comm_id(self) -> bytes:
+    def comm_available(self) -> bool:
+        """librccl can be loaded in this process (check on every rank BEFORE the collective comm_init)"""
+        return bool(self.lib.bella_hip_comm_available())
+
+    def comm_id(self, local: bool = False) -> bytes:
+        """the 128-byte id rank 0 hands to every rank; local=True: the in-process transport (contexts of one process)"""
         buf = C.create_string_buffer(128)
-        rc = self.lib.bella_hip_comm_id(buf)
+        rc = (self.lib.bella_hip_comm_id_local if local else self.lib.bella_hip_comm_id)(buf)
         if rc:
             raise BellaHipError(rc, "librccl could not be loaded")
         return buf.raw
 
-    def comm_init(self, nranks: int, rank: int, comm_id: bytes):
+    def comm_init(self, nranks: int, rank: int, comm_id: bytes, local: bool = False):
         buf = C.create_string_buffer(bytes(comm_id), 128)
-        self._chk(self.lib.bella_hip_comm_init(self.h, nranks, rank, buf))
+        self._chk((self.lib.bella_hip_comm_init_local if local else self.lib.bella_hip_comm_init)(self.h, nranks, rank, buf))
 
     def comm_destroy(self):
         self._chk(self.lib.bella_hip_comm_destroy(self.h))
@@ -221,6 +226,13 @@ class Engine:
         self._chk(self.lib.bella_hip_set_debug(self.h, flags))
 
     # ---- HashSpGEMM ----
+    TUNE = {"lds_tiers": 0, "kcount_budget": 1, "wide_budget": 2, "xdrop_variant": 3}
+
+    def set_tuning(self, what: str, *values):
+        """bella_hip_set_tuning: per-context tuning parameters (tests, A/B measurements); no values = the default"""
+        v = np.asarray(values, dtype=np.uint64)
+        self._chk(self.lib.bella_hip_set_tuning(self.h, self.TUNE[what], v.ctypes.data if len(v) else None, len(v)))
+
     def overlap(self, pars: BellaPars):
         n, f = C.c_uint64(0), C.c_uint64(0)
         cp = pars.c()

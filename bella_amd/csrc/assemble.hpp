@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "core.hpp"
+#include "slotorder.hpp"
 #include "util.hpp"
 
 namespace bella {
@@ -60,57 +61,76 @@ struct AsmArgs {
     uint8_t* ws;            // global tables for reads with more than kAsmLdsSlots tuples
     uint64_t ws_stride;
     uint32_t* status;
-    uint32_t ht_lo, ht_hi;  // this launch: the reads whose table size ht satisfies ht_lo < ht <= ht_hi
-    uint32_t ht_cover;      // largest table size any launch of this assembly covers (sized from the longest read)
+    const uint32_t* list;   // the reads of this launch (k_asm_classify)
+    uint32_t nlist;
 };
+
+// reads by table size: class c holds the reads with kAsmClassHt[c-1] < ht <= kAsmClassHt[c]; the last class takes global tables.
+// (Exact grids per class: an empty workgroup that reserves tens of KB of LDS still waits for the LDS.)
+constexpr uint32_t kAsmClasses = 5;
+__device__ __forceinline__ uint32_t asm_class_of(uint32_t ht) { return ht <= 1024u ? 0u : ht <= 2048u ? 1u : ht <= 4096u ? 2u : ht <= 8192u ? 3u : 4u; }
+__global__ void k_asm_classify(const uint64_t* tstart, uint32_t nreads, uint32_t* lists, uint32_t* counts, uint32_t* rowcnt, uint32_t* status) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nreads) return;
+    const uint64_t n = tstart[r + 1] - tstart[r];
+    if (n == 0 || n >= 65536ull) { rowcnt[r] = 0; if (n) atomicOr(status, 16u); return; }
+    const uint32_t c = asm_class_of(pow2_at_least(16u, (uint32_t)n));
+    lists[(size_t)c * nreads + atomicAdd(&counts[c], 1u)] = r;
+}
 constexpr uint32_t kAsmLdsSlots = 8192;                    // largest table held in LDS (one 1024-thread workgroup per CU)
 constexpr uint32_t kAsmScratchBytes = 128;
-__host__ __device__ inline size_t asm_lds_bytes(uint32_t ht) { return kAsmScratchBytes + (size_t)12 * ht; }
+// the de-duplication table holds 1.4 slots per tuple (any size: multiplicative hash + range reduction)
+__host__ __device__ inline uint32_t asm_dedup_slots(uint32_t n) { return (uint32_t)(((uint64_t)n * 7 + 4) / 5) | 1u; }
+__host__ __device__ inline size_t asm_lds_bytes(uint32_t ht) { return kAsmScratchBytes + (size_t)8 * (asm_dedup_slots(ht) + 1) + (size_t)6 * ht; }
 
-// One read: de-duplicate (keep FIRST occurrence index for the slot order, LAST occurrence's position as the
-// value: CSC.cpp:344 with main.cpp:477-480's lambda), then emulate the insertion order into the reference's
-// table of size ht = 2^n >= max(16, #tuples) (CSC.cpp:322-326) with the atomicMin displacement scheme
-// (see spgemm.hpp phase O), and emit the slots in order (CSC.cpp:358-373).
-// K[s]: k-mer id; FL[s]: first occurrence << 16 | last occurrence (tuple indices inside the read, < 65536); T2: the slot-order table.
-// One compare-and-swap per tuple: the thread that claims a slot stores FL with a plain store; a duplicate k-mer inside a read
-// (rare: repeats) only raises a flag, and a flagged read takes one more pass that folds every tuple into FL with a CAS loop.
+// One read: de-duplicate (keep the FIRST occurrence index for the slot order, the LAST occurrence's position as the
+// value: CSC.cpp:344 with main.cpp:477-480's lambda), then reproduce the insertion order into the reference's
+// table of size ht = 2^n >= max(16, #tuples) (CSC.cpp:322-326) -- slotorder.hpp: rounds by insertion time -- and emit the slots in
+// order (CSC.cpp:358-373).
+// Kk / Kf: de-duplication table of KS slots (k-mer id; first occurrence << 16 | last occurrence, tuple indices inside the read);
+// T2: the slot-order table (first occurrence in both halves of the word); nf: its next-free table.
+// One compare-and-swap per tuple: the thread that claims a slot stores Kf with a plain store; a duplicate k-mer inside a read
+// (rare: repeats) only raises a flag, and a flagged read takes one more pass that folds every tuple into Kf with a CAS loop.
 template <int BLK>
-__device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* scr, uint32_t* K, uint32_t* FL, uint32_t* T2, uint32_t ht) {
+__device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* scr, uint32_t* Kk, uint32_t* Kf, uint32_t KS, uint32_t* T2,
+                                        uint16_t* nf, uint32_t ht) {
     constexpr int NW = BLK / 64;
     const uint32_t tid = threadIdx.x;
     const uint64_t ts = a.tstart[r];
     const uint32_t n = (uint32_t)(a.tstart[r + 1] - ts);
-    uint32_t* s_d = scr + 16;
-    uint32_t* s_dup = scr + 17;
-    for (uint32_t s = tid; s < ht; s += BLK) { K[s] = kEmpty; T2[s] = kEmpty; }
+    uint32_t* s_d = scr + 24;
+    uint32_t* s_dup = scr + 25;
+    for (uint32_t s = tid; s < KS; s += BLK) Kk[s] = kEmpty;
+    for (uint32_t s = tid; s < ht; s += BLK) T2[s] = kEmpty;
     if (tid == 0) { *s_d = 0; *s_dup = 0; }
     __syncthreads();
     uint32_t mine = 0;
     for (uint32_t t = tid; t < n; t += BLK) {
         const uint32_t key = a.t_kmer[ts + t];
-        uint32_t h = (key * 107u) & (ht - 1);
+        uint32_t h = hash_range(key, KS);
         uint32_t old;
         for (;;) {
-            old = atomicCAS(&K[h], kEmpty, key);
+            old = atomicCAS(&Kk[h], kEmpty, key);
             if (old == kEmpty || old == key) break;
-            h = (h + 1) & (ht - 1);
+            h = h + 1 == KS ? 0 : h + 1;
         }
-        if (old == kEmpty) { FL[h] = (t << 16) | t; ++mine; }
+        if (old == kEmpty) { Kf[h] = (t << 16) | t; ++mine; }
         else *s_dup = 1;
     }
     if (mine) atomicAdd(s_d, mine);
     __syncthreads();
-    if (*s_dup) {                                            // some k-mer occurs twice in this read: first = min, last = max over ALL tuples
+    const bool dup = *s_dup != 0;
+    if (dup) {                                               // some k-mer occurs twice in this read: first = min, last = max over ALL tuples
         for (uint32_t t = tid; t < n; t += BLK) {
             const uint32_t key = a.t_kmer[ts + t];
-            uint32_t h = (key * 107u) & (ht - 1);
-            while (K[h] != key) h = (h + 1) & (ht - 1);
-            uint32_t cur = FL[h];
+            uint32_t h = hash_range(key, KS);
+            while (Kk[h] != key) h = h + 1 == KS ? 0 : h + 1;
+            uint32_t cur = Kf[h];
             for (;;) {
                 const uint32_t f = cur >> 16, l = cur & 0xFFFFu;
                 const uint32_t want = ((t < f ? t : f) << 16) | (t > l ? t : l);
                 if (want == cur) break;
-                const uint32_t got = atomicCAS(&FL[h], cur, want);
+                const uint32_t got = atomicCAS(&Kf[h], cur, want);
                 if (got == cur) break;
                 cur = got;
             }
@@ -118,21 +138,34 @@ __device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* 
         __syncthreads();
     }
     const uint32_t d = *s_d;
-    for (uint32_t s = tid; s < ht; s += BLK) {
-        const uint32_t key = K[s];
-        if (key == kEmpty) continue;
-        uint32_t item = (FL[s] & 0xFFFF0000u) | s;
-        uint32_t h = (key * 107u) & (ht - 1);
-        for (;;) {
-            const uint32_t old = atomicMin(&T2[h], item);
-            if (old == kEmpty) break;
-            if (old > item) item = old;
-            h = (h + 1) & (ht - 1);
+    // the distinct k-mers enter the reference's table in the order of their first occurrences, in rounds (slotorder.hpp)
+    uint32_t prev = 0;
+    for (uint32_t rd = 0;; ++rd) {
+        const uint32_t bound = round_bound(rd, ht, d, n);
+        if (rd) { (void)build_next_free<BLK>(T2, nf, ht, scr); __syncthreads(); }
+        if (!dup) {                                           // every tuple is the first occurrence of its k-mer: straight from the tuples
+            for (uint32_t t = prev + tid; t < bound; t += BLK) {
+                const uint32_t home = (a.t_kmer[ts + t] * 107u) & (ht - 1);
+                if (rd) slot_insert<true>(T2, nf, ht - 1, home, (t << 16) | t);
+                else slot_insert<false>(T2, nf, ht - 1, home, (t << 16) | t);
+            }
+        } else {
+            for (uint32_t s = tid; s < KS; s += BLK) {
+                const uint32_t key = Kk[s];
+                if (key == kEmpty) continue;
+                const uint32_t first = Kf[s] >> 16;
+                if (first < prev || first >= bound) continue;
+                const uint32_t home = (key * 107u) & (ht - 1);
+                if (rd) slot_insert<true>(T2, nf, ht - 1, home, (first << 16) | first);
+                else slot_insert<false>(T2, nf, ht - 1, home, (first << 16) | first);
+            }
         }
+        __syncthreads();
+        if (bound >= n) break;
+        prev = bound;
     }
-    __syncthreads();
     const uint32_t c = (ht + BLK - 1) / BLK;
-    const uint32_t lo = tid * c;
+    const uint32_t lo = tid * c < ht ? tid * c : ht;
     const uint32_t hi = lo + c < ht ? lo + c : ht;
     uint32_t occ = 0;
     for (uint32_t s = lo; s < hi; ++s) occ += (T2[s] != kEmpty);
@@ -141,44 +174,49 @@ __device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* 
     for (uint32_t s = lo; s < hi; ++s) {
         const uint32_t it = T2[s];
         if (it == kEmpty) continue;
-        const uint32_t g = it & 0xFFFFu;
-        a.Bk_tmp[ts + rank] = K[g];
-        a.Bpos_tmp[ts + rank] = a.t_pos[ts + (FL[g] & 0xFFFFu)];
+        const uint32_t f = it & 0xFFFFu;
+        const uint32_t key = a.t_kmer[ts + f];
+        uint32_t last = f;
+        if (dup) {
+            uint32_t h = hash_range(key, KS);
+            while (Kk[h] != key) h = h + 1 == KS ? 0 : h + 1;
+            last = Kf[h] & 0xFFFFu;
+        }
+        a.Bk_tmp[ts + rank] = key;
+        a.Bpos_tmp[ts + rank] = a.t_pos[ts + last];
         rank++;
     }
     if (tid == 0) a.rowcnt[r] = d;
     __syncthreads();
 }
 
-// LDS classes by table size: one workgroup per read, the workgroup size grows with the table so that a CU's wavefront slots
-// stay filled; a launch covers the reads with ht_lo < ht <= ht_hi (the others leave at once)
+// LDS classes by table size: one workgroup per read of the class's list, the workgroup size grows with the table so that a CU's
+// wavefront slots stay filled
 template <int BLK>
 __global__ __launch_bounds__(BLK) void k_asm_rows_lds(AsmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t r = blockIdx.x;
+    const uint32_t r = a.list[blockIdx.x];
     const uint32_t n = (uint32_t)(a.tstart[r + 1] - a.tstart[r]);
-    if (n == 0 || n >= 65536u) {
-        if (a.ht_lo == 0 && threadIdx.x == 0) { a.rowcnt[r] = 0; if (n) atomicOr(a.status, 16u); }
-        return;
-    }
     const uint32_t ht = pow2_at_least(16u, n);
-    if (a.ht_lo == 0 && ht > a.ht_cover && threadIdx.x == 0) atomicOr(a.status, 256u);   // more tuples than the read has bases
-    if (ht <= a.ht_lo || ht > a.ht_hi) return;
+    const uint32_t KS = asm_dedup_slots(n);
     uint32_t* scr = (uint32_t*)smem;
-    uint32_t* L = (uint32_t*)(smem + kAsmScratchBytes);
-    asm_row<BLK>(a, r, scr, L, L + ht, L + 2 * ht, ht);
+    uint32_t* T2 = (uint32_t*)(smem + kAsmScratchBytes);
+    uint32_t* Kk = T2 + ht;
+    uint32_t* Kf = Kk + KS;
+    uint16_t* nf = (uint16_t*)(Kf + KS);
+    asm_row<BLK>(a, r, scr, Kk, Kf, KS, T2, nf, ht);
 }
 
 // reads whose table does not fit LDS (> 8192 tuples): tables in a global workspace, persistent workgroups
 __global__ __launch_bounds__(1024) void k_asm_rows_global(AsmArgs a) {
     __shared__ uint32_t scr[kAsmScratchBytes / 4];
     uint32_t* W = (uint32_t*)(a.ws + (uint64_t)blockIdx.x * a.ws_stride);
-    for (uint32_t r = blockIdx.x; r < a.nreads; r += gridDim.x) {
+    for (uint32_t x = blockIdx.x; x < a.nlist; x += gridDim.x) {
+        const uint32_t r = a.list[x];
         const uint32_t n = (uint32_t)(a.tstart[r + 1] - a.tstart[r]);
-        if (n == 0 || n >= 65536u) continue;
         const uint32_t ht = pow2_at_least(16u, n);
-        if (ht <= a.ht_lo) continue;
-        asm_row<1024>(a, r, scr, W, W + ht, W + 2 * ht, ht);
+        const uint32_t KS = asm_dedup_slots(n);
+        asm_row<1024>(a, r, scr, W + ht, W + ht + KS, KS, W, (uint16_t*)(W + ht + 2 * KS), ht);
     }
 }
 
@@ -211,22 +249,25 @@ __global__ __launch_bounds__(kBlock) void k_layout_prep(const uint32_t* Bptr, co
     const uint32_t b0 = Bptr[r], b1 = Bptr[r + 1];
     for (uint32_t e = b0 + lane_id(); e < b1; e += 64) {
         const uint32_t km = Bk[e], pos = Bpos[e];
-        uint32_t ori = 0;
+        uint32_t ori = 0, pal = 0;
         if (km >= nkmers) atomicOr(status, 32u);
         if (pos + k > len) atomicOr(status, 128u);                       // the k-mer would run past the end of its read
         else {
             const uint64_t le = kmer_le(packed, base + pos, k);
-            ori = kmer_fw_from_le(le, k) > kmer_rc_from_le(le, k) ? 1u : 0u;
+            const uint64_t fw = kmer_fw_from_le(le, k), rc = kmer_rc_from_le(le, k);
+            ori = fw > rc ? 1u : 0u;
+            pal = fw == rc ? 1u : 0u;                                    // (a property of the k-mer: the same for all its occurrences)
         }
         key[e] = km;
-        val[e] = ((uint64_t)(r | (ori << 31)) << 32) | (pos | ((e - b0) << 16));
+        // read ids below 2^30 leave bit 30 of the high word to the palindrome flag: the emit pass then reads no sequence at all
+        val[e] = ((uint64_t)(r | (ori << 31) | (nreads <= (1u << 30) ? pal << 30 : 0u)) << 32) | (pos | ((e - b0) << 16));
         w[e] = 0;
     }
 }
 
 // per run head of the sorted entries: its length (the k-mer's degree) lands at the entry of its first (= smallest) read; the
 // exclusive scan of that array over the entries of B is the "first appearance" layout of A': the owner row streams its lists.
-__global__ void k_layout_heads(const uint32_t* skey, const uint64_t* sval, uint64_t nnz, const uint32_t* Bptr, uint32_t* w,
+__global__ void k_layout_heads(const uint32_t* skey, const uint64_t* sval, uint64_t nnz, const uint32_t* Bptr, uint32_t rmask, uint32_t* w,
                                uint32_t* status) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= nnz) return;
@@ -236,7 +277,7 @@ __global__ void k_layout_heads(const uint32_t* skey, const uint64_t* sval, uint6
     while (x + dg < nnz && dg <= 16384u && skey[x + dg] == km) ++dg;
     if (dg > 16383u) { atomicOr(status, 64u); dg = 0; }                  // Bent's product count field holds 14 bits
     const uint64_t v = sval[x];
-    w[Bptr[(uint32_t)(v >> 32) & 0x7FFFFFFFu] + ((uint32_t)v >> 16)] = dg;
+    w[Bptr[(uint32_t)(v >> 32) & rmask] + ((uint32_t)v >> 16)] = dg;
 }
 
 // first / one-past-last position of the run of equal keys around x (runs are short: a few steps; long ones by bisection)
@@ -261,24 +302,38 @@ __device__ __forceinline__ void run_bounds(const uint32_t* skey, uint64_t nnz, u
     lo = a; hi = b;
 }
 
-// per sorted entry: its place in A' and the final A' and B' entries (coalesced reads; A' written run by run, B' scattered)
+// per sorted entry: its place in A' and the final A' and B' entries (coalesced reads; A' written run by run).  The B' entry belongs at
+// the entry's own index e -- a random 8-byte write per nonzero if done from here -- so it leaves as (e, entry) in sorted order; one
+// radix pass on the top bits of e and k_layout_place then write B' region by region (the writes of a region meet in the caches).
 __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64_t nnz, const uint32_t* Bptr, const uint32_t* wscan,
-                              const uint32_t* packed, const uint64_t* roff, uint32_t k, uint2* Aent, uint2* Bent) {
+                              const uint32_t* packed, const uint64_t* roff, uint32_t k, uint32_t rmask, uint2* Aent, uint32_t* ekey, uint64_t* eval) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= nnz) return;
     uint64_t lo, hi;
     run_bounds(skey, nnz, x, lo, hi);
     const uint32_t dg = (uint32_t)(hi - lo), rk = (uint32_t)(x - lo);
     const uint64_t vf = sval[lo], v = sval[x];
-    const uint32_t rf = (uint32_t)(vf >> 32) & 0x7FFFFFFFu;
+    const uint32_t rf = (uint32_t)(vf >> 32) & rmask;
     const uint32_t cs = wscan[Bptr[rf] + ((uint32_t)vf >> 16)];
-    const uint64_t le = kmer_le(packed, roff[rf] + ((uint32_t)vf & 0xFFFFu), k);   // palindrome: a property of the k-mer
-    const uint32_t pal = kmer_fw_from_le(le, k) == kmer_rc_from_le(le, k) ? 1u : 0u;
-    const uint32_t hiw = (uint32_t)(v >> 32), r = hiw & 0x7FFFFFFFu, pos = (uint32_t)v & 0xFFFFu;
+    const uint32_t hiw = (uint32_t)(v >> 32), r = hiw & rmask, pos = (uint32_t)v & 0xFFFFu;
+    uint32_t pal;
+    if (rmask == 0x3FFFFFFFu) pal = (hiw >> 30) & 1u;
+    else {                                                                // (2^30 reads or more: from the sequence of the first occurrence)
+        const uint64_t le = kmer_le(packed, roff[rf] + ((uint32_t)vf & 0xFFFFu), k);
+        pal = kmer_fw_from_le(le, k) == kmer_rc_from_le(le, k) ? 1u : 0u;
+    }
     const uint32_t ori = pal ? 0u : hiw >> 31;                            // (palindromes count as canonical)
     const uint32_t len = (uint32_t)(roff[r + 1] - roff[r]);
     Aent[cs + rk] = make_uint2(r | (ori << 31), pos | (len << 16));
-    Bent[Bptr[r] + ((uint32_t)v >> 16)] = make_uint2(cs + rk + 1, pos | ((dg - 1 - rk) << 16) | (pal << 30) | (ori << 31));
+    ekey[x] = Bptr[r] + ((uint32_t)v >> 16);
+    eval[x] = (uint64_t)(cs + rk + 1) | ((uint64_t)(pos | ((dg - 1 - rk) << 16) | (pal << 30) | (ori << 31)) << 32);
+}
+
+__global__ void k_layout_place(const uint32_t* ekey, const uint64_t* eval, uint64_t nnz, uint2* Bent) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nnz) return;
+    const uint64_t v = eval[x];
+    Bent[ekey[x]] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 
 // the products of every entry once more, compact: estimateFLOP streams 2 B per nonzero

@@ -62,7 +62,7 @@ constexpr uint32_t kLongListMaxCap = BELLA_LONG_LIST_MAX_CAP;   // long-list inp
 constexpr uint32_t kMidToWideMin = 16;      // columns above the LDS tiers in one pass from which on they take the sort-based path
 constexpr uint32_t kRerunGrid = 256;        // persistent workgroups of the rerun launch (columns an LDS tier handed over)
 constexpr uint32_t kGlobalGrid = 1024;      // persistent workgroups of the global path (1024 threads each: latency-bound, two resident per CU)
-constexpr uint32_t kAsmGrid = 512;
+constexpr uint32_t kAsmGrid = 128;
 
 struct CastU64 {
     __host__ __device__ uint64_t operator()(const uint32_t& v) const { return (uint64_t)v; }
@@ -104,7 +104,7 @@ struct bella_ctx {
     uint32_t panel_first = 0, panel_rows = 0;
     uint64_t panel_nnz = 0;
     // assembly temporaries
-    Buf t_kmer, t_read, t_pos, tstart, Bk_tmp, Bpos_tmp, rowcnt, asm_ws;
+    Buf t_kmer, t_read, t_pos, tstart, Bk_tmp, Bpos_tmp, rowcnt, asm_ws, asm_cls;
     Buf lk_key, lk_key2, lk_val, lk_val2, w, wscan;
     // overlap
     uint64_t flops = 0, npairs = 0;
@@ -122,13 +122,14 @@ struct bella_ctx {
     uint32_t n_overflow = 0;
     // alignment
     uint64_t nalns = 0;
-    Buf alns, seeds, xest, xest2, xids, xorder, xres, lg_res, lg_redo, lg_scratch;
+    Buf alns, seeds, xest, xest2, xids, xorder, xres, xstate, xlive, lg_res, lg_redo, lg_scratch;
     bella_timings tm{};
     hipEvent_t ev[10]{};
     uint32_t* pinned = nullptr;          // 128 host words the per-pass read backs land in
     Stager stager;                       // pinned bounce buffers of the large host <-> device copies
     int caps_state = 0;
-    ncclComm_t comm = nullptr;           // RCCL communicator of bella_hip_comm_init (one rank per context)
+    ncclComm_t comm = nullptr;           // communicator of bella_hip_comm_init (one rank per context)
+    const Rccl* api = nullptr;           // its transport: RCCL (comm.hpp: rccl()) or the in-process one (loopback())
     int comm_ranks = 0, comm_rank = 0;
     Buf comm_meta;
     bool pass_known = false;             // tier lengths and product total of the last pass (valid for pass_sig)
@@ -138,7 +139,10 @@ struct bella_ctx {
     bool pass_rare_free = false;         // the last pass on pass_sig needed no rerun, no overflow fold, no wide column
     uint32_t tier_caps[kNumTiers] = {};  // ascending LDS caps, last = 65535 (global-workspace tier); per context
     uint32_t ntiers = 0;
-    bool tiers_from_env = false;
+    bool tiers_from_env = false;         // custom tier table (bella_hip_set_tuning)
+    uint64_t kcount_budget = 1ull << 30, wide_budget = 1ull << 30;   // items per pass of the counting sort / of the wide-column path
+    bool lane_order_ok = true;           // k_lane_order_selftest at init
+    uint32_t xdrop_variant = 0;          // 0: one launch in length-sorted order (production); 1: slices with compaction; 2: packed kernel in pair order; 3: scalar statement
     size_t lds_attr[16] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
     hipStream_t side[kNumTiers + 1]{};   // independent tier launches / fold instances run concurrently
     hipEvent_t fork = nullptr, join[kNumTiers + 1]{};
@@ -167,7 +171,7 @@ int fail(bella_ctx* c, int code, const char* fmt, ...) {
     do {                                                                                                          \
         ncclResult_t r_ = (call);                                                                                 \
         if (r_ != ncclSuccess)                                                                                    \
-            return fail(c, BELLA_ERR_HIP, "%s failed: %s", #call, rccl().GetErrorString ? rccl().GetErrorString(r_) : "RCCL error"); \
+            return fail(c, BELLA_ERR_HIP, "%s failed: %s", #call, c->api && c->api->GetErrorString ? c->api->GetErrorString(r_) : "RCCL error"); \
     } while (0)
 
 int ensure_bytes(bella_ctx* c, Buf& b, size_t bytes) {
@@ -215,7 +219,6 @@ int status_to_error(bella_ctx* c, uint32_t st) {
     if (st & 32u) return fail(c, BELLA_ERR_BAD_ARG, "k-mer id >= nkmers");
     if (st & 64u) return fail(c, BELLA_ERR_BAD_ARG, "a k-mer occurs in more than 16383 reads");
     if (st & 128u) return fail(c, BELLA_ERR_BAD_ARG, "a tuple's position + k exceeds the length of its read");
-    if (st & 256u) return fail(c, BELLA_ERR_BAD_ARG, "a read has more tuples than bases");
     if (st & 2u) return fail(c, BELLA_ERR_ROW_TOO_LARGE, "an output column has >= 65536 products");
     return 0;
 }
@@ -282,13 +285,30 @@ int build_layout(bella_ctx* c) {
         HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb, dk, dv, (uint64_t)nnz, 0, kbits, c->stream));
         const uint32_t* skey = dk.Current();
         const uint64_t* sval = dv.Current();
-        k_layout_heads<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->w), ptr<uint32_t>(c->status));
+        const uint32_t rmask = c->nreads <= (1u << 30) ? 0x3FFFFFFFu : 0x7FFFFFFFu;   // read id field of the sort value
+        k_layout_heads<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), rmask, ptr<uint32_t>(c->w), ptr<uint32_t>(c->status));
         KCHK(c);
         int rc = scan_u32(c, ptr<uint32_t>(c->w), ptr<uint32_t>(c->wscan), nnz);
         if (rc) return rc;
+        uint32_t* ekey = dk.Alternate();                           // (the sort's other buffers are free now)
+        uint64_t* eval = dv.Alternate();
         k_layout_emit<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->wscan), ptr<uint32_t>(c->packed),
-                                                        ptr<uint64_t>(c->roff), c->kmer_size, ptr<uint2>(c->Aent), ptr<uint2>(c->Bent));
+                                                        ptr<uint64_t>(c->roff), c->kmer_size, rmask, ptr<uint2>(c->Aent), ekey, eval);
         KCHK(c);
+        {   // one radix pass on the top 8 bits of the entry index: B' is then written region by region
+            int ebits = 1;
+            while (ebits < 32 && (1ull << ebits) < nnz) ++ebits;
+            hipcub::DoubleBuffer<uint32_t> ek(ekey, const_cast<uint32_t*>(skey));
+            hipcub::DoubleBuffer<uint64_t> ev(eval, const_cast<uint64_t*>(sval));
+            if (ebits > 12) {
+                size_t tb2 = 0;
+                HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, ek, ev, (uint64_t)nnz, ebits - 8, ebits, c->stream));
+                ENSURE(c, c->cubtmp, tb2);
+                HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb2, ek, ev, (uint64_t)nnz, ebits - 8, ebits, c->stream));
+            }
+            k_layout_place<<<nblk(nnz), 256, 0, c->stream>>>(ek.Current(), ev.Current(), nnz, ptr<uint2>(c->Bent));
+            KCHK(c);
+        }
         k_layout_bcnt<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint2>(c->Bent), nnz, ptr<uint16_t>(c->Bcnt));
         KCHK(c);
     }
@@ -377,22 +397,6 @@ int bella_hip_init(int device, bella_ctx** out) {
     c->device = device;
     c->ntiers = 0;
     for (uint32_t t = 0; t < kNumTiers; ++t) { c->tier_caps[t] = kTierCapsDefault[t]; c->ntiers = t + 1; if (kTierCapsDefault[t] == 65535) break; }
-    if (const char* tv = getenv("BELLA_HIP_TIERS")) {             // tuning aid / tests: ascending LDS caps, each <= 11008
-        uint32_t n = 0;
-        uint32_t caps[kNumTiers];
-        for (const char* q = tv; *q && n + 1 < kNumTiers;) {
-            const uint32_t v = (uint32_t)strtoul(q, nullptr, 10);
-            if (v >= 64 && v <= 11008 && (n == 0 || v > caps[n - 1])) caps[n++] = v;   // (>= 64: the slot-order table of a tier holds >= 16 slots)
-            while (*q && *q != ',') ++q;
-            if (*q == ',') ++q;
-        }
-        if (n) {
-            for (uint32_t t = 0; t < n; ++t) c->tier_caps[t] = caps[t];
-            c->tier_caps[n] = 65535;
-            c->ntiers = n + 1;
-            c->tiers_from_env = true;
-        }
-    }
     hipError_t he = hipSetDevice(device);
     if (he == hipSuccess) he = hipStreamCreate(&c->stream);
     for (auto& e : c->ev) if (he == hipSuccess) he = hipEventCreate(&e);
@@ -411,6 +415,14 @@ int bella_hip_init(int device, bella_ctx** out) {
     if (hipHostMalloc((void**)&c->pinned, 512, hipHostMallocDefault) != hipSuccess) { delete c; return BELLA_ERR_NOMEM; }
     if (ensure_bytes(c, c->status, 256)) { delete c; return BELLA_ERR_NOMEM; }
     (void)hipMemset(c->status.p, 0, 256);
+    {   // the LDS tiers of the row kernels rely on lane-ordered same-address LDS atomics (spgemm.hpp, phase S): checked once per context
+        uint32_t bad = 1;
+        k_lane_order_selftest<<<1, 64, 0, c->stream>>>(ptr<uint32_t>(c->status) + 12);
+        if (hipMemcpyAsync(&bad, ptr<uint32_t>(c->status) + 12, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) bad = 1;
+        c->lane_order_ok = bad == 0;
+        c->tm.lane_order = c->lane_order_ok ? 1u : 2u;
+    }
     *out = c;
     return 0;
 }
@@ -419,15 +431,15 @@ void bella_hip_destroy(bella_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
+    if (c->comm && c->api) { (void)c->api->CommDestroy(c->comm); c->comm = nullptr; }
     release(c->comm_meta);
     Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Bcnt, &c->Aent, &c->t_kmer, &c->t_read, &c->t_pos,
-                  &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->lk_key, &c->lk_key2, &c->lk_val, &c->lk_val2,
+                  &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->asm_cls, &c->lk_key, &c->lk_key2, &c->lk_val, &c->lk_val2,
                   &c->w, &c->wscan, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC,
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
                   &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->orderlist, &c->order_ws, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx, &c->w_idx2, &c->w_hv, &c->w_ovfl,
                   &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_redo, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
-                  &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->lg_res, &c->lg_redo, &c->lg_scratch};
+                  &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& st : c->side) (void)hipStreamDestroy(st);
@@ -437,6 +449,38 @@ void bella_hip_destroy(bella_ctx* c) {
     if (c->pinned) (void)hipHostFree(c->pinned);
     c->stager.destroy();
     delete c;
+}
+
+int bella_hip_set_tuning(bella_ctx* c, uint32_t what, const uint64_t* values, uint32_t n) {
+    if (!c || (n && !values)) return BELLA_ERR_BAD_ARG;
+    switch (what) {
+        case BELLA_TUNE_LDS_TIERS: {                               // ascending product capacities of the LDS tiers, each in [64, 11008]; n = 0: defaults
+            uint32_t caps[kNumTiers];
+            uint32_t m = 0;
+            for (uint32_t q = 0; q < n && m + 1 < kNumTiers; ++q) {
+                const uint64_t v = values[q];
+                if (v < 64 || v > 11008 || (m && v <= caps[m - 1])) return fail(c, BELLA_ERR_BAD_ARG, "tier caps must ascend within [64, 11008]");
+                caps[m++] = (uint32_t)v;
+            }
+            if (m) {
+                for (uint32_t t = 0; t < m; ++t) c->tier_caps[t] = caps[t];
+                c->tier_caps[m] = 65535;
+                c->ntiers = m + 1;
+                c->tiers_from_env = true;
+            } else {
+                c->ntiers = 0;
+                for (uint32_t t = 0; t < kNumTiers; ++t) { c->tier_caps[t] = kTierCapsDefault[t]; c->ntiers = t + 1; if (kTierCapsDefault[t] == 65535) break; }
+                c->tiers_from_env = false;
+            }
+            c->caps_state = 0;
+            c->pass_known = false;
+            return 0;
+        }
+        case BELLA_TUNE_KCOUNT_BUDGET: c->kcount_budget = n && values[0] ? values[0] : (1ull << 30); return 0;
+        case BELLA_TUNE_WIDE_BUDGET: c->wide_budget = n && values[0] ? values[0] : (1ull << 30); return 0;
+        case BELLA_TUNE_XDROP_VARIANT: c->xdrop_variant = n ? (uint32_t)values[0] : 0u; return c->xdrop_variant > 3 ? fail(c, BELLA_ERR_BAD_ARG, "x-drop variant 0..3") : 0;
+    }
+    return fail(c, BELLA_ERR_BAD_ARG, "unknown tuning parameter %u", what);
 }
 
 int bella_hip_set_debug(bella_ctx* c, uint32_t flags) {
@@ -595,13 +639,8 @@ static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint6
     ENSURE(c, c->Bpos_tmp, 2 * ntuples);
     ENSURE(c, c->rowcnt, 4 * ((size_t)nr + 2));
     ENSURE(c, c->Bptr, 4 * ((size_t)nr + 2));
-    const uint64_t ws_stride = (uint64_t)12 * 65536;
-    // the longest row decides which table classes run (known on the host for tuples that came through the ABI; device-resident
-    // tuples: the longest read bounds it)
-    uint32_t maxrow = 0;
-    for (uint32_t r = first; r < first + nr && r < c->host_lens.size(); ++r) maxrow = c->host_lens[r] > maxrow ? c->host_lens[r] : maxrow;
-    if (maxrow > 65535u) maxrow = 65535u;
-    ENSURE(c, c->asm_ws, maxrow > kAsmLdsSlots ? ws_stride * kAsmGrid : 16);
+    const uint64_t ws_stride = ((uint64_t)8 * (asm_dedup_slots(65536) + 1) + (uint64_t)6 * 65536 + 255) & ~(uint64_t)255;
+    ENSURE(c, c->asm_cls, 4 * ((size_t)kAsmClasses * (nr + 1) + 16));
     if (ntuples && t_kmer) {                          // nullptr: the tuples are already there (bella_hip_count_kmers)
         HIPCHK(c, c->stager.h2d(c->t_kmer.p, t_kmer, 4 * ntuples, c->stream));
         HIPCHK(c, c->stager.h2d(c->t_read.p, t_read, 4 * ntuples, c->stream));
@@ -610,10 +649,19 @@ static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint6
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->rowcnt.p, 0, 4 * ((size_t)nr + 2), c->stream));
+    uint32_t* const cls_lists = ptr<uint32_t>(c->asm_cls);
+    uint32_t* const cls_counts = cls_lists + (size_t)kAsmClasses * (nr + 1);
+    HIPCHK(c, hipMemsetAsync(cls_counts, 0, 4 * 8, c->stream));
     k_tuple_bounds<<<nblk(ntuples + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->t_read) + toff, ntuples, first, nr, ptr<uint64_t>(c->tstart),
                                                              ptr<uint32_t>(c->status));
     KCHK(c);
+    if (nr) {
+        k_asm_classify<<<nblk(nr), 256, 0, c->stream>>>(ptr<uint64_t>(c->tstart), nr, cls_lists, cls_counts, ptr<uint32_t>(c->rowcnt), ptr<uint32_t>(c->status));
+        KCHK(c);
+    }
     uint32_t st = 0;
+    uint32_t ccount[8] = {};
+    HIPCHK(c, hipMemcpyAsync(ccount, cls_counts, sizeof(ccount), hipMemcpyDeviceToHost, c->stream));
     int rc = read_status(c, &st);
     if (rc) return rc;
     rc = status_to_error(c, st);
@@ -626,27 +674,25 @@ static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint6
     a.Bk_tmp = ptr<uint32_t>(c->Bk_tmp);
     a.Bpos_tmp = ptr<uint16_t>(c->Bpos_tmp);
     a.rowcnt = ptr<uint32_t>(c->rowcnt);
-    a.ws = ptr<uint8_t>(c->asm_ws);
     a.ws_stride = ws_stride;
     a.status = ptr<uint32_t>(c->status);
-    a.ht_cover = 16;
-    while (a.ht_cover < maxrow) a.ht_cover <<= 1;
-    if (nr) {
-        // one launch per LDS class (table sizes <= 1024, 2048, 4096, 8192 slots: 256, 256, 512, 1024 threads), then the global tables
-        struct Cls { uint32_t lo, hi; int blk; void (*kern)(AsmArgs); };
-        const Cls cls[4] = {{0u, 1024u, 256, k_asm_rows_lds<256>}, {1024u, 2048u, 256, k_asm_rows_lds<256>},
-                            {2048u, 4096u, 512, k_asm_rows_lds<512>}, {4096u, 8192u, 1024, k_asm_rows_lds<1024>}};
-        for (const Cls& k2 : cls) {
-            if (maxrow <= k2.lo && k2.lo) continue;           // no read needs this class
-            const size_t lds = asm_lds_bytes(k2.hi);
-            HIPCHK(c, hipFuncSetAttribute((const void*)k2.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asm_lds_bytes(kAsmLdsSlots)));
-            a.ht_lo = k2.lo; a.ht_hi = k2.hi;
-            k2.kern<<<nr, k2.blk, lds, c->stream>>>(a);
+    {
+        // one launch per LDS class (table sizes <= 1024, 2048, 4096, 8192 slots: 256, 512, 1024, 1024 threads), then the global tables
+        struct Cls { uint32_t hi; int blk; void (*kern)(AsmArgs); };
+        const Cls cls[4] = {{1024u, 256, k_asm_rows_lds<256>}, {2048u, 512, k_asm_rows_lds<512>}, {4096u, 1024, k_asm_rows_lds<1024>},
+                            {8192u, 1024, k_asm_rows_lds<1024>}};
+        for (int q = 0; q < 4; ++q) {
+            if (!ccount[q]) continue;
+            HIPCHK(c, hipFuncSetAttribute((const void*)cls[q].kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asm_lds_bytes(kAsmLdsSlots)));
+            a.list = cls_lists + (size_t)q * nr; a.nlist = ccount[q];
+            cls[q].kern<<<ccount[q], cls[q].blk, asm_lds_bytes(cls[q].hi), c->stream>>>(a);
             KCHK(c);
         }
-        if (maxrow > kAsmLdsSlots) {
-            a.ht_lo = kAsmLdsSlots; a.ht_hi = 65536u;
-            k_asm_rows_global<<<kAsmGrid, 1024, 0, c->stream>>>(a);
+        if (ccount[4]) {
+            ENSURE(c, c->asm_ws, ws_stride * kAsmGrid);
+            a.ws = ptr<uint8_t>(c->asm_ws);
+            a.list = cls_lists + (size_t)4 * nr; a.nlist = ccount[4];
+            k_asm_rows_global<<<ccount[4] < kAsmGrid ? ccount[4] : kAsmGrid, 1024, 0, c->stream>>>(a);
             KCHK(c);
         }
     }
@@ -714,6 +760,8 @@ static int grow_keep(bella_ctx* c, Buf& b, size_t need, size_t used) {
 // dist: collective over the context's communicator -- rank r counts the canonical words of ITS range of histogram bins over all
 // reads (1/N of the sort), the partial dictionaries (ascending, so their concatenation in rank order is the whole ascending
 // dictionary) are exchanged with one grouped send/recv, and tuples are generated for the reads bfirst .. bfirst + brows - 1 only
+static int comm_agree(bella_ctx* c, int local_rc);
+
 static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t mode, uint32_t window,
                             uint32_t* nkmers_out, uint64_t* ntuples_out, uint64_t* ndistinct_out, bool dist = false, uint32_t bfirst = 0,
                             uint32_t brows = 0xFFFFFFFFu) {
@@ -730,6 +778,11 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     if (dist && !c->comm) return fail(c, BELLA_ERR_STATE, "bella_hip_comm_init first");
     if (brows == 0xFFFFFFFFu) { bfirst = 0; brows = nr; }
     if ((uint64_t)bfirst + brows > nr) return fail(c, BELLA_ERR_BAD_ARG, "read block exceeds the read set");
+    // Local phase (histogram, sort passes, partial dictionary): a rank that fails here still takes part in the status exchange below,
+    // so that all ranks leave the call together instead of waiting for it in the dictionary exchange.
+    const uint8_t* d_sel = nullptr;
+    uint64_t nk_total = 0, ndistinct = 0;
+    int rc = [&]() -> int {
     const unsigned rgrid = nr < 16384u ? (nr ? nr : 1u) : 16384u;
     ENSURE(c, c->kc_nk, 4 * ((size_t)nr + 2));
     ENSURE(c, c->kc_koff, 8 * ((size_t)nr + 2));
@@ -747,7 +800,6 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     uint64_t ntot = 0;
     HIPCHK(c, hipMemcpyAsync(&ntot, ptr<uint64_t>(c->kc_koff) + nr, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const uint8_t* d_sel = nullptr;
     if (mode == 2) {
         const uint32_t cap = window + 2;
         ENSURE(c, c->kc_sel, ntot + 16);
@@ -769,8 +821,7 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     HIPCHK(c, hipMemcpyAsync(hist, c->kc_hist.p, sizeof(hist), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // passes = runs of consecutive bins holding at most `budget` k-mers (28 bytes of HBM per k-mer in flight)
-    uint64_t budget = 1ull << 30;
-    if (const char* e = getenv("BELLA_HIP_KCOUNT_BUDGET")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) budget = v; }
+    uint64_t budget = c->kcount_budget;
     if (budget > 0x7FFF0000ull) budget = 0x7FFF0000ull;               // rocPRIM item counts are 32-bit
     // this rank's bins: consecutive, balanced by their word counts (every rank derives the same split from the same histogram)
     uint32_t bin_lo = 0, bin_hi = kCountBins;
@@ -799,7 +850,6 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
         pass_lo.push_back(b); pass_hi.push_back(e); pass_n.push_back(n);
         b = e;
     }
-    uint64_t nk_total = 0, ndistinct = 0;
     const bool single = pass_n.size() == 1 && mode == 0 && NR == 1;    // every position contributes: word j of read r has a fixed place
     for (size_t p = 0; p < pass_n.size(); ++p) {
         const uint64_t np = pass_n[p];
@@ -850,6 +900,10 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
         nk_total += nrel;
         ndistinct += nruns;
     }
+    return 0;
+    }();
+    if (NR > 1) rc = comm_agree(c, rc);
+    if (rc) return rc;
     release(c->kc_alt); release(c->kc_runlen); release(c->kc_flag); release(c->kc_slot);
     if (NR > 1) {
         // partial dictionaries -> the whole dictionary on every rank
@@ -857,37 +911,46 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
         uint64_t mine[4] = {nk_total, ndistinct, 0, 0};
         uint64_t* d_meta = ptr<uint64_t>(c->comm_meta);
         HIPCHK(c, hipMemcpyAsync(d_meta + 4 * (size_t)NR, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
-        NCCLCHK(c, rccl().AllGather(d_meta + 4 * (size_t)NR, d_meta, 4, ncclUint64, c->comm, c->stream));
+        NCCLCHK(c, c->api->AllGather(d_meta + 4 * (size_t)NR, d_meta, 4, ncclUint64, c->comm, c->stream));
         std::vector<uint64_t> meta(4 * (size_t)NR);
         HIPCHK(c, hipMemcpyAsync(meta.data(), d_meta, 8 * 4 * (size_t)NR, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         std::vector<uint64_t> off((size_t)NR + 1, 0);
         uint64_t nd_all = 0;
         for (int r = 0; r < NR; ++r) { off[r + 1] = off[r] + meta[4 * r]; nd_all += meta[4 * r + 1]; }
-        if (off[NR] >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "more than 2^32 reliable k-mers");
         Buf ncode, ncount;
-        int r2 = ensure_bytes(c, ncode, 8 * off[NR]);
+        int r2 = off[NR] >= 0xFFFFFFF0ull ? fail(c, BELLA_ERR_BAD_ARG, "more than 2^32 reliable k-mers") : 0;
+        if (!r2) r2 = ensure_bytes(c, ncode, 8 * off[NR]);
         if (!r2) r2 = ensure_bytes(c, ncount, 2 * off[NR] + 16);
+        r2 = comm_agree(c, r2);                                    // all ranks hold their receive buffers, or all leave
         if (r2) { release(ncode); release(ncount); return r2; }
+        hipError_t he = hipSuccess;
         if (nk_total) {
-            HIPCHK(c, hipMemcpyAsync(ptr<uint64_t>(ncode) + off[me], c->kc_dcode.p, 8 * nk_total, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(ptr<uint8_t>(ncount) + 2 * off[me], c->kc_dcount.p, 2 * nk_total, hipMemcpyDeviceToDevice, c->stream));
+            he = hipMemcpyAsync(ptr<uint64_t>(ncode) + off[me], c->kc_dcode.p, 8 * nk_total, hipMemcpyDeviceToDevice, c->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(ptr<uint8_t>(ncount) + 2 * off[me], c->kc_dcount.p, 2 * nk_total, hipMemcpyDeviceToDevice, c->stream);
         }
-        NCCLCHK(c, rccl().GroupStart());
-        for (int p2 = 0; p2 < NR; ++p2) {
+        ncclResult_t nr2 = c->api->GroupStart();
+        for (int p2 = 0; p2 < NR && nr2 == ncclSuccess; ++p2) {
             if (p2 == me) continue;
             const uint64_t pn = meta[4 * p2];
             if (nk_total) {
-                NCCLCHK(c, rccl().Send(c->kc_dcode.p, nk_total, ncclUint64, p2, c->comm, c->stream));
-                NCCLCHK(c, rccl().Send(c->kc_dcount.p, 2 * nk_total, ncclUint8, p2, c->comm, c->stream));
+                nr2 = c->api->Send(c->kc_dcode.p, nk_total, ncclUint64, p2, c->comm, c->stream);
+                if (nr2 == ncclSuccess) nr2 = c->api->Send(c->kc_dcount.p, 2 * nk_total, ncclUint8, p2, c->comm, c->stream);
             }
-            if (pn) {
-                NCCLCHK(c, rccl().Recv(ptr<uint64_t>(ncode) + off[p2], pn, ncclUint64, p2, c->comm, c->stream));
-                NCCLCHK(c, rccl().Recv(ptr<uint8_t>(ncount) + 2 * off[p2], 2 * pn, ncclUint8, p2, c->comm, c->stream));
+            if (pn && nr2 == ncclSuccess) {
+                nr2 = c->api->Recv(ptr<uint64_t>(ncode) + off[p2], pn, ncclUint64, p2, c->comm, c->stream);
+                if (nr2 == ncclSuccess) nr2 = c->api->Recv(ptr<uint8_t>(ncount) + 2 * off[p2], 2 * pn, ncclUint8, p2, c->comm, c->stream);
             }
         }
-        NCCLCHK(c, rccl().GroupEnd());
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        {   // the group is closed on every path
+            const ncclResult_t ge = c->api->GroupEnd();
+            if (nr2 == ncclSuccess) nr2 = ge;
+        }
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (nr2 != ncclSuccess || he != hipSuccess) {
+            release(ncode); release(ncount);
+            return fail(c, BELLA_ERR_HIP, "dictionary exchange failed: %s", nr2 != ncclSuccess ? (c->api->GetErrorString ? c->api->GetErrorString(nr2) : "RCCL error") : hipGetErrorString(he));
+        }
         release(c->kc_dcode); release(c->kc_dcount);
         c->kc_dcode = ncode; c->kc_dcount = ncount;
         nk_total = off[NR];
@@ -1122,57 +1185,93 @@ int bella_hip_set_B_device(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, co
 }
 
 // ---- multi-GPU: RCCL communicator + panel all-gather -------------------------------------------------------------------------
-int bella_hip_comm_id(uint8_t id[BELLA_HIP_COMM_ID_BYTES]) {
+int bella_hip_comm_available(void) { return rccl().ok() ? 1 : 0; }
+
+static int comm_id_impl(const Rccl& api, uint8_t id[BELLA_HIP_COMM_ID_BYTES]) {
     if (!id) return BELLA_ERR_BAD_ARG;
-    if (!rccl().ok()) return BELLA_ERR_STATE;
+    if (!api.ok()) return BELLA_ERR_STATE;
     ncclUniqueId u;
     static_assert(sizeof(u) == BELLA_HIP_COMM_ID_BYTES, "ncclUniqueId size");
-    if (rccl().GetUniqueId(&u) != ncclSuccess) return BELLA_ERR_HIP;
+    if (api.GetUniqueId(&u) != ncclSuccess) return BELLA_ERR_HIP;
     std::memcpy(id, &u, sizeof(u));
     return 0;
 }
+int bella_hip_comm_id(uint8_t id[BELLA_HIP_COMM_ID_BYTES]) { return comm_id_impl(rccl(), id); }
+int bella_hip_comm_id_local(uint8_t id[BELLA_HIP_COMM_ID_BYTES]) { return comm_id_impl(loopback(), id); }
 
-int bella_hip_comm_init(bella_ctx* c, int nranks, int rank, const uint8_t id[BELLA_HIP_COMM_ID_BYTES]) {
+static int comm_init_impl(bella_ctx* c, const Rccl& api, int nranks, int rank, const uint8_t id[BELLA_HIP_COMM_ID_BYTES]) {
     if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, BELLA_ERR_BAD_ARG, "bad communicator arguments");
-    if (!rccl().ok()) return fail(c, BELLA_ERR_STATE, "librccl could not be loaded");
+    if (!api.ok()) return fail(c, BELLA_ERR_STATE, "librccl could not be loaded");
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
+    if (c->comm && c->api) { (void)c->api->CommDestroy(c->comm); c->comm = nullptr; }
+    c->api = &api;
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof(u));
-    NCCLCHK(c, rccl().CommInitRank(&c->comm, nranks, u, rank));
+    NCCLCHK(c, api.CommInitRank(&c->comm, nranks, u, rank));
     c->comm_ranks = nranks;
     c->comm_rank = rank;
     return 0;
 }
+int bella_hip_comm_init(bella_ctx* c, int nranks, int rank, const uint8_t id[BELLA_HIP_COMM_ID_BYTES]) {
+    return comm_init_impl(c, rccl(), nranks, rank, id);
+}
+int bella_hip_comm_init_local(bella_ctx* c, int nranks, int rank, const uint8_t id[BELLA_HIP_COMM_ID_BYTES]) {
+    return comm_init_impl(c, loopback(), nranks, rank, id);
+}
 
 int bella_hip_comm_destroy(bella_ctx* c) {
     if (!c) return BELLA_ERR_BAD_ARG;
-    if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
+    if (c->comm && c->api) { (void)c->api->CommDestroy(c->comm); c->comm = nullptr; }
     c->comm_ranks = 0;
+    return 0;
+}
+
+// Collective agreement: every rank contributes its local status; if any rank failed, ALL return an error here, together (a rank
+// that left a collective entry point on a local error would leave its peers waiting in the next exchange).
+static int comm_agree(bella_ctx* c, int local_rc) {
+    const int N = c->comm_ranks;
+    if (ensure_bytes(c, c->comm_meta, 8 * 4 * ((size_t)N + 1))) local_rc = local_rc ? local_rc : BELLA_ERR_NOMEM;
+    if (!c->comm_meta.p) return local_rc ? local_rc : BELLA_ERR_NOMEM;      // (nothing to exchange through: cannot happen after the first call)
+    uint64_t* d_meta = ptr<uint64_t>(c->comm_meta);
+    const uint64_t mine = local_rc ? 1 : 0;
+    std::vector<uint64_t> all((size_t)N, 0);
+    hipError_t e = hipMemcpyAsync(d_meta + 4 * (size_t)N, &mine, 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    ncclResult_t r = c->api->AllGather(d_meta + 4 * (size_t)N, d_meta, 1, ncclUint64, c->comm, c->stream);
+    if (r != ncclSuccess) return local_rc ? local_rc : fail(c, BELLA_ERR_HIP, "status exchange failed");
+    if (e == hipSuccess) e = hipMemcpyAsync(all.data(), d_meta, 8 * (size_t)N, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return local_rc ? local_rc : fail(c, BELLA_ERR_HIP, "status exchange: %s", hipGetErrorString(e));
+    if (local_rc) return local_rc;
+    for (int q = 0; q < N; ++q)
+        if (all[(size_t)q]) return fail(c, BELLA_ERR_STATE, "rank %d failed inside the collective call; all ranks leave it", q);
     return 0;
 }
 
 int bella_hip_allgather_panels(bella_ctx* c) {
     if (!c) return BELLA_ERR_BAD_ARG;
     if (!c->comm) return fail(c, BELLA_ERR_STATE, "bella_hip_comm_init first");
-    if (!c->have_panel) return fail(c, BELLA_ERR_STATE, "assemble_panel first");
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->comm_ranks, me = c->comm_rank;
+    // a rank without a panel still takes part in the status exchange: all ranks leave the call together
+    int rc = comm_agree(c, c->have_panel ? 0 : fail(c, BELLA_ERR_STATE, "assemble_panel first"));
+    if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     // who holds what: {first read, rows, nnz} of every rank
     ENSURE(c, c->comm_meta, 8 * 4 * ((size_t)N + 1));
     uint64_t mine[4] = {c->panel_first, c->panel_rows, c->panel_nnz, c->nkmers};
     uint64_t* d_meta = ptr<uint64_t>(c->comm_meta);
     HIPCHK(c, hipMemcpyAsync(d_meta + 4 * (size_t)N, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
-    NCCLCHK(c, rccl().AllGather(d_meta + 4 * (size_t)N, d_meta, 4, ncclUint64, c->comm, c->stream));
+    NCCLCHK(c, c->api->AllGather(d_meta + 4 * (size_t)N, d_meta, 4, ncclUint64, c->comm, c->stream));
     std::vector<uint64_t> meta(4 * (size_t)N);
     HIPCHK(c, hipMemcpyAsync(meta.data(), d_meta, 8 * 4 * (size_t)N, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // (the checks below see the same numbers on every rank: all ranks fail them together)
     std::vector<uint64_t> roff((size_t)N + 1, 0), eoff((size_t)N + 1, 0);
     for (int r = 0; r < N; ++r) {
         if (meta[4 * r] != roff[r]) return fail(c, BELLA_ERR_BAD_ARG, "panels must be consecutive read blocks in rank order (rank %d starts at %llu, expected %llu)",
                                                 r, (unsigned long long)meta[4 * r], (unsigned long long)roff[r]);
-        if (meta[4 * r + 3] != c->nkmers) return fail(c, BELLA_ERR_BAD_ARG, "rank %d counted a different k-mer dictionary", r);
+        if (meta[4 * r + 3] != meta[3]) return fail(c, BELLA_ERR_BAD_ARG, "rank %d counted a different k-mer dictionary", r);
         roff[r + 1] = roff[r] + meta[4 * r + 1];
         eoff[r + 1] = eoff[r] + meta[4 * r + 2];
     }
@@ -1180,38 +1279,44 @@ int bella_hip_allgather_panels(bella_ctx* c) {
     const uint64_t nnz = eoff[N];
     if (nnz >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "nnz(A) must be < 2^32");
     Buf nCnt, nBk, nBpos, nBptr;
-    int rc = ensure_bytes(c, nCnt, 4 * ((size_t)c->nreads + 2));
+    rc = ensure_bytes(c, nCnt, 4 * ((size_t)c->nreads + 2));
     if (!rc) rc = ensure_bytes(c, nBptr, 4 * ((size_t)c->nreads + 2));
     if (!rc) rc = ensure_bytes(c, nBk, 4 * nnz);
     if (!rc) rc = ensure_bytes(c, nBpos, 2 * nnz + 16);
+    rc = comm_agree(c, rc);                                       // all ranks hold the full arrays, or all leave
     if (rc) { release(nCnt); release(nBk); release(nBpos); release(nBptr); return rc; }
     // one grouped exchange: to every peer my block, from every peer its block, straight to its place in the full arrays
     uint32_t* cnt = ptr<uint32_t>(nCnt);
     uint32_t* bk = ptr<uint32_t>(nBk);
     uint8_t* bpos = ptr<uint8_t>(nBpos);
-    HIPCHK(c, hipMemsetAsync(cnt + c->nreads, 0, 8, c->stream));
-    HIPCHK(c, hipMemcpyAsync(cnt + roff[me], c->rowcnt.p, 4 * (size_t)c->panel_rows, hipMemcpyDeviceToDevice, c->stream));
-    if (c->panel_nnz) {
-        HIPCHK(c, hipMemcpyAsync(bk + eoff[me], c->Bk.p, 4 * (size_t)c->panel_nnz, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(bpos + 2 * eoff[me], c->Bpos.p, 2 * (size_t)c->panel_nnz, hipMemcpyDeviceToDevice, c->stream));
-    }
+    hipError_t he = hipMemsetAsync(cnt + c->nreads, 0, 8, c->stream);
+    if (he == hipSuccess && c->panel_rows) he = hipMemcpyAsync(cnt + roff[me], c->rowcnt.p, 4 * (size_t)c->panel_rows, hipMemcpyDeviceToDevice, c->stream);
+    if (he == hipSuccess && c->panel_nnz) he = hipMemcpyAsync(bk + eoff[me], c->Bk.p, 4 * (size_t)c->panel_nnz, hipMemcpyDeviceToDevice, c->stream);
+    if (he == hipSuccess && c->panel_nnz) he = hipMemcpyAsync(bpos + 2 * eoff[me], c->Bpos.p, 2 * (size_t)c->panel_nnz, hipMemcpyDeviceToDevice, c->stream);
+    ncclResult_t nr2 = ncclSuccess;
     if (N > 1) {
-        NCCLCHK(c, rccl().GroupStart());
-        for (int p = 0; p < N; ++p) {
+        nr2 = c->api->GroupStart();
+        for (int p = 0; p < N && nr2 == ncclSuccess; ++p) {
             if (p == me) continue;
             const uint64_t prow = meta[4 * p + 1], pnnz = meta[4 * p + 2];
-            if (c->panel_rows) NCCLCHK(c, rccl().Send(c->rowcnt.p, c->panel_rows, ncclUint32, p, c->comm, c->stream));
-            if (prow) NCCLCHK(c, rccl().Recv(cnt + roff[p], prow, ncclUint32, p, c->comm, c->stream));
-            if (c->panel_nnz) {
-                NCCLCHK(c, rccl().Send(c->Bk.p, c->panel_nnz, ncclUint32, p, c->comm, c->stream));
-                NCCLCHK(c, rccl().Send(c->Bpos.p, 2 * c->panel_nnz, ncclUint8, p, c->comm, c->stream));
+            if (c->panel_rows) nr2 = c->api->Send(c->rowcnt.p, c->panel_rows, ncclUint32, p, c->comm, c->stream);
+            if (prow && nr2 == ncclSuccess) nr2 = c->api->Recv(cnt + roff[p], prow, ncclUint32, p, c->comm, c->stream);
+            if (c->panel_nnz && nr2 == ncclSuccess) {
+                nr2 = c->api->Send(c->Bk.p, c->panel_nnz, ncclUint32, p, c->comm, c->stream);
+                if (nr2 == ncclSuccess) nr2 = c->api->Send(c->Bpos.p, 2 * c->panel_nnz, ncclUint8, p, c->comm, c->stream);
             }
-            if (pnnz) {
-                NCCLCHK(c, rccl().Recv(bk + eoff[p], pnnz, ncclUint32, p, c->comm, c->stream));
-                NCCLCHK(c, rccl().Recv(bpos + 2 * eoff[p], 2 * pnnz, ncclUint8, p, c->comm, c->stream));
+            if (pnnz && nr2 == ncclSuccess) {
+                nr2 = c->api->Recv(bk + eoff[p], pnnz, ncclUint32, p, c->comm, c->stream);
+                if (nr2 == ncclSuccess) nr2 = c->api->Recv(bpos + 2 * eoff[p], 2 * pnnz, ncclUint8, p, c->comm, c->stream);
             }
         }
-        NCCLCHK(c, rccl().GroupEnd());
+        const ncclResult_t ge = c->api->GroupEnd();               // the group is closed on every path
+        if (nr2 == ncclSuccess) nr2 = ge;
+    }
+    if (nr2 != ncclSuccess || he != hipSuccess) {
+        (void)hipStreamSynchronize(c->stream);
+        release(nCnt); release(nBk); release(nBpos); release(nBptr);
+        return fail(c, BELLA_ERR_HIP, "panel exchange failed: %s", nr2 != ncclSuccess ? (c->api->GetErrorString ? c->api->GetErrorString(nr2) : "RCCL error") : hipGetErrorString(he));
     }
     rc = scan_u32(c, cnt, ptr<uint32_t>(nBptr), (uint64_t)c->nreads + 1);
     if (!rc) { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) rc = fail(c, BELLA_ERR_HIP, "allgather_panels: %s", hipGetErrorString(e)); }
@@ -1361,8 +1466,7 @@ static int run_wide(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint3
     std::vector<uint32_t> wf((size_t)nw + 1);
     HIPCHK(c, hipMemcpyAsync(wf.data(), c->w_f.p, 4 * ((size_t)nw + 1), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    uint64_t budget = 1ull << 30;
-    if (const char* e = getenv("BELLA_HIP_WIDE_BUDGET")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) budget = v; }
+    const uint64_t budget = c->wide_budget;
     for (uint32_t b = 0; b < nw;) {
         uint64_t t = wf[b];
         uint32_t e = b + 1;
@@ -1376,7 +1480,7 @@ static int run_wide(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint3
 
 static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out, int depth = 0) {
     const uint32_t nr = c->nreads;
-    const bool force_global = (c->debug & 1u) != 0;
+    const bool force_global = (c->debug & 1u) != 0 || !c->lane_order_ok;   // (self-test failed: every column on the repairing path)
     const bool want_ext = (c->debug & 2u) == 0;
     const uint64_t ws_stride = (row_mem_bytes(65535, 65535, false) + 255) & ~(size_t)255;
     ENSURE(c, c->flopsr, 4 * ((size_t)nr + 2));
@@ -1688,6 +1792,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         if (nr) {
             OrderArgs oa;
             oa.flopptr = ptr<uint64_t>(c->flopptr); oa.colptrC = ptr<uint64_t>(c->colptrC); oa.nnzC = ptr<uint32_t>(c->nnzC);
+            oa.flops = ptr<uint32_t>(c->flopsr);
             oa.nreads = nr; oa.i0 = i0; oa.stride = c->part_stride; oa.nown = nown;
             oa.tmp_pairs = ptr<bella_pair>(c->tmp_pairs); oa.tmp_ext = want_ext ? ptr<bella_pair_ext>(c->tmp_ext) : nullptr;
             oa.pairs = ptr<bella_pair>(c->pairs); oa.ext = want_ext ? ptr<bella_pair_ext>(c->ext) : nullptr;
@@ -1869,10 +1974,10 @@ static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_se
     a.delta = p->delta_chernoff;
     HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
     if (n) {
-        if (getenv("BELLA_HIP_XDROP_SCALAR")) {
+        if (c->xdrop_variant == 3) {
             k_xdrop<<<nblk(n, kXdropPairsPerBlock), kXdropBlock, 0, c->stream>>>(a);
             KCHK(c);
-        } else if (getenv("BELLA_HIP_XDROP_UNSORTED")) {
+        } else if (c->xdrop_variant == 2) {
             k_xdrop_packed<<<nblk(n, kXdropPairsPerBlock), kXdropBlock, 0, c->stream>>>(a);
             KCHK(c);
         } else {
@@ -1899,8 +2004,42 @@ static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_se
             HIPCHK(c, hipcub::DeviceRadixSort::SortPairsDescending(c->cubtmp.p, tb, ptr<uint32_t>(c->xest), ptr<uint32_t>(c->xest2),
                                                                   ptr<uint32_t>(c->xids), ptr<uint32_t>(c->xorder), (int)ne, 0, 18,
                                                                   c->stream));
-            k_xdrop_sorted<<<nblk(ne, kXdropBlock), kXdropBlock, 0, c->stream>>>(sa);
-            KCHK(c);
+            if (c->xdrop_variant == 0) {                           // one launch: a wavefront runs until its longest lane ends (measured equal to the slices: DESIGN 4.2)
+                k_xdrop_sorted<<<nblk(ne, kXdropBlock), kXdropBlock, 0, c->stream>>>(sa);
+                KCHK(c);
+            } else {
+                // slices (xdrop_packed.hpp): the state of the live extensions lives in HBM between launches of at most kXdropSlice steps;
+                // every launch runs full wavefronts of survivors.  Batches bound the state memory (288 B per extension).
+                const uint64_t capB = ne < (16ull << 20) ? ne : (16ull << 20);
+                ENSURE(c, c->xstate, 4 * (size_t)kXStateWords * capB);
+                ENSURE(c, c->xlive, 2 * 4 * capB + 64);
+                XdropSliceArgs xa;
+                xa.s = sa;
+                xa.state = ptr<uint32_t>(c->xstate);
+                xa.cap = capB;
+                uint32_t* const lists[2] = {ptr<uint32_t>(c->xlive), ptr<uint32_t>(c->xlive) + capB};
+                uint32_t* const counts = ptr<uint32_t>(c->xlive) + 2 * capB;     // two counters
+                for (uint64_t first = 0; first < ne; first += capB) {
+                    xa.first = first;
+                    xa.count = ne - first < capB ? ne - first : capB;
+                    k_xdrop_begin<<<nblk(xa.count, kXdropBlock), kXdropBlock, 0, c->stream>>>(xa);
+                    KCHK(c);
+                    uint64_t live = xa.count;
+                    xa.live_in = nullptr; xa.nlive_in = nullptr;
+                    for (int it = 0; live; ++it) {
+                        const int o = it & 1;
+                        xa.live_out = lists[o]; xa.nlive_out = counts + o;
+                        HIPCHK(c, hipMemsetAsync(xa.nlive_out, 0, 4, c->stream));
+                        k_xdrop_slice<<<nblk(live, kXdropBlock), kXdropBlock, 0, c->stream>>>(xa);
+                        KCHK(c);
+                        HIPCHK(c, hipMemcpyAsync(c->pinned + 100, xa.nlive_out, 4, hipMemcpyDeviceToHost, c->stream));
+                        HIPCHK(c, hipStreamSynchronize(c->stream));
+                        live = c->pinned[100];
+                        xa.live_in = xa.live_out; xa.nlive_in = xa.nlive_out;
+                        if (it > 4096) return fail(c, BELLA_ERR_STATE, "internal: X-drop slices do not terminate");
+                    }
+                }
+            }
             k_xdrop_finish<<<nblk(n), 256, 0, c->stream>>>(sa);
             KCHK(c);
         }

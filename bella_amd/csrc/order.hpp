@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include "../../include/bella_hip.h"
 #include "core.hpp"
+#include "slotorder.hpp"
 #include "util.hpp"
 
 namespace bella {
@@ -31,6 +32,7 @@ struct OrderArgs {
     const uint64_t* flopptr;     // where a column's records stand in tmp_pairs
     const uint64_t* colptrC;     // ... and where they go
     const uint32_t* nnzC;        // pairs per column (| kOrderedBit: already in slot order, cid already the column)
+    const uint32_t* flops;       // products per column: the first product indices (insertion times) lie below it
     uint32_t nreads, i0, stride, nown;
     const bella_pair* tmp_pairs;
     const bella_pair_ext* tmp_ext;
@@ -72,21 +74,33 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_wave(OrderArgs a) {
         return;
     }
     uint32_t* T2 = s_T2[wave_id()];
-    uint16_t* ord = s_ord[wave_id()];
+    uint16_t* ord = s_ord[wave_id()];                        // next-free table during the rounds, then rank -> record
     for (uint32_t s = lane; s < ht; s += 64) T2[s] = kEmpty;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // (one wavefront: its LDS operations execute in order; this keeps the compiler's order)
-    for (uint32_t j = lane; j < d; j += 64) {
-        const uint2 kf = *(const uint2*)(a.tmp_pairs + src + j);          // {key, first product}
-        uint32_t item = (kf.y << 16) | j;
-        uint32_t h = (kf.x * 107u) & (ht - 1);
-        for (;;) {
-            const uint32_t old = atomicMin(&T2[h], item);
-            if (old == kEmpty) break;
-            if (old > item) item = old;                       // we took the slot; the displaced entry resumes probing
-            h = (h + 1) & (ht - 1);
-        }
+    constexpr uint32_t NI = kOrderWaveHt / 64;               // records per lane
+    uint32_t key[NI], fp[NI];
+#pragma unroll
+    for (uint32_t u = 0; u < NI; ++u) {
+        const uint32_t j = lane + 64 * u;
+        key[u] = 0; fp[u] = 0xFFFFFFFFu;
+        if (j < d) { const uint2 kf = *(const uint2*)(a.tmp_pairs + src + j); key[u] = kf.x; fp[u] = kf.y; }   // {key, first product}
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    group_sync<64>();
+    const uint32_t tmax = a.flops[i];
+    uint32_t prev = 0;
+    for (uint32_t rd = 0;; ++rd) {                            // rounds by insertion time (slotorder.hpp)
+        const uint32_t bound = round_bound(rd, ht, d, tmax);
+        if (rd) { (void)build_next_free<64>(T2, ord, ht, nullptr); group_sync<64>(); }
+#pragma unroll
+        for (uint32_t u = 0; u < NI; ++u) {
+            if (fp[u] < prev || fp[u] >= bound) continue;
+            const uint32_t home = (key[u] * 107u) & (ht - 1), item = (fp[u] << 16) | (lane + 64 * u);
+            if (rd) slot_insert<true>(T2, ord, ht - 1, home, item);
+            else slot_insert<false>(T2, ord, ht - 1, home, item);
+        }
+        group_sync<64>();
+        if (bound >= tmax) break;
+        prev = bound;
+    }
     {
         const uint32_t c = ht >= 64 ? ht / 64 : 1u;
         const uint32_t lo = lane * c < ht ? lane * c : ht, hi = lo + c < ht ? lo + c : ht;
@@ -98,8 +112,22 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_wave(OrderArgs a) {
             if (it != kEmpty) ord[rank++] = (uint16_t)(it & 0xFFFFu);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    for (uint32_t r = lane; r < d; r += 64) order_copy_record(a, src + ord[r], dst + r, i);
+    group_sync<64>();
+    {   // four records in flight per lane
+        uint32_t r = lane;
+        for (; r + 192 < d; r += 256) {
+            uint4 rec[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) rec[u] = *(const uint4*)(a.tmp_pairs + src + ord[r + 64 * u]);
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) { rec[u].y = i; *(uint4*)(a.pairs + dst + r + 64 * u) = rec[u]; }
+            if (a.ext) {
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) a.ext[dst + r + 64 * u] = a.tmp_ext[src + ord[r + 64 * u]];
+            }
+        }
+        for (; r < d; r += 64) order_copy_record(a, src + ord[r], dst + r, i);
+    }
 }
 
 // one workgroup per column (persistent): the columns k_order_wave listed
@@ -119,18 +147,22 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_block(OrderArgs a) {
         else { uint8_t* w = a.ws + (uint64_t)blockIdx.x * kOrderWsBytes; T2 = (uint32_t*)w; ord = (uint16_t*)(w + (size_t)4 * 65536); }
         for (uint32_t s = tid; s < ht; s += kOrderBlock) T2[s] = kEmpty;
         __syncthreads();
-        for (uint32_t j = tid; j < d; j += kOrderBlock) {
-            const uint2 kf = *(const uint2*)(a.tmp_pairs + src + j);
-            uint32_t item = (kf.y << 16) | j;
-            uint32_t h = (kf.x * 107u) & (ht - 1);
-            for (;;) {
-                const uint32_t old = atomicMin(&T2[h], item);
-                if (old == kEmpty) break;
-                if (old > item) item = old;
-                h = (h + 1) & (ht - 1);
+        const uint32_t tmax = a.flops[i];
+        uint32_t prev = 0;
+        for (uint32_t rd = 0;; ++rd) {                        // rounds by insertion time (slotorder.hpp); ord doubles as the next-free table
+            const uint32_t bound = round_bound(rd, ht, d, tmax);
+            if (rd) { (void)build_next_free<(int)kOrderBlock>(T2, ord, ht, scr); __syncthreads(); }
+            for (uint32_t j = tid; j < d; j += kOrderBlock) {
+                const uint2 kf = *(const uint2*)(a.tmp_pairs + src + j);
+                if (kf.y < prev || kf.y >= bound) continue;
+                const uint32_t home = (kf.x * 107u) & (ht - 1), item = (kf.y << 16) | j;
+                if (rd) slot_insert<true>(T2, ord, ht - 1, home, item);
+                else slot_insert<false>(T2, ord, ht - 1, home, item);
             }
+            __syncthreads();
+            if (bound >= tmax) break;
+            prev = bound;
         }
-        __syncthreads();
         {
             const uint32_t c = (ht + kOrderBlock - 1) / kOrderBlock;
             const uint32_t lo = tid * c < ht ? tid * c : ht, hi = lo + c < ht ? lo + c : ht;

@@ -99,7 +99,7 @@ inline int write_output_impl(const char* path, const bella_params* p, int paf, u
     int T = nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency();
     if (T < 1) T = 1;
     if (T > 256) T = 256;
-    if ((uint64_t)T > npairs / 4096 + 1) T = (int)(npairs / 4096 + 1);
+    if ((uint64_t)T > npairs / 32768 + 1) T = (int)(npairs / 32768 + 1);       // (a thread per ~2 MB of text: below that its start-up costs more)
     std::vector<uint32_t> name_len(nreads);
     for (uint32_t r = 0; r < nreads; ++r) name_len[r] = (uint32_t)std::strlen(names[r]);
     std::vector<WriteShare> W((size_t)T);

@@ -359,6 +359,283 @@ __global__ __launch_bounds__(kXdropBlock) void k_xdrop_sorted(XdropSortedArgs sa
     sa.res[e] = make_int4(res.best, res.endH, res.endV, (res.flagged & 1) | (ran ? 2 : 0) | (res.steps << 2));
 }
 
+// ---- slices: no lane waits for the longest extension of its wavefront ------------------------------------------------------
+// k_xdrop_sorted runs a wavefront until its LONGEST lane ends: even in length-sorted order about a fifth of the lane-steps are
+// idle tails.  Here an extension's state lives in HBM between launches (72 words: the two band vectors and the two sequence
+// windows of the band, the scalars) and the work goes in SLICES of at most kXdropSlice anti-diagonal steps: k_xdrop_begin runs
+// Phase 1 (xavier.h:20-103) for every extension and stores its state; every launch of k_xdrop_slice loads the state of the
+// extensions still alive -- compacted: every wavefront is full --, steps them, and stores the survivors for the next launch.
+// A lane idles at most the rest of ONE slice (half a slice on average against ~4,300 steps per extension).  Phase 2 and
+// Phase 4 (xavier.h:105-183 / :185-251) are one loop body with a per-lane mode.  Same arithmetic as
+// xavier_one_direction_packed, same results.
+#ifndef BELLA_XDROP_SLICE
+#define BELLA_XDROP_SLICE 256
+#endif
+constexpr int kXdropSlice = BELLA_XDROP_SLICE;
+constexpr uint32_t kXStateWords = 72;       // a1[16] a2[16] qh[16] qv[16] best off hoff voff endH endV flags e
+struct XdropSliceArgs {
+    XdropSortedArgs s;
+    uint32_t* state;             // [kXStateWords][cap]: word w of slot t at state[w * cap + t]
+    uint64_t cap;                // slots of this batch
+    uint64_t first;              // position of the batch's first extension in the sorted order
+    uint64_t count;              // extensions of the batch
+    const uint32_t* live_in;     // slots to step (nullptr: all slots of the batch, first launch)
+    const uint32_t* nlive_in;    // their number (device)
+    uint32_t* live_out;          // survivors
+    uint32_t* nlive_out;
+};
+
+// flags word: maxpos (5 bits) | first << 5 | flagged << 6 | mode4 << 7 | dir << 8 | it4 << 9 (5 bits) | dead << 15
+__global__ __launch_bounds__(kXdropBlock) void k_xdrop_begin(XdropSliceArgs xa) {
+    __shared__ int8_t dpm[132 * kXdropBlock];
+    const XdropSortedArgs& sa = xa.s;
+    const XdropArgs& a = sa.a;
+    const uint64_t t = (uint64_t)blockIdx.x * kXdropBlock + threadIdx.x;
+    if (t >= xa.count) return;
+    const uint32_t e = sa.order[xa.first + t];
+    uint32_t* const st = xa.state + t;
+    const uint64_t cap = xa.cap;
+    uint32_t rid, cid, seedH, seedV;
+    xdrop_load_pair(a, e >> 1, rid, cid, seedH, seedV);
+    const uint64_t goffH = a.roff[rid], goffV = a.roff[cid];
+    PairGeom g;
+    make_geom(a.packed, goffH, (uint32_t)(a.roff[rid + 1] - goffH), goffV, (uint32_t)(a.roff[cid + 1] - goffV), seedH, seedV, a.k, g);
+    SeqAcc Hacc, Vacc;
+    make_accessors(a.packed, goffH, goffV, g, (int)(e & 1), Hacc, Vacc);
+    st[71 * cap] = e;
+    if (!(Hacc.len >= (uint32_t)kXW && Vacc.len >= (uint32_t)kXW)) {
+        sa.res[e] = make_int4(0, 0, 0, 0);                         // did not run (xavier.h:338-342 / :356-360)
+        st[70 * cap] = 1u << 15;
+        return;
+    }
+    SeqWin H, V;
+    H.packed = Hacc.packed; H.g0 = Hacc.g0; H.dir = Hacc.dir; H.comp = Hacc.comp ? 0xFFFFFFFFu : 0u; H.len = Hacc.len;
+    V.packed = Vacc.packed; V.g0 = Vacc.g0; V.dir = Vacc.dir; V.comp = Vacc.comp ? 0xFFFFFFFFu : 0u; V.len = Vacc.len;
+    // ---- Phase 1 (xavier.h:20-103): scalar DP on the 33x33 upper-left triangle (once per extension)
+    int8_t* const dp = dpm + threadIdx.x;
+    constexpr int dps = kXdropBlock;
+    const uint64_t hp = (uint64_t)H.block16(0) | ((uint64_t)H.block16(16) << 32);
+    const uint64_t vp = (uint64_t)V.block16(0) | ((uint64_t)V.block16(16) << 32);
+    int8_t* prev = dp;
+    int8_t* cur = dp + 34 * dps;
+    int8_t* ex1 = dp + 68 * dps;
+    int8_t* ex2 = dp + 100 * dps;
+    for (int j = 0; j < 34; ++j) prev[j * dps] = (int8_t)(-j);
+    int DPmax = 0;
+    for (int i = 1; i < kXLW + 2; ++i) {
+        cur[0] = (int8_t)(-i);
+        const int hc = (int)((hp >> (2 * (i - 1))) & 3);
+        int left = -i;
+        for (int j = 1; j <= kXLW + 2 - i; ++j) {
+            const int vc = (int)((vp >> (2 * (j - 1))) & 3);
+            const int oneF = (int)prev[(j - 1) * dps] + (hc == vc ? 1 : -1);
+            const int twoF = imax_((int)prev[j * dps], left) - 1;
+            const int val = imax_(oneF, twoF);
+            cur[j * dps] = (int8_t)val;
+            left = val;
+            DPmax = imax_(DPmax, val);
+        }
+        if (i <= kXLW) ex1[(i - 1) * dps] = cur[(kXLW + 1 - i) * dps];
+        if (i >= 2) ex2[(i - 1) * dps] = cur[(kXLW + 2 - i) * dps];
+        int8_t* tmp = prev; prev = cur; cur = tmp;
+    }
+    int adm = -128;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e0 = 2 * i, e1 = 2 * i + 1;
+        const int a1x = (int)ex1[e0 * dps], a1y = e1 < kXLW ? (int)ex1[e1 * dps] : kXNinf;
+        const int a2x = e0 >= 1 ? (int)ex2[e0 * dps] : kXNinf, a2y = (int)ex2[e1 * dps];
+        adm = imax_(adm, a1x);
+        if (e1 < kXLW) adm = imax_(adm, a1y);
+        // vqueryh[e] = queryh[e+1], vqueryv[e] = queryv[31-e] for e < 31; cell 31 = a marker that equals itself
+        const int hx = (int)((hp >> (2 * (e0 + 1))) & 3), hy = e1 < kXLW ? (int)((hp >> (2 * ((e1 + 1) & 31))) & 3) : 7;
+        const int vx = (int)((vp >> (2 * (kXLW - e0))) & 3), vy = e1 < kXLW ? (int)((vp >> (2 * (kXLW - e1))) & 3) : 7;
+        st[(uint64_t)i * cap] = u32_of(mk2(a1x * kXScale, a1y * kXScale));
+        st[(uint64_t)(16 + i) * cap] = u32_of(mk2(a2x * kXScale, a2y * kXScale));
+        st[(uint64_t)(32 + i) * cap] = u32_of(mk2(hx * kQScale, hy * kQScale));
+        st[(uint64_t)(48 + i) * cap] = u32_of(mk2(vx * kQScale, vy * kQScale));
+    }
+    if (adm < DPmax - a.xdrop) {                                   // xavier.h:96-101: X-drop inside Phase 1
+        sa.res[e] = make_int4(DPmax, kXLW, kXLW, 2);
+        st[70 * cap] = 1u << 15;
+        return;
+    }
+    st[64 * cap] = (uint32_t)DPmax; st[65 * cap] = 0u; st[66 * cap] = (uint32_t)kXLW; st[67 * cap] = (uint32_t)kXLW;
+    st[68 * cap] = (uint32_t)kXLW; st[69 * cap] = (uint32_t)kXLW;
+    st[70 * cap] = 1u << 5;                                        // maxpos 0, first, not flagged, Phase 2
+}
+
+__global__ __launch_bounds__(kXdropBlock, 4) void k_xdrop_slice(XdropSliceArgs xa) {
+    const XdropSortedArgs& sa = xa.s;
+    const XdropArgs& a = sa.a;
+    const uint64_t x = (uint64_t)blockIdx.x * kXdropBlock + threadIdx.x;
+    const uint64_t nlive = xa.live_in ? (uint64_t)*xa.nlive_in : xa.count;
+    const uint64_t cap = xa.cap;
+    bool active = x < nlive;
+    uint64_t t = 0;
+    uint32_t flags = 1u << 15;
+    if (active) {
+        t = xa.live_in ? (uint64_t)xa.live_in[x] : x;
+        flags = xa.state[70 * cap + t];
+        active = !(flags >> 15);
+    }
+    const unsigned long long any = __ballot(active);
+    if (!any) return;
+    uint32_t* const st = xa.state + t;
+    s2 a1[16], a2[16], a3[16], qh[16], qv[16];
+    int best = 0, off = 0, hoff = kXLW, voff = kXLW, endH = 0, endV = 0;
+    uint32_t e = 0;
+    SeqWin H, V;
+    H.packed = a.packed; V.packed = a.packed; H.g0 = 0; V.g0 = 0; H.dir = 1; V.dir = 1; H.comp = 0; V.comp = 0; H.len = 64; V.len = 64;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            a1[i] = s2_of(st[(uint64_t)i * cap]); a2[i] = s2_of(st[(uint64_t)(16 + i) * cap]);
+            qh[i] = s2_of(st[(uint64_t)(32 + i) * cap]); qv[i] = s2_of(st[(uint64_t)(48 + i) * cap]);
+        }
+        best = (int)st[64 * cap]; off = (int)st[65 * cap]; hoff = (int)st[66 * cap]; voff = (int)st[67 * cap];
+        endH = (int)st[68 * cap]; endV = (int)st[69 * cap]; e = st[71 * cap];
+        uint32_t rid, cid, seedH, seedV;
+        xdrop_load_pair(a, e >> 1, rid, cid, seedH, seedV);
+        const uint64_t goffH = a.roff[rid], goffV = a.roff[cid];
+        PairGeom g;
+        make_geom(a.packed, goffH, (uint32_t)(a.roff[rid + 1] - goffH), goffV, (uint32_t)(a.roff[cid + 1] - goffV), seedH, seedV, a.k, g);
+        SeqAcc Hacc, Vacc;
+        make_accessors(a.packed, goffH, goffV, g, (int)(e & 1), Hacc, Vacc);
+        H.g0 = Hacc.g0; H.dir = Hacc.dir; H.comp = Hacc.comp ? 0xFFFFFFFFu : 0u; H.len = Hacc.len;
+        V.g0 = Vacc.g0; V.dir = Vacc.dir; V.comp = Vacc.comp ? 0xFFFFFFFFu : 0u; V.len = Vacc.len;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a1[i] = splat2(0); a2[i] = splat2(0); qh[i] = splat2(0); qv[i] = splat2(0); }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a3[i] = splat2(0);
+    H.init((uint32_t)hoff);
+    V.init((uint32_t)voff);
+    const int hl = (int)H.len + 1, vl = (int)V.len + 1;
+    int maxpos = (int)(flags & 31u), flagged = (int)((flags >> 6) & 1u), dir = (int)((flags >> 8) & 1u), it4 = (int)((flags >> 9) & 31u);
+    bool first = ((flags >> 5) & 1u) != 0, mode4 = ((flags >> 7) & 1u) != 0;
+    const int X = a.xdrop;
+    const s2 one = splat2(kXScale), mone = splat2(-kXScale), ninf = splat2(kXNinf * kXScale), top = splat2(kXTop), q1 = splat2(kQScale);
+
+#define BELLA_PSTEP()                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                 \
+        const s2 xr = s2_of(u32_of(qh[i]) ^ u32_of(qv[i]));                                                           \
+        const s2 mt = one - pmin(xr, q1);                                                                             \
+        const s2 a1f = pmin(adds2(a1[i], mt), top);                                                                   \
+        const s2 shv = shl_cell(a2[i], i < 15 ? a2[i < 15 ? i + 1 : 15] : ninf);                                      \
+        const s2 a2f = adds2(pmax(shv, a2[i]), mone);                                                                 \
+        a3[i] = pmax(a1f, a2f);                                                                                       \
+    }                                                                                                                 \
+    a3[15].y = (short)(kXNinf * kXScale);
+#define BELLA_PKEY(keyout)                                                                                           \
+    {                                                                                                                 \
+        s2 kk = a3[0] + mk2(31, 30);                                                                                  \
+        _Pragma("unroll") for (int i = 1; i < 16; ++i) kk = pmax(kk, a3[i] + mk2(31 - 2 * i, 30 - 2 * i));            \
+        keyout = imax_((int)kk.x, (int)kk.y);                                                                         \
+    }
+#define BELLA_PREBASE()                                                                                              \
+    {                                                                                                                 \
+        s2 mn2 = a3[0];                                                                                               \
+        _Pragma("unroll") for (int i = 1; i < 15; ++i) mn2 = pmin(mn2, a3[i]);                                        \
+        const int mn = imin_(imin_((int)mn2.x, (int)mn2.y), (int)a3[15].x) >> 8;                                      \
+        const s2 mnv = splat2(mn * kXScale);                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) { a2[i] = pmin(subs2(a2[i], mnv), top); a3[i] = pmin(subs2(a3[i], mnv), top); } \
+        off += mn;                                                                                                    \
+    }
+#define BELLA_PMOVE(right, c)                                                                                        \
+    {                                                                                                                 \
+        const uint32_t selL = (right) ? 0x05040302u : 0x03020100u;                                                    \
+        const uint32_t selD = (right) ? 0x07060504u : 0x05040302u;                                                    \
+        const uint32_t nf = u32_of(ninf);                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                                \
+            a1[i] = s2_of(__builtin_amdgcn_perm(i < 15 ? u32_of(a2[i < 15 ? i + 1 : 15]) : nf, u32_of(a2[i]), selL));      \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                                \
+            a2[i] = s2_of(__builtin_amdgcn_perm(u32_of(a3[i]), i > 0 ? u32_of(a3[i > 0 ? i - 1 : 0]) : nf, selD));        \
+        _Pragma("unroll") for (int i = 0; i < 15; ++i)                                                                \
+            qh[i] = s2_of(__builtin_amdgcn_perm(u32_of(qh[i + 1]), u32_of(qh[i]), selL));                              \
+        qh[15] = (right) ? mk2((c) * kQScale, 7 * kQScale) : qh[15];                                                  \
+        {                                                                                                             \
+            const uint32_t q0 = u32_of(qv[0]);                                                                        \
+            _Pragma("unroll") for (int i = 15; i >= 1; --i)                                                           \
+                qv[i] = s2_of(__builtin_amdgcn_perm(u32_of(qv[i]), u32_of(qv[i - 1]), selD));                          \
+            qv[0] = (right) ? s2_of(q0) : s2_of((q0 << 16) | (uint32_t)((c) * kQScale));                              \
+        }                                                                                                             \
+    }
+
+    // one loop, single exit (an in-loop return makes the compiler keep two copies of the band state): a finished lane stores
+    // its result and idles for the rest of the slice
+    bool done = false;
+    for (int step = 0; step < kXdropSlice; ++step) {
+        if (!__ballot(active && !done)) break;                    // (wave-uniform)
+        if ((step & 15) == 0) { H.checkpoint((uint32_t)hoff); V.checkpoint((uint32_t)voff); }
+        BELLA_PSTEP()
+        int key;
+        BELLA_PKEY(key)
+        const int adb = key >> 8;
+        const int curr = adb + off;
+        const bool live = active && !done;
+        const bool drop = curr < best - X;
+        if (live && drop) {
+            // xavier.h:128-135 (Phase 2: the seed ends at the current offsets) / :212-219 (Phase 4: at the last Phase-2 offsets)
+            sa.res[e] = make_int4(best, mode4 ? endH : hoff, mode4 ? endV : voff, (flagged & 1) | 2 | (((hoff - kXLW) + (voff - kXLW)) << 2));
+            done = true;
+        }
+        if (live && !drop) {
+            if (adb > kXCutoff) {
+                BELLA_PREBASE()
+                if (!mode4) BELLA_PKEY(key)
+            }
+            if (curr > best) best = curr;
+            bool right;
+            if (!mode4) {
+                if ((key >> 8) > 0) maxpos = 31 - (key & 31);
+                else if (first) flagged = 1;
+                first = false;
+                endH = hoff; endV = voff;
+                right = maxpos > kXMiddle;
+            } else {
+                dir ^= 1;
+                right = dir == 0;
+            }
+            const int c = right ? H.code((uint32_t)hoff) : V.code((uint32_t)voff);
+            hoff += right ? 1 : 0;
+            voff += right ? 0 : 1;
+            BELLA_PMOVE(right, c)
+            if (!mode4) {
+                if (!(hoff < hl && voff < vl)) { mode4 = true; dir = hoff >= hl ? 1 : 0; it4 = 0; }   // xavier.h:185-190
+            } else if (++it4 == kXLW - 3) {
+                sa.res[e] = make_int4(best, endH, endV, (flagged & 1) | 2 | (((hoff - kXLW) + (voff - kXLW)) << 2));
+                done = true;
+            }
+        }
+    }
+#undef BELLA_PSTEP
+#undef BELLA_PKEY
+#undef BELLA_PREBASE
+#undef BELLA_PMOVE
+    if (active && done) st[70 * cap] = 1u << 15;
+    const bool keep = active && !done;
+    if (keep) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            st[(uint64_t)i * cap] = u32_of(a1[i]); st[(uint64_t)(16 + i) * cap] = u32_of(a2[i]);
+            st[(uint64_t)(32 + i) * cap] = u32_of(qh[i]); st[(uint64_t)(48 + i) * cap] = u32_of(qv[i]);
+        }
+        st[64 * cap] = (uint32_t)best; st[65 * cap] = (uint32_t)off; st[66 * cap] = (uint32_t)hoff; st[67 * cap] = (uint32_t)voff;
+        st[68 * cap] = (uint32_t)endH; st[69 * cap] = (uint32_t)endV;
+        st[70 * cap] = (uint32_t)maxpos | ((first ? 1u : 0u) << 5) | ((uint32_t)flagged << 6) | ((mode4 ? 1u : 0u) << 7) | ((uint32_t)dir << 8) | ((uint32_t)it4 << 9);
+    }
+    // survivors, compacted: one atomic per wavefront, the wavefront's survivors stay together (similar remaining lengths)
+    const unsigned long long km = __ballot(keep);
+    if (km) {
+        uint32_t base = 0;
+        if (lane_id() == (uint32_t)(__ffsll((long long)km) - 1)) base = atomicAdd(xa.nlive_out, (uint32_t)__popcll(km));
+        base = (uint32_t)__shfl((int)base, __ffsll((long long)km) - 1, 64);
+        if (keep) xa.live_out[base + (uint32_t)__popcll(km & ((1ull << lane_id()) - 1ull))] = (uint32_t)t;
+    }
+}
+
 __global__ void k_xdrop_finish(XdropSortedArgs sa) {
     const XdropArgs& a = sa.a;
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

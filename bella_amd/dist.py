@@ -90,24 +90,46 @@ def allgather_panels(rowcnt, rowids, values, group=None):
 def init_comm(eng, device_index: int, backend: str = "nccl") -> bool:
     """All ranks call once: creates the library's own RCCL communicator (bella_hip_comm_init); the 128-byte id travels over
     torch.distributed.  Returns False (and leaves the context without a communicator) when that is not possible -- "gloo"
-    backend in CPU-rendezvous tests, or librccl missing: the callers then use the torch.distributed paths."""
+    backend in CPU-rendezvous tests, or librccl missing: the callers then use the torch.distributed paths.
+    The sequence of collectives is the same on every rank whatever fails where: (1) all-reduce "librccl loads here" -- the only
+    way the collective bella_hip_comm_init can fail on SOME ranks, so nobody enters it unless everybody can; (2) broadcast of
+    (flag, id) from rank 0 -- a rank 0 that could not make the id says so in the flag; (3) comm_init; (4) all-reduce of its status."""
+    import sys
     import torch
     import torch.distributed as dist
     if backend != "nccl":
         return False
     world, rank = dist.get_world_size(), dist.get_rank()
+    dev = torch.device("cuda", device_index)
     try:
-        dev = torch.device("cuda", device_index)
-        raw = eng.comm_id() if rank == 0 else bytes(128)
-        t = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
-        dist.broadcast(t, src=0)
-        eng.comm_init(world, rank, bytes(t.cpu().tolist()))
-        ok = 1
+        can = 1 if eng.comm_available() else 0
+    except Exception:
+        can = 0
+    flag = torch.tensor([can], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if rank == 0:
+            print("[bella_amd.dist] librccl is not loadable on every rank; using torch.distributed", file=sys.stderr)
+        return False
+    raw, ok_id = bytes(128), 1
+    if rank == 0:
+        try:
+            raw = eng.comm_id()
+        except Exception as e:
+            print("[bella_amd.dist] bella_hip_comm_id failed (%r); using torch.distributed" % (e,), file=sys.stderr)
+            ok_id = 0
+    t = torch.tensor([ok_id] + list(raw), dtype=torch.uint8, device=dev)
+    dist.broadcast(t, src=0)                                 # unconditional: every rank is here
+    vals = t.cpu().tolist()
+    if vals[0] == 0:
+        return False
+    ok = 1
+    try:
+        eng.comm_init(world, rank, bytes(vals[1:]))
     except Exception as e:
-        import sys
-        print("[bella_amd.dist] library communicator unavailable (%r); using torch.distributed" % (e,), file=sys.stderr)
+        print("[bella_amd.dist] rank %d: bella_hip_comm_init failed (%r)" % (rank, e), file=sys.stderr)
         ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", device_index))
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # all ranks take the same path
     if int(flag.item()) == 0:
         try:

@@ -103,7 +103,7 @@ def timed_passes(eng, pars, steps, warmup, sync):
         acc["rows"] += tm.spgemm_ms
         acc["fold"] += tm.fold_ms
         acc["sym"] += tm.symbolic_ms
-        acc["comp"] += tm.compact_ms
+        acc["comp"] += tm.compact_ms                       # k_order_*: slot order + move to the final place
         acc["launches"] += tm.spgemm_launches
         acc["retry"] = max(acc.get("retry", 0), int(tm.retry_columns))
     sync()
@@ -114,28 +114,101 @@ def timed_passes(eng, pars, steps, warmup, sync):
 
 def roofline_of(acc, nnz_share, copy_gbps, traffic_key):
     alg_bytes = 14.0 * nnz_share + 6.0 * float(acc["flops"]) + 16.0 * float(acc["npairs"])
-    k_ms = (acc["rows"] + acc["fold"]) / acc["steps"]
+    k_ms = (acc["rows"] + acc["fold"] + acc["comp"]) / acc["steps"]
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-         "kernel": "SpGEMM = k_spgemm_rows_lds (one launch set = the concurrent LDS-class launches of a pass) + k_fold_overflow",
+         "kernel": "SpGEMM numeric phase = k_spgemm_rows_lds (one launch set = the concurrent LDS-class launches of a pass) + k_fold_overflow "
+                   "+ k_order_wave/_block (the reference's slot order inside every column and the move of the records to their final place)",
          "kernel_ms_per_step": k_ms, "launches_per_step": acc["launches"] / acc["steps"], "algorithmic_bytes_per_step": alg_bytes,
          "columns_redone_on_global_path": acc.get("retry", 0),
          "measured_copy_ceiling_GBps": copy_gbps}
     # HBM traffic of the same kernels from the PMC counters (tools/collect_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes,
     # gfx950 FETCH_SIZE x2 correction calibrated on our own stream): a profiling run, so read from the committed summary
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))[traffic_key]
-        if abs(tr["algorithmic_bytes"] - alg_bytes) < 1e-3 * alg_bytes:
-            r["traffic"] = tr["hbm_bytes_corrected"]
-            r["traffic_source"] = "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per step)"
-    except Exception:
-        pass
+    for tag in ("r03", "r02"):
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag)))[traffic_key]
+            if abs(tr["algorithmic_bytes"] - alg_bytes) < 1e-3 * alg_bytes:
+                r["traffic"] = tr["hbm_bytes_corrected"]
+                r["traffic_source"] = "profiles/%s_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per step)" % tag
+                break
+        except Exception:
+            pass
     return r
 
 
 def phases_of(acc):
     s = acc["steps"]
-    return {"symbolic+tiering": acc["sym"] / s, "row_kernels": acc["rows"] / s, "overflow_fold": acc["fold"] / s, "compaction": acc["comp"] / s}
+    return {"symbolic+tiering": acc["sym"] / s, "row_kernels": acc["rows"] / s, "overflow_fold": acc["fold"] / s,
+            "slot_order+placement": acc["comp"] / s}
+
+
+def assemble_record(info, nnz):
+    """assembly (tuples -> rows of B in MergeDuplicates slot order -> device layout B' / A'): SURVEY 8d bytes 8*T + 6*nnz(A)"""
+    alg = 8.0 * info["ntuples"] + 6.0 * nnz
+    ms = info["asm_ms"]
+    ach = alg / (ms * 1e-3) / 1e9 if ms else 0.0
+    return {"ms": ms, "rows_ms": info.get("rows_ms"), "layout_ms": info.get("layout_ms"), "tuples": int(info["ntuples"]),
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                         "algorithmic_bytes": alg, "kernel": "k_asm_rows_* + radix sort of the entries by k-mer + k_layout_* (one call)"}}
+
+
+def xdrop_record(eng, workload):
+    """RunPairWiseAlignments on the candidate pairs the engine holds (one pass, outside the SpGEMM timing)"""
+    from bella_amd import BellaPars
+    apars = BellaPars()
+    eng.overlap(apars)
+    npass = eng.align_pairs(apars)
+    xms = eng.timings().xdrop_ms
+    al = eng.get_alignments()
+    steps_tot = float(al["steps"].astype(np.float64).sum())
+    rec = {"workload": workload % len(al), "pairs": int(len(al)), "passed": int(npass), "ms": xms,
+           "pairs_per_s": len(al) / (xms * 1e-3) if xms else None, "antidiagonal_steps": steps_tot,
+           "gcups": 31 * steps_tot / (xms * 1e-3) / 1e9 if xms else None, "flagged": int(al["flagged"].sum()),
+           "bound": "VALU issue: packed-i16 / v_perm band updates issue one wavefront-instruction per SIMD every 4 cycles "
+                    "(profiles/r03_valu_rates.txt)"}
+    del al
+    return rec
+
+
+def dropin_call_record(rs, Bhost, nk, device):
+    """The call the drop-in shim makes (bella_amd/host/bella_hip_shim.hpp: HashSpGEMM --skip-alignment), step by step through the C
+    ABI on a FRESH context, wall-clock: host reads in, the reference's CSC of B in, ONE cold pass, records out, output file."""
+    import tempfile
+    from bella_amd import BellaPars, Engine
+    from bella_amd.api import write_output, _ACGT
+    pars = BellaPars(skipAlignment=True)
+    asc = np.ascontiguousarray(_ACGT[rs.codes])
+    offs = np.ascontiguousarray(rs.offsets, dtype=np.uint64)
+    rec = {}
+    t_all = time.perf_counter()
+    t0 = time.perf_counter(); eng = Engine(device); rec["init_ms"] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter(); eng.set_reads_raw(asc, offs, names=rs.names); rec["set_reads_ms"] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter(); eng.set_B(17, nk, *Bhost); rec["set_B_ms"] = (time.perf_counter() - t0) * 1e3
+    rec["set_B_device_layout_ms"] = eng.timings().layout_ms
+    t0 = time.perf_counter(); npairs, flops = eng.overlap(pars); rec["cold_overlap_ms"] = (time.perf_counter() - t0) * 1e3
+    rec["cold_overlap_device_ms"] = eng.timings().overlap_total_ms
+    t0 = time.perf_counter(); pairs, _, colptr = eng.get_pairs(ext=False); rec["get_pairs_ms"] = (time.perf_counter() - t0) * 1e3
+    with tempfile.TemporaryDirectory() as tmp:
+        f = os.path.join(tmp, "out.out")
+        open(f, "wb").close()
+        st = write_output(f, pars, rs.names, rs.lengths, pairs)
+        rec["writer_ms"] = st.seconds * 1e3
+        rec["writer_format_ms"] = st.format_seconds * 1e3
+        rec["writer_threads"] = int(st.threads)
+        rec["output_bytes"] = int(st.bytes)
+        rec["output_lines"] = int(st.lines)
+        # one host thread on a bounded sample (<= 2M lines): what the multi-threaded writer is measured against
+        ns = min(len(pairs), 2000000)
+        open(f, "wb").close()
+        s1 = write_output(f, pars, rs.names, rs.lengths, pairs[:ns], nthreads=1)
+        rec["writer_1thread_ms_scaled"] = s1.seconds * 1e3 * (len(pairs) / max(ns, 1))
+        rec["writer_speedup_vs_1thread"] = rec["writer_1thread_ms_scaled"] / rec["writer_ms"] if rec["writer_ms"] else None
+    rec["total_ms"] = (time.perf_counter() - t_all) * 1e3 - s1.seconds * 1e3
+    rec["pairs"] = int(npairs)
+    rec["what"] = ("fresh context -> bella_hip_set_reads (ASCII bases from pageable host memory) -> bella_hip_set_B (the reference's CSC "
+                   "arrays) -> bella_hip_overlap (first pass) -> bella_hip_get_pairs -> bella_hip_write_output; wall clock on the host")
+    eng.close()
+    return rec
 
 
 def main():
@@ -147,7 +220,9 @@ def main():
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-100k", action="store_true", help="N=1: skip the config_100k sub-record")
-    ap.add_argument("--no-xdrop", action="store_true", help="N=1: skip the X-drop record (configs[2])")
+    ap.add_argument("--no-xdrop", action="store_true", help="N=1: skip the X-drop records (configs[2]; configs[3]'s alignment stage)")
+    ap.add_argument("--no-hifi", action="store_true", help="N=1: skip the config_hifi sub-record (configs[4]'s regime, 10k HiFi reads)")
+    ap.add_argument("--no-dropin", action="store_true", help="N=1: skip the dropin_call records (the shim's call sequence, cold, wall clock)")
     ap.add_argument("--debug-flags", type=int, default=0, help="extra bella_hip_set_debug bits (development A/B)")
     ap.add_argument("--cpu-baseline-child", default=None)
     ap.add_argument("--threads", type=int, default=0)
@@ -219,7 +294,7 @@ def main():
             nk, nt, ndistinct = eng.count_kmers(17, 2, 8)
         else:
             have_dist_count = True
-        info = {"rs": rs, "nk": nk, "kcount_ms": eng.timings().kcount_ms, "xchg_ms": None, "xchg_path": None, "have_comm": have_comm,
+        info = {"rs": rs, "nk": nk, "ntuples": nt, "kcount_ms": eng.timings().kcount_ms, "xchg_ms": None, "xchg_path": None, "have_comm": have_comm,
                 "kcount_path": "bella_hip_count_kmers_dist (code space split over the ranks)" if have_dist_count else "bella_hip_count_kmers (every rank, all reads)"}
         info["tup"] = synth.Tuples(*eng.get_tuples(), nk) if want_host_tuples else None
         if rank == 0:
@@ -228,6 +303,8 @@ def main():
         if world == 1:
             eng.assemble_counted()
             info["asm_ms"] = eng.timings().assemble_ms
+            info["rows_ms"] = eng.timings().rows_ms
+            info["layout_ms"] = eng.timings().layout_ms
         else:
             eng.assemble_counted_panel(lo, npanel)             # from the device-resident tuples of this rank's read block
             info["asm_ms"] = eng.timings().assemble_ms
@@ -288,35 +365,37 @@ def main():
             "phases_ms_per_step": phases_of(acc),
             "kcount_ms": info["kcount_ms"], "assemble_ms": info["asm_ms"], "panel_allgather_ms": None,
         }
+        out["assemble"] = assemble_record(info, nnz)
         if not a.no_xdrop:
             # configs[2]: the X-drop stage on the same candidate pairs (one pass, outside the SpGEMM timing)
-            apars = BellaPars()
-            eng.overlap(apars)
-            npass = eng.align_pairs(apars)
-            xms = eng.timings().xdrop_ms
-            al = eng.get_alignments()
-            steps_tot = float(al["steps"].astype(np.float64).sum())
-            out["xdrop"] = {"workload": "configs[2]: X-drop (xdrop=7) on the %d candidate pairs of the 10k set" % len(al), "pairs": int(len(al)),
-                            "passed": int(npass), "ms": xms, "pairs_per_s": len(al) / (xms * 1e-3) if xms else None,
-                            "antidiagonal_steps": steps_tot, "gcups": 31 * steps_tot / (xms * 1e-3) / 1e9 if xms else None,
-                            "flagged": int(al["flagged"].sum()), "bound": "VALU issue (profiles/r02_xdrop_sq.txt)"}
-            try:   # VALU issue rate of k_xdrop_sorted from the committed SQ counters (a profiling run): wave-instructions per SIMD-cycle / 0.25
+            out["xdrop"] = xdrop_record(eng, "configs[2]: X-drop (xdrop=7) on the %d candidate pairs of the 10k set")
+            try:   # VALU issue rate of k_xdrop_sorted from the committed SQ counters (a profiling run) against the MEASURED issue rate of
+                   # its instruction mix (tools/ubench/valu_rates.hip: v_pk_* / v_perm_b32 issue every 4.15 cycles per SIMD at ~2.4 GHz)
                 import re
-                ln = [l for l in open(os.path.join(ROOT, "profiles", "r02_xdrop_sq.txt")) if "k_xdrop_sorted" in l][0]
-                us = float(re.search(r"\| ([0-9.]+) us \|", ln).group(1))
-                valu = float(re.search(r"SQ_INSTS_VALU=([0-9.e+]+)", ln).group(1))
-                out["xdrop"]["valu_issue_frac"] = valu / (us * 1e-6 * 2.4e9 * 1024 * 0.25)
-                out["xdrop"]["valu_issue_frac_source"] = "profiles/r02_xdrop_sq.txt: SQ_INSTS_VALU / (kernel time x 2.4 GHz x 1024 SIMDs x 1/4)"
+                for tag in ("r03", "r02"):
+                    fn = os.path.join(ROOT, "profiles", "%s_xdrop_sq.txt" % tag)
+                    if not os.path.exists(fn):
+                        continue
+                    ln = [l for l in open(fn) if "k_xdrop_sorted" in l or "k_xdrop_refill" in l][0]
+                    us = float(re.search(r"\| ([0-9.]+) us \|", ln).group(1))
+                    valu = float(re.search(r"SQ_INSTS_VALU=([0-9.e+]+)", ln).group(1))
+                    out["xdrop"]["valu_issue_frac"] = valu / (us * 1e-6 * 2.4e9 * 1024 / 4.15)
+                    out["xdrop"]["valu_issue_frac_source"] = ("profiles/%s_xdrop_sq.txt: SQ_INSTS_VALU / (kernel time x 2.4 GHz x 1024 SIMDs / 4.15 "
+                                                              "cycles per packed/perm wavefront-instruction, profiles/r03_valu_rates.txt)" % tag)
+                    break
             except Exception:
                 pass
-            del al
+        Bhost = eng.get_B() if not a.no_dropin else None
         if not a.no_cpu_baseline:
             tup = info["tup"]
             cb = run_cpu_baseline(info["rs"].codes, info["rs"].offsets, tup.kmer, tup.read, tup.pos, tup.nkmers, "the whole workload (%d reads)" % nreads)
             cb["pairs_match_gpu"] = cb.pop("pairs") == int(acc["npairs"])
             out["cpu_baseline"] = cb
         eng.close()
-        del eng, info
+        if not a.no_dropin:
+            out["dropin_call"] = dropin_call_record(info["rs"], Bhost, info["nk"], local)
+            out["dropin_call"]["pairs_match_step"] = out["dropin_call"]["pairs"] == int(acc["npairs"])
+        del eng, info, Bhost
         if not a.no_100k and not a.reads:
             # configs[3]'s read set on ONE GPU: the configuration the 40 % HBM-roofline target is quoted on
             eng, info = prepare(BIG_READS, False)
@@ -328,7 +407,10 @@ def main():
                    "ms_per_step": acc["elapsed"] * 1e3 / 5, "value": acc["npairs"] / (acc["elapsed"] / 5), "unit": "pairs/s",
                    "reads": BIG_READS, "nkmers": info["nk"], "nnzA": nnz, "flops": int(acc["flops"]), "pairs": int(acc["npairs"]),
                    "roofline": roofline_of(acc, nnz, copy_gbps, "100k"), "phases_ms_per_step": phases_of(acc),
-                   "kcount_ms": info["kcount_ms"], "assemble_ms": info["asm_ms"]}
+                   "kcount_ms": info["kcount_ms"], "assemble_ms": info["asm_ms"], "assemble": assemble_record(info, nnz)}
+            if not a.no_xdrop:
+                # configs[3] is SpGEMM + alignment: the X-drop stage on ALL candidate pairs of the 100k set
+                sub["xdrop"] = xdrop_record(eng, "configs[3]'s alignment stage on one GPU: X-drop (xdrop=7) on the %d candidate pairs of the 100k set")
             if not a.no_cpu_baseline:
                 # bounded sample: the sub-problem of the first SAMPLE_READS reads (their rows of B, the 100k set's k-mer dictionary)
                 tk, tr, tp = eng.get_tuples()
@@ -339,26 +421,72 @@ def main():
                                       "bounded sample: reads 0..%d of the 100k set with the set's own k-mer dictionary" % (SAMPLE_READS - 1))
                 cb.pop("pairs")
                 sub["cpu_baseline"] = cb
-            out["config_100k"] = sub
+                del tk, tr, tp, keep
+            Bhost = eng.get_B() if not a.no_dropin else None
             eng.close()
+            if not a.no_dropin:
+                sub["dropin_call"] = dropin_call_record(info["rs"], Bhost, info["nk"], local)
+                sub["dropin_call"]["pairs_match_step"] = sub["dropin_call"]["pairs"] == int(acc["npairs"])
+            out["config_100k"] = sub
+            del eng, info, Bhost
+        if not a.no_hifi and not a.reads:
+            # configs[4]'s regime at single-GPU scale: 10k HiFi reads (15 kb, 0.5 % error, 30x), syncmer selection (-s), the reference's
+            # default bound -u 8 and the raised -u 40: hundreds of products per pair, columns above the LDS tiers
+            rs = synth.make_reads(10000, read_len=15000, coverage=30.0, err=0.005, seed=2, mix=(1 / 3, 1 / 3, 1 / 3))
+            hp = BellaPars(skipAlignment=True, errorRate=0.005)
+            hifi = {"workload": "configs[4]'s regime on one GPU: 10000 synthetic HiFi reads (15000 b, 0.5% err, 30x) k=17 syncmer mode (-s), SpGEMM-only"}
+            for upper in (8, 40):
+                eng = Engine(local)
+                eng.set_reads(rs)
+                nk, nt, _ = eng.count_kmers(17, 2, upper, syncmer=True)
+                kc = eng.timings().kcount_ms
+                eng.assemble_counted()
+                asm_ms = eng.timings().assemble_ms
+                eng.set_debug(2 | a.debug_flags)
+                acc = timed_passes(eng, hp, 5, 2, sync)
+                colptr, _, _ = eng.get_B()
+                nnz = int(colptr[-1])
+                hifi["u%d" % upper] = {"upper": upper, "nkmers": nk, "nnzA": nnz, "flops": int(acc["flops"]), "pairs": int(acc["npairs"]),
+                                       "ms_per_step": acc["elapsed"] * 1e3 / 5, "products_per_s": acc["flops"] / (acc["elapsed"] / 5),
+                                       "pairs_per_s": acc["npairs"] / (acc["elapsed"] / 5), "roofline": roofline_of(acc, nnz, copy_gbps, "hifi_u%d" % upper),
+                                       "phases_ms_per_step": phases_of(acc), "kcount_ms": kc, "assemble_ms": asm_ms}
+                eng.close()
+            out["config_hifi"] = hifi
         print(json.dumps(out))
         return
 
-    # ---- N > 1: strong scaling on the fixed 100k-read set ----
+    # ---- N > 1: strong scaling on the fixed 100k-read set (configs[3]: SpGEMM + alignment) ----
     nreads = a.reads or BIG_READS
-    eng, info = prepare(nreads, False)
-    eng.set_partition(rank, n_gpus)
-    eng.set_debug(2 | a.debug_flags)
-    acc = timed_passes(eng, pars, a.steps, a.warmup, sync)
     tdev = dev if backend == "nccl" else "cpu"
-    tt = torch.tensor([acc["elapsed"], float(acc["npairs"]), float(acc["flops"]), acc["rows"] + acc["fold"], info["kcount_ms"], info["asm_ms"]],
-                      dtype=torch.float64, device=tdev)
-    mx = tt.clone()
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    sm = tt.clone()
-    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-    elapsed = float(mx[0])
-    tot_pairs, tot_flops = float(sm[1]), float(sm[2])
+
+    def measure(eng, info):
+        """the timed SpGEMM step on this rank's columns; max over ranks of the times, sums of the counts"""
+        eng.set_partition(rank, n_gpus)
+        eng.set_debug(2 | a.debug_flags)
+        acc = timed_passes(eng, pars, a.steps, a.warmup, sync)
+        tt = torch.tensor([acc["elapsed"], acc["rows"] + acc["fold"] + acc["comp"], info["kcount_ms"], info["asm_ms"], info["xchg_ms"] or 0.0,
+                           float(acc["npairs"]), float(acc["flops"])], dtype=torch.float64, device=tdev)
+        mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        return {"acc": acc, "elapsed": float(mx[0]), "kernel_ms": float(mx[1]) / a.steps, "kcount_ms_max": float(mx[2]), "assemble_ms_max": float(mx[3]),
+                "xchg_ms_max": float(mx[4]), "pairs": float(sm[5]), "flops": float(sm[6])}
+
+    eng, info = prepare(nreads, False)                       # set-up through torch.distributed (every rank counts all reads)
+    mA = measure(eng, info)
+    xd = None
+    if not a.no_xdrop:
+        # configs[3]'s alignment stage: every rank aligns the candidate pairs of ITS columns (no exchange: reads are replicated)
+        apars = BellaPars()
+        eng.set_debug(a.debug_flags)
+        np_loc, _ = eng.overlap(apars)
+        npass = eng.align_pairs(apars)
+        xt = torch.tensor([eng.timings().xdrop_ms, float(np_loc), float(npass)], dtype=torch.float64, device=tdev)
+        xm = xt.clone(); dist.all_reduce(xm, op=dist.ReduceOp.MAX)
+        xs = xt.clone(); dist.all_reduce(xs, op=dist.ReduceOp.SUM)
+        xd = {"workload": "configs[3]'s alignment stage: X-drop (xdrop=7), every rank on the pairs of its own columns", "ms_max_over_ranks": float(xm[0]),
+              "pairs": int(xs[1]), "passed": int(xs[2]), "pairs_per_s": float(xs[1]) / (float(xm[0]) * 1e-3) if float(xm[0]) else None,
+              "largest_rank_share": float(xm[1]) / max(float(xs[1]), 1.0)}
+        eng.set_debug(2 | a.debug_flags)
     single = None
     if rank == 0:
         # the same workload on ONE GPU (rank 0 holds all operands): the denominator of the speed-up
@@ -366,75 +494,82 @@ def main():
         acc1 = timed_passes(eng, pars, 3, 1, torch.cuda.synchronize)
         single = {"ms_per_step": acc1["elapsed"] * 1e3 / 3, "value": acc1["npairs"] / (acc1["elapsed"] / 3), "pairs": int(acc1["npairs"])}
     dist.barrier()
+    colptr, _, _ = eng.get_B()
+    nnz = int(colptr[-1])
+
+    def line(m, setup):
+        elapsed = m["elapsed"]
+        return {
+            "metric": "candidate overlap pairs/sec", "value": m["pairs"] / (elapsed / a.steps), "unit": "pairs/s", "n_gpus": n_gpus, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": elapsed * 1e3 / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u16/u32 integer", "data": "synthetic",
+            "config": {"workload": "configs[3]: %d synthetic PacBio reads (%d b templates, 15%% err, 30x) k=17, row-block panels + one all-gather, "
+                                   "SpGEMM step on %d GPUs (fixed set: strong scaling); alignment stage reported in xdrop" % (nreads, a.read_len, n_gpus),
+                       "reads": nreads, "nkmers": info["nk"], "nnzA": nnz, "flops": int(m["flops"]), "pairs": int(m["pairs"]),
+                       "partition": "columns i %% %d == rank" % n_gpus, "setup": setup},
+            "roofline": roofline_of(m["acc"], nnz / n_gpus, copy_gbps, "none"),
+            "phases_ms_per_step": phases_of(m["acc"]),
+            "kcount_ms_max": m["kcount_ms_max"], "assemble_ms_max": m["assemble_ms_max"], "panel_allgather_ms": m["xchg_ms_max"],
+            "xdrop": xd,
+            "single_gpu_same_workload": single,
+            "speedup_vs_single_gpu": (single["ms_per_step"] / (elapsed * 1e3 / a.steps)) if single else None,
+            "pairs_match_single_gpu": (single["pairs"] == int(m["pairs"])) if single else None,
+        }
+
+    outA = line(mA, {"kcount": info["kcount_path"], "panel_allgather": info["xchg_path"]})
     import threading
     printed = threading.Lock()
-    out_box = {}
 
     def emit(o):
         if printed.acquire(blocking=False):
             print(json.dumps(o), flush=True)
 
-    lib = {"status": "not run"}
-    if (backend == "nccl" or os.environ.get("BELLA_BENCH_FORCE_LIB_PROBE")) and not os.environ.get("BELLA_BENCH_NO_LIBCOMM"):
-        def fire():                                          # watchdog: the measured line goes out without the library-path record
-            if rank == 0 and "out" in out_box:
-                o = dict(out_box["out"])
-                o["library_rccl_path"] = {"status": "timed out after %d s" % WATCHDOG_S}
-                emit(o)
-            os._exit(0)
-        WATCHDOG_S = int(os.environ.get("BELLA_BENCH_LIB_TIMEOUT", "240"))
-        lib["status"] = "pending"
-    else:
-        fire = None
-    def library_path_probe():
-        eng2, info2 = prepare(nreads, False, use_lib=True, rs=info["rs"])
-        if not info2["have_comm"]:
-            eng2.close()
-            return {"status": "communicator unavailable"}
-        eng2.set_partition(rank, n_gpus)
-        eng2.set_debug(2)
-        np2, fl2 = eng2.overlap(pars)
-        t2 = torch.tensor([float(np2), info2["kcount_ms"], info2["xchg_ms"] or 0.0], dtype=torch.float64, device=tdev)
-        s2 = t2.clone(); dist.all_reduce(s2, op=dist.ReduceOp.SUM)
-        m2 = t2.clone(); dist.all_reduce(m2, op=dist.ReduceOp.MAX)
-        eng2.close()
-        return {"status": "ok", "kcount_path": info2["kcount_path"], "kcount_ms_max": float(m2[1]), "panel_allgather_path": info2["xchg_path"],
-                "panel_allgather_ms": float(m2[2]), "pairs_match": int(s2[0]) == int(tot_pairs)}
-    colptr, _, _ = eng.get_B()
-    nnz = int(colptr[-1])
-    out = {
-        "metric": "candidate overlap pairs/sec", "value": tot_pairs / (elapsed / a.steps), "unit": "pairs/s", "n_gpus": n_gpus, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": elapsed * 1e3 / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "u16/u32 integer", "data": "synthetic",
-        "config": {"workload": "configs[3]: %d synthetic PacBio reads (%d b templates, 15%% err, 30x) k=17, row-block panels + one all-gather, "
-                               "SpGEMM-only step on %d GPUs (fixed set: strong scaling)" % (nreads, a.read_len, n_gpus),
-                   "reads": nreads, "nkmers": info["nk"], "nnzA": nnz, "flops": int(tot_flops), "pairs": int(tot_pairs),
-                   "partition": "columns i %% %d == rank" % n_gpus},
-        "roofline": roofline_of(acc, nnz / n_gpus, copy_gbps, "none"),
-        "phases_ms_per_step": phases_of(acc),
-        "kcount_ms_max": float(mx[4]), "assemble_ms_max": float(mx[5]), "panel_allgather_ms": info["xchg_ms"], "panel_allgather_path": info["xchg_path"], "kcount_path": info["kcount_path"],
-        "single_gpu_same_workload": single,
-        "speedup_vs_single_gpu": (single["ms_per_step"] / (elapsed * 1e3 / a.steps)) if single else None,
-        "pairs_match_single_gpu": (single["pairs"] == int(tot_pairs)) if single else None,
-    }
-    out_box["out"] = out
-    if fire is not None:
-        timer = threading.Timer(WATCHDOG_S, fire)
-        timer.daemon = True
-        timer.start()
-        try:
-            lib = library_path_probe()
-        except Exception as e:
-            lib = {"status": "failed: %r" % (e,)}
-        timer.cancel()
-    out["library_rccl_path"] = lib
-    if rank != 0:
+    # The library's own RCCL communicator (C ABI: bella_hip_comm_init, bella_hip_count_kmers_dist, bella_hip_allgather_panels) is the
+    # path the line reports when it works: the whole set-up and the timed step are run again through it; the torch.distributed
+    # measurement above is the fallback (and stays on the line as torch_distributed_path).  A watchdog prints the fallback line
+    # should the library path stall.
+    use_lib = (backend == "nccl" or os.environ.get("BELLA_BENCH_FORCE_LIB_PROBE")) and not os.environ.get("BELLA_BENCH_NO_LIBCOMM")
+    if not use_lib:
+        outA["library_rccl_path"] = {"status": "not run (%s backend)" % backend}
+        if rank == 0:
+            emit(outA)
         dist.destroy_process_group()
         return
-    # The same set-up once more through the library's own RCCL communicator (C ABI: bella_hip_comm_init, bella_hip_count_kmers_dist,
-    # bella_hip_allgather_panels), checked against the result above.  It runs AFTER the measurement and under a watchdog: should that
-    # path stall on this box, the line above is printed without it.
-    emit(out)
+    WATCHDOG_S = int(os.environ.get("BELLA_BENCH_LIB_TIMEOUT", "300"))
+
+    def fire():
+        if rank == 0:
+            o = dict(outA)
+            o["library_rccl_path"] = {"status": "timed out after %d s" % WATCHDOG_S}
+            emit(o)
+        os._exit(0)
+
+    timer = threading.Timer(WATCHDOG_S, fire)
+    timer.daemon = True
+    timer.start()
+    out = outA
+    try:
+        eng.close()
+        eng2, info2 = prepare(nreads, False, use_lib=True, rs=info["rs"])
+        if not info2["have_comm"]:
+            outA["library_rccl_path"] = {"status": "communicator unavailable"}
+        else:
+            mB = measure(eng2, info2)
+            ok = int(mB["pairs"]) == int(mA["pairs"])
+            if ok:
+                out = line(mB, {"kcount": info2["kcount_path"], "panel_allgather": info2["xchg_path"]})
+                out["library_rccl_path"] = {"status": "ok: this line", "pairs_match_torch_path": True}
+                out["torch_distributed_path"] = {"ms_per_step": outA["ms_per_step"], "value": outA["value"], "kcount_ms_max": outA["kcount_ms_max"],
+                                                 "assemble_ms_max": outA["assemble_ms_max"], "panel_allgather_ms": outA["panel_allgather_ms"]}
+            else:
+                outA["library_rccl_path"] = {"status": "pair count differs: %d vs %d" % (int(mB["pairs"]), int(mA["pairs"]))}
+        eng2.close()
+    except Exception as e:
+        outA["library_rccl_path"] = {"status": "failed: %r" % (e,)}
+        out = outA
+    timer.cancel()
+    if rank == 0:
+        emit(out)
     dist.destroy_process_group()
 
 

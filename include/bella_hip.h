@@ -108,6 +108,9 @@ typedef struct {
     uint32_t overflow_pairs;  /* last pass: pairs that ended with > 16 bins (serial fold with libstdc++'s sort order)       */
     float layout_ms;          /* part of assemble_ms: CSR of B -> device layout B' / A' (sort + segmented passes)           */
     float rows_ms;            /* part of assemble_ms: tuples -> rows of B in MergeDuplicates slot order (CSC.cpp:301-420)    */
+    uint32_t lane_order;      /* init-time self-test of the LDS-atomic lane order the LDS tiers rely on (phase S):
+                                 1 = holds; 2 = does not hold on this device/driver: every column takes the repairing
+                                 global-workspace path (correct, slower)                                                 */
 } bella_timings;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */
@@ -255,6 +258,13 @@ int bella_hip_xdrop_batch_exact(bella_ctx* ctx, const bella_seed* seeds, uint64_
 int bella_hip_comm_id(uint8_t id[BELLA_HIP_COMM_ID_BYTES]);
 int bella_hip_comm_init(bella_ctx* ctx, int nranks, int rank, const uint8_t id[BELLA_HIP_COMM_ID_BYTES]);
 int bella_hip_comm_destroy(bella_ctx* ctx);
+/* 1 if librccl can be loaded in this process (every rank can check this BEFORE the collective bella_hip_comm_init) */
+int bella_hip_comm_available(void);
+/* The same communicator interface over an in-process transport: the "ranks" are contexts of ONE process (each driven by its own
+ * host thread, on one GPU or several), rendezvous on the host, bytes moved with device-to-device copies.  Runs the N > 1 logic of
+ * the two collective entry points below without RCCL (tests on a single GPU; several contexts inside one host program). */
+int bella_hip_comm_id_local(uint8_t id[BELLA_HIP_COMM_ID_BYTES]);
+int bella_hip_comm_init_local(bella_ctx* ctx, int nranks, int rank, const uint8_t id[BELLA_HIP_COMM_ID_BYTES]);
 /* collective: needs a panel (rank r: rows [first_r, first_r + rows_r), the blocks in rank order covering all reads) */
 int bella_hip_allgather_panels(bella_ctx* ctx);
 /* collective k-mer counting (kmercount.hpp:467-677 + main.cpp:393-416 across the ranks; the reference's relative is --split-count,
@@ -273,6 +283,14 @@ int bella_hip_get_timings(bella_ctx* ctx, bella_timings* t);
  * LDS tiers takes the sort-based path of the wide columns (default: from 16 such columns in a pass on); bit6 = tests: that path
  * sorts on 64-bit keys on any input (default: 32-bit keys when column bits + read-id bits fit) */
 int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
+/* Per-context tuning parameters (tests and A/B measurements; nothing here changes results).  what:
+ *   BELLA_TUNE_LDS_TIERS      values = ascending product capacities of the row kernels' LDS tiers, each in [64, 11008] (n = 0: defaults)
+ *   BELLA_TUNE_KCOUNT_BUDGET  values[0] = k-mers per pass of the counting sort (default 2^30)
+ *   BELLA_TUNE_WIDE_BUDGET    values[0] = products per batch of the sort-based path of the wide columns (default 2^30)
+ *   BELLA_TUNE_XDROP_VARIANT  values[0] = 0 one launch in length-sorted order (default), 1 slices of 256 steps with compaction of the
+ *                             live extensions between launches, 2 packed kernel in pair order, 3 the scalar statement of xavier.h */
+enum { BELLA_TUNE_LDS_TIERS = 0, BELLA_TUNE_KCOUNT_BUDGET = 1, BELLA_TUNE_WIDE_BUDGET = 2, BELLA_TUNE_XDROP_VARIANT = 3 };
+int bella_hip_set_tuning(bella_ctx* ctx, uint32_t what, const uint64_t* values, uint32_t n);
 
 #ifdef __cplusplus
 }

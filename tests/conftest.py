@@ -6,6 +6,15 @@ import sys
 import numpy as np
 import pytest
 
+try:
+    # PyTorch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, no soname); libbella_hip.so links /opt/rocm's.  A
+    # process that initialises /opt/rocm's first and torch's afterwards holds two runtimes and torch finds "no HIP GPUs"; with torch
+    # loaded first both bind to one runtime (what `pytest tests/` does anyway: collecting test_multiproc_cpu.py imports torch).
+    # The tests that hand device memory to torch (panel tensors) need that order whatever subset of the suite runs.
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    pass
+
 # the reference (oracle/_ref) is only reproducible at one OpenMP thread; libgomp reads this at load
 os.environ.setdefault("OMP_NUM_THREADS", "1")
 

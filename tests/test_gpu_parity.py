@@ -120,6 +120,16 @@ def test_alignments_match_oracle_fieldwise(eng, golden):
         got = (int(a["score"]), int(a["begH"]), int(a["endH"]), int(a["begV"]), int(a["endV"]), int(a["ov"]), int(a["strand"]),
                int(a["passed"]), int(a["steps"]), int(a["flagged"]))
         assert got == exp, (rid, cid)
+    # the other statements of the same kernel (slices of 256 steps with compaction between launches; pair order; the scalar
+    # statement of xavier.h) give the same records, every field, every pair
+    for variant in (1, 2, 3):
+        eng.set_tuning("xdrop_variant", variant)
+        try:
+            assert eng.align_pairs(pars) == npass
+            other = eng.get_alignments()
+        finally:
+            eng.set_tuning("xdrop_variant")
+        assert np.array_equal(other, alns), variant
 
 
 def test_xavier_known_answers_on_gpu(eng):
@@ -139,10 +149,14 @@ def test_xavier_known_answers_on_gpu(eng):
         sd = np.zeros(1, api.SEED_DT)
         sd[0] = (rid, cid, i, j)
         a = eng.xdrop_batch(sd, BellaPars(kmerSize=k, xDrop=x))[0]
-        if a["flagged"]:
-            continue
         got = [int(a["score"]), int(a["begH"]), int(a["endH"]), int(a["begV"]), int(a["endV"])]
-        assert got == kat["expect"], kat["name"]
+        # every answer, flagged ones included, against the oracle (which defines the first maxpos as 0 where the reference reads an
+        # uninitialised variable, xavier.h:165); the reference's own answer for the unflagged ones
+        o = O.xavier_align(seqs[rid], seqs[cid], i, j, x, k)
+        assert got == [int(o["score"]), int(o["begH"]), int(o["endH"]), int(o["begV"]), int(o["endV"])], kat["name"]
+        assert int(a["flagged"]) == int(o["flagged"]), kat["name"]
+        if not a["flagged"]:
+            assert got == kat["expect"], kat["name"]
         if kat["kind"] == "align":
             assert ("c" if a["strand"] else "n") == kat["strand"]
 
@@ -565,7 +579,7 @@ def test_baseline_config3_100k_read_set_parity(eng):
     """BASELINE configs[3]'s read set (100k reads x 10 kb) on one GPU, the size the roofline target is quoted on and a different
     regime from 10k reads (~500 pairs per column, 92 % of them single-product, half-size key tables, four LDS classes):
       * every column's product count and pair count (colptrC) against the oracle's symbolic phase (all 100k columns, host cores),
-      * every record of 2,500 sampled columns (incl. the largest ones) against the oracle's numeric phase,
+      * every record of a quarter of the columns (every fourth column and the 200 pair-richest) against the oracle's numeric phase,
       * size-independent properties of all ~50 M records,
       * X-drop on ALL pairs, 20,000 of them (mostly chance pairs) against the oracle's scalar Xavier."""
     import time
@@ -592,7 +606,7 @@ def test_baseline_config3_100k_read_set_parity(eng):
         assert np.array_equal(a_, b_)
     per_row = np.diff(colptrC.astype(np.int64))
     big = np.argsort(per_row)[-200:]                                                 # the columns with the most pairs
-    sample = np.unique(np.concatenate([np.arange(0, rs.nreads, 43), big])).astype(np.uint32)
+    sample = np.unique(np.concatenate([np.arange(0, rs.nreads, 4), big])).astype(np.uint32)   # 25 % of the columns
     flop, nnzc, per_col = O.spgemm_parallel(seqs, nk, Bc, Br, Bv, sample, 17)
     t2 = time.time()
     assert flops == int(flop.astype(np.int64).sum())
@@ -671,51 +685,52 @@ def test_count_kmers_parameter_sweep(eng, k, lower, upper):
 
 
 @pytest.mark.parametrize("k,lower,upper", [(17, 2, 8), (6, 2, 60000), (11, 2, 30), (21, 2, 4), (32, 2, 8), (7, 3, 65535)])
-def test_count_syncmers_parameter_sweep(eng, k, lower, upper, monkeypatch):
+def test_count_syncmers_parameter_sweep(eng, k, lower, upper):
     """the reference's -s mode (SyncmerCount + canonical-lookup tuple loop), low-error reads so that syncmers repeat"""
     rs = synth.make_reads(60, read_len=1200, coverage=10.0, err=0.01, seed=13, mix=(1 / 3, 1 / 3, 1 / 3))
     eng.set_reads(rs)
     codes, counts, tk, tr, tp, ndist = O.count_kmers(rs.seqs(), k, lower, upper, True)
-    for budget in (None, "3000"):                                    # one pass, then several passes over the bins
-        if budget:
-            monkeypatch.setenv("BELLA_HIP_KCOUNT_BUDGET", budget)
+    for budget in (0, 3000):                                         # one pass, then several passes over the bins
+        eng.set_tuning("kcount_budget", budget)
         nk, nt, nd = eng.count_kmers(k, lower, upper, True)
         assert (nk, nt, nd) == (len(codes), len(tk), ndist)
         dc, dn = eng.get_dictionary()
         gk, gr, gp = eng.get_tuples()
         assert np.array_equal(dc, codes) and np.array_equal(dn, counts)
         assert np.array_equal(gk, tk) and np.array_equal(gr, tr) and np.array_equal(gp, tp)
+    eng.set_tuning("kcount_budget")
     with pytest.raises(BellaHipError):
         eng.count_kmers(5, 2, 8, True)
 
 
 @pytest.mark.parametrize("k,window,lower,upper", [(17, 10, 2, 8), (15, 1, 2, 30), (21, 50, 2, 8), (32, 7, 2, 8), (5, 3, 2, 65535),
                                                   (17, 3000, 2, 8)])
-def test_count_minimizers_parameter_sweep(eng, k, window, lower, upper, monkeypatch):
+def test_count_minimizers_parameter_sweep(eng, k, window, lower, upper):
     """the reference's -w mode (getMinimizers' deque incl. its size_t range test, MinimizerCount, minimizer tuple branch);
     window 3000 exceeds every read: nothing is ever sampled"""
     rs = synth.make_reads(60, read_len=1200, coverage=10.0, err=0.02, seed=29, mix=(1 / 3, 1 / 3, 1 / 3))
     eng.set_reads(rs)
     codes, counts, tk, tr, tp, ndist = O.count_kmers(rs.seqs(), k, lower, upper, False, window)
-    for budget in (None, "2000"):
-        if budget:
-            monkeypatch.setenv("BELLA_HIP_KCOUNT_BUDGET", budget)
+    for budget in (0, 2000):
+        eng.set_tuning("kcount_budget", budget)
         nk, nt, nd = eng.count_kmers(k, lower, upper, False, window)
         assert (nk, nt, nd) == (len(codes), len(tk), ndist)
         dc, dn = eng.get_dictionary()
         gk, gr, gp = eng.get_tuples()
         assert np.array_equal(dc, codes) and np.array_equal(dn, counts)
         assert np.array_equal(gk, tk) and np.array_equal(gr, tr) and np.array_equal(gp, tp)
+    eng.set_tuning("kcount_budget")
 
 
-def test_count_kmers_multi_pass_equals_single_pass(eng, monkeypatch):
+def test_count_kmers_multi_pass_equals_single_pass(eng):
     rs = synth.make_reads(120, read_len=1500, coverage=15.0, err=0.12, seed=3)
     eng.set_reads(rs)
     eng.count_kmers(17, 2, 8)
     one = (eng.get_dictionary(), eng.get_tuples())
-    monkeypatch.setenv("BELLA_HIP_KCOUNT_BUDGET", "20000")           # ~ten passes over the bins of the canonical word
+    eng.set_tuning("kcount_budget", 20000)                           # ~ten passes over the bins of the canonical word
     eng.count_kmers(17, 2, 8)
     many = (eng.get_dictionary(), eng.get_tuples())
+    eng.set_tuning("kcount_budget")
     for a, b in zip(one[0] + one[1], many[0] + many[1]):
         assert np.array_equal(a, b)
 
@@ -800,12 +815,11 @@ def test_file_to_file_pipeline_reproduces_reference_up_to_kmer_labels(eng, tmp_p
 
 # ---- columns with >= 65,536 products (wide.hpp) -----------------------------------------------------------------------------
 
-@pytest.mark.parametrize("budget", [None, "300000"])
-def test_wide_columns_bit_exact(eng, monkeypatch, budget):
+@pytest.mark.parametrize("budget", [0, 300000])
+def test_wide_columns_bit_exact(eng, budget):
     """70 near-identical reads with -u 80: every k-mer is shared by all of them, column 0 has ~200k products (the row kernels
     index products with 16 bits); strands mixed, two reads carry a 700-base deletion plus a random tail (a second overlap bin)"""
-    if budget:
-        monkeypatch.setenv("BELLA_HIP_WIDE_BUDGET", budget)           # several batches of wide columns
+    eng.set_tuning("wide_budget", budget)                            # 300000: several batches of wide columns
     rng = np.random.default_rng(17)
     base = rng.integers(0, 4, size=3000, dtype=np.uint8)
     comp = (3 - base)[::-1]
@@ -867,16 +881,52 @@ def test_hifi_syncmer_medium_set_parity(eng):
     assert bad == 0, bad
 
 
+@pytest.mark.parametrize("upper", [8, 40])
+def test_baseline_config4_hifi_10k_reads_parity(eng, upper):
+    """BASELINE configs[4] at single-GPU scale: 10,000 HiFi reads (15 kb, 0.5 % error, 30x), syncmer selection (-s), with the
+    reference's default bounds (-u 8: almost every true syncmer exceeds the bound) and with -u 40 (hundreds of
+    products per pair, columns above the LDS tiers).  Every column's product and pair count against the oracle's symbolic phase,
+    every record of more than a tenth of the columns (every ninth and the 100 pair-richest) against its numeric phase,
+    size-independent properties of all records."""
+    rs = synth.make_reads(10000, read_len=15000, coverage=30.0, err=0.005, seed=2, mix=(1 / 3, 1 / 3, 1 / 3))
+    seqs = rs.seqs()
+    eng.set_reads(rs)
+    nk, nt, _ = eng.count_kmers(17, 2, upper, syncmer=True)
+    tk, tr, tp = eng.get_tuples()
+    eng.assemble_counted()
+    pars = BellaPars(errorRate=0.005, skipAlignment=True)
+    n, flops = eng.overlap(pars)
+    pairs, ext, colptrC = eng.get_pairs()
+    assert n > 1000
+    assert (pairs["rid"] > pairs["cid"]).all() and (np.diff(pairs["cid"].astype(np.int64)) >= 0).all()
+    key = pairs["cid"].astype(np.uint64) << np.uint64(32) | pairs["rid"].astype(np.uint64)
+    assert len(np.unique(key)) == len(key)
+    Bc, Br, Bv = O.build_B(rs.nreads, tk, tr, tp)
+    for a_, b_ in zip(eng.get_B(), (Bc, Br, Bv)):
+        assert np.array_equal(a_, b_)
+    per_row = np.diff(colptrC.astype(np.int64))
+    sample = np.unique(np.concatenate([np.arange(0, rs.nreads, 9), np.argsort(per_row)[-100:]])).astype(np.uint32)
+    assert len(sample) >= rs.nreads // 10
+    flop, nnzc, per_col = O.spgemm_parallel(seqs, nk, Bc, Br, Bv, sample, 17)
+    assert flops == int(flop.astype(np.int64).sum())
+    assert np.array_equal(per_row, nnzc.astype(np.int64))
+    got_idx = np.concatenate([np.arange(int(colptrC[c]), int(colptrC[c + 1])) for c in sample])
+    exp = np.concatenate([per_col[int(c)] for c in sample])
+    check_pairs(pairs[got_idx], ext[got_idx], exp, rs.lengths, 17)
+    print("HiFi 10k reads -u %d: %d reliable syncmers, %d tuples, %d products, %d pairs, %d records compared"
+          % (upper, nk, nt, flops, n, len(exp)))
+
+
 @pytest.mark.parametrize("name,dbg", [("toy120", 32), ("toyrep90", 32), ("toyhifi50", 32), ("toysync60", 32), ("toyrep90", 32 | 64)])
-def test_columns_above_the_lds_tiers_on_the_sort_based_path(monkeypatch, name, dbg):
+def test_columns_above_the_lds_tiers_on_the_sort_based_path(name, dbg):
     """the path of the columns with more products than the largest LDS tier when a pass has many of them (wide.hpp: expand, radix
     sort, slot order, one workgroup per pair with the closed-form fold): with a 64-product LDS tier and debug bit 5 most
     columns of a golden set take it -- single- and multi-bin pairs, long lists, both strands; then the many-bins set (serial
     fold for > 16 bins)"""
     g = load_golden(name)
+    e = Engine(0)
     try:
-        monkeypatch.setenv("BELLA_HIP_TIERS", "64")
-        e = Engine(0)
+        e.set_tuning("lds_tiers", 64)                                # (per context: no process-wide state)
         e.set_debug(dbg)                                             # bit 6: 64-bit sort keys (the default here is 32-bit)
         e.set_reads(g.rs)
         e.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
@@ -895,19 +945,17 @@ def test_columns_above_the_lds_tiers_on_the_sort_based_path(monkeypatch, name, d
             exp2 = _run_constructed(e, [30000, 30000, 6000, 6000], [a, b, c, d], 300)
             by = {(int(p["rid"]), int(p["cid"])): p for p in exp2}
             assert by[(1, 0)]["nbins"] > 16 and by[(3, 2)]["support"] > 64
-        e.close()
     finally:
-        monkeypatch.setenv("BELLA_HIP_TIERS", "768,1280,2048,3072,4096,6144,8192,11008")
-        Engine(0).close()
+        e.close()
 
 
 @pytest.mark.parametrize("tier", ["8192", "11008"])
-def test_big_lds_tiers_bit_exact(monkeypatch, tier):
+def test_big_lds_tiers_bit_exact(tier):
     """every column through the 8192-product LDS tier (the 16-positions-per-thread instance of the row kernel)"""
     g = load_golden("toyrep90")
+    e = Engine(0)
     try:
-        monkeypatch.setenv("BELLA_HIP_TIERS", tier)
-        e = Engine(0)
+        e.set_tuning("lds_tiers", int(tier))
         e.set_reads(g.rs)
         e.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
         n, flops = e.overlap(BellaPars(skipAlignment=True))
@@ -915,10 +963,8 @@ def test_big_lds_tiers_bit_exact(monkeypatch, tier):
         _, flop, ecol, exp = oracle_pairs(g.rs, g.seqs, g.nkmers, g.tk, g.tr, g.tp, g.k)
         assert flops == int(flop.sum()) and n == len(exp)
         check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
-        e.close()
     finally:
-        monkeypatch.setenv("BELLA_HIP_TIERS", "768,1280,2048,3072,4096,6144,8192,11008")
-        Engine(0).close()                                            # the tier table is process-wide: back to the default
+        e.close()
 
 
 def test_counted_panels_equal_one_shot_assembly(eng):
@@ -1047,3 +1093,95 @@ def test_staged_output_equals_single_stage(eng, golden, tmp_path):
     api.hash_spgemm(eng, BellaPars(errorRate=g.err, kmerSize=g.k), f, stdout=so, stages=3)
     assert open(f, "rb").read() == open(one, "rb").read()
     assert int(so.getvalue().split()[0]) == int(g.stdout["align"][2])
+
+
+def _run_ranks(nranks, body, timeout=300):
+    """one host thread per context (ctypes releases the GIL): the collective entry points rendezvous inside the library"""
+    import threading
+    out, err = [None] * nranks, []
+
+    def work(r):
+        try:
+            out[r] = body(r)
+        except Exception as e:  # noqa: BLE001
+            err.append((r, e))
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout)
+    assert not any(t.is_alive() for t in th), "a rank is still inside a collective call: the ranks did not leave it together"
+    return out, err
+
+
+@pytest.mark.parametrize("bounds", [[0, 70, 150], [0, 90, 90, 150], [0, 1, 60, 150]])
+def test_collectives_with_several_ranks_on_the_in_process_transport(bounds):
+    """The N > 1 logic of bella_hip_count_kmers_dist and bella_hip_allgather_panels -- code-space split, dictionary concatenation,
+    grouped send/recv offsets, uneven panels, an empty panel -- on the one GPU there is: N contexts, one host thread each, the
+    library's in-process transport (bella_hip_comm_init_local) in RCCL's place.  Bit-exact against the one-shot assembly."""
+    from bella_amd import dist as bd
+    nranks = len(bounds) - 1
+    rs = synth.make_reads(150, read_len=2000, coverage=15.0, err=0.15, seed=43)
+    e0 = Engine(0)
+    e0.set_reads(rs)
+    nk, nt, _ = e0.count_kmers(17, 2, 8)
+    d0 = e0.get_dictionary()
+    e0.assemble_counted()
+    B1 = e0.get_B()
+    e0.overlap(BellaPars(skipAlignment=True))
+    p1 = e0.get_pairs()
+    cid = e0.comm_id(local=True)
+    engines = [Engine(0) for _ in range(nranks)]
+
+    def body(r):
+        e = engines[r]
+        e.set_reads(rs)
+        e.comm_init(nranks, r, cid, local=True)
+        lo, n = bounds[r], bounds[r + 1] - bounds[r]
+        nk_r, _, _ = e.count_kmers_dist(lo, n, 17, 2, 8)
+        dic = e.get_dictionary()
+        e.assemble_counted_panel(lo, n)
+        e.allgather_panels()
+        B = e.get_B()
+        e.set_partition(r, nranks)
+        e.overlap(BellaPars(skipAlignment=True))
+        return nk_r, dic, B, e.get_pairs()
+    out, err = _run_ranks(nranks, body)
+    assert not err, err
+    for r in range(nranks):
+        nk_r, dic, B, _ = out[r]
+        assert nk_r == nk
+        assert np.array_equal(dic[0], d0[0]) and np.array_equal(dic[1], d0[1])
+        for a, b in zip(B, B1):
+            assert np.array_equal(a, b)
+    merged = bd.merge_in_reference_order([out[r][3][0] for r in range(nranks)])
+    assert np.array_equal(merged, p1[0])
+    for e in engines:
+        e.comm_destroy()
+        e.close()
+    e0.close()
+
+
+def test_a_failing_rank_takes_all_ranks_out_of_the_collective():
+    """one rank enters bella_hip_allgather_panels without a panel: every rank returns an error (nobody waits for the exchange)"""
+    rs = synth.make_reads(60, read_len=1500, coverage=10.0, err=0.15, seed=7)
+    e0 = Engine(0)
+    cid = e0.comm_id(local=True)
+    engines = [Engine(0) for _ in range(3)]
+    bounds = [0, 20, 40, 60]
+
+    def body(r):
+        e = engines[r]
+        e.set_reads(rs)
+        e.comm_init(3, r, cid, local=True)
+        e.count_kmers_dist(bounds[r], bounds[r + 1] - bounds[r], 17, 2, 8)
+        if r != 1:
+            e.assemble_counted_panel(bounds[r], bounds[r + 1] - bounds[r])
+        e.allgather_panels()
+        return True
+    out, err = _run_ranks(3, body, timeout=120)
+    assert sorted(r for r, _ in err) == [0, 1, 2] and all(isinstance(e, BellaHipError) for _, e in err)
+    for e in engines:
+        e.comm_destroy()
+        e.close()
+    e0.close()

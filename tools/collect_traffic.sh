@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/traffic
 mkdir -p "$OUT"; rm -rf "$OUT/$KEY"_*
 STEPS=4
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/${KEY}_$C" -o t -- python "$R/bench.py" --steps $STEPS --warmup 1 --no-cpu-baseline --no-100k --no-xdrop "$@" > "$OUT/${KEY}_bench_$C.json" 2> "$OUT/${KEY}_bench_$C.err" || true
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/${KEY}_$C" -o t -- python "$R/bench.py" --steps $STEPS --warmup 1 --no-cpu-baseline --no-100k --no-xdrop --no-dropin --no-hifi "$@" > "$OUT/${KEY}_bench_$C.json" 2> "$OUT/${KEY}_bench_$C.err" || true
 done
 python - <<PY
 import csv, collections, json, glob
@@ -28,14 +28,14 @@ bench = json.loads([l for l in open("$OUT/${KEY}_bench_FETCH_SIZE.json") if l.st
 passes = $STEPS + 1
 def tot(c, pred):
     return sum(v["sum_kb"] for k, v in out.get(c, {}).items() if pred(k)) * 1024 / passes
-sp = lambda k: "k_spgemm_rows" in k or "k_fold" in k
+sp = lambda k: "k_spgemm_rows" in k or "k_fold" in k or "k_order" in k
 fetch, write = tot("FETCH_SIZE", sp), tot("WRITE_SIZE", sp)
 # calibration of FETCH_SIZE on our own coalesced stream: k_row_flops reads 2 B per nonzero of B' (the compact count array)
 nnz = bench["config"]["nnzA"]
 rf = tot("FETCH_SIZE", lambda k: "k_row_flops" in k)
 summary = {
  "workload": "%d reads, 1 GPU" % bench["config"]["reads"],
- "kernels": "k_spgemm_rows_lds (all LDS classes) + k_fold_overflow", "per": "step (= one launch set)",
+ "kernels": "k_spgemm_rows_lds (all LDS classes) + k_fold_overflow + k_order_wave/_block", "per": "step (= one launch set)",
  "FETCH_SIZE_raw_bytes": fetch, "WRITE_SIZE_raw_bytes": write,
  "fetch_calibration": {"kernel": "k_row_flops", "expected_bytes": 2 * nnz, "ratio_measured_over_expected": rf / (2.0 * nnz),
                        "note": "FETCH_SIZE reads 1/2 of the streamed bytes on gfx950 (MI355X_MICROARCH.md, HBM); checked on our own coalesced u16 stream"},
