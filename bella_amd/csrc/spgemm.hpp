@@ -53,9 +53,6 @@ constexpr uint32_t kScatterChunk = 64;                    // phase S appends one
 #ifndef BELLA_SCATTER_WAVES
 #define BELLA_SCATTER_WAVES 1
 #endif
-#ifndef BELLA_WALK_IW
-#define BELLA_WALK_IW 2
-#endif
 #ifndef BELLA_WALK_W_GLOBAL
 #define BELLA_WALK_W_GLOBAL 32
 #endif
@@ -245,43 +242,24 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             bw[u] = 0;
             if (p < F) { ae[u] = a.Aent[m.A_hv[p]]; bw[u] = m.A_gov[p]; }
         }
-        // the XB key look-ups of a lane go together: one compare-and-swap each per round trip (a probe sequence is a chain of
-        // dependent LDS round trips; one product at a time leaves the LDS pipe idle in between)
-        uint32_t keyv[XB], hv2[XB];
-        bool pend[XB];
-        bool anyp = false;
 #pragma unroll
         for (uint32_t u = 0; u < XB; ++u) {
             const uint32_t p = base + u * kRowBlock + tid;
-            keyv[u] = ae[u].x & 0x7FFFFFFFu;
-            hv2[u] = hash_range(keyv[u], H1);
-            pend[u] = p < F;
-            anyp = anyp || pend[u];
-        }
-        for (uint32_t probes = 0; anyp; ++probes) {
-            uint32_t oldv[XB];
-#pragma unroll
-            for (uint32_t u = 0; u < XB; ++u)
-                if (pend[u]) oldv[u] = atomicCAS(&m.T1key[hv2[u]], kEmpty, keyv[u]);
-            anyp = false;
-#pragma unroll
-            for (uint32_t u = 0; u < XB; ++u)
-                if (pend[u]) {
-                    if (oldv[u] == kEmpty || oldv[u] == keyv[u]) pend[u] = false;
-                    else if (probes + 1 == H1) { *s_fail = 1; pend[u] = false; hv2[u] = kEmpty; }   // more pairs than this tier's key table holds
-                    else hv2[u] = (hv2[u] + 1 == H1) ? 0 : hv2[u] + 1;
-                    anyp = anyp || pend[u];
-                }
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < XB; ++u) {
-            const uint32_t p = base + u * kRowBlock + tid;
-            if (p >= F || hv2[u] == kEmpty) continue;
-            const uint32_t h = hv2[u];
+            if (p >= F) continue;
+            const uint32_t key = ae[u].x & 0x7FFFFFFFu;
             const uint32_t posH = ae[u].y & 0xFFFFu, lenH = ae[u].y >> 16;
             const uint32_t posV = bw[u] & 0xFFFFu, pal = (bw[u] >> 30) & 1u;
             const bool oriented = (ae[u].x >> 31) == (bw[u] >> 31);
             const uint32_t ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, k) & 0xFFFFu;
+            uint32_t h = hash_range(key, H1);
+            uint32_t old = 0;
+            uint32_t probes = 0;
+            for (; probes < H1; ++probes) {
+                old = atomicCAS(&m.T1key[h], kEmpty, key);
+                if (old == kEmpty || old == key) break;
+                h = (h + 1 == H1) ? 0 : h + 1;
+            }
+            if (probes == H1) { *s_fail = 1; continue; }     // more pairs than this tier's key table holds
             const uint32_t q = (p >= RB ? 1u : 0u) + (p >= 2u * RB ? 1u : 0u) + (p >= 3u * RB ? 1u : 0u);
             atomicAdd((q & 2u) ? &m.T1first[h] : &m.T1cnt[h], (q & 1u) ? 0x10000u : 1u);
             m.A_hv[p] = posH | (posV << 16);
@@ -562,94 +540,59 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     const us2 kk2 = {(unsigned short)a.k, (unsigned short)a.k};
     const us2 lim2 = {(unsigned short)(2 * a.k + 1), (unsigned short)(2 * a.k + 1)};
     const uint32_t lim = __builtin_bit_cast(uint32_t, lim2);
-    // A lane walks IW of its list positions at the same time: the LDS round trips of the walks overlap (a walk is a chain of
-    // dependent round trips, W products each; one at a time leaves the LDS pipe idle in between).
-    constexpr uint32_t IW = OVERLAY ? BELLA_WALK_IW : 1;      // (the global path already keeps 32 reads in flight per walk)
-    constexpr uint32_t W = OVERLAY ? BELLA_WALK_W : BELLA_WALK_W_GLOBAL;   // products per test (global path: latency per round trip, not issue, is what counts)
-    const uint32_t* const lst = m.L_hv;
-    for (uint32_t y0 = tid; y0 < Fm; y0 += IW * kRowBlock) {
-        uint32_t xv[IW], gv[IW], mmv[IW], tv[IW];
-        bool plain[IW], slow[IW], run[IW];
+    for (uint32_t y = tid; y < Fm; y += kRowBlock) {
+        const uint32_t gov = m.L_gov[y];
+        const uint32_t x = m.L_hv[y];
+        if (is_last(y, gov)) continue;                        // nothing after it: no comparison, no contribution
+        const uint32_t g = (gov >> 16) & GMASK;
+        const uint32_t mm = m.T1first[g] & 0xFFFFu;           // END of the list: the walk runs on absolute positions s = y .. mm
+        const uint32_t* lst = m.L_hv;
+        const uint32_t s = y;
+        if (!need_parents || !(m.T1key[g] >> 31)) {           // (all-plain column: no look-up)
+            // plain chain: the position is compared with every later product until one is within k of it.
+            // within k  <=>  (x + k - q) mod 2^16 <= 2k  in either half (k-mer starts are <= 65535 - k): eight products per test
+            const us2 xk = __builtin_bit_cast(us2, x) + kk2;
+            // The last group of a list reads up to W - 1 words beyond its end (the next list, or the words behind the lists: always
+            // inside the column's arrays); a "hit" found there lies at or beyond the end and is cut off below -- no masked tail.
+            uint32_t t = s + 1;
+            constexpr uint32_t W = OVERLAY ? BELLA_WALK_W : BELLA_WALK_W_GLOBAL;   // products per test (global path: latency per round trip, not issue, is what counts)
+            uint32_t q[W];
+            bool hit = false;
+            while (t < mm) {
+                us2 acc = lim2;
 #pragma unroll
-        for (uint32_t v = 0; v < IW; ++v) {
-            const uint32_t y = y0 + v * kRowBlock;
-            const bool ok = y < Fm;
-            const uint32_t gov = m.L_gov[ok ? y : 0u];
-            xv[v] = lst[ok ? y : 0u];
-            gv[v] = (gov >> 16) & GMASK;
-            plain[v] = ok && !is_last(ok ? y : 0u, gov);       // the last product of a list: nothing after it, no comparison, no contribution
-            tv[v] = y + 1;
-        }
-#pragma unroll
-        for (uint32_t v = 0; v < IW; ++v) {
-            mmv[v] = m.T1first[gv[v]] & 0xFFFFu;              // END of the list: the walk runs on absolute positions s = y .. mm
-            const bool np = need_parents && (m.T1key[gv[v]] >> 31);   // (all-plain column: no look-up)
-            slow[v] = plain[v] && np;
-            plain[v] = plain[v] && !np;
-            run[v] = plain[v] && tv[v] < mmv[v];
-        }
-        // plain chain: the position is compared with every later product until one is within k of it.
-        // within k  <=>  (x + k - q) mod 2^16 <= 2k  in either half (k-mer starts are <= 65535 - k): W products per test.
-        // The last group of a list reads up to W - 1 words beyond its end (the next list, or the words behind the lists: always
-        // inside the column's arrays); a "hit" found there lies at or beyond the end and is cut off below -- no masked tail.
-        bool any = false;
-#pragma unroll
-        for (uint32_t v = 0; v < IW; ++v) any = any || run[v];
-        while (any) {
-            uint32_t q[IW][W];
-#pragma unroll
-            for (uint32_t v = 0; v < IW; ++v)
-                if (run[v]) {
-#pragma unroll
-                    for (uint32_t u = 0; u < W; ++u) q[v][u] = lst[tv[v] + u];
+                for (uint32_t u = 0; u < W; ++u) {
+                    q[u] = lst[t + u];
+                    acc = __builtin_elementwise_min(acc, (us2)(xk - __builtin_bit_cast(us2, q[u])));
                 }
-            any = false;
-#pragma unroll
-            for (uint32_t v = 0; v < IW; ++v)
-                if (run[v]) {
-                    const us2 xk = __builtin_bit_cast(us2, xv[v]) + kk2;
-                    us2 acc = lim2;
-#pragma unroll
-                    for (uint32_t u = 0; u < W; ++u) acc = __builtin_elementwise_min(acc, (us2)(xk - __builtin_bit_cast(us2, q[v][u])));
-                    if (__builtin_bit_cast(uint32_t, acc) != lim) {   // first product of the group that is within k
-                        uint32_t f = W - 1;
-#pragma unroll
-                        for (int u = (int)W - 2; u >= 0; --u) {
-                            const us2 dd = __builtin_elementwise_min(lim2, (us2)(xk - __builtin_bit_cast(us2, q[v][u])));
-                            f = __builtin_bit_cast(uint32_t, dd) != lim ? (uint32_t)u : f;
-                        }
-                        tv[v] += f;
-                        run[v] = false;
-                    } else {
-                        tv[v] += W;
-                        run[v] = tv[v] < mmv[v];
-                    }
-                    any = any || run[v];
-                }
-        }
-#pragma unroll
-        for (uint32_t v = 0; v < IW; ++v) {
-            if (plain[v]) {
-                const uint32_t s = y0 + v * kRowBlock;
-                const uint32_t t = tv[v] < mmv[v] ? tv[v] : mmv[v];   // ran off the end, or the first product within k lies beyond it
-                const uint32_t contrib = t - s - 1;
-                if (contrib) atomicAdd(&m.T1cnt[gv[v]], (contrib & 0xFFFFu) << 16);   // the cursor half already holds m
-                if (a.tmp_ext && t == mmv[v]) atomicAdd(&m.Gaux[gv[v]], 1u);
+                if (__builtin_bit_cast(uint32_t, acc) != lim) { hit = true; break; }
+                t += W;
             }
-            if (slow[v]) {
-                const uint32_t s = y0 + v * kRowBlock;
-                const par_t* pr = Par;
-                uint32_t root = s, contrib = 0, t = pr[s];
-                bool dead = false;
-                while (!(t & kRoot)) {
-                    if (!far_apart(xv[v], lst[t], a.k)) { dead = true; break; }
-                    contrib++; root = t; t = pr[t];
+            if (hit) {                                        // first product of the group that is within k
+                uint32_t f = W - 1;
+#pragma unroll
+                for (int u = (int)W - 2; u >= 0; --u) {
+                    const us2 dd = __builtin_elementwise_min(lim2, (us2)(xk - __builtin_bit_cast(us2, q[u])));
+                    f = __builtin_bit_cast(uint32_t, dd) != lim ? (uint32_t)u : f;
                 }
-                if (contrib) atomicAdd(&m.T1cnt[gv[v]], (contrib & 0xFFFFu) << 16);
-                if (!dead) {                                  // the root's support (a u16 counter is half of an LDS word)
-                    if (OVERLAY) atomicAdd((uint32_t*)Par + (root >> 1), (root & 1u) ? 0x10000u : 1u);
-                    else atomicAdd((uint32_t*)Par + root, 1u);
-                }
+                t += f;
+            }
+            t = t < mm ? t : mm;                              // ran off the end, or the first product within k lies beyond it
+            const uint32_t contrib = t - s - 1;
+            if (contrib) atomicAdd(&m.T1cnt[g], (contrib & 0xFFFFu) << 16);   // the cursor half already holds m
+            if (a.tmp_ext && t == mm) atomicAdd(&m.Gaux[g], 1u);
+        } else {
+            const par_t* pr = Par;
+            uint32_t root = s, contrib = 0, t = pr[s];
+            bool dead = false;
+            while (!(t & kRoot)) {
+                if (!far_apart(x, lst[t], a.k)) { dead = true; break; }
+                contrib++; root = t; t = pr[t];
+            }
+            if (contrib) atomicAdd(&m.T1cnt[g], (contrib & 0xFFFFu) << 16);
+            if (!dead) {                                      // the root's support (a u16 counter is half of an LDS word)
+                if (OVERLAY) atomicAdd((uint32_t*)Par + (root >> 1), (root & 1u) ? 0x10000u : 1u);
+                else atomicAdd((uint32_t*)Par + root, 1u);
             }
         }
     }
