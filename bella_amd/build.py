@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbella_hip.so")
 SOURCES = ["bella_hip.hip"]
-HEADERS = ["core.hpp", "util.hpp", "assemble.hpp", "kcount.hpp", "fastq.hpp", "wide.hpp", "spgemm.hpp", "xdrop.hpp", "xdrop_packed.hpp", "logan.hpp", "comm.hpp", os.path.join("..", "..", "include", "bella_hip.h")]
+HEADERS = ["core.hpp", "util.hpp", "assemble.hpp", "kcount.hpp", "fastq.hpp", "wide.hpp", "spgemm.hpp", "order.hpp", "slotorder.hpp", "writer.hpp", "xdrop.hpp", "xdrop_packed.hpp", "logan.hpp", "comm.hpp", os.path.join("..", "..", "include", "bella_hip.h")]
 
 
 def needs_build() -> bool:

@@ -1916,7 +1916,7 @@ int bella_hip_get_pairs(bella_ctx* c, bella_pair* pairs, bella_pair_ext* ext, ui
 // the exact gapped X-drop of the reference's CUDA build (logan.hpp): one wavefront per extension, LDS rings; the rare extension
 // whose band outgrows them is redone on rings in HBM
 static int run_logan(bella_ctx* c, const bella_params* p, const bella_seed* d_seeds, const bella_pair* d_pairs, uint64_t n, bella_aln* d_out) {
-    if (2 * n >= 0x7FFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "too many pairs for one batch (2^30)");
+    if (2 * n >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "too many pairs for one batch (2^31; the redo list indexes extensions with 32 bits)");
     LoganArgs a;
     a.seeds = d_seeds; a.pairs = d_pairs; a.n = n;
     a.packed = ptr<uint32_t>(c->packed); a.roff = ptr<uint64_t>(c->roff);
@@ -1934,13 +1934,23 @@ static int run_logan(bella_ctx* c, const bella_params* p, const bella_seed* d_se
     HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
     if (n) {
         HIPCHK(c, hipMemsetAsync(a.nredo, 0, 4, c->stream));
-        k_logan_lds<<<(unsigned)(2 * n), 64, 0, c->stream>>>(a);
-        KCHK(c);
+        // one 64-thread workgroup per extension; grid x block must stay below 2^32 threads: chunks of 2^24 extensions
+        HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 14, 0, 4, c->stream));
+        a.status = ptr<uint32_t>(c->status) + 14;
+        const uint64_t kChunk = (c->debug & 256u) ? 1000ull : (1ull << 24);   // debug bit 8: tests, tiny chunks
+        for (uint64_t eb = 0; eb < 2 * n; eb += kChunk) {
+            a.ebase = eb;
+            const uint64_t cnt = 2 * n - eb < kChunk ? 2 * n - eb : kChunk;
+            k_logan_lds<<<(unsigned)cnt, 64, 0, c->stream>>>(a);
+            KCHK(c);
+        }
         uint32_t nredo = 0;
         HIPCHK(c, hipMemcpyAsync(&nredo, a.nredo, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (nredo) {
-            const uint32_t cap = 65536 + 8;                       // reads are < 65536 bases
+            uint32_t longest = 0;
+            for (uint32_t l : c->host_lens) longest = l > longest ? l : longest;
+            const uint32_t cap = longest + 8;                     // a band is never wider than the shorter sequence (+ the rings' slack)
             const unsigned grid = nredo < 256u ? nredo : 256u;
             ENSURE(c, c->lg_scratch, (size_t)grid * 3 * cap * 2);
             a.scratch = ptr<int16_t>(c->lg_scratch);
@@ -1950,6 +1960,10 @@ static int run_logan(bella_ctx* c, const bella_params* p, const bella_seed* d_se
         }
         k_logan_finish<<<nblk(n), 256, 0, c->stream>>>(a);
         KCHK(c);
+        uint32_t lst = 0;
+        HIPCHK(c, hipMemcpyAsync(&lst, a.status, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (lst & 512u) return fail(c, BELLA_ERR_STATE, "internal: an extension's band outgrew the rings in HBM");
     }
     HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev[9]));

@@ -40,6 +40,8 @@ struct LoganArgs {
     uint32_t* nredo;
     int16_t* scratch;                  // rings in HBM for the second launch: 3 * scratch_cap per wavefront
     uint32_t scratch_cap;
+    uint64_t ebase;                    // first extension of this launch (k_logan_lds is launched in chunks: grid x block < 2^32)
+    uint32_t* status;                  // bit 9: an extension outgrew even the rings in HBM (cannot happen for reads < 65536 bases)
 };
 
 // the two sequences of an extension in READING order (element t of the query = column t + 1, of the database = row t + 1)
@@ -195,7 +197,7 @@ __device__ __forceinline__ bool logan_setup(const LoganArgs& a, uint64_t e, Pair
 // first launch: one extension per 64-thread workgroup (the barriers inside are single-wavefront barriers), rings in LDS
 __global__ __launch_bounds__(64) void k_logan_lds(LoganArgs a) {
     __shared__ int16_t rings[3][kLoganCap];
-    const uint64_t e = blockIdx.x;
+    const uint64_t e = a.ebase + blockIdx.x;
     PairGeom g;
     SeqAcc Q, D;
     logan_setup(a, e, g, Q, D);
@@ -217,8 +219,8 @@ __global__ __launch_bounds__(64) void k_logan_hbm(LoganArgs a) {
         SeqAcc Q, D;
         logan_setup(a, e, g, Q, D);
         int4 res;
-        (void)logan_one_direction(Q, D, a.xdrop, RingHbm{base}, RingHbm{base + a.scratch_cap}, RingHbm{base + 2 * a.scratch_cap}, (int)a.scratch_cap, res);
-        if (threadIdx.x == 0) a.res[e] = res;
+        const bool ok = logan_one_direction(Q, D, a.xdrop, RingHbm{base}, RingHbm{base + a.scratch_cap}, RingHbm{base + 2 * a.scratch_cap}, (int)a.scratch_cap, res);
+        if (threadIdx.x == 0) { a.res[e] = res; if (!ok) atomicOr(a.status, 512u); }
     }
 }
 

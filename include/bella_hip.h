@@ -242,7 +242,8 @@ int bella_hip_write_output(const char* path, const bella_params* p, int paf, uin
 /* The exact (growing band) gapped X-drop of the reference's CUDA build instead of Xavier's 32-cell adaptive band: the scores and
  * seed positions of loganGPU/functions.cuh:223-408,505-547,680-682 (= SeqAn's extendSeed(GappedXDrop), include/align.hpp:93-139)
  * and the pass test of PostAlignDecisionGPU (include/overlap.hpp:797-871).  Same inputs and outputs as the two calls above;
- * bella_aln::steps = anti-diagonals computed, flagged = 0. */
+ * bella_aln::steps = anti-diagonals computed, flagged = 0.  Extension scores live in int16 rings as in the CUDA kernel (`short`
+ * anti-diagonals, loganGPU/functions.cuh:236-240): a one-direction score above 32,767 wraps there and here. */
 int bella_hip_align_pairs_exact(bella_ctx* ctx, const bella_params* p, uint64_t* npassed);
 int bella_hip_xdrop_batch_exact(bella_ctx* ctx, const bella_seed* seeds, uint64_t n, const bella_params* p, bella_aln* out);
 
@@ -281,7 +282,8 @@ int bella_hip_get_timings(bella_ctx* ctx, bella_timings* t);
  * bit3 = tests: 512-thread workgroups in every LDS class (default: 1024 threads where a CU holds one or two columns);
  * bit4 = tests: key tables of cap/2 slots (the layout of pair-rich inputs) on any input; bit5 = tests: every column above the
  * LDS tiers takes the sort-based path of the wide columns (default: from 16 such columns in a pass on); bit6 = tests: that path
- * sorts on 64-bit keys on any input (default: 32-bit keys when column bits + read-id bits fit) */
+ * sorts on 64-bit keys on any input (default: 32-bit keys when column bits + read-id bits fit); bit8 = tests: the exact X-drop mode
+ * launches its extensions in chunks of 1,000 (default 2^24: grid x block stays below 2^32 threads) */
 int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
 /* Per-context tuning parameters (tests and A/B measurements; nothing here changes results).  what:
  *   BELLA_TUNE_LDS_TIERS      values = ascending product capacities of the row kernels' LDS tiers, each in [64, 11008] (n = 0: defaults)

@@ -6,6 +6,10 @@ import sys
 import numpy as np
 import pytest
 
+
+# the reference (oracle/_ref) is only reproducible at one OpenMP thread (SURVEY.md A.6); libgomp reads this at load
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+
 try:
     # PyTorch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, no soname); libbella_hip.so links /opt/rocm's.  A
     # process that initialises /opt/rocm's first and torch's afterwards holds two runtimes and torch finds "no HIP GPUs"; with torch
@@ -14,9 +18,6 @@ try:
     import torch  # noqa: F401
 except Exception:  # pragma: no cover
     pass
-
-# the reference (oracle/_ref) is only reproducible at one OpenMP thread (SURVEY.md A.6); libgomp reads this at load
-os.environ.setdefault("OMP_NUM_THREADS", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -199,6 +199,13 @@ def test_exact_xdrop_mode_matches_logan_oracle_and_seqan_answers(eng):
             ok_cnt += int(ok)
         assert npass == int(alns["passed"].sum()) and (step > 1 or ok_cnt == npass)
         assert not alns["flagged"].any()
+        # the launch goes in chunks of extensions (grid x block stays below 2^32 threads at 100k-read scale): tiny chunks, same records
+        eng.set_debug(256)
+        try:
+            assert eng.align_pairs(pars, exact=True) == npass
+            assert np.array_equal(eng.get_alignments(), alns)
+        finally:
+            eng.set_debug(0)
 
 
 def test_partition_union_equals_whole(eng):

@@ -1,13 +1,13 @@
 #!/usr/bin/env bash
 # development aid (GPU box, profiling build of tools/prof_build.sh): SQ instruction counts and durations of the row kernels cut after
-# each phase (BELLA_DEV_STOP=n: 0 expand, 1 gather+insert, 2 slot order, 3 ranks+singles, 4 scatter, 5 rank/overlay, 6 parents,
-# 7 walks, -1 whole).  Differences between consecutive cuts = the phase.  usage: BENCH_ARGS="--reads 100000" bash tools/sq_phases.sh
+# each phase (BELLA_DEV_STOP=n: 0 expand, 1 gather+insert, 2 count-scan, 3 scatter+singles, 4 rank/overlay, 5 parents, 6 walks,
+# 7 emit = -1 whole).  Differences between consecutive cuts = the phase.  usage: BENCH_ARGS="--reads 100000" bash tools/sq_phases.sh
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cp $R/bella_amd/libbella_hip.so /tmp/prod.so; cp $R/tools/_old/libbella_prof.so $R/bella_amd/libbella_hip.so
-for S in ${STOPS:-0 1 2 3 4 5 6 7 -1}; do
+for S in ${STOPS:-0 1 2 3 4 5 6 -1}; do
   OUT=$R/gpurun_out/sqp/s$S; rm -rf $OUT; mkdir -p $OUT
-  BELLA_DEV_STOP=$S rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT -o t -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-xdrop --no-100k ${BENCH_ARGS:-} > /dev/null 2>&1
+  BELLA_DEV_STOP=$S rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT -o t -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-xdrop --no-100k --no-dropin --no-hifi ${BENCH_ARGS:-} > /dev/null 2>&1
   python - <<PY
 import csv, collections, glob
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
