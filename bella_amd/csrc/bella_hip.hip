@@ -1617,7 +1617,6 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     a.k = p->kmer_size;
     a.binSize = p->bin_size;
     a.inject_unordered = (c->debug & 4u) ? 1 : 0;
-    a.pf_dist = 0;
 #ifdef BELLA_DEV_PROF
     ENSURE(c, c->prof, 8 * 10 * kNumTiers);
     HIPCHK(c, hipMemsetAsync(c->prof.p, 0, 8 * 10 * kNumTiers, c->stream));
@@ -1686,9 +1685,6 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         a.tcount_valid = ln[l].hi - ln[l].lo <= 3 ? 1u : 0u;
         for (int k2 = 0; k2 < 4; ++k2) a.tcount[k2] = ln[l].lo + k2 <= ln[l].hi ? tcnt[ln[l].lo + k2] : 0u;
         a.nrows = ln[l].rows;
-        // touch distance: about two generations of resident workgroups ahead (256 CUs x columns per CU of the class), a multiple of 8
-        // so that the toucher and the taker share an XCD's L2 (workgroup b runs on XCD b % 8)
-        a.pf_dist = (c->debug & 512u) ? 0u : 2u * 256u * (uint32_t)(kClassLds[kNumClasses - 1] / kClassLds[ln[l].cls]);
         a.cap = tier_caps[ln[l].hi];
         a.dcap = dcap_of(a.cap);
         const size_t lds = ln[l].lds;

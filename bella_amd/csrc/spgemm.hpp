@@ -106,7 +106,6 @@ struct SpgemmArgs {
     int stop_phase;              // development builds only: leave the column after this phase (instruction counts per phase)
 #endif
     int inject_unordered;        // tests: pretend every fifth column's lists came out of order in phase S (exercises the fallback)
-    uint32_t pf_dist;            // class launches: workgroup b touches the B' entries of workgroup b + pf_dist (0: off)
 };
 
 constexpr uint32_t kRowScratchBytes = 256;                   // block scan scratch, counters
@@ -162,7 +161,7 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dc
 // the column again).
 template <bool OVERLAY, uint32_t NX, int BLK = BELLA_ROW_BLOCK>
 __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t i, const uint32_t b0, const uint32_t n, const uint32_t lenV,
-                                            const RowMem& m, const uint4 pfd = make_uint4(0u, 0u, 0u, 0u)) {
+                                            const RowMem& m) {
     constexpr int kRowBlock = BLK;                            // threads of this workgroup
     constexpr int kRowWaves = BLK / 64;
     const uint32_t tid = threadIdx.x;
@@ -272,14 +271,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     __syncthreads();
     BELLA_BPROF(1)
     if (*s_fail) return false;
-    // The head of a column is two dependent HBM round trips (descriptor, then B' entries).  A workgroup therefore touches the B'
-    // entries of a column that a LATER workgroup of this launch will take (its descriptor was requested at kernel entry and has
-    // arrived by now): one line per lane, the value is never used -- the later workgroup finds them in the L2 / Infinity Cache.
-    uint32_t pf_sink = 0;
-    {
-        const uint32_t pn = pfd.z & 0xFFFFu;                  // entries of that column (0: nothing to touch)
-        for (uint32_t e8 = tid * 8u; e8 < pn; e8 += kRowBlock * 8u) pf_sink ^= a.Bent[pfd.y + e8].x;
-    }
 
     // ---- C: every pair gets its output index (table-slot order), the multi-product pairs their list and four scatter cursors ----
     const uint64_t obase = a.flopptr[i];
@@ -654,7 +645,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     if (tid == 0) a.nnzC[i] = d;
-    if (pf_sink == 0x9E3779B9u && a.pf_dist == 0xFFFFFFFFu) a.nnzC[i] = d + 1;   // (never true: keeps the touch loads alive)
     BELLA_BPROF(7)
 #ifdef BELLA_DEV_PROF
     if (tid == 0 && a.prof) atomicAdd(a.prof + 9, 1ull);
@@ -668,32 +658,24 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 template <uint32_t NX, int BLK = BELLA_ROW_BLOCK>
 __global__ __launch_bounds__(BLK, (BLK == 1024 ? (NX <= 4 ? 8 : 4) : BLK <= 256 ? 8 : (NX <= 8 ? 6 : 2))) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // the launch covers the tiers of one LDS class, largest columns first: workgroup b -> (tier, place in the tier's list)
-    auto locate = [&](uint32_t b, uint32_t& t, uint32_t& x) -> bool {
-        x = b; t = a.tier_hi;
-        if (a.tcount_valid) {
+    // the launch covers the tiers of one LDS class, largest columns first: workgroup x -> (tier, place in the tier's list)
+    uint32_t x = blockIdx.x, t = a.tier_hi;
+    if (a.tcount_valid) {
 #pragma unroll
-            for (int k2 = 3; k2 >= 1; --k2)
-                if (a.tier_lo + (uint32_t)k2 == t && x >= a.tcount[k2]) { x -= a.tcount[k2]; --t; }
-            const uint32_t rel = t - a.tier_lo;
-            const uint32_t ct = rel == 0 ? a.tcount[0] : rel == 1 ? a.tcount[1] : rel == 2 ? a.tcount[2] : a.tcount[3];
-            return x < ct;
-        }
+        for (int k2 = 3; k2 >= 1; --k2)
+            if (a.tier_lo + (uint32_t)k2 == t && x >= a.tcount[k2]) { x -= a.tcount[k2]; --t; }
+        const uint32_t rel = t - a.tier_lo;
+        const uint32_t ct = rel == 0 ? a.tcount[0] : rel == 1 ? a.tcount[1] : rel == 2 ? a.tcount[2] : a.tcount[3];
+        if (x >= ct) return;
+    } else {
         const uint32_t* tc = a.ctl + kCtlTierCnt;
         while (t > a.tier_lo && x >= tc[t]) { x -= tc[t]; --t; }
-        return x < tc[t];
-    };
-    uint32_t x, t;
-    if (!locate(blockIdx.x, t, x)) return;
-    const uint4 ds = a.rowdesc[(size_t)t * a.nreads + x];
-    uint4 pfd = make_uint4(0u, 0u, 0u, 0u);                    // the descriptor of the column whose B' entries this workgroup touches
-    {
-        uint32_t xn, tn;
-        if (a.pf_dist && blockIdx.x + a.pf_dist < gridDim.x && locate(blockIdx.x + a.pf_dist, tn, xn)) pfd = a.rowdesc[(size_t)tn * a.nreads + xn];
+        if (x >= tc[t]) return;
     }
+    const uint4 ds = a.rowdesc[(size_t)t * a.nreads + x];
     const uint32_t i = ds.x;
     const RowMem m = carve(smem, a.cap, a.dcap, true);
-    if (!process_row<true, NX, BLK>(a, i, ds.y, ds.z & 0xFFFFu, ds.z >> 16, m, pfd) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
+    if (!process_row<true, NX, BLK>(a, i, ds.y, ds.z & 0xFFFFu, ds.z >> 16, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
 }
 
 // Global-workspace path: columns with more products than the largest LDS tier (< 65536), and -- second launch, list and
