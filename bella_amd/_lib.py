@@ -30,6 +30,11 @@ class WriteStats(C.Structure):
                 ("format_seconds", C.c_double), ("threads", C.c_uint32), ("pad", C.c_uint32)]
 
 
+class IngestStats(C.Structure):
+    _fields_ = [("file_bytes", C.c_uint64), ("bases", C.c_uint64), ("reads", C.c_uint32), ("threads", C.c_uint32),
+                ("index_ms", C.c_double), ("upload_ms", C.c_double)]
+
+
 class Timings(C.Structure):
     _fields_ = [("assemble_ms", C.c_float), ("symbolic_ms", C.c_float), ("spgemm_ms", C.c_float), ("fold_ms", C.c_float),
                 ("compact_ms", C.c_float), ("xdrop_ms", C.c_float), ("overlap_total_ms", C.c_float), ("spgemm_launches", C.c_uint32),
@@ -48,6 +53,7 @@ SIGNATURES = [
     ("bella_hip_last_error", C.c_char_p, [vp]),
     ("bella_hip_set_reads", C.c_int, [vp, vp, vp, C.c_uint32]),
     ("bella_hip_load_fastq", C.c_int, [vp, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    ("bella_hip_get_ingest_stats", C.c_int, [vp, C.c_void_p]),
     ("bella_hip_get_read_names", C.c_int, [vp, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]),
     ("bella_hip_get_read_lengths", C.c_int, [vp, vp]),
     ("bella_hip_count_kmers", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),

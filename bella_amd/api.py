@@ -94,6 +94,12 @@ class Engine:
         self.lengths = lens[:self.nreads]
         return self.nreads, nb.value
 
+    def ingest_stats(self):
+        """what the last load_fastq did: file bytes, bases, reads, host threads, index_ms, upload_ms"""
+        st = _lib.IngestStats()
+        self._chk(self.lib.bella_hip_get_ingest_stats(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
     def set_reads_raw(self, ascii_bases: np.ndarray, offsets: np.ndarray, names=None):
         offs = np.ascontiguousarray(offsets, dtype=np.uint64)
         asc = np.ascontiguousarray(ascii_bases, dtype=np.uint8)

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -127,6 +128,7 @@ struct bella_ctx {
     hipEvent_t ev[10]{};
     uint32_t* pinned = nullptr;          // 128 host words the per-pass read backs land in
     Stager stager;                       // pinned bounce buffers of the large host <-> device copies
+    bella_ingest_stats ingest{};         // of the last bella_hip_load_fastq
     int caps_state = 0;
     ncclComm_t comm = nullptr;           // communicator of bella_hip_comm_init (one rank per context)
     const Rccl* api = nullptr;           // its transport: RCCL (comm.hpp: rccl()) or the in-process one (loopback())
@@ -505,8 +507,10 @@ int bella_hip_set_partition(bella_ctx* c, uint32_t first, uint32_t stride) {
     return 0;
 }
 
-int bella_hip_set_reads(bella_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads) {
-    if (!c || !offsets || (nreads && !bases)) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+// the reads onto the device: `fill(pinned, o, n)` produces bytes [o, o + n) of the concatenated bases (Stager::h2d_fill)
+extern "C++" {
+template <typename Fill>
+static int set_reads_impl(bella_ctx* c, const uint64_t* offsets, uint32_t nreads, Fill&& fill) {
     HIPCHK(c, hipSetDevice(c->device));
     const uint64_t total = offsets[nreads];
     for (uint32_t r = 0; r < nreads; ++r) {
@@ -521,7 +525,7 @@ int bella_hip_set_reads(bella_ctx* c, const uint8_t* bases, const uint64_t* offs
     Buf raw;
     int rc = ensure_bytes(c, raw, total);
     if (rc) return rc;
-    hipError_t e = c->stager.h2d(raw.p, bases, total, c->stream);
+    hipError_t e = total ? c->stager.h2d_fill(raw.p, total, c->stream, fill) : hipSuccess;
     if (e == hipSuccess) e = hipMemcpyAsync(c->roff.p, offsets, 8 * ((size_t)nreads + 1), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->packed.p, 0, 4 * (nwords + 16), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->status.p, 0, 4, c->stream);
@@ -548,19 +552,39 @@ int bella_hip_set_reads(bella_ctx* c, const uint8_t* bases, const uint64_t* offs
     return 0;
 }
 
+}  // extern "C++"
+
+int bella_hip_set_reads(bella_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads) {
+    if (!c || !offsets || (nreads && !bases)) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+    return set_reads_impl(c, offsets, nreads, [bases](void* pinned, size_t o, size_t n) { Stager::par_memcpy(pinned, bases + o, n); });
+}
+
 // ---- FASTQ ingest (fastq.hpp) ---------------------------------------------------------------------------------------------
+// The file is mapped and indexed on all cores; the bases go mapping -> pinned buffer -> device one 64 MB chunk at a time, the
+// gather of chunk i+1 overlapping the transfer of chunk i.  The concatenated bases never exist on the host.
 int bella_hip_load_fastq(bella_ctx* c, const char* path, uint32_t* nreads, uint64_t* nbases) {
     if (!c || !path) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
-    FastqData fq;
+    FastqIndex ix;
     std::string err;
-    if (parse_fastq(path, fq, err)) return fail(c, BELLA_ERR_BAD_ARG, "%s", err.c_str());
-    if (fq.names.size() >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "more than 2^32 reads");
-    const uint8_t dummy = 0;
-    int rc = bella_hip_set_reads(c, fq.bases.empty() ? &dummy : fq.bases.data(), fq.offsets.data(), (uint32_t)fq.names.size());
+    const auto t0 = std::chrono::steady_clock::now();
+    if (ix.build(path, err)) return fail(c, BELLA_ERR_BAD_ARG, "%s", err.c_str());
+    if (ix.names.size() >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "more than 2^32 reads");
+    const auto t1 = std::chrono::steady_clock::now();
+    int rc = set_reads_impl(c, ix.offsets.data(), ix.nreads(),
+                            [&ix](void* pinned, size_t o, size_t n) { ix.gather_parallel((uint8_t*)pinned, o, n); });
     if (rc) return rc;
-    c->names = std::move(fq.names);
+    const auto t2 = std::chrono::steady_clock::now();
+    c->ingest = {(uint64_t)ix.file.n, ix.nbases(), ix.nreads(), ix.threads, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                 std::chrono::duration<double, std::milli>(t2 - t1).count()};
+    c->names = std::move(ix.names);
     if (nreads) *nreads = c->nreads;
     if (nbases) *nbases = c->total_bases;
+    return 0;
+}
+
+int bella_hip_get_ingest_stats(bella_ctx* c, bella_ingest_stats* out) {
+    if (!c || !out) return BELLA_ERR_BAD_ARG;
+    *out = c->ingest;
     return 0;
 }
 

@@ -211,6 +211,30 @@ def dropin_call_record(rs, Bhost, nk, device):
     return rec
 
 
+def ingest_record(rs, device):
+    """FASTQ file -> packed reads on the device (bella_hip_load_fastq) on a fresh context, the file in the page cache"""
+    import tempfile
+    from bella_amd import Engine
+    from bella_testkit import synth
+    with tempfile.TemporaryDirectory() as tmp:
+        f = os.path.join(tmp, "reads.fastq")
+        synth.write_fastq(f, rs)
+        eng = Engine(device)
+        eng.load_fastq(f)                                      # first call: pinned buffers are allocated, pages are mapped
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter(); n, nb = eng.load_fastq(f); wall = (time.perf_counter() - t0) * 1e3
+            st = eng.ingest_stats()
+            if best is None or wall < best["ms"]:
+                best = {"ms": wall, "index_ms": st["index_ms"], "upload_and_pack_ms": st["upload_ms"], "host_threads": int(st["threads"]),
+                        "file_bytes": int(st["file_bytes"]), "reads": int(n), "bases": int(nb),
+                        "file_gb_per_s": st["file_bytes"] / (wall * 1e-3) / 1e9}
+        eng.close()
+    best["what"] = ("bella_hip_load_fastq, warm: mmap + threaded line index, bases gathered into pinned 64 MB chunks under the previous "
+                    "chunk's transfer, 2-bit pack on the device, names and lengths kept; wall clock on the host")
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -395,6 +419,7 @@ def main():
         if not a.no_dropin:
             out["dropin_call"] = dropin_call_record(info["rs"], Bhost, info["nk"], local)
             out["dropin_call"]["pairs_match_step"] = out["dropin_call"]["pairs"] == int(acc["npairs"])
+            out["ingest"] = ingest_record(info["rs"], local)
         del eng, info, Bhost
         if not a.no_100k and not a.reads:
             # configs[3]'s read set on ONE GPU: the configuration the 40 % HBM-roofline target is quoted on
@@ -427,6 +452,7 @@ def main():
             if not a.no_dropin:
                 sub["dropin_call"] = dropin_call_record(info["rs"], Bhost, info["nk"], local)
                 sub["dropin_call"]["pairs_match_step"] = sub["dropin_call"]["pairs"] == int(acc["npairs"])
+                sub["ingest"] = ingest_record(info["rs"], local)
             out["config_100k"] = sub
             del eng, info, Bhost
         if not a.no_hifi and not a.reads:

@@ -126,9 +126,21 @@ const char* bella_hip_last_error(const bella_ctx* ctx);
 int bella_hip_set_reads(bella_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint32_t nreads);
 /* FASTQ ingest: replaces ParallelFASTQ::fill_block / get_next_fq_record (kmercode/fq_reader.c:540-610) and the
  * name handling of get_fq_name (fq_reader.c:88-130) + src/main.cpp:352-360 for one plain (not compressed, as in the
- * reference's NO_GZIP build) 4-line FASTQ file: parse on the host, pack to 2 bit/base on the device.  Same effect as
- * bella_hip_set_reads; the names (without '@', cut at the comment as the reference does) stay in the context. */
+ * reference's NO_GZIP build) 4-line FASTQ file: the file is mapped and indexed on all host cores (records are found by line
+ * number, not by looking for '@'), the bases stream mapping -> pinned buffer -> device in 64 MB chunks (gather of chunk i+1 under
+ * the transfer of chunk i) and are packed to 2 bit/base on the device.  Same effect as bella_hip_set_reads; the names (without
+ * '@', cut at the comment as the reference does) stay in the context. */
 int bella_hip_load_fastq(bella_ctx* ctx, const char* path, uint32_t* nreads, uint64_t* nbases);
+/* what the last bella_hip_load_fastq did */
+typedef struct bella_ingest_stats {
+    uint64_t file_bytes;
+    uint64_t bases;
+    uint32_t reads;
+    uint32_t threads;     /* host threads of the index and of the gather */
+    double index_ms;      /* map + both passes over the file */
+    double upload_ms;     /* gather + host->device + pack, until the packed reads are on the device */
+} bella_ingest_stats;
+int bella_hip_get_ingest_stats(bella_ctx* ctx, bella_ingest_stats* out);
 /* names back to back, NUL-terminated; offsets[nreads+1] into buf; *needed = bytes required (call with buf = NULL first) */
 int bella_hip_get_read_names(bella_ctx* ctx, char* buf, uint64_t buflen, uint64_t* offsets, uint64_t* needed);
 int bella_hip_get_read_lengths(bella_ctx* ctx, uint32_t* lens);
@@ -221,7 +233,8 @@ int bella_hip_xdrop_batch(bella_ctx* ctx, const bella_seed* seeds, uint64_t n, c
  * p->skip_alignment (overlap.hpp:577-588), else the passed alignments as BELLA's 12 columns (:472-473) or PAF (paf != 0,
  * :476-489) -- and APPENDS the text to `path` (the reference opens its file in append mode, :613).  names[nreads]: NUL-terminated
  * read names (readType_::nametag); lens[nreads]: read lengths; alns may be NULL when p->skip_alignment.  nthreads host threads
- * (0 = all hardware threads) each format a contiguous share into their own buffer and write it at its offset of the file.
+ * (0 = all hardware threads) each measure a contiguous share (exact bytes), the file is grown and mapped, and every thread formats
+ * its share at its offset of the mapping (through buffers and offset writes where the file cannot be mapped).
  * Plain host code: no context, usable from any thread.  stats (nullable): what RunPairWiseAlignments returns (:644) + timings. */
 typedef struct {
     uint64_t lines;            /* outputted                                                       */
@@ -231,8 +244,8 @@ typedef struct {
     uint64_t total_read_len;   /* sum of both read lengths (:545)                                 */
     uint64_t bases_passed;     /* numBasesAlignedTrue (:491)                                      */
     uint64_t bases_failed;     /* numBasesAlignedFalse (:495)                                     */
-    double seconds;            /* formatting + file write                                          */
-    double format_seconds;
+    double seconds;            /* whole call                                                       */
+    double format_seconds;     /* of which: validation + measuring pass (before the file is touched) */
     uint32_t threads;
     uint32_t pad;
 } bella_write_stats;

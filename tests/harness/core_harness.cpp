@@ -94,6 +94,38 @@ long h_parse_fastq(const char* path, uint8_t* bases, uint64_t bases_cap, uint64_
     return (long)fq.names.size();
 }
 
+// the same through the serial restatement (mode 0) or the index with `threads` threads over slices of `slice` bytes (mode 1);
+// -1 with the message in `names` on a parse error.  gather_off/gather_n != 0: bases = that range of the base stream only.
+long h_parse_fastq2(const char* path, int mode, unsigned threads, uint64_t slice, uint8_t* bases, uint64_t bases_cap, uint64_t* offsets,
+                    uint64_t offsets_cap, char* names, uint64_t names_cap, uint64_t* nbases, uint64_t gather_off, uint64_t gather_n) {
+    FastqData fq;
+    std::string err;
+    if (mode == 0) {
+        if (parse_fastq_serial(path, fq, err)) { std::strncpy(names, err.c_str(), names_cap - 1); names[names_cap - 1] = 0; return -1; }
+    } else {
+        FastqIndex ix;
+        if (ix.build(path, err, threads, (size_t)slice)) { std::strncpy(names, err.c_str(), names_cap - 1); names[names_cap - 1] = 0; return -1; }
+        if (gather_n) {
+            if (gather_n > bases_cap || gather_off + gather_n > ix.nbases()) return -2;
+            ix.gather_parallel(bases, gather_off, gather_n);
+            *nbases = gather_n;
+            return (long)ix.nreads();
+        }
+        fq.bases.resize((size_t)ix.nbases());
+        ix.gather_parallel(fq.bases.data(), 0, ix.nbases());
+        fq.offsets = ix.offsets;
+        fq.names = ix.names;
+    }
+    std::string joined;
+    for (const auto& n : fq.names) { joined += n; joined += '\n'; }
+    *nbases = fq.bases.size();
+    if (fq.bases.size() > bases_cap || fq.offsets.size() > offsets_cap || joined.size() + 1 > names_cap) return -2;
+    std::memcpy(bases, fq.bases.data(), fq.bases.size());
+    std::memcpy(offsets, fq.offsets.data(), 8 * fq.offsets.size());
+    std::memcpy(names, joined.c_str(), joined.size() + 1);
+    return (long)fq.names.size();
+}
+
 void h_fastq_name(const char* header, char* out, uint64_t cap) {
     const std::string n = fastq_read_name(header);
     std::strncpy(out, n.c_str(), cap - 1);

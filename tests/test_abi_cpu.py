@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert _lib.PAIR_DT.itemsize == 16 and _lib.EXT_DT.itemsize == 8 and _lib.ALN_DT.itemsize == 32 and _lib.SEED_DT.itemsize == 12
     import ctypes
-    assert ctypes.sizeof(_lib.Params) == 24 and ctypes.sizeof(_lib.Timings) == 56 and ctypes.sizeof(_lib.WriteStats) == 80
+    assert ctypes.sizeof(_lib.Params) == 24 and ctypes.sizeof(_lib.Timings) == 56 and ctypes.sizeof(_lib.WriteStats) == 80 and ctypes.sizeof(_lib.IngestStats) == 40
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -35,6 +35,9 @@ def H():
     h.h_parse_fastq.restype = C.c_long
     h.h_parse_fastq.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
     h.h_fastq_name.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64]
+    h.h_parse_fastq2.restype = C.c_long
+    h.h_parse_fastq2.argtypes = [C.c_char_p, C.c_int, C.c_uint, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_char_p,
+                                 C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64]
     return h
 
 
@@ -272,3 +275,64 @@ def test_fastq_edge_cases(H, tmp_path):
     assert _parse(H, str(p))[0] == 0
     p.write_bytes(b"")
     assert _parse(H, str(p))[0] == 0
+
+
+def _parse2(H, path, mode, threads=1, slice_bytes=0, gather=(0, 0)):
+    size = os.path.getsize(path)
+    bases = np.zeros(size + 1, np.uint8)
+    offs = np.zeros(size // 4 + 4, np.uint64)
+    names = C.create_string_buffer(size + 256)
+    nb = C.c_uint64(0)
+    n = H.h_parse_fastq2(os.fsencode(path), mode, threads, slice_bytes, bases.ctypes.data, bases.size, offs.ctypes.data, offs.size, names,
+                         size + 256, C.byref(nb), gather[0], gather[1])
+    if n == -1:
+        return -1, names.value.decode()
+    assert n >= 0, n
+    if gather[1]:
+        return n, bases[:nb.value].tobytes()
+    return n, bases[:nb.value].tobytes(), offs[:n + 1].tolist(), names.value.decode().split("\n")[:-1]
+
+
+def _random_fastq(rng, nrec):
+    """records with the things that could fool a parallel splitter: '@' and '+' at the start of quality lines, CRLF, one-base reads"""
+    out = []
+    for i in range(nrec):
+        ln = int(rng.integers(1, 40))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), ln))
+        q0 = [b"@", b"+", b"!", b"I"][int(rng.integers(0, 4))]
+        qual = q0 + bytes(rng.integers(33, 74, ln - 1).astype(np.uint8))
+        cr = b"\r" if rng.integers(0, 5) == 0 else b""
+        hdr = b"@r%d" % i + [b"", b" 1:N:0:ACG", b"\tcomment", b"/2", b"   "][int(rng.integers(0, 5))]
+        out.append(hdr + b"\n" + seq + cr + b"\n+" + (b"r%d" % i if rng.integers(0, 2) else b"") + b"\n" + qual + b"\n")
+    return out
+
+
+def test_fastq_index_equals_the_serial_parse_for_any_slicing(H, tmp_path):
+    """fastq.hpp: the threaded index (what bella_hip_load_fastq uses) against the line-by-line restatement, slices down to 1 byte so
+    that every slice boundary falls inside headers, bases, '+' lines and quality strings that begin with '@'"""
+    rng = np.random.default_rng(5)
+    p = tmp_path / "x.fastq"
+    for trial in range(12):
+        recs = _random_fastq(rng, int(rng.integers(1, 60)))
+        data = b"".join(recs)
+        kind = trial % 6
+        if kind == 1: data = data[:-1]                                           # no final newline
+        if kind == 2: data = data[:len(data) - len(recs[-1]) // 2]               # cut inside the last record
+        if kind == 3: data = b"".join(recs[:len(recs) // 2]) + b"\n" + b"".join(recs[len(recs) // 2:])   # an empty line in the middle
+        if kind == 4: data = data + b"\n\n"
+        if kind == 5 and len(recs) > 2:                                          # a header without '@' after some good records
+            data = b"".join(recs[:2]) + b"oops\nAC\n+\n!!\n" + b"".join(recs[2:])
+        p.write_bytes(data)
+        want = _parse2(H, str(p), 0)
+        for threads, sl in ((1, 1), (3, 1), (4, 7), (2, 64), (8, 1 << 20), (0, 0)):
+            got = _parse2(H, str(p), 1, threads, sl)
+            assert got == want, (trial, threads, sl)
+        if want[0] > 0 and len(want[1]) > 3:
+            nb = len(want[1])
+            for _ in range(5):
+                o = int(rng.integers(0, nb - 1)); n = int(rng.integers(1, nb - o + 1))
+                assert _parse2(H, str(p), 1, 3, 5, gather=(o, n))[1] == want[1][o:o + n]
+    p.write_bytes(b"\n@a\nAC\n+\n!!\n")                                          # empty first line: nothing is read
+    assert _parse2(H, str(p), 0)[0] == 0 and _parse2(H, str(p), 1, 2, 1)[0] == 0
+    p.write_bytes(b"@a\nAC\n+\n!!\nbad")                                          # header of a short last record is still checked
+    assert _parse2(H, str(p), 0) == _parse2(H, str(p), 1, 2, 3) and _parse2(H, str(p), 0)[0] == -1

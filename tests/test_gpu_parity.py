@@ -794,6 +794,27 @@ def test_load_fastq_equals_set_reads(eng, golden, tmp_path):
         assert np.array_equal(x, y)
 
 
+def test_load_fastq_streams_a_file_larger_than_the_pinned_chunk(eng, tmp_path):
+    """configs[1]'s 10k reads as a 208 MB FASTQ: 104 M bases = two 64 MB chunks through the pinned buffers, the index on several
+    threads; the packed reads on the device are those of set_reads (same tuples), names and lengths come back"""
+    rs = synth.make_reads(10000, read_len=10000, coverage=30.0, err=0.15, seed=1)
+    p = tmp_path / "big.fastq"
+    synth.write_fastq(str(p), rs)
+    n, nb = eng.load_fastq(str(p))
+    st = eng.ingest_stats()
+    assert (n, nb) == (rs.nreads, int(rs.offsets[-1])) and st["reads"] == n and st["bases"] == nb and st["file_bytes"] == p.stat().st_size
+    assert nb > (64 << 20) and st["threads"] >= 1 and st["index_ms"] > 0 and st["upload_ms"] > 0
+    assert eng.names == rs.names and np.array_equal(eng.lengths, rs.lengths)
+    eng.count_kmers(17, 2, 8)
+    a = eng.get_tuples()
+    eng.set_reads(rs)
+    eng.count_kmers(17, 2, 8)
+    b = eng.get_tuples()
+    assert len(a[0]) > 1000000
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
 def test_file_to_file_pipeline_reproduces_reference_up_to_kmer_labels(eng, tmp_path):
     """FASTQ file -> load_fastq -> count_kmers -> assemble_counted -> HashSpGEMM-shaped driver -> output file.  K-mer ids
     differ from the reference's (labels): the candidate pair set is identical, seeds -- and so a few borderline alignment
