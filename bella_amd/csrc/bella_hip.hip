@@ -1473,8 +1473,26 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
         ENSURE(c, c->w_redo, 4 * ((size_t)np + 1));
         a.redo = ptr<uint32_t>(c->w_redo);
         HIPCHK(c, hipMemsetAsync(a.redo + np, 0, 4, c->stream));
+#ifdef BELLA_WF_CLOCK
+        static unsigned long long* d_clk = nullptr;
+        if (!d_clk) (void)hipMalloc(&d_clk, 64);
+        (void)hipMemsetAsync(d_clk, 0, 64, c->stream);
+        a.clk = d_clk;
+#endif
         k_wide_fold_wg<<<np < 16384u ? np : 16384u, kWideFoldBlock, 0, c->stream>>>(a);
         KCHK(c);
+#ifdef BELLA_WF_CLOCK
+        {
+            unsigned long long h[8];
+            (void)hipMemcpyAsync(h, d_clk, 64, hipMemcpyDeviceToHost, c->stream);
+            (void)hipStreamSynchronize(c->stream);
+            unsigned long long tot = 0;
+            for (int i = 0; i < 8; ++i) tot += h[i];
+            std::fprintf(stderr, "[wf clock] pairs %u:", np);
+            for (int i = 0; i < 8; ++i) std::fprintf(stderr, " p%d %.1f%%", i, 100.0 * (double)h[i] / (double)tot);
+            std::fprintf(stderr, " | cycles per pair %.0f\n", (double)tot / np);
+        }
+#endif
         k_wide_fold<<<nblk(np, 64), 64, 0, c->stream>>>(a);
         KCHK(c);
     }

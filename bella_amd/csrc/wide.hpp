@@ -54,6 +54,9 @@ struct WideArgs {
     bella_pair_ext* tmp_ext;
     uint32_t* nnzC;
     uint32_t* status;            // ctl word: bit0 = > 16 bins without scratch (never here)
+#ifdef BELLA_WF_CLOCK
+    unsigned long long* clk;
+#endif
     uint32_t* redo;              // [npairs] pairs left to the serial fold (k_wide_fold) by k_wide_fold_wg; redo[npairs] = their number
 };
 
@@ -172,15 +175,25 @@ __global__ __launch_bounds__(kBlock) void k_wide_ranks(WideArgs a) {
     }
 }
 
-__device__ __forceinline__ void wide_write_pair(const WideArgs& a, uint32_t r, const FoldResult& fr) {
-    const uint32_t seg = (uint32_t)(wide_rkey(a, r) >> a.rbits), key = (uint32_t)(wide_rkey(a, r) & ((1ull << a.rbits) - 1ull));
-    const uint32_t cid = a.cols[seg];
+// where a pair's record goes and where its two reads start: everything wide_write_pair needs besides the fold's result
+struct WidePairAddr { uint32_t key, cid; uint64_t roffH, roffV, out; };
+__device__ __forceinline__ WidePairAddr wide_pair_addr(const WideArgs& a, uint32_t r) {
+    WidePairAddr q;
+    const uint32_t seg = (uint32_t)(wide_rkey(a, r) >> a.rbits);
+    q.key = (uint32_t)(wide_rkey(a, r) & ((1ull << a.rbits) - 1ull));
+    q.cid = a.cols[seg];
+    q.roffH = a.roff[q.key]; q.roffV = a.roff[q.cid];
+    q.out = a.flopptr[q.cid] + a.R_rank[r];
+    return q;
+}
+__device__ __forceinline__ void wide_write_pair(const WideArgs& a, const WidePairAddr& q, const FoldResult& fr) {
+    const uint32_t key = q.key, cid = q.cid;
     const uint32_t k = (uint32_t)a.k;
     const uint32_t seedH = fr.seed & 0xFFFFu, seedV = fr.seed >> 16;
-    const uint64_t leH = kmer_le(a.packed, a.roff[key] + seedH, k);
-    const uint64_t leV = kmer_le(a.packed, a.roff[cid] + seedV, k);
+    const uint64_t leH = kmer_le(a.packed, q.roffH + seedH, k);
+    const uint64_t leV = kmer_le(a.packed, q.roffV + seedV, k);
     const uint32_t flags = (leH == leV ? 1u : 0u) | (kmer_rc_from_le(leH, k) == kmer_fw_from_le(leV, k) ? 2u : 0u);
-    const uint64_t o = a.flopptr[cid] + a.R_rank[r];
+    const uint64_t o = q.out;
     bella_pair pr;
     pr.rid = key; pr.cid = cid; pr.count = fr.count; pr.seedH = (uint16_t)seedH; pr.seedV = (uint16_t)seedV; pr.flags = (uint16_t)flags;
     a.tmp_pairs[o] = pr;
@@ -206,50 +219,87 @@ __device__ __forceinline__ void wide_write_pair(const WideArgs& a, uint32_t r, c
 #define BELLA_WIDE_FOLD_W 16
 #endif
 constexpr int kWideFoldBlock = BELLA_WIDE_FOLD_BLOCK;
-#ifndef BELLA_WIDE_GRID_SLOTS
-#define BELLA_WIDE_GRID_SLOTS 1024
-#endif
 #ifndef BELLA_WIDE_FOLD_LDS
 #define BELLA_WIDE_FOLD_LDS 4096
 #endif
-constexpr uint32_t kGridSlots = BELLA_WIDE_GRID_SLOTS, kGridMax = 4096, kGridMin = 96;   // lists of kGridMin < m <= kGridMax products use the grid
-constexpr uint32_t kWideFoldLds = BELLA_WIDE_FOLD_LDS;                    // products of a list staged in LDS (positions + overlap estimates, 24 KB; with the grid 48 KB: three workgroups per CU)
-__global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
+#ifndef BELLA_WIDE_VISIT
+#define BELLA_WIDE_VISIT 8
+#endif
+#ifndef BELLA_WIDE_GRID_BUCKETS
+#define BELLA_WIDE_GRID_BUCKETS 4096
+#endif
+constexpr uint32_t kGridBuckets = BELLA_WIDE_GRID_BUCKETS, kGridMax = BELLA_WIDE_FOLD_LDS < 4096 ? BELLA_WIDE_FOLD_LDS : 4096, kGridMin = 96;   // lists of kGridMin < m <= kGridMax products use the grid
+constexpr uint32_t kWideFoldLds = BELLA_WIDE_FOLD_LDS;                    // products of a list staged in LDS (positions + overlap estimates, 24 KB; with the grid 72 KB: two workgroups per CU)
+__global__ __launch_bounds__(kWideFoldBlock, 4) void k_wide_fold_wg(WideArgs a) {
     __shared__ uint32_t s_flag, s_contrib, s_surv, s_roots;
     __shared__ unsigned long long s_best;
     __shared__ uint32_t s_hv[kWideFoldLds + 16];
     __shared__ uint16_t s_ov[kWideFoldLds + 16];
-    // position grid of a long plain-chain list: per coordinate, chains of list positions by bucket floor(pos / 2^sh) (2^sh > k), heads
-    // hashed into kGridSlots slots.  Two positions within k of each other sit in the same or in adjacent buckets, so "the first later
-    // product within k" is a look at three chains per coordinate instead of a walk over all later products (quadratic in the list).
-    __shared__ uint32_t s_head[2][kGridSlots];
-    __shared__ uint16_t s_next[2][kGridMax];
+    // position grid of a long plain-chain list: per coordinate, the list positions counting-sorted by bucket floor(pos / 4) (hashed into
+    // NB buckets).  s_cnt[b] packs both coordinates' counters (H low half, V high half: a list has at most 4,096 products); after the
+    // scan and the scatter it holds the bucket ends, s_sorted {pos << 16 | list index} bucket by bucket, all of H, then all of V.
+    // The products within k of a position stand in the buckets floor((pos - k) / 4) .. floor((pos + k) / 4), one contiguous range of
+    // s_sorted, so "the first later product within k" is a scan of that range (about 1.1 x the products really within k) instead of
+    // a walk over all later products (quadratic in the list).
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kGridBuckets];
+    constexpr uint32_t kVisit = BELLA_WIDE_VISIT;
+    __shared__ uint32_t s_sorted[2 * kGridMax + 2 * kVisit];
+    __shared__ uint32_t s_scr[kWideFoldBlock / 64];
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t kRoot = 0x8000u;
+    // Two pairs ahead: the descriptors (length, start) of the pair after the next one are in flight while the next pair's list is
+    // loaded into registers (lists that fit the LDS staging) under the current pair's fold.
+    constexpr uint32_t kPre = kWideFoldLds / kWideFoldBlock;
+    static_assert(kWideFoldLds % kWideFoldBlock == 0, "a whole number of staged products per thread");
+#ifdef BELLA_WF_CLOCK
+    unsigned long long c_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c_prev = clock64();
+#define WFCLK(i) do { if (tid == 0) { const unsigned long long c_now = clock64(); c_acc[i] += c_now - c_prev; c_prev = c_now; } } while (0)
+#else
+#define WFCLK(i) do {} while (0)
+#endif
+    uint2 pre[kPre];
+    uint32_t mm1 = 0, mm2 = 0;                                     // lengths of the pairs r, r + gridDim.x
+    uint64_t lo1 = 0, lo2 = 0;
+    if (blockIdx.x < a.npairs) { mm1 = a.R_len[blockIdx.x]; lo1 = a.R_start[blockIdx.x]; }
+    if (blockIdx.x + gridDim.x < a.npairs) { mm2 = a.R_len[blockIdx.x + gridDim.x]; lo2 = a.R_start[blockIdx.x + gridDim.x]; }
+    if (mm1 <= kWideFoldLds) {
+#pragma unroll
+        for (uint32_t u = 0; u < kPre; ++u) { const uint32_t y = tid + u * kWideFoldBlock; if (y < mm1) pre[u] = a.plist[lo1 + y]; }
+    }
     for (uint32_t r = blockIdx.x; r < a.npairs; r += gridDim.x) {
-        const uint32_t mm = a.R_len[r];
-        const uint64_t lo = a.R_start[r];
+        const uint32_t mm = mm1;
+        const uint64_t lo = lo1;
         uint2* w = a.plist + lo;
+        const bool staged = mm <= kWideFoldLds;
+        // a list that fits is staged in LDS (positions and overlap estimates): one streaming read of the pair's list
+        if (staged) {
+#pragma unroll
+            for (uint32_t u = 0; u < kPre; ++u) {
+                const uint32_t y = tid + u * kWideFoldBlock;
+                if (y < mm) { s_hv[y] = pre[u].x; s_ov[y] = (uint16_t)pre[u].y; }
+            }
+        }
+        mm1 = mm2; lo1 = lo2;                                      // the next pair: its list now, the descriptors of the one after it
+        if (mm1 <= kWideFoldLds && r + gridDim.x < a.npairs) {
+#pragma unroll
+            for (uint32_t u = 0; u < kPre; ++u) { const uint32_t y = tid + u * kWideFoldBlock; if (y < mm1) pre[u] = a.plist[lo1 + y]; }
+        }
+        mm2 = 0;
+        if ((uint64_t)r + 2ull * gridDim.x < a.npairs) { mm2 = a.R_len[r + 2 * gridDim.x]; lo2 = a.R_start[r + 2 * gridDim.x]; }
         if (mm >= kRoot) {                                         // parent links are u16
             if (tid == 0) a.redo[atomicAdd(&a.redo[a.npairs], 1u)] = r;
             continue;
         }
         uint16_t* Par = a.sort_scratch + lo;
-        if (tid == 0) { s_flag = 0; s_contrib = 0; s_surv = 0; s_roots = 0; s_best = 0; }
-        const bool staged = mm <= kWideFoldLds;
+        WidePairAddr addr{};                                       // loads issued now, used when the pair is folded
+        if (tid == 0) { s_flag = 0; s_contrib = 0; s_surv = 0; s_roots = 0; s_best = 0; addr = wide_pair_addr(a, r); }
         const bool grid = mm > kGridMin && mm <= kGridMax && mm <= kWideFoldLds;    // (used if the chain turns out plain)
-        const uint32_t sh = a.k < 32 ? 5u : 6u;                    // bucket width > k
-        uint32_t T = 64;
-        while (T < mm && T < kGridSlots) T <<= 1;
-        if (grid) for (uint32_t x = tid; x < T; x += kWideFoldBlock) { s_head[0][x] = 0xFFFFu; s_head[1][x] = 0xFFFFu; }
-        // a list that fits is staged in LDS (positions and overlap estimates): one streaming read of the pair's list
-        if (staged) {
-            for (uint32_t y = tid; y < mm; y += kWideFoldBlock) {
-                const uint2 e0 = w[y];
-                s_hv[y] = e0.x; s_ov[y] = (uint16_t)e0.y;
-            }
-        }
+        constexpr uint32_t sh = 2;                                 // bucket width 4
+        uint32_t NB = kWideFoldBlock;                              // buckets: >= 8 per product, a whole number per thread
+        while (NB < 8 * mm && NB < kGridBuckets) NB <<= 1;
+        if (grid) for (uint32_t x = tid; x < NB; x += kWideFoldBlock) s_cnt[x] = 0;
         __syncthreads();
+        WFCLK(0);
         // is it a plain chain (every product's parent is its successor)?  Only otherwise the parent links are stored and the flag
         // halves of the list words cleared (they become the support counters).  The grid is filled in the same sweep.
         for (uint32_t y = tid; y < mm; y += kWideFoldBlock) {
@@ -259,11 +309,12 @@ __global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
             }
             if (grid) {
                 const uint32_t hv = s_hv[y];
-                s_next[0][y] = (uint16_t)atomicExch(&s_head[0][((hv & 0xFFFFu) >> sh) & (T - 1)], y);
-                s_next[1][y] = (uint16_t)atomicExch(&s_head[1][((hv >> 16) >> sh) & (T - 1)], y);
+                atomicAdd(&s_cnt[((hv & 0xFFFFu) >> sh) & (NB - 1)], 1u);
+                atomicAdd(&s_cnt[((hv >> 16) >> sh) & (NB - 1)], 0x10000u);
             }
         }
         __syncthreads();
+        WFCLK(1);
         if (s_flag) {
             for (uint32_t y = tid; y < mm; y += kWideFoldBlock) {
                 const uint32_t ovw = staged ? (uint32_t)s_ov[y] : w[y].y & 0xFFFFu;
@@ -278,29 +329,96 @@ __global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
         }
         const bool plain = s_flag == 0;
         uint32_t contrib = 0, surv = 0;
+#ifdef BELLA_WF_CUT
+        if (BELLA_WF_CUT == 2 && plain && grid) {} else
+#endif
         if (plain && grid) {
             const uint32_t kk = (uint32_t)a.k;
+            {   // bucket counts -> bucket starts (one scan, both halves at once), then the scatter turns the starts into ends
+                constexpr uint32_t kPer = kGridBuckets / kWideFoldBlock;
+                static_assert(kPer % 4 == 0, "whole 16-byte words per thread");
+                const uint32_t per = NB / kWideFoldBlock;          // 1 .. kPer consecutive buckets per thread
+                uint32_t loc[kPer], sum = 0;
+                if (per == kPer) {                                 // the usual case: 16-byte LDS accesses, no bank conflicts
+#pragma unroll
+                    for (uint32_t u = 0; u < kPer; u += 4) {
+                        const uint4 q = *(const uint4*)&s_cnt[tid * kPer + u];
+                        loc[u] = q.x; loc[u + 1] = q.y; loc[u + 2] = q.z; loc[u + 3] = q.w;
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < kPer; ++u) sum += loc[u];
+                } else {
+#pragma unroll
+                    for (uint32_t u = 0; u < kPer; ++u) { loc[u] = u < per ? s_cnt[tid * per + u] : 0u; sum += loc[u]; }
+                }
+                uint32_t tot;
+                uint32_t ex = block_excl_scan<kWideFoldBlock / 64>(sum, s_scr, &tot);
+                if (per == kPer) {
+#pragma unroll
+                    for (uint32_t u = 0; u < kPer; u += 4) {
+                        uint4 q;
+                        q.x = ex; q.y = q.x + loc[u]; q.z = q.y + loc[u + 1]; q.w = q.z + loc[u + 2];
+                        ex = q.w + loc[u + 3];
+                        *(uint4*)&s_cnt[tid * kPer + u] = q;
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t u = 0; u < kPer; ++u) { if (u < per) s_cnt[tid * per + u] = ex; ex += loc[u]; }
+                }
+            }
+            __syncthreads();
+            WFCLK(2);
+            for (uint32_t y = tid; y < mm; y += kWideFoldBlock) {
+                const uint32_t hv = s_hv[y];
+                s_sorted[atomicAdd(&s_cnt[((hv & 0xFFFFu) >> sh) & (NB - 1)], 1u) & 0xFFFFu] = (hv << 16) | y;
+                s_sorted[mm + kVisit + (atomicAdd(&s_cnt[((hv >> 16) >> sh) & (NB - 1)], 0x10000u) >> 16)] = (hv & 0xFFFF0000u) | y;
+            }
+            // kVisit entries that match nothing behind either coordinate's part: the scans below read whole groups of kVisit
+            if (tid < 2 * kVisit) s_sorted[tid < kVisit ? mm + tid : 2 * mm + tid] = 0xFFFFFFFFu;
+            __syncthreads();
+            WFCLK(3);
+#ifdef BELLA_WF_CUT
+            if (BELLA_WF_CUT != 1)
+#endif
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            const uint32_t lim = (2 * kk) << 16 | 0xFFFFu;         // high half (position - (pos - k)) <= 2k
             for (uint32_t y = tid; y + 1 < mm; y += kWideFoldBlock) {
                 const uint32_t hv = s_hv[y];
-                uint32_t t = mm;                                   // the first later product within k in either coordinate
+                // distance (in list positions, minus one) to the first later product within k in either coordinate: the running minimum
+                // sits in the low half of tt, both tests of an entry {pos << 16 | index} come out of one packed subtraction
+                us2 tt = {(unsigned short)(mm - y - 1), 0};
 #pragma unroll
                 for (uint32_t cdn = 0; cdn < 2; ++cdn) {
                     const uint32_t pos = cdn ? hv >> 16 : hv & 0xFFFFu;
-                    const uint32_t b = pos >> sh;
-                    for (uint32_t db = 0; db < 3; ++db) {
-                        if (db == 0 && b == 0) continue;           // bucket -1
-                        uint32_t e = s_head[cdn][(b + db - 1) & (T - 1)];
-                        while (e != 0xFFFFu) {
-                            const uint32_t q = s_hv[e];
-                            const uint32_t qp = cdn ? q >> 16 : q & 0xFFFFu;
-                            const uint32_t dlt = qp > pos ? qp - pos : pos - qp;
-                            if (e > y && e < t && dlt <= kk) t = e;
-                            e = s_next[cdn][e];
+                    const uint32_t i0 = ((pos > kk ? pos - kk : 0u) >> sh) & (NB - 1), i1 = ((pos + kk) >> sh) & (NB - 1);
+                    const uint32_t c0 = i0 ? s_cnt[i0 - 1] : 0u, c1 = s_cnt[i1];
+                    const uint32_t sec = cdn ? mm + kVisit : 0u;   // where the coordinate's part of s_sorted begins
+                    uint32_t xs = sec + (cdn ? c0 >> 16 : c0 & 0xFFFFu), xe = sec + (cdn ? c1 >> 16 : c1 & 0xFFFFu);
+                    uint32_t xs2 = 0, xe2 = 0;
+                    if (i0 > i1) { xs2 = sec; xe2 = xe; xe = sec + mm; }     // the bucket range wraps
+                    const us2 ref = {(unsigned short)(y + 1), (unsigned short)(pos - kk)};
+                    for (;;) {
+                        // whole groups of kVisit entries: what stands behind xe lies in later buckets (positions beyond pos + k, or a
+                        // multiple of 4 NB away) or is one of the kVisit fillers behind the part -- it fails the position test
+                        for (uint32_t x = xs; x < xe; x += kVisit) {
+                            uint32_t v[kVisit];
+#pragma unroll
+                            for (uint32_t u = 0; u < kVisit; ++u) v[u] = s_sorted[x + u];
+#pragma unroll
+                            for (uint32_t u = 0; u < kVisit; ++u) {
+                                const us2 d = __builtin_bit_cast(us2, v[u]) - ref;     // {index - (y + 1), position - (pos - k)} mod 2^16
+                                const uint32_t dw = __builtin_bit_cast(uint32_t, d);
+                                const uint32_t cand = dw <= lim ? dw : 0xFFFFFFFFu;    // within k: the index distance competes (earlier products: >= 61,440)
+                                tt = __builtin_elementwise_min(tt, __builtin_bit_cast(us2, cand));
+                            }
                         }
+                        if (xs2 == xe2) break;
+                        xs = xs2; xe = xe2; xs2 = xe2 = 0;
                     }
                 }
-                contrib += t - y - 1;
-                surv += t == mm ? 1u : 0u;
+                const uint32_t dist = tt.x;                        // t - y - 1
+                contrib += dist;
+                surv += dist == mm - y - 1 ? 1u : 0u;
             }
         } else if (plain) {
             // plain chain: every position is compared with the later products until one is within k of it (16 per round trip)
@@ -350,9 +468,16 @@ __global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
                 if (!dead) atomicAdd(&w[root].y, 0x10000u);
             }
         }
-        if (contrib) atomicAdd(&s_contrib, contrib);
-        if (surv) atomicAdd(&s_surv, surv);
+        WFCLK(4);
+        {   // one LDS atomic per wavefront, not per thread (512 same-address atomics queue up behind each other)
+            const uint32_t cw = wave_incl_scan(contrib), sw = wave_incl_scan(surv);
+            if (lane_id() == 63) { if (cw) atomicAdd(&s_contrib, cw); if (sw) atomicAdd(&s_surv, sw); }
+        }
         __syncthreads();
+        WFCLK(5);
+#ifdef BELLA_WF_CUT
+        if (BELLA_WF_CUT == 3) continue;
+#endif
         FoldResult fr;
         fr.many_bins = 0;
         fr.count = (uint16_t)(mm + s_contrib);
@@ -380,12 +505,17 @@ __global__ __launch_bounds__(kWideFoldBlock) void k_wide_fold_wg(WideArgs a) {
             fr.nbins = (uint16_t)nroots; fr.support = (uint16_t)(s_best >> 32);
         }
         if (tid == 0) {
-            const uint2 e = w[win];
-            fr.seed = e.x; fr.binov = (uint16_t)(e.y & 0xFFFFu);
-            wide_write_pair(a, r, fr);
+            if (staged) { fr.seed = s_hv[win]; fr.binov = s_ov[win]; }
+            else { const uint2 e = w[win]; fr.seed = e.x; fr.binov = (uint16_t)(e.y & 0xFFFFu); }
+            wide_write_pair(a, addr, fr);
         }
+        WFCLK(6);
         __syncthreads();
+        WFCLK(7);
     }
+#ifdef BELLA_WF_CLOCK
+    if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&a.clk[i], c_acc[i]);
+#endif
 }
 
 // the serial fold of the pairs k_wide_fold_wg left over: one lane per pair, serial statement of the semiring on the pair's own
@@ -401,7 +531,7 @@ __global__ __launch_bounds__(64) void k_wide_fold(WideArgs a) {
     struct S2 { uint32_t* base; __device__ uint32_t& operator[](uint32_t e) const { return base[2u * e]; } };
     FoldResult fr;
     fold_pair(S2{w}, S2{w + 1}, mm, a.k, a.binSize, a.sort_scratch + lo, fr);
-    wide_write_pair(a, r, fr);
+    wide_write_pair(a, wide_pair_addr(a, r), fr);
 }
 
 // column ids of a tier's descriptor list (the columns above the LDS tiers join the wide columns)
