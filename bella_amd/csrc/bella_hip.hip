@@ -117,7 +117,7 @@ struct bella_ctx {
         status, cubtmp, plist_hv, overflow, ctl, retry, orderlist, order_ws;
     bool order_attr = false;
     Buf w_f, w_off, w_key, w_key2, w_idx, w_idx2, w_hv, w_ovfl, w_plist, w_scr, w_rlen, w_rstart, w_rrank, w_redo, w_segfirst,
-        w_toff, w_table, w_nruns;
+        w_toff, w_table, w_nruns, w_desc;
     uint32_t n_wide = 0;
     uint32_t n_retry = 0;
     uint32_t n_overflow = 0;
@@ -440,7 +440,7 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->w, &c->wscan, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC,
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
                   &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->orderlist, &c->order_ws, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx, &c->w_idx2, &c->w_hv, &c->w_ovfl,
-                  &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_redo, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
+                  &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_redo, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->w_desc, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
                   &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -1473,6 +1473,10 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
         ENSURE(c, c->w_redo, 4 * ((size_t)np + 1));
         a.redo = ptr<uint32_t>(c->w_redo);
         HIPCHK(c, hipMemsetAsync(a.redo + np, 0, 4, c->stream));
+        ENSURE(c, c->w_desc, sizeof(WidePairAddr) * (size_t)np);
+        a.desc = (WidePairAddr*)c->w_desc.p;
+        k_wide_desc<<<nblk(np), 256, 0, c->stream>>>(a);
+        KCHK(c);
 #ifdef BELLA_WF_CLOCK
         static unsigned long long* d_clk = nullptr;
         if (!d_clk) (void)hipMalloc(&d_clk, 64);

@@ -17,6 +17,7 @@
 
 namespace bella {
 
+struct WidePairAddr;
 struct WideArgs {
     const uint32_t* cols;        // [nw] the wide columns
     uint32_t nw;
@@ -57,6 +58,7 @@ struct WideArgs {
 #ifdef BELLA_WF_CLOCK
     unsigned long long* clk;
 #endif
+    WidePairAddr* desc;          // [npairs] (k_wide_desc)
     uint32_t* redo;              // [npairs] pairs left to the serial fold (k_wide_fold) by k_wide_fold_wg; redo[npairs] = their number
 };
 
@@ -175,16 +177,36 @@ __global__ __launch_bounds__(kBlock) void k_wide_ranks(WideArgs a) {
     }
 }
 
-// where a pair's record goes and where its two reads start: everything wide_write_pair needs besides the fold's result
-struct WidePairAddr { uint32_t key, cid; uint64_t roffH, roffV, out; };
+// a pair's list (start, length), where its record goes and where its two reads start: everything the fold of the pair needs
+// besides the list itself.  k_wide_desc fills one per pair (48 bytes), so that the fold reads a single record per pair, two pairs
+// ahead, instead of chasing key -> column -> read offsets when the pair is done.
+struct __attribute__((aligned(16))) WidePairAddr { uint64_t lo; uint32_t mm, key; uint32_t cid, pad; uint64_t roffH, roffV, out; };
+static_assert(sizeof(WidePairAddr) == 48, "three 16-byte words");
 __device__ __forceinline__ WidePairAddr wide_pair_addr(const WideArgs& a, uint32_t r) {
     WidePairAddr q;
     const uint32_t seg = (uint32_t)(wide_rkey(a, r) >> a.rbits);
+    q.lo = a.R_start[r]; q.mm = a.R_len[r];
     q.key = (uint32_t)(wide_rkey(a, r) & ((1ull << a.rbits) - 1ull));
-    q.cid = a.cols[seg];
+    q.cid = a.cols[seg]; q.pad = 0;
     q.roffH = a.roff[q.key]; q.roffV = a.roff[q.cid];
     q.out = a.flopptr[q.cid] + a.R_rank[r];
     return q;
+}
+// A descriptor travels as one dword per lane (lane i holds word i of the 12): a per-lane load is not waited for where it is issued
+// (a wave-uniform one is, the compiler moves it to scalar registers at once), only where desc_decode reads the lanes an iteration later.
+__device__ __forceinline__ uint32_t desc_load_raw(const WidePairAddr* d) { return ((const uint32_t*)d)[lane_id() % 12u]; }
+__device__ __forceinline__ WidePairAddr desc_decode(uint32_t raw) {
+    uint32_t w[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)raw, i);
+    WidePairAddr q;
+    q.lo = w[0] | ((uint64_t)w[1] << 32); q.mm = w[2]; q.key = w[3]; q.cid = w[4]; q.pad = w[5];
+    q.roffH = w[6] | ((uint64_t)w[7] << 32); q.roffV = w[8] | ((uint64_t)w[9] << 32); q.out = w[10] | ((uint64_t)w[11] << 32);
+    return q;
+}
+__global__ void k_wide_desc(WideArgs a) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < a.npairs) a.desc[r] = wide_pair_addr(a, r);
 }
 __device__ __forceinline__ void wide_write_pair(const WideArgs& a, const WidePairAddr& q, const FoldResult& fr) {
     const uint32_t key = q.key, cid = q.cid;
@@ -245,6 +267,10 @@ __global__ __launch_bounds__(kWideFoldBlock, 4) void k_wide_fold_wg(WideArgs a) 
     constexpr uint32_t kVisit = BELLA_WIDE_VISIT;
     __shared__ uint32_t s_sorted[2 * kGridMax + 2 * kVisit];
     __shared__ uint32_t s_scr[kWideFoldBlock / 64];
+    constexpr uint32_t kPend = 8;                                  // folded pairs waiting for their records to be written
+    __shared__ FoldResult s_pfr[kPend];
+    __shared__ uint32_t s_pr[kPend];
+    uint32_t npend = 0;
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t kRoot = 0x8000u;
     // Two pairs ahead: the descriptors (length, start) of the pair after the next one are in flight while the next pair's list is
@@ -252,23 +278,25 @@ __global__ __launch_bounds__(kWideFoldBlock, 4) void k_wide_fold_wg(WideArgs a) 
     constexpr uint32_t kPre = kWideFoldLds / kWideFoldBlock;
     static_assert(kWideFoldLds % kWideFoldBlock == 0, "a whole number of staged products per thread");
 #ifdef BELLA_WF_CLOCK
-    unsigned long long c_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c_prev = clock64();
+    __shared__ unsigned long long c_acc[8];
+    if (tid == 0) for (int i = 0; i < 8; ++i) c_acc[i] = 0;
+    unsigned long long c_prev = clock64();
 #define WFCLK(i) do { if (tid == 0) { const unsigned long long c_now = clock64(); c_acc[i] += c_now - c_prev; c_prev = c_now; } } while (0)
 #else
 #define WFCLK(i) do {} while (0)
 #endif
     uint2 pre[kPre];
-    uint32_t mm1 = 0, mm2 = 0;                                     // lengths of the pairs r, r + gridDim.x
-    uint64_t lo1 = 0, lo2 = 0;
-    if (blockIdx.x < a.npairs) { mm1 = a.R_len[blockIdx.x]; lo1 = a.R_start[blockIdx.x]; }
-    if (blockIdx.x + gridDim.x < a.npairs) { mm2 = a.R_len[blockIdx.x + gridDim.x]; lo2 = a.R_start[blockIdx.x + gridDim.x]; }
-    if (mm1 <= kWideFoldLds) {
+    WidePairAddr d1{};                                             // of the pair r
+    uint32_t d2raw = 0;                                            // of the pair r + gridDim.x (mm = 0 beyond the last pair)
+    if (blockIdx.x < a.npairs) d1 = a.desc[blockIdx.x];
+    if (blockIdx.x + gridDim.x < a.npairs) d2raw = desc_load_raw(a.desc + blockIdx.x + gridDim.x);
+    if (d1.mm <= kWideFoldLds) {
 #pragma unroll
-        for (uint32_t u = 0; u < kPre; ++u) { const uint32_t y = tid + u * kWideFoldBlock; if (y < mm1) pre[u] = a.plist[lo1 + y]; }
+        for (uint32_t u = 0; u < kPre; ++u) { const uint32_t y = tid + u * kWideFoldBlock; if (y < d1.mm) pre[u] = a.plist[d1.lo + y]; }
     }
     for (uint32_t r = blockIdx.x; r < a.npairs; r += gridDim.x) {
-        const uint32_t mm = mm1;
-        const uint64_t lo = lo1;
+        const uint32_t mm = d1.mm;
+        const uint64_t lo = d1.lo;
         uint2* w = a.plist + lo;
         const bool staged = mm <= kWideFoldLds;
         // a list that fits is staged in LDS (positions and overlap estimates): one streaming read of the pair's list
@@ -276,28 +304,39 @@ __global__ __launch_bounds__(kWideFoldBlock, 4) void k_wide_fold_wg(WideArgs a) 
 #pragma unroll
             for (uint32_t u = 0; u < kPre; ++u) {
                 const uint32_t y = tid + u * kWideFoldBlock;
-                if (y < mm) { s_hv[y] = pre[u].x; s_ov[y] = (uint16_t)pre[u].y; }
+                if (u * kWideFoldBlock < mm) {                     // (wave-uniform: whole groups beyond the list are skipped by a scalar branch)
+                    if (y < mm) { s_hv[y] = pre[u].x; s_ov[y] = (uint16_t)pre[u].y; }
+                }
             }
         }
-        mm1 = mm2; lo1 = lo2;                                      // the next pair: its list now, the descriptors of the one after it
-        if (mm1 <= kWideFoldLds && r + gridDim.x < a.npairs) {
+        d1 = desc_decode(d2raw);                                   // the next pair: its list now, the descriptor of the one after it
+        if (d1.mm <= kWideFoldLds && r + gridDim.x < a.npairs) {
 #pragma unroll
-            for (uint32_t u = 0; u < kPre; ++u) { const uint32_t y = tid + u * kWideFoldBlock; if (y < mm1) pre[u] = a.plist[lo1 + y]; }
+            for (uint32_t u = 0; u < kPre; ++u) {
+                const uint32_t y = tid + u * kWideFoldBlock;
+                if (u * kWideFoldBlock < d1.mm) { if (y < d1.mm) pre[u] = a.plist[d1.lo + y]; }
+            }
         }
-        mm2 = 0;
-        if ((uint64_t)r + 2ull * gridDim.x < a.npairs) { mm2 = a.R_len[r + 2 * gridDim.x]; lo2 = a.R_start[r + 2 * gridDim.x]; }
+        d2raw = 0;
+        if ((uint64_t)r + 2ull * gridDim.x < a.npairs) d2raw = desc_load_raw(a.desc + r + 2 * gridDim.x);
         if (mm >= kRoot) {                                         // parent links are u16
             if (tid == 0) a.redo[atomicAdd(&a.redo[a.npairs], 1u)] = r;
             continue;
         }
         uint16_t* Par = a.sort_scratch + lo;
-        WidePairAddr addr{};                                       // loads issued now, used when the pair is folded
-        if (tid == 0) { s_flag = 0; s_contrib = 0; s_surv = 0; s_roots = 0; s_best = 0; addr = wide_pair_addr(a, r); }
+        if (tid == 0) { s_flag = 0; s_contrib = 0; s_surv = 0; s_roots = 0; s_best = 0; }
         const bool grid = mm > kGridMin && mm <= kGridMax && mm <= kWideFoldLds;    // (used if the chain turns out plain)
         constexpr uint32_t sh = 2;                                 // bucket width 4
         uint32_t NB = kWideFoldBlock;                              // buckets: >= 8 per product, a whole number per thread
         while (NB < 8 * mm && NB < kGridBuckets) NB <<= 1;
-        if (grid) for (uint32_t x = tid; x < NB; x += kWideFoldBlock) s_cnt[x] = 0;
+        if (grid) {
+            if (NB == kGridBuckets) {
+#pragma unroll
+                for (uint32_t u = 0; u < kGridBuckets / kWideFoldBlock; u += 4) *(uint4*)&s_cnt[4 * tid + u * kWideFoldBlock] = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                for (uint32_t x = tid; x < NB; x += kWideFoldBlock) s_cnt[x] = 0;
+            }
+        }
         __syncthreads();
         WFCLK(0);
         // is it a plain chain (every product's parent is its successor)?  Only otherwise the parent links are stored and the flag
@@ -329,9 +368,6 @@ __global__ __launch_bounds__(kWideFoldBlock, 4) void k_wide_fold_wg(WideArgs a) 
         }
         const bool plain = s_flag == 0;
         uint32_t contrib = 0, surv = 0;
-#ifdef BELLA_WF_CUT
-        if (BELLA_WF_CUT == 2 && plain && grid) {} else
-#endif
         if (plain && grid) {
             const uint32_t kk = (uint32_t)a.k;
             {   // bucket counts -> bucket starts (one scan, both halves at once), then the scatter turns the starts into ends
@@ -377,9 +413,6 @@ __global__ __launch_bounds__(kWideFoldBlock, 4) void k_wide_fold_wg(WideArgs a) 
             if (tid < 2 * kVisit) s_sorted[tid < kVisit ? mm + tid : 2 * mm + tid] = 0xFFFFFFFFu;
             __syncthreads();
             WFCLK(3);
-#ifdef BELLA_WF_CUT
-            if (BELLA_WF_CUT != 1)
-#endif
             typedef unsigned short us2 __attribute__((ext_vector_type(2)));
             const uint32_t lim = (2 * kk) << 16 | 0xFFFFu;         // high half (position - (pos - k)) <= 2k
             for (uint32_t y = tid; y + 1 < mm; y += kWideFoldBlock) {
@@ -475,9 +508,6 @@ __global__ __launch_bounds__(kWideFoldBlock, 4) void k_wide_fold_wg(WideArgs a) 
         }
         __syncthreads();
         WFCLK(5);
-#ifdef BELLA_WF_CUT
-        if (BELLA_WF_CUT == 3) continue;
-#endif
         FoldResult fr;
         fr.many_bins = 0;
         fr.count = (uint16_t)(mm + s_contrib);
@@ -504,15 +534,24 @@ __global__ __launch_bounds__(kWideFoldBlock, 4) void k_wide_fold_wg(WideArgs a) 
             win = (uint32_t)s_best;
             fr.nbins = (uint16_t)nroots; fr.support = (uint16_t)(s_best >> 32);
         }
+        // the record is not written here: reading the two seed k-mers and storing costs two trips to HBM that the whole workgroup
+        // would wait for (and the store would hold up wavefront 0 at its next wait for loads); up to kPend results collect in LDS and
+        // wavefront 0 writes them lane-parallel
         if (tid == 0) {
             if (staged) { fr.seed = s_hv[win]; fr.binov = s_ov[win]; }
             else { const uint2 e = w[win]; fr.seed = e.x; fr.binov = (uint16_t)(e.y & 0xFFFFu); }
-            wide_write_pair(a, addr, fr);
+            s_pfr[npend] = fr; s_pr[npend] = r;
+        }
+        ++npend;
+        if (npend == kPend) {
+            if (tid < kPend) wide_write_pair(a, a.desc[s_pr[tid]], s_pfr[tid]);
+            npend = 0;
         }
         WFCLK(6);
         __syncthreads();
         WFCLK(7);
     }
+    if (tid < npend) wide_write_pair(a, a.desc[s_pr[tid]], s_pfr[tid]);
 #ifdef BELLA_WF_CLOCK
     if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&a.clk[i], c_acc[i]);
 #endif
