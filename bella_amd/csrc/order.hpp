@@ -60,10 +60,14 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_wave(OrderArgs a) {
     if (j0 == 0 && lane == 0) a.totals[0] = a.colptrC[a.nreads];   // nnz(C): read back once with the control block
     if (j0 >= a.nown) return;
     const uint32_t i = a.i0 + j0 * a.stride;
-    const uint32_t nz = a.nnzC[i];
+    // everything the column needs from its descriptors in ONE round trip (each of these is wave-uniform, so the compiler waits for
+    // it where it is loaded: loaded one after the other they are four dependent trips to HBM per column)
+    uint32_t nz = a.nnzC[i];
+    uint64_t src = a.flopptr[i], dst = a.colptrC[i];
+    uint32_t tmax = a.flops[i];
+    asm volatile("" : "+v"(nz), "+v"(src), "+v"(dst), "+v"(tmax));   // (all four are issued before the first is waited for)
     const uint32_t d = nz & ~kOrderedBit;
     if (!d) return;
-    const uint64_t src = a.flopptr[i], dst = a.colptrC[i];
     if (nz & kOrderedBit) {
         for (uint32_t r = lane; r < d; r += 64) order_copy_record(a, src + r, dst + r, i);
         return;
@@ -85,7 +89,6 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_wave(OrderArgs a) {
         if (j < d) { const uint2 kf = *(const uint2*)(a.tmp_pairs + src + j); key[u] = kf.x; fp[u] = kf.y; }   // {key, first product}
     }
     group_sync<64>();
-    const uint32_t tmax = a.flops[i];
     uint32_t prev = 0;
     for (uint32_t rd = 0;; ++rd) {                            // rounds by insertion time (slotorder.hpp)
         const uint32_t bound = round_bound(rd, ht, d, tmax);

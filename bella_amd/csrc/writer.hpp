@@ -253,7 +253,17 @@ struct Stager {
     // buffer while the previous chunk is on the wire (FASTQ ingest gathers the bases out of the mapped file this way)
     template <typename Fill>
     hipError_t h2d_fill(void* dst, size_t bytes, hipStream_t st, Fill&& fill) {
-        if (!init()) return hipErrorOutOfMemory;
+        if (bytes < ((size_t)1 << 20) || !init()) {               // small, or no pinned memory to be had: pageable chunks, synchronous copies
+            std::vector<char> tmp(std::min(kChunk, bytes));
+            for (size_t o = 0; o < bytes; o += kChunk) {
+                const size_t n = std::min(kChunk, bytes - o);
+                fill(tmp.data(), o, n);
+                hipError_t e = hipMemcpyAsync((char*)dst + o, tmp.data(), n, hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        }
         int b = 0;
         for (size_t o = 0; o < bytes; o += kChunk, b ^= 1) {
             const size_t n = std::min(kChunk, bytes - o);
