@@ -150,22 +150,29 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
     V.init((uint32_t)kXLW);
     const s2 one = splat2(kXScale), mone = splat2(-kXScale), ninf = splat2(kXNinf * kXScale), top = splat2(kXTop), q1 = splat2(kQScale);
 
-#define BELLA_PSTEP()                                                                                               \
+// CLAMP = 0 leaves out the upper clamp of adds_epi8 (one v_pk_min_i16 per word): exact whenever no cell of antiDiag1 holds 127, which
+// the caller knows from the bounds it tracks (h1 below); antiDiag3 cells above CUTOFF = 102 are rebased away, so in practice always.
+#define BELLA_PSTEP(CLAMP)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                 \
         const s2 xr = s2_of(u32_of(qh[i]) ^ u32_of(qv[i]));                       /* 0 iff the bases match, else >= 512 */ \
         const s2 mt = one - pmin(xr, q1);                                         /* +1 match, -1 mismatch (x 256) */    \
-        const s2 a1f = pmin(adds2(a1[i], mt), top);                               /* adds_epi8 */                        \
+        const s2 a1s = adds2(a1[i], mt);                                          /* adds_epi8 */                        \
+        const s2 a1f = (CLAMP) ? pmin(a1s, top) : a1s;                                                                \
         const s2 shv = shl_cell(a2[i], i < 15 ? a2[i < 15 ? i + 1 : 15] : ninf);  /* shiftLeft(antiDiag2) */            \
         const s2 a2f = adds2(pmax(shv, a2[i]), mone);                             /* lower clamp = NINF exactly */       \
         a3[i] = pmax(a1f, a2f);                                                                                       \
     }                                                                                                                 \
     a3[15].y = (short)(kXNinf * kXScale);
+// the step with the clamp only where some lane of the wavefront may need it (h1 = upper bound of this lane's antiDiag1 cells)
+#define BELLA_PSTEP_AUTO()                                                                                          \
+    if (__builtin_amdgcn_ballot_w64(h1 >= 127) != 0ull) { BELLA_PSTEP(1) } else { BELLA_PSTEP(0) }
 
-// arg-max key: value in the upper byte (the lower byte of a cell is zero), 31 - cell in the lower one: first maximum wins
+// arg-max key: value in the upper byte (the lower byte of a cell is zero), 31 - cell in the lower one: first maximum wins.
+// (the position goes in with an OR -- full rate -- not a packed add: the byte it lands in is zero)
 #define BELLA_PKEY(keyout)                                                                                           \
     {                                                                                                                 \
-        s2 kk = a3[0] + mk2(31, 30);                                                                                  \
-        _Pragma("unroll") for (int i = 1; i < 16; ++i) kk = pmax(kk, a3[i] + mk2(31 - 2 * i, 30 - 2 * i));            \
+        s2 kk = s2_of(u32_of(a3[0]) | (31u | (30u << 16)));                                                           \
+        _Pragma("unroll") for (int i = 1; i < 16; ++i) kk = pmax(kk, s2_of(u32_of(a3[i]) | ((uint32_t)(31 - 2 * i) | ((uint32_t)(30 - 2 * i) << 16)))); \
         keyout = imax_((int)kk.x, (int)kk.y);                                                                         \
     }
 
@@ -205,21 +212,27 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
     // ---- Phase 2 (xavier.h:105-183)
     int maxpos = 0;
     int endH = hoff, endV = voff;
+    // upper bounds (cell values) of this lane's antiDiag1 / antiDiag2: antiDiag1 of a step is the antiDiag2 of the step before, which is
+    // the antiDiag3 of the step before that (moves only shift cells); a rebase subtracts mn from antiDiag2 and antiDiag3
+    int h1 = DPmax, h2 = DPmax;
     bool first = true;
     uint32_t tick = 0;
     bool dropped = false;
     while (hoff < hl && voff < vl) {
         if ((tick & 15u) == 0u) { H.checkpoint((uint32_t)hoff); V.checkpoint((uint32_t)voff); }
         ++tick;
-        BELLA_PSTEP()
+        BELLA_PSTEP_AUTO()
         int key;
         BELLA_PKEY(key)
         const int adb = key >> 8;
         const int curr = adb + off;
         if (curr < best - X) { dropped = true; break; }        // xavier.h:128-135: X-drop termination
+        h1 = h2; h2 = adb;                                      // (what the move below makes of antiDiag2 / antiDiag3)
         if (adb > kXCutoff) {
+            const int off0 = off;
             BELLA_PREBASE()
             BELLA_PKEY(key)
+            h1 = imin_(h1 - (off - off0), 127); h2 = imin_(h2 - (off - off0), 127);
         }
         if (curr > best) best = curr;
         if ((key >> 8) > 0) maxpos = 31 - (key & 31);
@@ -237,13 +250,18 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
     int dir = hoff >= hl ? 1 : 0;
     H.checkpoint((uint32_t)hoff); V.checkpoint((uint32_t)voff);      // 28 more steps: at most 14 per stream, inside the window
     for (int it = 0; it < kXLW - 3; ++it) {
-        BELLA_PSTEP()
+        BELLA_PSTEP_AUTO()
         int key;
         BELLA_PKEY(key)
         const int adb = key >> 8;
         const int curr = adb + off;
         if (curr < best - X) break;
-        if (adb > kXCutoff) { BELLA_PREBASE() }
+        h1 = h2; h2 = adb;
+        if (adb > kXCutoff) {
+            const int off0 = off;
+            BELLA_PREBASE()
+            h1 = imin_(h1 - (off - off0), 127); h2 = imin_(h2 - (off - off0), 127);
+        }
         if (curr > best) best = curr;
         const int next = dir ^ 1;
         const bool right = next == 0;
@@ -255,6 +273,7 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
     }
     r.best = best; r.endH = endH; r.endV = endV; r.steps = (hoff - kXLW) + (voff - kXLW);
 #undef BELLA_PSTEP
+#undef BELLA_PSTEP_AUTO
 #undef BELLA_PKEY
 #undef BELLA_PREBASE
 #undef BELLA_PMOVE
