@@ -100,13 +100,17 @@ __device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* 
     const uint32_t n = (uint32_t)(a.tstart[r + 1] - ts);
     uint32_t* s_d = scr + 24;
     uint32_t* s_dup = scr + 25;
+    // the first kPre * BLK k-mer ids (every tuple of a read whose table is in LDS) travel while the tables are initialised
+    constexpr uint32_t kPre = 4;
+    uint32_t k0[kPre];
+#pragma unroll
+    for (uint32_t u = 0; u < kPre; ++u) { const uint32_t t = tid + u * BLK; k0[u] = t < n ? a.t_kmer[ts + t] : 0u; }
     for (uint32_t s = tid; s < KS; s += BLK) Kk[s] = kEmpty;
     for (uint32_t s = tid; s < ht; s += BLK) T2[s] = kEmpty;
     if (tid == 0) { *s_d = 0; *s_dup = 0; }
     __syncthreads();
     uint32_t mine = 0;
-    for (uint32_t t = tid; t < n; t += BLK) {
-        const uint32_t key = a.t_kmer[ts + t];
+    auto insert = [&](uint32_t key, uint32_t t) {
         uint32_t h = hash_range(key, KS);
         uint32_t old;
         for (;;) {
@@ -116,8 +120,14 @@ __device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* 
         }
         if (old == kEmpty) { Kf[h] = (t << 16) | t; ++mine; }
         else *s_dup = 1;
+    };
+#pragma unroll
+    for (uint32_t u = 0; u < kPre; ++u) { const uint32_t t = tid + u * BLK; if (t < n) insert(k0[u], t); }
+    for (uint32_t t = tid + kPre * BLK; t < n; t += BLK) insert(a.t_kmer[ts + t], t);
+    {   // one LDS atomic per wavefront (BLK same-address atomics would queue up behind each other)
+        const uint32_t mw = wave_incl_scan(mine);
+        if (lane_id() == 63 && mw) atomicAdd(s_d, mw);
     }
-    if (mine) atomicAdd(s_d, mine);
     __syncthreads();
     const bool dup = *s_dup != 0;
     if (dup) {                                               // some k-mer occurs twice in this read: first = min, last = max over ALL tuples
