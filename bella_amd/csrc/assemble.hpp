@@ -63,6 +63,9 @@ struct AsmArgs {
     uint32_t* status;
     const uint32_t* list;   // the reads of this launch (k_asm_classify)
     uint32_t nlist;
+#ifdef BELLA_ASM_CLOCK
+    unsigned long long* clk;
+#endif
 };
 
 // reads by table size: class c holds the reads with kAsmClassHt[c-1] < ht <= kAsmClassHt[c]; the last class takes global tables.
@@ -96,6 +99,12 @@ __device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* 
                                         uint16_t* nf, uint32_t ht) {
     constexpr int NW = BLK / 64;
     const uint32_t tid = threadIdx.x;
+#ifdef BELLA_ASM_CLOCK
+    unsigned long long c_prev = clock64();
+#define ACLK(i) do { if (tid == 0) { const unsigned long long c_now = clock64(); atomicAdd(&a.clk[i], c_now - c_prev); c_prev = c_now; } } while (0)
+#else
+#define ACLK(i) do {} while (0)
+#endif
     const uint64_t ts = a.tstart[r];
     const uint32_t n = (uint32_t)(a.tstart[r + 1] - ts);
     uint32_t* s_d = scr + 24;
@@ -109,6 +118,7 @@ __device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* 
     for (uint32_t s = tid; s < ht; s += BLK) T2[s] = kEmpty;
     if (tid == 0) { *s_d = 0; *s_dup = 0; }
     __syncthreads();
+    ACLK(0);
     uint32_t mine = 0;
     auto insert = [&](uint32_t key, uint32_t t) {
         uint32_t h = hash_range(key, KS);
@@ -129,6 +139,7 @@ __device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* 
         if (lane_id() == 63 && mw) atomicAdd(s_d, mw);
     }
     __syncthreads();
+    ACLK(1);
     const bool dup = *s_dup != 0;
     if (dup) {                                               // some k-mer occurs twice in this read: first = min, last = max over ALL tuples
         for (uint32_t t = tid; t < n; t += BLK) {
@@ -147,18 +158,24 @@ __device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* 
         }
         __syncthreads();
     }
+    ACLK(2);
     const uint32_t d = *s_d;
     // the distinct k-mers enter the reference's table in the order of their first occurrences, in rounds (slotorder.hpp)
     uint32_t prev = 0;
     for (uint32_t rd = 0;; ++rd) {
         const uint32_t bound = round_bound(rd, ht, d, n);
         if (rd) { (void)build_next_free<BLK>(T2, nf, ht, scr); __syncthreads(); }
-        if (!dup) {                                           // every tuple is the first occurrence of its k-mer: straight from the tuples
-            for (uint32_t t = prev + tid; t < bound; t += BLK) {
-                const uint32_t home = (a.t_kmer[ts + t] * 107u) & (ht - 1);
-                if (rd) slot_insert<true>(T2, nf, ht - 1, home, (t << 16) | t);
-                else slot_insert<false>(T2, nf, ht - 1, home, (t << 16) | t);
+        if (!dup && rd == 0) {                                // every tuple is the first occurrence of its k-mer: straight from the tuples,
+#pragma unroll
+            for (uint32_t u = 0; u < kPre; ++u) {             // whose ids are still in registers
+                const uint32_t t = tid + u * BLK;
+                if (t < bound) slot_insert<false>(T2, nf, ht - 1, (k0[u] * 107u) & (ht - 1), (t << 16) | t);
             }
+            for (uint32_t t = tid + kPre * BLK; t < bound; t += BLK)
+                slot_insert<false>(T2, nf, ht - 1, (a.t_kmer[ts + t] * 107u) & (ht - 1), (t << 16) | t);
+        } else if (!dup) {
+            for (uint32_t t = prev + tid; t < bound; t += BLK)
+                slot_insert<true>(T2, nf, ht - 1, (a.t_kmer[ts + t] * 107u) & (ht - 1), (t << 16) | t);
         } else {
             for (uint32_t s = tid; s < KS; s += BLK) {
                 const uint32_t key = Kk[s];
@@ -174,6 +191,7 @@ __device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* 
         if (bound >= n) break;
         prev = bound;
     }
+    ACLK(3);
     const uint32_t c = (ht + BLK - 1) / BLK;
     const uint32_t lo = tid * c < ht ? tid * c : ht;
     const uint32_t hi = lo + c < ht ? lo + c : ht;
@@ -181,6 +199,7 @@ __device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* 
     for (uint32_t s = lo; s < hi; ++s) occ += (T2[s] != kEmpty);
     uint32_t tot;
     uint32_t rank = block_excl_scan<NW>(occ, scr, &tot);
+    ACLK(4);
     for (uint32_t s = lo; s < hi; ++s) {
         const uint32_t it = T2[s];
         if (it == kEmpty) continue;
@@ -198,6 +217,7 @@ __device__ __forceinline__ void asm_row(const AsmArgs& a, uint32_t r, uint32_t* 
     }
     if (tid == 0) a.rowcnt[r] = d;
     __syncthreads();
+    ACLK(5);
 }
 
 // LDS classes by table size: one workgroup per read of the class's list, the workgroup size grows with the table so that a CU's
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(BLK) void k_asm_rows_lds(AsmArgs a) {
     const uint32_t r = a.list[blockIdx.x];
     const uint32_t n = (uint32_t)(a.tstart[r + 1] - a.tstart[r]);
     const uint32_t ht = pow2_at_least(16u, n);
-    const uint32_t KS = asm_dedup_slots(n);
+    const uint32_t KS = asm_dedup_slots(ht);                 // what the LDS of a table of ht slots holds: 1.4 ... 2.8 slots per tuple, short probes
     uint32_t* scr = (uint32_t*)smem;
     uint32_t* T2 = (uint32_t*)(smem + kAsmScratchBytes);
     uint32_t* Kk = T2 + ht;

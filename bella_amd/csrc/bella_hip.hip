@@ -700,6 +700,12 @@ static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint6
     a.rowcnt = ptr<uint32_t>(c->rowcnt);
     a.ws_stride = ws_stride;
     a.status = ptr<uint32_t>(c->status);
+#ifdef BELLA_ASM_CLOCK
+    static unsigned long long* d_aclk = nullptr;
+    if (!d_aclk) (void)hipMalloc(&d_aclk, 64 * 8);
+    (void)hipMemsetAsync(d_aclk, 0, 64 * 8, c->stream);
+    a.clk = d_aclk;
+#endif
     {
         // one launch per LDS class (table sizes <= 1024, 2048, 4096, 8192 slots: 256, 512, 1024, 1024 threads), then the global tables
         struct Cls { uint32_t hi; int blk; void (*kern)(AsmArgs); };
@@ -709,6 +715,9 @@ static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint6
             if (!ccount[q]) continue;
             HIPCHK(c, hipFuncSetAttribute((const void*)cls[q].kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asm_lds_bytes(kAsmLdsSlots)));
             a.list = cls_lists + (size_t)q * nr; a.nlist = ccount[q];
+#ifdef BELLA_ASM_CLOCK
+            a.clk = d_aclk + 8 * q;
+#endif
             cls[q].kern<<<ccount[q], cls[q].blk, asm_lds_bytes(cls[q].hi), c->stream>>>(a);
             KCHK(c);
         }
@@ -720,6 +729,23 @@ static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint6
             KCHK(c);
         }
     }
+#ifdef BELLA_ASM_CLOCK
+    {
+        unsigned long long hh[64];
+        (void)hipMemcpyAsync(hh, d_aclk, 64 * 8, hipMemcpyDeviceToHost, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long* h = hh + 8 * q;
+            unsigned long long tot = 0;
+            for (int i = 0; i < 6; ++i) tot += h[i];
+            if (!tot) continue;
+            std::fprintf(stderr, "[asm clock] class %d reads %u:", q, ccount[q]);
+            const char* nm[6] = {"head+init", "insert", "dup", "rounds", "scan", "emit"};
+            for (int i = 0; i < 6; ++i) std::fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h[i] / (double)tot);
+            std::fprintf(stderr, " | cycles per read %.0f\n", (double)tot / ccount[q]);
+        }
+    }
+#endif
     rc = scan_u32(c, ptr<uint32_t>(c->rowcnt), ptr<uint32_t>(c->Bptr), (uint64_t)nr + 1);
     if (rc) return rc;
     uint32_t nnz32 = 0;
