@@ -335,8 +335,11 @@ __device__ __forceinline__ void run_bounds(const uint32_t* skey, uint64_t nnz, u
 // per sorted entry: its place in A' and the final A' and B' entries (coalesced reads; A' written run by run).  The B' entry belongs at
 // the entry's own index e -- a random 8-byte write per nonzero if done from here -- so it leaves as (e, entry) in sorted order; one
 // radix pass on the top bits of e and k_layout_place then write B' region by region (the writes of a region meet in the caches).
+// by_kmer (the row-list layout, k_layout_rowlists below): the lists of A' stay in k-mer order = the sorted order itself -- no list
+// starts to scatter, scan and look up (k_layout_heads is not run), A' is written in place.
 __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64_t nnz, const uint32_t* Bptr, const uint32_t* wscan,
-                              const uint32_t* packed, const uint64_t* roff, uint32_t k, uint32_t rmask, uint2* Aent, uint32_t* ekey, uint64_t* eval) {
+                              const uint32_t* packed, const uint64_t* roff, uint32_t k, uint32_t rmask, uint2* Aent, uint32_t* ekey, uint64_t* eval,
+                              uint32_t by_kmer, uint32_t* status) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= nnz) return;
     uint64_t lo, hi;
@@ -344,7 +347,8 @@ __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64
     const uint32_t dg = (uint32_t)(hi - lo), rk = (uint32_t)(x - lo);
     const uint64_t vf = sval[lo], v = sval[x];
     const uint32_t rf = (uint32_t)(vf >> 32) & rmask;
-    const uint32_t cs = wscan[Bptr[rf] + ((uint32_t)vf >> 16)];
+    if (by_kmer && dg > 16383u && rk == 0) atomicOr(status, 64u);       // Bent's product count field holds 14 bits (k_layout_heads otherwise)
+    const uint32_t cs = by_kmer ? (uint32_t)lo : wscan[Bptr[rf] + ((uint32_t)vf >> 16)];
     const uint32_t hiw = (uint32_t)(v >> 32), r = hiw & rmask, pos = (uint32_t)v & 0xFFFFu;
     uint32_t pal;
     if (rmask == 0x3FFFFFFFu) pal = (hiw >> 30) & 1u;
@@ -370,6 +374,67 @@ __global__ void k_layout_place(const uint32_t* ekey, const uint64_t* eval, uint6
 __global__ void k_layout_bcnt(const uint2* Bent, uint64_t nnz, uint16_t* Bcnt) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < nnz) Bcnt[e] = (uint16_t)((Bent[e].y >> 16) & 0x3FFFu);
+}
+
+// ---- row lists: the products of every column, ready-made, in product order -----------------------------------------------------
+// The SpGEMM of column i reads, for each entry of row i, the tail of that k-mer's list in A' (the later reads): with A' alone that is
+// one random 8..56-byte read per entry and pass, plus the expansion of the entries into products and the overlap estimate of every
+// product.  None of it depends on the pass: here the products are written ONCE, at assembly time, in the order a column generates
+// them (entry by entry, then down the list): Aent2[Arow[i] + p] = {partner read | palindrome << 30 | same orientation << 31,
+// posH | posV << 16}, Aov[...] = the u16 overlap estimate (chain.hpp:47-71).  The numeric phase streams them -- coalesced, no index
+// per product, no B' entries, no expansion.  10 bytes per product of the whole SpGEMM (1.8 GB at 100k reads); needs read ids < 2^30.
+// products per row (sum of the suffix counts), all rows
+__global__ __launch_bounds__(kBlock) void k_layout_rowflops(const uint32_t* Bptr, const uint16_t* Bcnt, uint32_t nreads, uint32_t* rowflops) {
+    const uint32_t i = blockIdx.x * kWaves + wave_id();
+    if (i > nreads) return;
+    uint32_t s = 0;
+    if (i < nreads) for (uint32_t e = Bptr[i] + lane_id(); e < Bptr[i + 1]; e += 64) s += Bcnt[e];
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) s += __shfl_xor(s, dlt, 64);
+    if (lane_id() == 0) rowflops[i] = s;                            // (rowflops[nreads] = 0: the scan's last element)
+}
+// one workgroup per row (grid-stride), its entries in rounds of 1024: block scan of the counts, then product-parallel copy (product q of
+// the round belongs to the last entry whose first product is <= q: binary search over the round's offsets in LDS)
+constexpr int kRowListBlock = 1024;
+__global__ __launch_bounds__(kRowListBlock) void k_layout_rowlists(const uint32_t* Bptr, const uint2* Bent, const uint2* Aent, const uint64_t* Arow,
+                                                                   const uint64_t* roff, uint32_t k, uint32_t nreads, uint2* Aent2, uint16_t* Aov) {
+    __shared__ uint32_t scr[kRowListBlock / 64];
+    __shared__ uint32_t s_off[kRowListBlock + 1];
+    __shared__ uint2 s_be[kRowListBlock];
+    for (uint32_t i = blockIdx.x; i < nreads; i += gridDim.x) {
+        const uint32_t b0 = Bptr[i], n = Bptr[i + 1] - b0;
+        const uint32_t lenV = (uint32_t)(roff[i + 1] - roff[i]);
+        const uint64_t o = Arow[i];
+        uint64_t running = 0;
+        for (uint32_t jb = 0; jb < n; jb += kRowListBlock) {
+            const uint32_t j = jb + threadIdx.x;
+            uint2 be = make_uint2(0u, 0u);
+            if (j < n) be = Bent[b0 + j];
+            const uint32_t cnt = (be.y >> 16) & 0x3FFFu;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kRowListBlock / 64>(cnt, scr, &tot);
+            s_off[threadIdx.x] = ex; s_be[threadIdx.x] = be;
+            if (threadIdx.x == 0) s_off[kRowListBlock] = tot;
+            __syncthreads();
+            for (uint32_t q = threadIdx.x; q < tot; q += kRowListBlock) {
+                uint32_t lo = 0, hi = kRowListBlock;                // s_off[lo] <= q < s_off[hi]
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_off[mid] <= q) lo = mid; else hi = mid;
+                }
+                const uint2 eb = s_be[lo];
+                const uint2 ae = Aent[(uint64_t)eb.x + (q - s_off[lo])];
+                const uint32_t posV = eb.y & 0xFFFFu, pal = (eb.y >> 30) & 1u;
+                const uint32_t posH = ae.y & 0xFFFFu, lenH = ae.y >> 16;
+                const bool oriented = (ae.x >> 31) == (eb.y >> 31);
+                const uint32_t ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, k) & 0xFFFFu;
+                Aent2[o + running + q] = make_uint2((ae.x & 0x3FFFFFFFu) | (pal << 30) | (oriented ? 0x80000000u : 0u), posH | (posV << 16));
+                Aov[o + running + q] = (uint16_t)ov;
+            }
+            __syncthreads();
+            running += tot;
+        }
+    }
 }
 
 }  // namespace bella

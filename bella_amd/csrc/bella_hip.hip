@@ -96,7 +96,8 @@ struct bella_ctx {
     uint32_t kc_bfirst = 0, kc_brows = 0; // the read block the device-resident tuples cover (all reads unless counted distributed)
     Buf kc_nk, kc_koff, kc_hist, kc_keys, kc_alt, kc_runlen, kc_flag, kc_slot, kc_nruns, kc_dcode, kc_dcount, kc_hkey, kc_hval, kc_found,
         kc_tstart, kc_cursor, kc_sel, kc_ringo, kc_ringp;
-    Buf Bptr, Bk, Bpos, Bent, Bcnt, Aent;
+    Buf Bptr, Bk, Bpos, Bent, Bcnt, Aent, Aent2, Aov, Arow;
+    bool have_rowlists = false;          // Aent2 / Arow hold the row lists of the current layout
     uint32_t part_first = 0, part_stride = 1;
     uint64_t sym_sig[6] = {};            // what flops / nnzC were last cleared for
     uint64_t layout_gen = 0;             // bumped by every build of the device layout
@@ -145,7 +146,7 @@ struct bella_ctx {
     uint64_t kcount_budget = 1ull << 30, wide_budget = 1ull << 30;   // items per pass of the counting sort / of the wide-column path
     bool lane_order_ok = true;           // k_lane_order_selftest at init
     uint32_t xdrop_variant = 0;          // 0: one launch in length-sorted order (production); 1: slices with compaction; 2: packed kernel in pair order; 3: scalar statement
-    size_t lds_attr[16] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
+    size_t lds_attr[18] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
     hipStream_t side[kNumTiers + 1]{};   // independent tier launches / fold instances run concurrently
     hipEvent_t fork = nullptr, join[kNumTiers + 1]{};
 };
@@ -265,6 +266,7 @@ int build_layout(bella_ctx* c) {
     ENSURE(c, c->Aent, 8 * nnz + 64);
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    c->have_rowlists = false;
     if (nnz) {
         k_layout_prep<<<nblk(c->nreads, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos), c->nreads,
                                                                         ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), c->kmer_size, nk,
@@ -288,14 +290,20 @@ int build_layout(bella_ctx* c) {
         const uint32_t* skey = dk.Current();
         const uint64_t* sval = dv.Current();
         const uint32_t rmask = c->nreads <= (1u << 30) ? 0x3FFFFFFFu : 0x7FFFFFFFu;   // read id field of the sort value
-        k_layout_heads<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), rmask, ptr<uint32_t>(c->w), ptr<uint32_t>(c->status));
-        KCHK(c);
-        int rc = scan_u32(c, ptr<uint32_t>(c->w), ptr<uint32_t>(c->wscan), nnz);
-        if (rc) return rc;
+        // the row-list layout (ready-made products, assemble.hpp) unless debug bit 10 asks for the expanding one (tests) or read ids need
+        // more than 30 bits; the products may also not fit (checked below, once their number is known: then the lists of A' stay in
+        // k-mer order and the pass expands from them -- correct, slower)
+        const uint32_t by_kmer = (c->debug & 1024u) == 0 && c->nreads <= (1u << 30) ? 1u : 0u;
+        if (!by_kmer) {
+            k_layout_heads<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), rmask, ptr<uint32_t>(c->w), ptr<uint32_t>(c->status));
+            KCHK(c);
+            int rc = scan_u32(c, ptr<uint32_t>(c->w), ptr<uint32_t>(c->wscan), nnz);
+            if (rc) return rc;
+        }
         uint32_t* ekey = dk.Alternate();                           // (the sort's other buffers are free now)
         uint64_t* eval = dv.Alternate();
         k_layout_emit<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->wscan), ptr<uint32_t>(c->packed),
-                                                        ptr<uint64_t>(c->roff), c->kmer_size, rmask, ptr<uint2>(c->Aent), ekey, eval);
+                                                        ptr<uint64_t>(c->roff), c->kmer_size, rmask, ptr<uint2>(c->Aent), ekey, eval, by_kmer, ptr<uint32_t>(c->status));
         KCHK(c);
         {   // one radix pass on the top 8 bits of the entry index: B' is then written region by region
             int ebits = 1;
@@ -313,6 +321,30 @@ int build_layout(bella_ctx* c) {
         }
         k_layout_bcnt<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint2>(c->Bent), nnz, ptr<uint16_t>(c->Bcnt));
         KCHK(c);
+        c->have_rowlists = false;
+        if (by_kmer) {
+            // row lists: products per row -> row starts -> the tails of the lists copied in product order
+            ENSURE(c, c->Arow, 8 * ((size_t)c->nreads + 2));
+            uint32_t* rf = ptr<uint32_t>(c->w);                     // (w is free: k_layout_heads did not run)
+            k_layout_rowflops<<<nblk((uint64_t)c->nreads + 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint16_t>(c->Bcnt), c->nreads, rf);
+            KCHK(c);
+            int rc = scan_u32_to_u64(c, rf, ptr<uint64_t>(c->Arow), (uint64_t)c->nreads + 1);
+            if (rc) return rc;
+            uint64_t F = 0;
+            HIPCHK(c, hipMemcpyAsync(&F, ptr<uint64_t>(c->Arow) + c->nreads, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            size_t mfree = 0, mtotal = 0;
+            HIPCHK(c, hipMemGetInfo(&mfree, &mtotal));
+            if (10 * F + 128 <= mfree / 2) {                       // 10 bytes per product, and the pass needs room of its own
+                ENSURE(c, c->Aent2, 8 * F + 64);
+                ENSURE(c, c->Aov, 2 * F + 64);
+                const uint32_t grid = c->nreads < 4096u ? c->nreads : 4096u;
+                if (grid) k_layout_rowlists<<<grid, kRowListBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint2>(c->Bent), ptr<uint2>(c->Aent), ptr<uint64_t>(c->Arow),
+                                                                                 ptr<uint64_t>(c->roff), c->kmer_size, c->nreads, ptr<uint2>(c->Aent2), ptr<uint16_t>(c->Aov));
+                KCHK(c);
+                c->have_rowlists = true;
+            }
+        }
     }
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     // pairs/products on a sample of columns -> key-table budget of the LDS tiers (see k_sample_pair_ratio)
@@ -435,7 +467,7 @@ void bella_hip_destroy(bella_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && c->api) { (void)c->api->CommDestroy(c->comm); c->comm = nullptr; }
     release(c->comm_meta);
-    Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Bcnt, &c->Aent, &c->t_kmer, &c->t_read, &c->t_pos,
+    Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Bcnt, &c->Aent, &c->Aent2, &c->Aov, &c->Arow, &c->t_kmer, &c->t_read, &c->t_pos,
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->asm_cls, &c->lk_key, &c->lk_key2, &c->lk_val, &c->lk_val2,
                   &c->w, &c->wscan, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC,
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
@@ -1426,7 +1458,7 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     ENSURE(c, c->w_toff, 8 * ((size_t)nw + 2));
     WideArgs a{};
     a.cols = d_cols; a.nw = nw; a.woff = ptr<uint64_t>(c->w_off);
-    a.Bptr = sa.Bptr; a.Bent = sa.Bent; a.Aent = sa.Aent; a.roff = sa.roff; a.packed = sa.packed; a.flopptr = sa.flopptr;
+    a.Bptr = sa.Bptr; a.Bent = sa.Bent; a.Aent = sa.Aent; a.Aent2 = sa.Aent2; a.Aov = sa.Aov; a.Arow = sa.Arow; a.roff = sa.roff; a.packed = sa.packed; a.flopptr = sa.flopptr;
     a.k = sa.k; a.binSize = sa.binSize;
     a.W_key = c->w_key.p; a.W_idx = ptr<uint32_t>(c->w_idx); a.W_rec = ptr<uint2>(c->w_hv);
     a.plist = ptr<uint2>(c->w_plist); a.sort_scratch = ptr<uint16_t>(c->w_scr);
@@ -1640,7 +1672,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     k_tier_lists<<<nblk(nown ? nown : 1), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, i0, c->part_stride, nown, ptr<uint32_t>(c->tiercaps), g_ntiers,
                                                   ptr<uint32_t>(c->Bptr), ptr<uint64_t>(c->roff), ptr<uint4>(c->rowlists),
                                                   (uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr), d_ctl + kCtlTierCnt,
-                                                  (unsigned long long*)(d_ctl + kCtlTotals) + 1, ptr<uint64_t>(c->flopptr));
+                                                  (unsigned long long*)(d_ctl + kCtlTotals) + 1, ptr<uint64_t>(c->flopptr),
+                                                  c->have_rowlists ? ptr<uint64_t>(c->Arow) : nullptr);
     KCHK(c);
     // The host needs two things from the symbolic kernels before it can launch the row kernels: the tiers' lengths (exact grids)
     // and the product total (buffer sizes).  Both are functions of the operands, the partition and the stage only, so they are
@@ -1671,6 +1704,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     a.Bptr = ptr<uint32_t>(c->Bptr);
     a.Bent = ptr<uint2>(c->Bent);
     a.Aent = ptr<uint2>(c->Aent);
+    a.Aent2 = c->have_rowlists ? ptr<uint2>(c->Aent2) : nullptr;
+    a.Aov = c->have_rowlists ? ptr<uint16_t>(c->Aov) : nullptr;
+    a.Arow = c->have_rowlists ? ptr<uint64_t>(c->Arow) : nullptr;
     a.roff = ptr<uint64_t>(c->roff);
     a.packed = ptr<uint32_t>(c->packed);
     a.flopptr = ptr<uint64_t>(c->flopptr);
@@ -1763,22 +1799,26 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         const int blk = (c->debug & 8u) ? 512 : kClassBlock[ln[l].cls];     // debug bit 3: tests, 512 threads everywhere
         int ki;
         void (*kern)(SpgemmArgs);
+        const bool rl = c->have_rowlists;
+#define BELLA_ROWS_KERN(NX, B) (rl ? k_spgemm_rows_lds<NX, B, true> : k_spgemm_rows_lds<NX, B, false>)
         if (blk == 512) {
             ki = a.cap <= 8 * 512 ? 0 : a.cap <= 16 * 512 ? 1 : 2;
-            kern = ki == 0 ? k_spgemm_rows_lds<8, 512> : ki == 1 ? k_spgemm_rows_lds<16, 512> : k_spgemm_rows_lds<22, 512>;
+            kern = ki == 0 ? BELLA_ROWS_KERN(8, 512) : ki == 1 ? BELLA_ROWS_KERN(16, 512) : BELLA_ROWS_KERN(22, 512);
         } else if (blk == 1024) {
             ki = a.cap <= 4 * 1024 ? 3 : a.cap <= 8 * 1024 ? 4 : 5;
-            kern = ki == 3 ? k_spgemm_rows_lds<4, 1024> : ki == 4 ? k_spgemm_rows_lds<8, 1024> : k_spgemm_rows_lds<11, 1024>;
+            kern = ki == 3 ? BELLA_ROWS_KERN(4, 1024) : ki == 4 ? BELLA_ROWS_KERN(8, 1024) : BELLA_ROWS_KERN(11, 1024);
         } else if (blk == 256 && a.cap <= 6 * 256) {              // cap <= 1394 <= 6 * 256
             ki = 6;
-            kern = k_spgemm_rows_lds<6, 256>;
+            kern = BELLA_ROWS_KERN(6, 256);
         } else if (blk == 256) {                                  // cap <= 2752 <= 11 * 256
             ki = 7;
-            kern = k_spgemm_rows_lds<11, 256>;
+            kern = BELLA_ROWS_KERN(11, 256);
         } else {                                                  // cap <= 689 <= 6 * 128
             ki = 8;
-            kern = k_spgemm_rows_lds<6, 128>;
+            kern = BELLA_ROWS_KERN(6, 128);
         }
+#undef BELLA_ROWS_KERN
+        if (rl) ki += 9;
         if (lds > c->lds_attr[ki]) {                             // once per kernel and size, not per launch
             HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             c->lds_attr[ki] = lds;
@@ -1809,7 +1849,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         a.cap = tier_caps[g_ntiers - 1];
         a.dcap = a.cap;
         const unsigned grid = a.nrows < kGlobalGrid ? a.nrows : kGlobalGrid;
-        k_spgemm_rows_global<<<grid, kGlobalBlock, 0, sst>>>(a);
+        if (c->have_rowlists) k_spgemm_rows_global<true><<<grid, kGlobalBlock, 0, sst>>>(a);
+        else k_spgemm_rows_global<false><<<grid, kGlobalBlock, 0, sst>>>(a);
         KCHK(c);
         launches++;
     }
@@ -1847,7 +1888,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         a.rowlist = ptr<uint32_t>(c->retry);
         a.rowdesc = nullptr;
         a.nrows_dev = ptr<uint32_t>(c->ctl) + kCtlRetry;
-        k_spgemm_rows_global<<<kRerunGrid, kGlobalBlock, 0, c->stream>>>(a);   // (the list is usually empty or a handful of columns)
+        if (c->have_rowlists) k_spgemm_rows_global<true><<<kRerunGrid, kGlobalBlock, 0, c->stream>>>(a);
+        else k_spgemm_rows_global<false><<<kRerunGrid, kGlobalBlock, 0, c->stream>>>(a);   // (the list is usually empty or a handful of columns)
         KCHK(c);
         return 0;
     };

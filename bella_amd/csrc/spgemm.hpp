@@ -83,6 +83,9 @@ struct SpgemmArgs {
     const uint32_t* Bptr;
     const uint2* Bent;
     const uint2* Aent;
+    const uint2* Aent2;          // ready-made products (assemble.hpp: k_layout_rowlists), nullptr: expand B' x A' in the pass
+    const uint16_t* Aov;         // their overlap estimates
+    const uint64_t* Arow;        // [nreads + 1] first product of every column
     const uint64_t* roff;
     const uint32_t* packed;
     const uint64_t* flopptr;     // where a column's temporary output / product lists start: flops[i] slots, handed out by k_tier_lists
@@ -159,9 +162,10 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dc
 // columns at a time (the insertion cascades are chains of dependent LDS round trips: in here they would hold a whole workgroup).
 // Returns false if the key table overflowed or a list came out of order (no global side effect happened yet; the caller queues
 // the column again).
-template <bool OVERLAY, uint32_t NX, int BLK = BELLA_ROW_BLOCK>
+// RL: the column's products come ready-made from the row lists (arow = Arow[i], Fdesc = flops[i]); b0 / n / lenV are unused then.
+template <bool OVERLAY, uint32_t NX, int BLK = BELLA_ROW_BLOCK, bool RL = false>
 __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t i, const uint32_t b0, const uint32_t n, const uint32_t lenV,
-                                            const RowMem& m) {
+                                            const RowMem& m, const uint64_t arow = 0, const uint32_t Fdesc = 0) {
     constexpr int kRowBlock = BLK;                            // threads of this workgroup
     constexpr int kRowWaves = BLK / 64;
     const uint32_t tid = threadIdx.x;
@@ -184,7 +188,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // round trips at the head of every column: descriptor, then entries)
     constexpr uint32_t RMAX = kRowBlock >= 1024 ? 4 : 8;      // B' entries per thread and round (registers: 1024-thread workgroups run at 64 VGPRs)
     uint2 be0[RMAX];
-    {
+    if (!RL) {
         const uint32_t nn = n < RMAX * kRowBlock ? n : RMAX * kRowBlock;
         const uint32_t R = (nn + kRowBlock - 1) / kRowBlock;
         const uint32_t j0 = tid * R;
@@ -201,7 +205,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // ---- X: expand products in reference order, group keys --------------------------------------------
     // X1/X2: each thread owns a CONTIGUOUS run of B' entries (so one block scan orders all products); it only records,
     // per product, where its A' entry lives and the B' side word -- LDS writes, no dependent global loads.
-    uint32_t running = 0;
+    uint32_t running = RL ? Fdesc : 0u;
+    if (!RL)
     for (uint32_t jb = 0; jb < n; jb += RMAX * kRowBlock) {
         const uint32_t nn = n - jb < RMAX * kRowBlock ? n - jb : RMAX * kRowBlock;
         const uint32_t R = (nn + kRowBlock - 1) / kRowBlock;
@@ -240,17 +245,28 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             const uint32_t p = base + u * kRowBlock + tid;
             ae[u] = make_uint2(0u, 0u);
             bw[u] = 0;
-            if (p < F) { ae[u] = a.Aent[m.A_hv[p]]; bw[u] = m.A_gov[p]; }
+            if (p < F) {
+                if (RL) { ae[u] = a.Aent2[arow + p]; bw[u] = a.Aov[arow + p]; }
+                else { ae[u] = a.Aent[m.A_hv[p]]; bw[u] = m.A_gov[p]; }
+            }
         }
 #pragma unroll
         for (uint32_t u = 0; u < XB; ++u) {
             const uint32_t p = base + u * kRowBlock + tid;
             if (p >= F) continue;
-            const uint32_t key = ae[u].x & 0x7FFFFFFFu;
-            const uint32_t posH = ae[u].y & 0xFFFFu, lenH = ae[u].y >> 16;
-            const uint32_t posV = bw[u] & 0xFFFFu, pal = (bw[u] >> 30) & 1u;
-            const bool oriented = (ae[u].x >> 31) == (bw[u] >> 31);
-            const uint32_t ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, k) & 0xFFFFu;
+            uint32_t key, hv, ov, pal;
+            bool oriented;
+            if (RL) {                                          // {partner | pal << 30 | oriented << 31, posH | posV << 16}, overlap estimate
+                key = ae[u].x & 0x3FFFFFFFu; pal = (ae[u].x >> 30) & 1u; oriented = (ae[u].x >> 31) != 0; hv = ae[u].y; ov = bw[u];
+            } else {
+                key = ae[u].x & 0x7FFFFFFFu;
+                const uint32_t posH = ae[u].y & 0xFFFFu, lenH = ae[u].y >> 16;
+                const uint32_t posV = bw[u] & 0xFFFFu;
+                pal = (bw[u] >> 30) & 1u;
+                oriented = (ae[u].x >> 31) == (bw[u] >> 31);
+                ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, k) & 0xFFFFu;
+                hv = posH | (posV << 16);
+            }
             uint32_t h = hash_range(key, H1);
             uint32_t old = 0;
             uint32_t probes = 0;
@@ -262,7 +278,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             if (probes == H1) { *s_fail = 1; continue; }     // more pairs than this tier's key table holds
             const uint32_t q = (p >= RB ? 1u : 0u) + (p >= 2u * RB ? 1u : 0u) + (p >= 3u * RB ? 1u : 0u);
             atomicAdd((q & 2u) ? &m.T1first[h] : &m.T1cnt[h], (q & 1u) ? 0x10000u : 1u);
-            m.A_hv[p] = posH | (posV << 16);
+            m.A_hv[p] = hv;
             const uint32_t fl = (oriented ? 1u : 0u) | (pal << 1);
             if (OVERLAY) m.A_gov[p] = (fl << 30) | (h << 16) | ov;
             else { m.A_gov[p] = (h << 16) | ov; m.A_fl[p] = (uint8_t)fl; }
@@ -655,7 +671,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 
 // LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap, dcap); NX * 512 >= cap (8: the tiers up to 4096 products,
 // 16: the two big tiers that keep HiFi-like columns with long lists off the global path)
-template <uint32_t NX, int BLK = BELLA_ROW_BLOCK>
+template <uint32_t NX, int BLK = BELLA_ROW_BLOCK, bool RL = false>
 __global__ __launch_bounds__(BLK, (BLK == 1024 ? (NX <= 4 ? 8 : 4) : BLK <= 256 ? 8 : (NX <= 8 ? 6 : 2))) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // the launch covers the tiers of one LDS class, largest columns first: workgroup x -> (tier, place in the tier's list)
@@ -675,7 +691,10 @@ __global__ __launch_bounds__(BLK, (BLK == 1024 ? (NX <= 4 ? 8 : 4) : BLK <= 256 
     const uint4 ds = a.rowdesc[(size_t)t * a.nreads + x];
     const uint32_t i = ds.x;
     const RowMem m = carve(smem, a.cap, a.dcap, true);
-    if (!process_row<true, NX, BLK>(a, i, ds.y, ds.z & 0xFFFFu, ds.z >> 16, m) && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
+    // row lists: the descriptor carries the column's first product (48 bits: y, low half of z) and its product count (w)
+    const bool ok = RL ? process_row<true, NX, BLK, true>(a, i, 0u, 0u, ds.z >> 16, m, (uint64_t)ds.y | ((uint64_t)(ds.z & 0xFFFFu) << 32), ds.w)
+                       : process_row<true, NX, BLK, false>(a, i, ds.y, ds.z & 0xFFFFu, ds.z >> 16, m);
+    if (!ok && threadIdx.x == 0) a.retry[atomicAdd(&a.ctl[kCtlRetry], 1u)] = i;
 }
 
 // Global-workspace path: columns with more products than the largest LDS tier (< 65536), and -- second launch, list and
@@ -684,6 +703,7 @@ __global__ __launch_bounds__(BLK, (BLK == 1024 ? (NX <= 4 ? 8 : 4) : BLK <= 256 
 #define BELLA_GLOBAL_BLOCK 1024
 #endif
 constexpr int kGlobalBlock = BELLA_GLOBAL_BLOCK;          // threads per column on the global-workspace path
+template <bool RL>
 __global__ __launch_bounds__(kGlobalBlock) void k_spgemm_rows_global(SpgemmArgs a) {
     uint8_t* ws = a.ws + (uint64_t)blockIdx.x * a.ws_stride;
     const uint32_t nrows = a.nrows_dev ? *a.nrows_dev : a.nrows;
@@ -693,7 +713,8 @@ __global__ __launch_bounds__(kGlobalBlock) void k_spgemm_rows_global(SpgemmArgs 
         if (f < 16u) f = 16u;
         const RowMem m = carve(ws, f, f, false);
         const uint32_t b0 = a.Bptr[i];
-        (void)process_row<false, 8, kGlobalBlock>(a, i, b0, a.Bptr[i + 1] - b0, (uint32_t)(a.roff[i + 1] - a.roff[i]), m);
+        if (RL) (void)process_row<false, 8, kGlobalBlock, true>(a, i, 0u, 0u, (uint32_t)(a.roff[i + 1] - a.roff[i]), m, a.Arow[i], a.flops[i]);
+        else (void)process_row<false, 8, kGlobalBlock, false>(a, i, b0, a.Bptr[i + 1] - b0, (uint32_t)(a.roff[i + 1] - a.roff[i]), m);
         __syncthreads();
     }
 }
@@ -822,7 +843,7 @@ __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, cons
 __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, uint32_t nreads, uint32_t i0, uint32_t stride, uint32_t nown,
                                                        const uint32_t* caps, uint32_t ntiers,
                                                        const uint32_t* Bptr, const uint64_t* roff, uint4* desc, uint32_t* widelist,
-                                                       uint32_t* counts, unsigned long long* total, uint64_t* obase) {
+                                                       uint32_t* counts, unsigned long long* total, uint64_t* obase, const uint64_t* Arow) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;      // the j-th column of this context
     const uint32_t i = i0 + j * stride;
     const uint32_t f = j < nown ? flops[i] : 0u;
@@ -835,6 +856,12 @@ __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, ui
         const uint32_t b0 = Bptr[i];
         ds.y = b0;
         ds.z = (Bptr[i + 1] - b0) | ((uint32_t)(roff[i + 1] - roff[i]) << 16);   // both < 65536 (checked at set_reads / assembly)
+        if (Arow) {                                        // row lists: first product (48 bits) instead of the entries, and the product count
+            const uint64_t ar = Arow[i];
+            ds.y = (uint32_t)ar;
+            ds.z = (uint32_t)((ar >> 32) & 0xFFFFu) | ((uint32_t)(roff[i + 1] - roff[i]) << 16);
+            ds.w = f;
+        }
     }
     // One global atomic per tier and WORKGROUP (a few hot counters serve all columns): the wavefronts first reserve their places
     // inside the workgroup in LDS.

@@ -25,6 +25,9 @@ struct WideArgs {
     const uint32_t* Bptr;
     const uint2* Bent;
     const uint2* Aent;
+    const uint2* Aent2;          // ready-made products (assemble.hpp: k_layout_rowlists; nullptr: expand from B' x A')
+    const uint16_t* Aov;
+    const uint64_t* Arow;
     const uint64_t* roff;
     const uint32_t* packed;
     const uint64_t* flopptr;
@@ -73,6 +76,20 @@ __global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
         const uint32_t b0 = a.Bptr[i], n = a.Bptr[i + 1] - b0;
         const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
         const uint64_t o = a.woff[s];
+        const uint64_t arow = a.Aent2 ? a.Arow[i] : 0ull;
+        if (a.Aent2) {                                          // ready-made products: a stream copy into the sort's input
+            const uint64_t Fc = a.woff[s + 1] - o;
+            for (uint64_t q = threadIdx.x; q < Fc; q += kWideExpandBlock) {
+                const uint2 r2 = a.Aent2[arow + q];
+                const uint32_t key = r2.x & 0x3FFFFFFFu, fl = (r2.x >> 31) | (((r2.x >> 30) & 1u) << 1);
+                const uint64_t p = o + q;
+                if (a.key32) ((uint32_t*)a.W_key)[p] = (s << a.rbits) | key;
+                else ((uint64_t*)a.W_key)[p] = ((uint64_t)s << a.rbits) | key;
+                a.W_idx[p] = (uint32_t)p;
+                a.W_rec[p] = make_uint2(r2.y, (uint32_t)a.Aov[arow + q] | (fl << 16));
+            }
+            continue;
+        }
         uint32_t running = 0;
         for (uint32_t jb = 0; jb < n; jb += kWideExpandBlock) {
             const uint32_t j = jb + threadIdx.x;
@@ -101,11 +118,12 @@ __global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
                 const bool oriented = (ae.x >> 31) == (eb.y >> 31);
                 const uint32_t ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, (uint32_t)a.k) & 0xFFFFu;
                 const uint32_t fl = (oriented ? 1u : 0u) | (pal << 1);
+                const uint32_t hvw = posH | (posV << 16);
                 const uint64_t p = o + running + q;
                 if (a.key32) ((uint32_t*)a.W_key)[p] = (s << a.rbits) | key;
                 else ((uint64_t*)a.W_key)[p] = ((uint64_t)s << a.rbits) | key;
                 a.W_idx[p] = (uint32_t)p;
-                a.W_rec[p] = make_uint2(posH | (posV << 16), ov | (fl << 16));
+                a.W_rec[p] = make_uint2(hvw, ov | (fl << 16));
             }
             __syncthreads();
             running += tot;
