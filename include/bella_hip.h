@@ -296,7 +296,9 @@ int bella_hip_get_timings(bella_ctx* ctx, bella_timings* t);
  * bit4 = tests: key tables of cap/2 slots (the layout of pair-rich inputs) on any input; bit5 = tests: every column above the
  * LDS tiers takes the sort-based path of the wide columns (default: from 16 such columns in a pass on); bit6 = tests: that path
  * sorts on 64-bit keys on any input (default: 32-bit keys when column bits + read-id bits fit); bit8 = tests: the exact X-drop mode
- * launches its extensions in chunks of 1,000 (default 2^24: grid x block stays below 2^32 threads) */
+ * launches its extensions in chunks of 1,000 (default 2^24: grid x block stays below 2^32 threads); bit10 (read when the operands are
+ * assembled) = tests: no row lists -- the layout that inputs whose products do not fit in memory (10 bytes each) fall back to: every pass
+ * expands the products from B' and A' itself */
 int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
 /* Per-context tuning parameters (tests and A/B measurements; nothing here changes results).  what:
  *   BELLA_TUNE_LDS_TIERS      values = ascending product capacities of the row kernels' LDS tiers, each in [64, 11008] (n = 0: defaults)
