@@ -381,8 +381,9 @@ __global__ void k_layout_bcnt(const uint2* Bent, uint64_t nnz, uint16_t* Bcnt) {
 // one random 8..56-byte read per entry and pass, plus the expansion of the entries into products and the overlap estimate of every
 // product.  None of it depends on the pass: here the products are written ONCE, at assembly time, in the order a column generates
 // them (entry by entry, then down the list): Aent2[Arow[i] + p] = {partner read | palindrome << 30 | same orientation << 31,
-// posH | posV << 16}, Aov[...] = the u16 overlap estimate (chain.hpp:47-71).  The numeric phase streams them -- coalesced, no index
-// per product, no B' entries, no expansion.  10 bytes per product of the whole SpGEMM (1.8 GB at 100k reads); needs read ids < 2^30.
+// posH | posV << 16}, Aov[...] = the partner's read length -- the two operand entries of the product side by side; the multiply of
+// the semiring (the overlap estimate, chain.hpp:47-71) stays in the pass.  The numeric phase streams them -- coalesced, no index per
+// product, no B' entries, no expansion.  10 bytes per product of the whole SpGEMM (1.8 GB at 100k reads); needs read ids < 2^30.
 // products per row (sum of the suffix counts), all rows
 __global__ __launch_bounds__(kBlock) void k_layout_rowflops(const uint32_t* Bptr, const uint16_t* Bcnt, uint32_t nreads, uint32_t* rowflops) {
     const uint32_t i = blockIdx.x * kWaves + wave_id();
@@ -397,13 +398,12 @@ __global__ __launch_bounds__(kBlock) void k_layout_rowflops(const uint32_t* Bptr
 // the round belongs to the last entry whose first product is <= q: binary search over the round's offsets in LDS)
 constexpr int kRowListBlock = 1024;
 __global__ __launch_bounds__(kRowListBlock) void k_layout_rowlists(const uint32_t* Bptr, const uint2* Bent, const uint2* Aent, const uint64_t* Arow,
-                                                                   const uint64_t* roff, uint32_t k, uint32_t nreads, uint2* Aent2, uint16_t* Aov) {
+                                                                   const uint64_t* roff, uint32_t nreads, uint2* Aent2, uint16_t* Aov) {
     __shared__ uint32_t scr[kRowListBlock / 64];
     __shared__ uint32_t s_off[kRowListBlock + 1];
     __shared__ uint2 s_be[kRowListBlock];
     for (uint32_t i = blockIdx.x; i < nreads; i += gridDim.x) {
         const uint32_t b0 = Bptr[i], n = Bptr[i + 1] - b0;
-        const uint32_t lenV = (uint32_t)(roff[i + 1] - roff[i]);
         const uint64_t o = Arow[i];
         uint64_t running = 0;
         for (uint32_t jb = 0; jb < n; jb += kRowListBlock) {
@@ -427,9 +427,8 @@ __global__ __launch_bounds__(kRowListBlock) void k_layout_rowlists(const uint32_
                 const uint32_t posV = eb.y & 0xFFFFu, pal = (eb.y >> 30) & 1u;
                 const uint32_t posH = ae.y & 0xFFFFu, lenH = ae.y >> 16;
                 const bool oriented = (ae.x >> 31) == (eb.y >> 31);
-                const uint32_t ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, k) & 0xFFFFu;
                 Aent2[o + running + q] = make_uint2((ae.x & 0x3FFFFFFFu) | (pal << 30) | (oriented ? 0x80000000u : 0u), posH | (posV << 16));
-                Aov[o + running + q] = (uint16_t)ov;
+                Aov[o + running + q] = (uint16_t)lenH;
             }
             __syncthreads();
             running += tot;

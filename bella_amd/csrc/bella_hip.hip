@@ -340,7 +340,7 @@ int build_layout(bella_ctx* c) {
                 ENSURE(c, c->Aov, 2 * F + 64);
                 const uint32_t grid = c->nreads < 4096u ? c->nreads : 4096u;
                 if (grid) k_layout_rowlists<<<grid, kRowListBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint2>(c->Bent), ptr<uint2>(c->Aent), ptr<uint64_t>(c->Arow),
-                                                                                 ptr<uint64_t>(c->roff), c->kmer_size, c->nreads, ptr<uint2>(c->Aent2), ptr<uint16_t>(c->Aov));
+                                                                                 ptr<uint64_t>(c->roff), c->nreads, ptr<uint2>(c->Aent2), ptr<uint16_t>(c->Aov));
                 KCHK(c);
                 c->have_rowlists = true;
             }

@@ -84,7 +84,7 @@ struct SpgemmArgs {
     const uint2* Bent;
     const uint2* Aent;
     const uint2* Aent2;          // ready-made products (assemble.hpp: k_layout_rowlists), nullptr: expand B' x A' in the pass
-    const uint16_t* Aov;         // their overlap estimates
+    const uint16_t* Aov;         // the partner read's length of every product
     const uint64_t* Arow;        // [nreads + 1] first product of every column
     const uint64_t* roff;
     const uint32_t* packed;
@@ -256,8 +256,9 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             if (p >= F) continue;
             uint32_t key, hv, ov, pal;
             bool oriented;
-            if (RL) {                                          // {partner | pal << 30 | oriented << 31, posH | posV << 16}, overlap estimate
-                key = ae[u].x & 0x3FFFFFFFu; pal = (ae[u].x >> 30) & 1u; oriented = (ae[u].x >> 31) != 0; hv = ae[u].y; ov = bw[u];
+            if (RL) {                                          // {partner | pal << 30 | oriented << 31, posH | posV << 16}, partner's length
+                key = ae[u].x & 0x3FFFFFFFu; pal = (ae[u].x >> 30) & 1u; oriented = (ae[u].x >> 31) != 0; hv = ae[u].y;
+                ov = (uint32_t)overlap_estimate(hv & 0xFFFFu, hv >> 16, bw[u], lenV, oriented, k) & 0xFFFFu;
             } else {
                 key = ae[u].x & 0x7FFFFFFFu;
                 const uint32_t posH = ae[u].y & 0xFFFFu, lenH = ae[u].y >> 16;

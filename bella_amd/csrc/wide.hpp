@@ -86,7 +86,8 @@ __global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
                 if (a.key32) ((uint32_t*)a.W_key)[p] = (s << a.rbits) | key;
                 else ((uint64_t*)a.W_key)[p] = ((uint64_t)s << a.rbits) | key;
                 a.W_idx[p] = (uint32_t)p;
-                a.W_rec[p] = make_uint2(r2.y, (uint32_t)a.Aov[arow + q] | (fl << 16));
+                const uint32_t ov = (uint32_t)overlap_estimate(r2.y & 0xFFFFu, r2.y >> 16, a.Aov[arow + q], lenV, (r2.x >> 31) != 0, (uint32_t)a.k) & 0xFFFFu;
+                a.W_rec[p] = make_uint2(r2.y, ov | (fl << 16));
             }
             continue;
         }
