@@ -1662,7 +1662,10 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         }
     }
     // (the control block is cleared by the first kernel of the pass)
-    if (nown) {
+    if (nown && c->have_rowlists) {
+        k_row_flops_rl<<<nblk(nown), kBlock, 0, c->stream>>>(ptr<uint64_t>(c->Arow), i0, c->part_stride, nown, ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC), d_ctl);
+        KCHK(c);
+    } else if (nown) {
         k_row_flops<<<nblk(nown, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint16_t>(c->Bcnt), i0, c->part_stride, nown,
                                                                   ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC), d_ctl);
         KCHK(c);

@@ -811,6 +811,17 @@ __global__ __launch_bounds__(kBlock) void k_sample_pair_ratio(const uint32_t* Bp
 // estimateFLOP (overlap.hpp:157-202, lowtri): products of column i = sum of the suffix counts of its entries.
 // One wavefront per column of this context (partition i % stride == first, stage [lo, hi)): column j is i0 + j * stride.  The
 // entries of the other columns are zero: the host clears the arrays when the operands, the partition or the stage change.
+// the same with row lists (assemble.hpp): the products of column i are Aent2[Arow[i] .. Arow[i + 1]) -- their number is a difference
+// of two row pointers, no count stream to read.  One thread per column.
+__global__ __launch_bounds__(kBlock) void k_row_flops_rl(const uint64_t* Arow, uint32_t i0, uint32_t stride, uint32_t nown, uint32_t* flops,
+                                                         uint32_t* nnzC, uint32_t* ctl) {
+    if (blockIdx.x == 0 && threadIdx.x < kCtlWords) ctl[threadIdx.x] = 0;   // the pass's control block (first kernel of the pass)
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nown) return;
+    const uint32_t i = i0 + j * stride;
+    nnzC[i] = 0;
+    flops[i] = (uint32_t)(Arow[i + 1] - Arow[i]);
+}
 __global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, const uint16_t* Bcnt, uint32_t i0, uint32_t stride, uint32_t nown,
                                                       uint32_t* flops, uint32_t* nnzC, uint32_t* ctl) {
     if (blockIdx.x == 0 && threadIdx.x < kCtlWords) ctl[threadIdx.x] = 0;   // the pass's control block (first kernel of the pass)
