@@ -1915,7 +1915,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
             oa.pairs = ptr<bella_pair>(c->pairs); oa.ext = want_ext ? ptr<bella_pair_ext>(c->ext) : nullptr;
             oa.totals = (uint64_t*)(d_ctl + kCtlTotals);
             oa.nbig = d_ctl + kCtlOrderBig; oa.biglist = ptr<uint32_t>(c->orderlist); oa.ws = ptr<uint8_t>(c->order_ws);
-            k_order_wave<<<nblk(nown ? nown : 1, kOrderBlock / 64), kOrderBlock, 0, c->stream>>>(oa);
+            k_order_wave<512, 0><<<nblk(nown ? nown : 1, kOrderBlock / 64), kOrderBlock, 0, c->stream>>>(oa);
+            KCHK(c);
+            k_order_wave<kOrderWaveHt, 512><<<nblk(nown ? nown : 1, kOrderBlock / 64), kOrderBlock, 0, c->stream>>>(oa);
             KCHK(c);
             k_order_block<<<kOrderBigGrid, kOrderBlock, (size_t)6 * kOrderLdsHt, c->stream>>>(oa);
             KCHK(c);

@@ -51,13 +51,16 @@ __device__ __forceinline__ void order_copy_record(const OrderArgs& a, uint64_t f
     if (a.ext) a.ext[to] = a.tmp_ext[from];
 }
 
-// one wavefront per column: tables of up to kOrderWaveHt slots
+// one wavefront per column: tables of HTLO < ht <= HT slots (HT <= kOrderWaveHt; two instances share the columns: the small one keeps
+// fewer records per lane in registers and half the LDS, so more of its columns are in flight per CU).  The instance with HTLO == 0
+// also copies the columns that are in order already and lists the ones above kOrderWaveHt for k_order_block.
+template <uint32_t HT, uint32_t HTLO>
 __global__ __launch_bounds__(kOrderBlock) void k_order_wave(OrderArgs a) {
-    __shared__ uint32_t s_T2[kOrderBlock / 64][kOrderWaveHt];
-    __shared__ uint16_t s_ord[kOrderBlock / 64][kOrderWaveHt];
+    __shared__ uint32_t s_T2[kOrderBlock / 64][HT];
+    __shared__ uint16_t s_ord[kOrderBlock / 64][HT];
     const uint32_t j0 = blockIdx.x * (kOrderBlock / 64) + wave_id();
     const uint32_t lane = lane_id();
-    if (j0 == 0 && lane == 0) a.totals[0] = a.colptrC[a.nreads];   // nnz(C): read back once with the control block
+    if (HTLO == 0 && j0 == 0 && lane == 0) a.totals[0] = a.colptrC[a.nreads];   // nnz(C): read back once with the control block
     if (j0 >= a.nown) return;
     const uint32_t i = a.i0 + j0 * a.stride;
     // everything the column needs from its descriptors in ONE round trip (each of these is wave-uniform, so the compiler waits for
@@ -69,18 +72,19 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_wave(OrderArgs a) {
     const uint32_t d = nz & ~kOrderedBit;
     if (!d) return;
     if (nz & kOrderedBit) {
-        for (uint32_t r = lane; r < d; r += 64) order_copy_record(a, src + r, dst + r, i);
+        if (HTLO == 0) for (uint32_t r = lane; r < d; r += 64) order_copy_record(a, src + r, dst + r, i);
         return;
     }
     const uint32_t ht = pow2_at_least(16u, d);
     if (ht > kOrderWaveHt) {
-        if (lane == 0) a.biglist[atomicAdd(a.nbig, 1u)] = i;
+        if (HTLO == 0 && lane == 0) a.biglist[atomicAdd(a.nbig, 1u)] = i;
         return;
     }
+    if (ht > HT || ht <= HTLO) return;                       // the other instance's column
     uint32_t* T2 = s_T2[wave_id()];
     uint16_t* ord = s_ord[wave_id()];                        // next-free table during the rounds, then rank -> record
     for (uint32_t s = lane; s < ht; s += 64) T2[s] = kEmpty;
-    constexpr uint32_t NI = kOrderWaveHt / 64;               // records per lane
+    constexpr uint32_t NI = HT / 64;                         // records per lane
     uint32_t key[NI], fp[NI];
 #pragma unroll
     for (uint32_t u = 0; u < NI; ++u) {
