@@ -74,11 +74,21 @@ constexpr uint32_t kAsmClasses = 5;
 __device__ __forceinline__ uint32_t asm_class_of(uint32_t ht) { return ht <= 1024u ? 0u : ht <= 2048u ? 1u : ht <= 4096u ? 2u : ht <= 8192u ? 3u : 4u; }
 __global__ void k_asm_classify(const uint64_t* tstart, uint32_t nreads, uint32_t* lists, uint32_t* counts, uint32_t* rowcnt, uint32_t* status) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nreads) return;
-    const uint64_t n = tstart[r + 1] - tstart[r];
-    if (n == 0 || n >= 65536ull) { rowcnt[r] = 0; if (n) atomicOr(status, 16u); return; }
-    const uint32_t c = asm_class_of(pow2_at_least(16u, (uint32_t)n));
-    lists[(size_t)c * nreads + atomicAdd(&counts[c], 1u)] = r;
+    uint32_t c = 0xFFFFFFFFu;
+    if (r < nreads) {
+        const uint64_t n = tstart[r + 1] - tstart[r];
+        if (n == 0 || n >= 65536ull) { rowcnt[r] = 0; if (n) atomicOr(status, 16u); }
+        else c = asm_class_of(pow2_at_least(16u, (uint32_t)n));
+    }
+    // one atomic per wavefront and class (five counters serve all reads: one atomic per read queues up behind the others)
+    for (uint32_t q = 0; q < kAsmClasses; ++q) {
+        const unsigned long long mask = __ballot(c == q);
+        if (mask == 0) continue;
+        uint32_t base = 0;
+        if (lane_id() == (uint32_t)(__ffsll((long long)mask) - 1)) base = atomicAdd(&counts[q], (uint32_t)__popcll(mask));
+        base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+        if (c == q) lists[(size_t)q * nreads + base + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull))] = r;
+    }
 }
 constexpr uint32_t kAsmLdsSlots = 8192;                    // largest table held in LDS (one 1024-thread workgroup per CU)
 constexpr uint32_t kAsmScratchBytes = 128;
