@@ -190,7 +190,11 @@ int bella_hip_assemble_tuples(bella_ctx* ctx, uint16_t kmer_size, uint32_t nkmer
                               const uint32_t* t_kmer, const uint32_t* t_read, const uint16_t* t_pos);
 /* From the reference's own B = transpmat CSC arrays (the HashSpGEMM boundary, overlap.hpp:650):
  * colptr[nreads+1], rowids = k-mer ids in MergeDuplicates slot order, values = positions.
- * A = spmat is derived on device (ascending read ids per k-mer = the reference's 1-thread Transpose). */
+ * A = spmat is derived on device (ascending read ids per k-mer = the reference's 1-thread Transpose).
+ * Every call that installs operands (this one, the assemble_* calls, bella_hip_allgather_panels) also lays them out for the passes:
+ * B', A', and -- when 10 bytes per product of the whole SpGEMM fit in half of the free device memory and read ids need at most 30
+ * bits -- the row lists (the two operand entries of every product side by side in product order), which a pass streams instead of
+ * expanding B' x A' itself.  Same results either way. */
 int bella_hip_set_B(bella_ctx* ctx, uint16_t kmer_size, uint32_t nkmers, const uint32_t* colptr,
                     const uint32_t* rowids, const uint16_t* values);
 /* Multi-GPU assembly: rank r builds only the rows of B of ITS reads (a row-block panel) from their tuples (global read ids,
