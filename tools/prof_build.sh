@@ -4,5 +4,5 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/_old
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wno-unused-result -DBELLA_DEV_PROF \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wno-unused-result -Wno-pass-failed -DBELLA_DEV_PROF \
     -o tools/_old/libbella_prof.so bella_amd/csrc/bella_hip.hip
