@@ -48,11 +48,11 @@ def test_assembly_matches_reference_layout(eng, golden):
         assert np.array_equal(a, b)           # colptr, k-mer ids in MergeDuplicates slot order, positions
 
 
-@pytest.mark.parametrize("debug", [0, 1, 1024, 1025])
+@pytest.mark.parametrize("debug", [0, 1, 1024, 1025, 2048])
 def test_spgemm_pairs_bit_exact(eng, golden, debug):
     g = golden
     eng.set_debug(debug)                       # 1 = force the global-workspace row path; 1024 = the layout without the row lists
-                                               # (the pass expands B' x A' itself: what inputs whose products do not fit fall back to)
+                                               # (the pass expands B' x A' itself); 2048 = as if the row lists did not fit in memory
     try:
         eng.set_reads(g.rs)
         eng.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
