@@ -844,11 +844,12 @@ def test_file_to_file_pipeline_reproduces_reference_up_to_kmer_labels(eng, tmp_p
 
 # ---- columns with >= 65,536 products (wide.hpp) -----------------------------------------------------------------------------
 
-@pytest.mark.parametrize("budget", [0, 300000])
-def test_wide_columns_bit_exact(eng, budget):
+@pytest.mark.parametrize("budget,layout", [(0, 0), (300000, 0), (0, 1024), (300000, 2048)])
+def test_wide_columns_bit_exact(eng, budget, layout):
     """70 near-identical reads with -u 80: every k-mer is shared by all of them, column 0 has ~200k products (the row kernels
     index products with 16 bits); strands mixed, two reads carry a 700-base deletion plus a random tail (a second overlap bin)"""
     eng.set_tuning("wide_budget", budget)                            # 300000: several batches of wide columns
+    eng.set_debug(layout)                                            # 1024 / 2048: the layouts without row lists (the pass expands the products)
     rng = np.random.default_rng(17)
     base = rng.integers(0, 4, size=3000, dtype=np.uint8)
     comp = (3 - base)[::-1]
@@ -863,6 +864,7 @@ def test_wide_columns_bit_exact(eng, budget):
     nk, nt, _ = eng.count_kmers(17, 2, 80)
     tk, tr, tp = eng.get_tuples()
     eng.assemble_counted()
+    eng.set_debug(0)
     n, flops = eng.overlap(BellaPars(skipAlignment=True))
     pairs, ext, colptrC = eng.get_pairs()
     _, flop, ecol, exp = oracle_pairs(rs, rs.seqs(), nk, tk, tr, tp, 17)
