@@ -20,7 +20,9 @@
 //       overlap.hpp:365-404; stages :682-710): ceil(1.5 * nnz(C) * (sizeof(spmatPtr_) + sizeof(uint32_t)) / free_memory), boundaries by
 //       upper_bound on colptrC.  With more than one stage the output is formed stage by stage (each pass holds its own columns
 //       only) and APPENDED -- the reference overwrites the file from offset 0 in every stage (overlap.hpp:613-636, a defect);
-//       the file written here is the single-stage one.
+//       the file written here is the single-stage one.  totalMemory shapes the OUTPUT stages only: the planning pass runs the SpGEMM
+//       over all columns on the device (device memory, not -m, bounds it: 24 bytes per product in flight) to obtain colptrC, and
+//       with more than one stage every stage is then computed again -- about twice the device work of a single-stage call.
 // Also here, in namespace bella_hip (the reference defines functions of the same names and signatures, so these cannot be
 // overloads): bella_hip::xavierAlign -- include/align.hpp:152, same arguments, same xavierResult -- and bella_hip::alignXavier,
 // the batched form shaped like alignLogan (include/align.hpp:210-211), both forwarding to bella_hip_xdrop_batch.
@@ -258,7 +260,9 @@ inline void alignXavier(const std::vector<std::string>& target, const std::vecto
     }
 }
 
-// include/align.hpp:152
+// include/align.hpp:152.  One pair per call: both reads are uploaded and one extension pair is launched every time (a thread-local
+// context keeps it safe inside the reference's OpenMP pair loop, overlap.hpp:565, not fast): a caller with many pairs uses alignXavier
+// above, or the HashSpGEMM overload, which aligns all candidate pairs of a stage in one batch.
 inline xavierResult xavierAlign(const std::string& row, const std::string& col, int rowLen, int i, int j, int xDrop, int kmerSize) {
     (void)rowLen;                                                              // == row.size() at the reference's call site (overlap.hpp:565)
     BELLApars bp;
