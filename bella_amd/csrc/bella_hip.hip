@@ -118,7 +118,7 @@ struct bella_ctx {
         status, cubtmp, plist_hv, overflow, ctl, retry, orderlist, order_ws;
     bool order_attr = false;
     Buf w_f, w_off, w_key, w_key2, w_idx, w_idx2, w_hv, w_ovfl, w_plist, w_scr, w_rlen, w_rstart, w_rrank, w_redo, w_segfirst,
-        w_toff, w_table, w_nruns, w_desc;
+        w_toff, w_table, w_nruns, w_desc, w_gtab, w_gcount, w_gbase, w_rfirst;
     uint32_t n_wide = 0;
     uint32_t n_retry = 0;
     uint32_t n_overflow = 0;
@@ -472,7 +472,7 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->w, &c->wscan, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC,
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
                   &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->orderlist, &c->order_ws, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx, &c->w_idx2, &c->w_hv, &c->w_ovfl,
-                  &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_redo, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->w_desc, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
+                  &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_redo, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->w_desc, &c->w_gtab, &c->w_gcount, &c->w_gbase, &c->w_rfirst, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
                   &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -1469,44 +1469,81 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     int seg_bits = 1;
     while ((1u << seg_bits) < nw) ++seg_bits;
     a.key32 = rbits + seg_bits <= 32 && !(c->debug & 64u) ? 1u : 0u;   // debug bit 6: tests, 64-bit keys on any input
-    k_wide_expand<<<nw < 2048u ? nw : 2048u, kWideExpandBlock, 0, c->stream>>>(a);
-    KCHK(c);
-    // sort by (column, partner read) over the meaningful bits, run-length encode into pairs; u32 keys when they fit
-    auto sort_and_encode = [&](auto key_tag) -> int {
-        using K = decltype(key_tag);
-        hipcub::DoubleBuffer<K> dk((K*)c->w_key.p, (K*)c->w_key2.p);
-        hipcub::DoubleBuffer<uint32_t> dv(ptr<uint32_t>(c->w_idx), ptr<uint32_t>(c->w_idx2));
-        size_t tb = 0;
-        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (int)T, 0, rbits + seg_bits, c->stream));
-        ENSURE(c, c->cubtmp, tb);
-        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb, dk, dv, (int)T, 0, rbits + seg_bits, c->stream));
-        a.S_key = dk.Current(); a.S_idx = dv.Current();
-        K* rkey = dk.Current() == (K*)c->w_key.p ? (K*)c->w_key2.p : (K*)c->w_key.p;
-        size_t tb2 = 0;
-        HIPCHK(c, hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, (const K*)a.S_key, rkey, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_nruns), (int)T, c->stream));
-        ENSURE(c, c->cubtmp, tb2);
-        HIPCHK(c, hipcub::DeviceRunLengthEncode::Encode(c->cubtmp.p, tb2, (const K*)a.S_key, rkey, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_nruns), (int)T, c->stream));
-        a.R_key = rkey;
-        return 0;
-    };
-    {
-        const int rc2 = a.key32 ? sort_and_encode(uint32_t{}) : sort_and_encode(uint64_t{});
-        if (rc2) return rc2;
-    }
+    a.R_first = nullptr;
     uint32_t np = 0;
-    HIPCHK(c, hipMemcpyAsync(&np, c->w_nruns.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->w_rlen) + np, 0, 4, c->stream));
-    rc = scan_u32(c, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_rstart), (uint64_t)np + 1);
-    if (rc) return rc;
-    a.R_len = ptr<uint32_t>(c->w_rlen); a.R_start = ptr<uint32_t>(c->w_rstart); a.npairs = np;
-    a.R_rank = ptr<uint32_t>(c->w_rrank); a.seg_first = ptr<uint32_t>(c->w_segfirst);
-    k_wide_gather<<<nblk(T), 256, 0, c->stream>>>(a, T);
-    KCHK(c);
-    k_wide_segments<<<nblk((uint64_t)np + 1), 256, 0, c->stream>>>(a);
-    KCHK(c);
+    bool grouped = false;
+    // wide columns with few partners (HiFi-like input): group in LDS, two streaming passes over the row lists (wide.hpp) -- unless a
+    // column's partners do not fit the table, the lane-order self-test failed, or debug bit 12 asks for the sort-based path (tests)
+    if (c->have_rowlists && c->lane_order_ok && !(c->debug & 4096u)) {
+        ENSURE(c, c->w_gtab, sizeof(uint4) * 2 * (size_t)nw * kWideGroupSlots);
+        ENSURE(c, c->w_gcount, 4 * ((size_t)nw + 4));
+        ENSURE(c, c->w_gbase, 4 * ((size_t)nw + 4));
+        a.gtab = ptr<uint4>(c->w_gtab); a.gcount = ptr<uint32_t>(c->w_gcount); a.gbase = ptr<uint32_t>(c->w_gbase);
+        HIPCHK(c, hipMemsetAsync(a.gcount + nw, 0, 8, c->stream));          // the scan's last element and the overflow flag
+        k_wide_group1<<<nw < 4096u ? nw : 4096u, kWideGroup1Block, 0, c->stream>>>(a);
+        KCHK(c);
+        rc = scan_u32(c, ptr<uint32_t>(c->w_gcount), ptr<uint32_t>(c->w_gbase), (uint64_t)nw + 1);
+        if (rc) return rc;
+        uint32_t fin[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(&fin[0], ptr<uint32_t>(c->w_gbase) + nw, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&fin[1], ptr<uint32_t>(c->w_gcount) + nw + 1, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (fin[1] == 0) {
+            np = fin[0];
+            ENSURE(c, c->w_rlen, 4 * ((size_t)np + 1)); ENSURE(c, c->w_rstart, 4 * ((size_t)np + 2)); ENSURE(c, c->w_rrank, 4 * ((size_t)np + 1));
+            ENSURE(c, c->w_rfirst, 4 * ((size_t)np + 1));
+            ENSURE(c, c->w_key2, 8 * ((size_t)np + 1));
+            a.R_len_w = ptr<uint32_t>(c->w_rlen); a.R_start_w = ptr<uint32_t>(c->w_rstart); a.R_key_w = c->w_key2.p;
+            a.R_first = ptr<uint32_t>(c->w_rfirst);
+            if (np) {
+                k_wide_group2<<<nw < 8192u ? nw : 8192u, kWideGroup2Block, 0, c->stream>>>(a);
+                KCHK(c);
+            }
+            a.R_key = c->w_key2.p; a.R_len = ptr<uint32_t>(c->w_rlen); a.R_start = ptr<uint32_t>(c->w_rstart); a.npairs = np;
+            a.R_rank = ptr<uint32_t>(c->w_rrank);
+            a.seg_first = ptr<uint32_t>(c->w_gbase);                 // first pair of every column = the prefix sums of the pair counts
+            grouped = true;
+        }
+    }
+    if (!grouped) {
+        k_wide_expand<<<nw < 2048u ? nw : 2048u, kWideExpandBlock, 0, c->stream>>>(a);
+        KCHK(c);
+        // sort by (column, partner read) over the meaningful bits, run-length encode into pairs; u32 keys when they fit
+        auto sort_and_encode = [&](auto key_tag) -> int {
+            using K = decltype(key_tag);
+            hipcub::DoubleBuffer<K> dk((K*)c->w_key.p, (K*)c->w_key2.p);
+            hipcub::DoubleBuffer<uint32_t> dv(ptr<uint32_t>(c->w_idx), ptr<uint32_t>(c->w_idx2));
+            size_t tb = 0;
+            HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (int)T, 0, rbits + seg_bits, c->stream));
+            ENSURE(c, c->cubtmp, tb);
+            HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb, dk, dv, (int)T, 0, rbits + seg_bits, c->stream));
+            a.S_key = dk.Current(); a.S_idx = dv.Current();
+            K* rkey = dk.Current() == (K*)c->w_key.p ? (K*)c->w_key2.p : (K*)c->w_key.p;
+            size_t tb2 = 0;
+            HIPCHK(c, hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, (const K*)a.S_key, rkey, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_nruns), (int)T, c->stream));
+            ENSURE(c, c->cubtmp, tb2);
+            HIPCHK(c, hipcub::DeviceRunLengthEncode::Encode(c->cubtmp.p, tb2, (const K*)a.S_key, rkey, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_nruns), (int)T, c->stream));
+            a.R_key = rkey;
+            return 0;
+        };
+        {
+            const int rc2 = a.key32 ? sort_and_encode(uint32_t{}) : sort_and_encode(uint64_t{});
+            if (rc2) return rc2;
+        }
+        HIPCHK(c, hipMemcpyAsync(&np, c->w_nruns.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->w_rlen) + np, 0, 4, c->stream));
+        rc = scan_u32(c, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_rstart), (uint64_t)np + 1);
+        if (rc) return rc;
+        a.R_len = ptr<uint32_t>(c->w_rlen); a.R_start = ptr<uint32_t>(c->w_rstart); a.npairs = np;
+        a.R_rank = ptr<uint32_t>(c->w_rrank); a.seg_first = ptr<uint32_t>(c->w_segfirst);
+        k_wide_gather<<<nblk(T), 256, 0, c->stream>>>(a, T);
+        KCHK(c);
+        k_wide_segments<<<nblk((uint64_t)np + 1), 256, 0, c->stream>>>(a);
+        KCHK(c);
+    }
     std::vector<uint32_t> segf((size_t)nw + 1);
-    HIPCHK(c, hipMemcpyAsync(segf.data(), c->w_segfirst.p, 4 * ((size_t)nw + 1), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(segf.data(), a.seg_first, 4 * ((size_t)nw + 1), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<uint64_t> toff((size_t)nw + 1, 0);
     for (uint32_t s = 0; s < nw; ++s) {

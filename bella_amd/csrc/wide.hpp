@@ -62,6 +62,15 @@ struct WideArgs {
     unsigned long long* clk;
 #endif
     WidePairAddr* desc;          // [npairs] (k_wide_desc)
+    // grouping in LDS (k_wide_group1 / _group2): per column a table image of kWideGroupSlots entries {key, list start, products, first product},
+    // the columns' pair counts and their prefix sums, a flag for columns whose pairs do not fit the table, the pairs' first products
+    uint4* gtab;
+    uint32_t* gcount;            // [nw + 2]: pairs per column; gcount[nw + 1] = overflow flag
+    const uint32_t* gbase;       // [nw + 1] exclusive scan of gcount
+    uint32_t* R_first;           // [npairs] first product of the pair inside its column (nullptr: S_idx[R_start[r]] - woff[seg])
+    uint32_t* R_len_w;           // writable views of R_len / R_start / R_key for k_wide_group2
+    uint32_t* R_start_w;
+    void* R_key_w;
     uint32_t* redo;              // [npairs] pairs left to the serial fold (k_wide_fold) by k_wide_fold_wg; redo[npairs] = their number
 };
 
@@ -132,6 +141,145 @@ __global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
     }
 }
 
+// ---- grouping by partner in LDS (row lists only) ---------------------------------------------------------------------------------
+// A wide column has many products but few partners (HiFi reads with a raised -u: 36,000 ... 200,000 products on ~50 ... 500 partners):
+// instead of sorting 16 bytes per product three or four times, the column's products are streamed twice.  k_wide_group1: one
+// workgroup per column inserts the partner of every product into an LDS table (compare-and-swap) and counts the pair's products per
+// RANGE of the column (four ranges of whole 64-product chunks) and its first product; a scan over the slots gives every pair its list
+// inside the column's part of plist.  k_wide_group2: four wavefronts per column, wavefront q appends the products of range q, 64 at a
+// time in product order, at the cursor of (pair, range) -- the same-address LDS atomics of one instruction are applied in lane
+// order (k_lane_order_selftest), so every list ends up in product order.  A column whose partners do not fit the table raises a flag and
+// the batch takes the sort-based path below.
+constexpr uint32_t kWideGroupSlots = 2048;                 // table slots per column (at most kWideGroupPairs pairs)
+constexpr uint32_t kWideGroupPairs = 1536;
+constexpr int kWideGroup1Block = 1024, kWideGroup2Block = 256;
+__device__ __forceinline__ uint32_t wide_group_range(uint64_t F) { return (uint32_t)(((F + 255u) >> 8) << 6); }   // products per range
+__global__ __launch_bounds__(kWideGroup1Block) void k_wide_group1(WideArgs a) {
+    __shared__ uint32_t s_key[kWideGroupSlots];
+    __shared__ uint32_t s_cnt[kWideGroupSlots][4];
+    __shared__ uint32_t s_first[kWideGroupSlots];
+    __shared__ uint32_t scr[kWideGroup1Block / 64];
+    __shared__ uint32_t s_n, s_fail;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t s = blockIdx.x; s < a.nw; s += gridDim.x) {
+        const uint32_t i = a.cols[s];
+        const uint64_t F = a.woff[s + 1] - a.woff[s], arow = a.Arow[i];
+        const uint32_t RB = wide_group_range(F);
+        for (uint32_t h = tid; h < kWideGroupSlots; h += kWideGroup1Block) {
+            s_key[h] = 0xFFFFFFFFu; s_first[h] = 0xFFFFFFFFu;
+            s_cnt[h][0] = 0; s_cnt[h][1] = 0; s_cnt[h][2] = 0; s_cnt[h][3] = 0;
+        }
+        if (tid == 0) { s_n = 0; s_fail = 0; }
+        __syncthreads();
+        uint32_t mine = 0;
+        for (uint64_t p = tid; p < F; p += kWideGroup1Block) {
+            const uint32_t key = a.Aent2[arow + p].x & 0x3FFFFFFFu;
+            uint32_t h = hash_range(key, kWideGroupSlots), probes = 0;
+            for (; probes < kWideGroupSlots; ++probes) {
+                const uint32_t old = atomicCAS(&s_key[h], 0xFFFFFFFFu, key);
+                if (old == 0xFFFFFFFFu) { ++mine; break; }
+                if (old == key) break;
+                h = h + 1 == kWideGroupSlots ? 0 : h + 1;
+            }
+            if (probes == kWideGroupSlots) { s_fail = 1; break; }
+            atomicAdd(&s_cnt[h][(uint32_t)(p / RB)], 1u);
+            atomicMin(&s_first[h], (uint32_t)p);
+        }
+        {
+            const uint32_t mw = wave_incl_scan(mine);
+            if (lane_id() == 63 && mw) atomicAdd(&s_n, mw);
+        }
+        __syncthreads();
+        const uint32_t d = s_n;
+        if (s_fail || d > kWideGroupPairs) {                        // (the table would run above 75 % load, or is full)
+            if (tid == 0) { a.gcount[s] = 0; a.gcount[a.nw + 1] = 1; }
+            __syncthreads();
+            continue;
+        }
+        // lists in slot order: exclusive scan of the pairs' product counts
+        constexpr uint32_t kPer = kWideGroupSlots / kWideGroup1Block;
+        uint32_t m[kPer], sum = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t h = tid * kPer + u;
+            m[u] = s_cnt[h][0] + s_cnt[h][1] + s_cnt[h][2] + s_cnt[h][3];
+            sum += m[u];
+        }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan<kWideGroup1Block / 64>(sum, scr, &tot);
+        uint4* G = a.gtab + (size_t)s * kWideGroupSlots;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t h = tid * kPer + u;
+            G[h] = make_uint4(s_key[h], ex, m[u], s_first[h]);       // {key (0xFFFFFFFF: empty), list start inside the column, products, first product}
+            ex += m[u];
+        }
+        // the per-range counts travel in the table image's second half (4 x u32 per slot)
+        uint4* GC = a.gtab + ((size_t)a.nw + s) * kWideGroupSlots;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) { const uint32_t h = tid * kPer + u; GC[h] = make_uint4(s_cnt[h][0], s_cnt[h][1], s_cnt[h][2], s_cnt[h][3]); }
+        if (tid == 0) a.gcount[s] = d;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(kWideGroup2Block) void k_wide_group2(WideArgs a) {
+    __shared__ uint32_t s_key[kWideGroupSlots];
+    __shared__ uint32_t s_cur[kWideGroupSlots][4];
+    __shared__ uint32_t scr[kWideGroup2Block / 64];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t s = blockIdx.x; s < a.nw; s += gridDim.x) {
+        const uint32_t i = a.cols[s];
+        const uint64_t wo = a.woff[s], F = a.woff[s + 1] - wo, arow = a.Arow[i];
+        const uint32_t RB = wide_group_range(F);
+        const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
+        const uint4* G = a.gtab + (size_t)s * kWideGroupSlots;
+        const uint4* GC = a.gtab + ((size_t)a.nw + s) * kWideGroupSlots;
+        const uint32_t pbase = a.gbase[s];
+        // pair numbers in slot order (any order does: the output order comes from k_wide_insert / k_wide_ranks), cursors per range
+        constexpr uint32_t kPer = kWideGroupSlots / kWideGroup2Block;
+        uint4 g[kPer];
+        uint32_t occ = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) { g[u] = G[tid * kPer + u]; occ += g[u].x != 0xFFFFFFFFu ? 1u : 0u; }
+        uint32_t tot;
+        uint32_t r = pbase + block_excl_scan<kWideGroup2Block / 64>(occ, scr, &tot);
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t h = tid * kPer + u;
+            const uint4 c4 = GC[h];
+            s_key[h] = g[u].x;
+            s_cur[h][0] = g[u].y; s_cur[h][1] = g[u].y + c4.x; s_cur[h][2] = g[u].y + c4.x + c4.y; s_cur[h][3] = g[u].y + c4.x + c4.y + c4.z;
+            if (g[u].x != 0xFFFFFFFFu) {
+                if (a.key32) ((uint32_t*)a.R_key_w)[r] = (s << a.rbits) | g[u].x;
+                else ((uint64_t*)a.R_key_w)[r] = ((uint64_t)s << a.rbits) | g[u].x;
+                a.R_len_w[r] = g[u].z;
+                a.R_start_w[r] = (uint32_t)wo + g[u].y;
+                a.R_first[r] = g[u].w;
+                ++r;
+            }
+        }
+        __syncthreads();
+        // wavefront q owns range q: 64 products at a time in product order
+        const uint32_t q = wave_id(), lane = lane_id();
+        const uint64_t lo = (uint64_t)q * RB, hi = lo + RB < F ? lo + RB : F;
+        for (uint64_t base = lo; base < hi; base += 64) {
+            const uint64_t p = base + lane;
+            if (p < hi) {
+                const uint2 r2 = a.Aent2[arow + p];
+                const uint32_t key = r2.x & 0x3FFFFFFFu;
+                uint32_t h = hash_range(key, kWideGroupSlots);
+                while (s_key[h] != key) h = h + 1 == kWideGroupSlots ? 0 : h + 1;
+                const uint32_t pos = atomicAdd(&s_cur[h][q], 1u);   // (same-address atomics of one instruction: lane order)
+                const bool oriented = (r2.x >> 31) != 0;
+                const uint32_t ov = (uint32_t)overlap_estimate(r2.y & 0xFFFFu, r2.y >> 16, a.Aov[arow + p], lenV, oriented, (uint32_t)a.k) & 0xFFFFu;
+                const uint32_t fl = (oriented ? 1u : 0u) | (((r2.x >> 30) & 1u) << 1);
+                a.plist[wo + pos] = make_uint2(r2.y, ov | (fl << 16));
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ uint64_t wide_rkey(const WideArgs& a, uint32_t r) {
     return a.key32 ? (uint64_t)((const uint32_t*)a.R_key)[r] : ((const uint64_t*)a.R_key)[r];
 }
@@ -165,7 +313,7 @@ __global__ void k_wide_insert(WideArgs a) {
     const uint32_t key = (uint32_t)(wide_rkey(a, r) & ((1ull << a.rbits) - 1ull));
     const uint64_t ht = a.toff[seg + 1] - a.toff[seg];
     unsigned long long* T = (unsigned long long*)(a.table + a.toff[seg]);
-    const uint32_t first = a.S_idx[a.R_start[r]] - (uint32_t)a.woff[seg];    // product index inside the column
+    const uint32_t first = a.R_first ? a.R_first[r] : a.S_idx[a.R_start[r]] - (uint32_t)a.woff[seg];    // product index inside the column
     unsigned long long item = ((unsigned long long)first << 32) | r;
     uint64_t h = (uint64_t)(key * 107u) & (ht - 1);
     for (;;) {

@@ -302,7 +302,8 @@ int bella_hip_get_timings(bella_ctx* ctx, bella_timings* t);
  * sorts on 64-bit keys on any input (default: 32-bit keys when column bits + read-id bits fit); bit8 = tests: the exact X-drop mode
  * launches its extensions in chunks of 1,000 (default 2^24: grid x block stays below 2^32 threads); bit10 (read when the operands are
  * assembled) = tests: no row lists -- the layout that inputs whose products do not fit in memory (10 bytes each) fall back to: every pass
- * expands the products from B' and A' itself; bit11 (same moment) = tests: as if the row lists did not fit (A' in k-mer order, no row lists) */
+ * expands the products from B' and A' itself; bit11 (same moment) = tests: as if the row lists did not fit (A' in k-mer order, no row lists);
+ * bit12 = tests: the columns above the LDS tiers are grouped by the radix sort also when the row lists would allow grouping in LDS */
 int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
 /* Per-context tuning parameters (tests and A/B measurements; nothing here changes results).  what:
  *   BELLA_TUNE_LDS_TIERS      values = ascending product capacities of the row kernels' LDS tiers, each in [64, 11008] (n = 0: defaults)

@@ -844,8 +844,8 @@ def test_file_to_file_pipeline_reproduces_reference_up_to_kmer_labels(eng, tmp_p
 
 # ---- columns with >= 65,536 products (wide.hpp) -----------------------------------------------------------------------------
 
-@pytest.mark.parametrize("budget,layout", [(0, 0), (300000, 0), (0, 1024), (300000, 2048)])
-def test_wide_columns_bit_exact(eng, budget, layout):
+@pytest.mark.parametrize("budget,layout,passdbg", [(0, 0, 0), (300000, 0, 0), (0, 1024, 0), (300000, 2048, 0), (0, 0, 4096), (300000, 0, 4096)])
+def test_wide_columns_bit_exact(eng, budget, layout, passdbg):
     """70 near-identical reads with -u 80: every k-mer is shared by all of them, column 0 has ~200k products (the row kernels
     index products with 16 bits); strands mixed, two reads carry a 700-base deletion plus a random tail (a second overlap bin)"""
     eng.set_tuning("wide_budget", budget)                            # 300000: several batches of wide columns
@@ -864,8 +864,9 @@ def test_wide_columns_bit_exact(eng, budget, layout):
     nk, nt, _ = eng.count_kmers(17, 2, 80)
     tk, tr, tp = eng.get_tuples()
     eng.assemble_counted()
-    eng.set_debug(0)
+    eng.set_debug(passdbg)                                           # 4096: the sort-based grouping of the wide columns also with row lists
     n, flops = eng.overlap(BellaPars(skipAlignment=True))
+    eng.set_debug(0)
     pairs, ext, colptrC = eng.get_pairs()
     _, flop, ecol, exp = oracle_pairs(rs, rs.seqs(), nk, tk, tr, tp, 17)
     assert int(flop.max()) >= 65536 and flops == int(flop.sum()) and n == len(exp)
