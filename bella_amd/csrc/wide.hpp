@@ -262,18 +262,34 @@ __global__ __launch_bounds__(kWideGroup2Block) void k_wide_group2(WideArgs a) {
         // wavefront q owns range q: 64 products at a time in product order
         const uint32_t q = wave_id(), lane = lane_id();
         const uint64_t lo = (uint64_t)q * RB, hi = lo + RB < F ? lo + RB : F;
-        for (uint64_t base = lo; base < hi; base += 64) {
-            const uint64_t p = base + lane;
-            if (p < hi) {
-                const uint2 r2 = a.Aent2[arow + p];
-                const uint32_t key = r2.x & 0x3FFFFFFFu;
-                uint32_t h = hash_range(key, kWideGroupSlots);
-                while (s_key[h] != key) h = h + 1 == kWideGroupSlots ? 0 : h + 1;
-                const uint32_t pos = atomicAdd(&s_cur[h][q], 1u);   // (same-address atomics of one instruction: lane order)
-                const bool oriented = (r2.x >> 31) != 0;
-                const uint32_t ov = (uint32_t)overlap_estimate(r2.y & 0xFFFFu, r2.y >> 16, a.Aov[arow + p], lenV, oriented, (uint32_t)a.k) & 0xFFFFu;
-                const uint32_t fl = (oriented ? 1u : 0u) | (((r2.x >> 30) & 1u) << 1);
-                a.plist[wo + pos] = make_uint2(r2.y, ov | (fl << 16));
+        // (the products of the next kAhead steps are on their way while a step is appended: a step alone is one trip to HBM)
+        constexpr uint32_t kAhead = 4;
+        uint2 nx[kAhead];
+        uint32_t nl[kAhead];
+#pragma unroll
+        for (uint32_t u = 0; u < kAhead; ++u) {
+            const uint64_t p = lo + 64ull * u + lane;
+            nx[u] = make_uint2(0u, 0u); nl[u] = 0;
+            if (p < hi) { nx[u] = a.Aent2[arow + p]; nl[u] = a.Aov[arow + p]; }
+        }
+        for (uint64_t base = lo; base < hi; base += 64ull * kAhead) {
+#pragma unroll
+            for (uint32_t u = 0; u < kAhead; ++u) {
+                const uint64_t p = base + 64ull * u + lane;
+                const uint2 r2 = nx[u];
+                const uint32_t lenH = nl[u];
+                const uint64_t pn = p + 64ull * kAhead;
+                if (pn < hi) { nx[u] = a.Aent2[arow + pn]; nl[u] = a.Aov[arow + pn]; }
+                if (p < hi) {
+                    const uint32_t key = r2.x & 0x3FFFFFFFu;
+                    uint32_t h = hash_range(key, kWideGroupSlots);
+                    while (s_key[h] != key) h = h + 1 == kWideGroupSlots ? 0 : h + 1;
+                    const uint32_t pos = atomicAdd(&s_cur[h][q], 1u);   // (same-address atomics of one instruction: lane order)
+                    const bool oriented = (r2.x >> 31) != 0;
+                    const uint32_t ov = (uint32_t)overlap_estimate(r2.y & 0xFFFFu, r2.y >> 16, lenH, lenV, oriented, (uint32_t)a.k) & 0xFFFFu;
+                    const uint32_t fl = (oriented ? 1u : 0u) | (((r2.x >> 30) & 1u) << 1);
+                    a.plist[wo + pos] = make_uint2(r2.y, ov | (fl << 16));
+                }
             }
         }
         __syncthreads();
