@@ -1452,7 +1452,7 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     ENSURE(c, c->w_key, 8 * T); ENSURE(c, c->w_key2, 8 * T);
     ENSURE(c, c->w_idx, 4 * T); ENSURE(c, c->w_idx2, 4 * T);
     ENSURE(c, c->w_hv, 8 * T);
-    ENSURE(c, c->w_plist, 8 * T); ENSURE(c, c->w_scr, 2 * T);
+    ENSURE(c, c->w_plist, 8 * (T + 64)); ENSURE(c, c->w_scr, 2 * T);
     ENSURE(c, c->w_rlen, 4 * (T + 1)); ENSURE(c, c->w_rstart, 4 * (T + 2)); ENSURE(c, c->w_rrank, 4 * T);
     ENSURE(c, c->w_segfirst, 4 * ((size_t)nw + 2));
     ENSURE(c, c->w_toff, 8 * ((size_t)nw + 2));
@@ -1461,7 +1461,7 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     a.Bptr = sa.Bptr; a.Bent = sa.Bent; a.Aent = sa.Aent; a.Aent2 = sa.Aent2; a.Aov = sa.Aov; a.Arow = sa.Arow; a.roff = sa.roff; a.packed = sa.packed; a.flopptr = sa.flopptr;
     a.k = sa.k; a.binSize = sa.binSize;
     a.W_key = c->w_key.p; a.W_idx = ptr<uint32_t>(c->w_idx); a.W_rec = ptr<uint2>(c->w_hv);
-    a.plist = ptr<uint2>(c->w_plist); a.sort_scratch = ptr<uint16_t>(c->w_scr);
+    a.plist = ptr<uint2>(c->w_plist); a.plist_pad = T; a.sort_scratch = ptr<uint16_t>(c->w_scr);
     a.tmp_pairs = sa.tmp_pairs; a.tmp_ext = sa.tmp_ext; a.nnzC = sa.nnzC; a.status = sa.ctl + kCtlStatus;
     int rbits = 1;
     while ((1ull << rbits) < (uint64_t)c->nreads) ++rbits;       // a partner read id fits rbits bits

@@ -43,7 +43,8 @@ struct WideArgs {
     // sorted
     const void* S_key;
     const uint32_t* S_idx;
-    uint2* plist;                // [totalF] {hv, ov} in sorted order = per-pair lists in product order
+    uint2* plist;                // [totalF + 64] {hv, ov} in sorted order = per-pair lists in product order
+    uint64_t plist_pad;          // totalF: 64 entries behind the lists that k_wide_group2's idle lanes write
     // pairs (runs of S_key)
     const void* R_key;           // [npairs]
     const uint32_t* R_len;
@@ -263,32 +264,37 @@ __global__ __launch_bounds__(kWideGroup2Block) void k_wide_group2(WideArgs a) {
         const uint32_t q = wave_id(), lane = lane_id();
         const uint64_t lo = (uint64_t)q * RB, hi = lo + RB < F ? lo + RB : F;
         // (the products of the next kAhead steps are on their way while a step is appended: a step alone is one trip to HBM)
-        constexpr uint32_t kAhead = 4;
+        // Loads and stores are unconditional (clamped index / a pad entry behind the lists for the lanes past the range's end): with a
+        // memory operation inside a branch the compiler can no longer count what is in flight and waits for everything at every step.
+        constexpr uint32_t kAhead = 16;
         uint2 nx[kAhead];
         uint32_t nl[kAhead];
-#pragma unroll
-        for (uint32_t u = 0; u < kAhead; ++u) {
-            const uint64_t p = lo + 64ull * u + lane;
-            nx[u] = make_uint2(0u, 0u); nl[u] = 0;
-            if (p < hi) { nx[u] = a.Aent2[arow + p]; nl[u] = a.Aov[arow + p]; }
-        }
-        for (uint64_t base = lo; base < hi; base += 64ull * kAhead) {
+        if (lo < hi) {
+            const uint64_t plast = hi - 1;
 #pragma unroll
             for (uint32_t u = 0; u < kAhead; ++u) {
-                const uint64_t p = base + 64ull * u + lane;
-                const uint2 r2 = nx[u];
-                const uint32_t lenH = nl[u];
-                const uint64_t pn = p + 64ull * kAhead;
-                if (pn < hi) { nx[u] = a.Aent2[arow + pn]; nl[u] = a.Aov[arow + pn]; }
-                if (p < hi) {
-                    const uint32_t key = r2.x & 0x3FFFFFFFu;
-                    uint32_t h = hash_range(key, kWideGroupSlots);
-                    while (s_key[h] != key) h = h + 1 == kWideGroupSlots ? 0 : h + 1;
-                    const uint32_t pos = atomicAdd(&s_cur[h][q], 1u);   // (same-address atomics of one instruction: lane order)
+                const uint64_t p = lo + 64ull * u + lane, pc = p < plast ? p : plast;
+                nx[u] = a.Aent2[arow + pc]; nl[u] = a.Aov[arow + pc];
+            }
+            for (uint64_t base = lo; base < hi; base += 64ull * kAhead) {
+#pragma unroll
+                for (uint32_t u = 0; u < kAhead; ++u) {
+                    const uint64_t p = base + 64ull * u + lane;
+                    const uint2 r2 = nx[u];
+                    const uint32_t lenH = nl[u];
+                    const uint64_t pn = p + 64ull * kAhead, pc = pn < plast ? pn : plast;
+                    nx[u] = a.Aent2[arow + pc]; nl[u] = a.Aov[arow + pc];
+                    uint64_t dst = a.plist_pad + lane;           // (lanes past the end write here)
                     const bool oriented = (r2.x >> 31) != 0;
                     const uint32_t ov = (uint32_t)overlap_estimate(r2.y & 0xFFFFu, r2.y >> 16, lenH, lenV, oriented, (uint32_t)a.k) & 0xFFFFu;
                     const uint32_t fl = (oriented ? 1u : 0u) | (((r2.x >> 30) & 1u) << 1);
-                    a.plist[wo + pos] = make_uint2(r2.y, ov | (fl << 16));
+                    if (p < hi) {
+                        const uint32_t key = r2.x & 0x3FFFFFFFu;
+                        uint32_t h = hash_range(key, kWideGroupSlots);
+                        while (s_key[h] != key) h = h + 1 == kWideGroupSlots ? 0 : h + 1;
+                        dst = wo + atomicAdd(&s_cur[h][q], 1u);  // (same-address atomics of one instruction: lane order)
+                    }
+                    a.plist[dst] = make_uint2(r2.y, ov | (fl << 16));
                 }
             }
         }
