@@ -402,6 +402,7 @@ struct XdropSliceArgs {
     const uint32_t* nlive_in;    // their number (device)
     uint32_t* live_out;          // survivors
     uint32_t* nlive_out;
+    int steps;                   // anti-diagonal steps of this launch (a multiple of 16, at most kXdropSlice)
 };
 
 // flags word: maxpos (5 bits) | first << 5 | flagged << 6 | mode4 << 7 | dir << 8 | it4 << 9 (5 bits) | dead << 15
@@ -484,7 +485,11 @@ __global__ __launch_bounds__(kXdropBlock) void k_xdrop_begin(XdropSliceArgs xa) 
     st[70 * cap] = 1u << 5;                                        // maxpos 0, first, not flagged, Phase 2
 }
 
-__global__ __launch_bounds__(kXdropBlock, 4) void k_xdrop_slice(XdropSliceArgs xa) {
+#ifndef BELLA_XSLICE_WAVES
+#define BELLA_XSLICE_WAVES 4                 // 128 VGPRs: this kernel lives on big batches, where the state loads want occupancy (with the
+                                             // clamp-free variant of the step next to the clamped one it needs 161: 3.35 s against 3.26 s on the 100k set)
+#endif
+__global__ __launch_bounds__(kXdropBlock, BELLA_XSLICE_WAVES) void k_xdrop_slice(XdropSliceArgs xa) {
     const XdropSortedArgs& sa = xa.s;
     const XdropArgs& a = sa.a;
     const uint64_t x = (uint64_t)blockIdx.x * kXdropBlock + threadIdx.x;
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(kXdropBlock, 4) void k_xdrop_slice(XdropSliceArgs x
     if (active) {
         t = xa.live_in ? (uint64_t)xa.live_in[x] : x;
         flags = xa.state[70 * cap + t];
-        active = !(flags >> 15);
+        active = !((flags >> 15) & 1u);
     }
     const unsigned long long any = __ballot(active);
     if (!any) return;
@@ -537,11 +542,12 @@ __global__ __launch_bounds__(kXdropBlock, 4) void k_xdrop_slice(XdropSliceArgs x
     const int X = a.xdrop;
     const s2 one = splat2(kXScale), mone = splat2(-kXScale), ninf = splat2(kXNinf * kXScale), top = splat2(kXTop), q1 = splat2(kQScale);
 
-#define BELLA_PSTEP()                                                                                               \
+#define BELLA_PSTEP(CLAMP)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                 \
         const s2 xr = s2_of(u32_of(qh[i]) ^ u32_of(qv[i]));                                                           \
         const s2 mt = one - pmin(xr, q1);                                                                             \
-        const s2 a1f = pmin(adds2(a1[i], mt), top);                                                                   \
+        const s2 a1s = adds2(a1[i], mt);                                                                              \
+        const s2 a1f = (CLAMP) ? pmin(a1s, top) : a1s;                                                                \
         const s2 shv = shl_cell(a2[i], i < 15 ? a2[i < 15 ? i + 1 : 15] : ninf);                                      \
         const s2 a2f = adds2(pmax(shv, a2[i]), mone);                                                                 \
         a3[i] = pmax(a1f, a2f);                                                                                       \
@@ -549,8 +555,8 @@ __global__ __launch_bounds__(kXdropBlock, 4) void k_xdrop_slice(XdropSliceArgs x
     a3[15].y = (short)(kXNinf * kXScale);
 #define BELLA_PKEY(keyout)                                                                                           \
     {                                                                                                                 \
-        s2 kk = a3[0] + mk2(31, 30);                                                                                  \
-        _Pragma("unroll") for (int i = 1; i < 16; ++i) kk = pmax(kk, a3[i] + mk2(31 - 2 * i, 30 - 2 * i));            \
+        s2 kk = s2_of(u32_of(a3[0]) | (31u | (30u << 16)));                                                           \
+        _Pragma("unroll") for (int i = 1; i < 16; ++i) kk = pmax(kk, s2_of(u32_of(a3[i]) | ((uint32_t)(31 - 2 * i) | ((uint32_t)(30 - 2 * i) << 16)))); \
         keyout = imax_((int)kk.x, (int)kk.y);                                                                         \
     }
 #define BELLA_PREBASE()                                                                                              \
@@ -585,10 +591,10 @@ __global__ __launch_bounds__(kXdropBlock, 4) void k_xdrop_slice(XdropSliceArgs x
     // one loop, single exit (an in-loop return makes the compiler keep two copies of the band state): a finished lane stores
     // its result and idles for the rest of the slice
     bool done = false;
-    for (int step = 0; step < kXdropSlice; ++step) {
+    for (int step = 0; step < xa.steps; ++step) {
         if (!__ballot(active && !done)) break;                    // (wave-uniform)
         if ((step & 15) == 0) { H.checkpoint((uint32_t)hoff); V.checkpoint((uint32_t)voff); }
-        BELLA_PSTEP()
+        BELLA_PSTEP(1)                                           // (always with the upper clamp: two variants of the step do not fit 128 VGPRs)
         int key;
         BELLA_PKEY(key)
         const int adb = key >> 8;
