@@ -146,7 +146,7 @@ struct bella_ctx {
     uint64_t kcount_budget = 1ull << 30, wide_budget = 1ull << 30;   // items per pass of the counting sort / of the wide-column path
     bool lane_order_ok = true;           // k_lane_order_selftest at init
     uint32_t xdrop_variant = 4;          // 0: one launch in length-sorted order; 1: slices with compaction; 2: packed kernel in pair order; 3: scalar statement;
-                                         // 4 (default): 1 for batches of 2 M pairs and more, else 0
+                                         // 4 (default): 1 for batches of 1 M pairs and more, else 0
     size_t lds_attr[18] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
     hipStream_t side[kNumTiers + 1]{};   // independent tier launches / fold instances run concurrently
     hipEvent_t fork = nullptr, join[kNumTiers + 1]{};
@@ -2180,7 +2180,7 @@ static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_se
             // before their step bound: in one launch their wavefronts idle behind the few that do not (5.2 s against 3.3 s in slices on the
             // 100k set); small batches of mostly true overlaps keep their lanes busy either way and save the slices' launches (75.3 against
             // 77.2 ms on the 10k set).
-            const bool one_launch = c->xdrop_variant == 0 || (c->xdrop_variant == 4 && n < (2ull << 20));
+            const bool one_launch = c->xdrop_variant == 0 || (c->xdrop_variant == 4 && n < (1ull << 20));
             if (one_launch) {                                      // a wavefront runs until its longest lane ends
                 k_xdrop_sorted<<<nblk(ne, kXdropBlock), kXdropBlock, 0, c->stream>>>(sa);
                 KCHK(c);
