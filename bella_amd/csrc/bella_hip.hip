@@ -145,8 +145,7 @@ struct bella_ctx {
     bool tiers_from_env = false;         // custom tier table (bella_hip_set_tuning)
     uint64_t kcount_budget = 1ull << 30, wide_budget = 1ull << 30;   // items per pass of the counting sort / of the wide-column path
     bool lane_order_ok = true;           // k_lane_order_selftest at init
-    uint32_t xdrop_variant = 4;          // 0: one launch in length-sorted order; 1: slices with compaction; 2: packed kernel in pair order; 3: scalar statement;
-                                         // 4 (default): 1 for batches of 1 M pairs and more, else 0
+    uint32_t xdrop_variant = 1;          // 0: one launch in length-sorted order; 1 (default): slices with compaction; 2: packed kernel in pair order; 3: scalar statement
     size_t lds_attr[18] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
     hipStream_t side[kNumTiers + 1]{};   // independent tier launches / fold instances run concurrently
     hipEvent_t fork = nullptr, join[kNumTiers + 1]{};
@@ -513,7 +512,7 @@ int bella_hip_set_tuning(bella_ctx* c, uint32_t what, const uint64_t* values, ui
         }
         case BELLA_TUNE_KCOUNT_BUDGET: c->kcount_budget = n && values[0] ? values[0] : (1ull << 30); return 0;
         case BELLA_TUNE_WIDE_BUDGET: c->wide_budget = n && values[0] ? values[0] : (1ull << 30); return 0;
-        case BELLA_TUNE_XDROP_VARIANT: c->xdrop_variant = n ? (uint32_t)values[0] : 4u; return c->xdrop_variant > 4 ? fail(c, BELLA_ERR_BAD_ARG, "x-drop variant 0..4") : 0;
+        case BELLA_TUNE_XDROP_VARIANT: c->xdrop_variant = n ? (uint32_t)values[0] : 1u; return c->xdrop_variant > 3 ? fail(c, BELLA_ERR_BAD_ARG, "x-drop variant 0..3") : 0;
     }
     return fail(c, BELLA_ERR_BAD_ARG, "unknown tuning parameter %u", what);
 }
@@ -2176,11 +2175,10 @@ static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_se
             HIPCHK(c, hipcub::DeviceRadixSort::SortPairsDescending(c->cubtmp.p, tb, ptr<uint32_t>(c->xest), ptr<uint32_t>(c->xest2),
                                                                   ptr<uint32_t>(c->xids), ptr<uint32_t>(c->xorder), (int)ne, 0, 18,
                                                                   c->stream));
-            // Large batches are mostly chance pairs (one shared k-mer: 92 % of the pairs of the 100k-read set), whose extensions end long
-            // before their step bound: in one launch their wavefronts idle behind the few that do not (5.2 s against 3.3 s in slices on the
-            // 100k set); small batches of mostly true overlaps keep their lanes busy either way and save the slices' launches (75.3 against
-            // 77.2 ms on the 10k set).
-            const bool one_launch = c->xdrop_variant == 0 || (c->xdrop_variant == 4 && n < (1ull << 20));
+            // In one launch a wavefront runs until its longest lane ends; chance pairs (one shared k-mer: 92 % of the pairs of the 100k-read
+            // set) end long before the step bound they are scheduled by, and their wavefronts idle behind the few lanes that run on: 5.2 s
+            // against 3.1 s in slices on the 100k set, 75.3 against 71.4 ms on the 10k set.
+            const bool one_launch = c->xdrop_variant == 0;
             if (one_launch) {                                      // a wavefront runs until its longest lane ends
                 k_xdrop_sorted<<<nblk(ne, kXdropBlock), kXdropBlock, 0, c->stream>>>(sa);
                 KCHK(c);

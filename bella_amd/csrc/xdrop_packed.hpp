@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kXdropBlock) void k_xdrop_sorted(XdropSortedArgs sa
 // Phase 4 (xavier.h:105-183 / :185-251) are one loop body with a per-lane mode.  Same arithmetic as
 // xavier_one_direction_packed, same results.
 #ifndef BELLA_XDROP_SLICE
-#define BELLA_XDROP_SLICE 256
+#define BELLA_XDROP_SLICE 512
 #endif
 constexpr int kXdropSlice = BELLA_XDROP_SLICE;
 constexpr uint32_t kXStateWords = 72;       // a1[16] a2[16] qh[16] qv[16] best off hoff voff endH endV flags e

@@ -309,9 +309,9 @@ int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
  *   BELLA_TUNE_LDS_TIERS      values = ascending product capacities of the row kernels' LDS tiers, each in [64, 11008] (n = 0: defaults)
  *   BELLA_TUNE_KCOUNT_BUDGET  values[0] = k-mers per pass of the counting sort (default 2^30)
  *   BELLA_TUNE_WIDE_BUDGET    values[0] = products per batch of the sort-based path of the wide columns (default 2^30)
- *   BELLA_TUNE_XDROP_VARIANT  values[0] = 0 one launch in length-sorted order, 1 slices of 256 steps with compaction of the live
- *                             extensions between launches, 2 packed kernel in pair order, 3 the scalar statement of xavier.h,
- *                             4 (default; n = 0) = 1 for batches of 1 M pairs and more, else 0.  Same results in every variant. */
+ *   BELLA_TUNE_XDROP_VARIANT  values[0] = 0 one launch in length-sorted order, 1 (default; n = 0) slices of 512 steps with compaction of
+ *                             the live extensions between launches, 2 packed kernel in pair order, 3 the scalar statement of xavier.h.
+ *                             Same results in every variant. */
 enum { BELLA_TUNE_LDS_TIERS = 0, BELLA_TUNE_KCOUNT_BUDGET = 1, BELLA_TUNE_WIDE_BUDGET = 2, BELLA_TUNE_XDROP_VARIANT = 3 };
 int bella_hip_set_tuning(bella_ctx* ctx, uint32_t what, const uint64_t* values, uint32_t n);
 

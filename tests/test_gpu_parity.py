@@ -121,7 +121,7 @@ def test_alignments_match_oracle_fieldwise(eng, golden):
         got = (int(a["score"]), int(a["begH"]), int(a["endH"]), int(a["begV"]), int(a["endV"]), int(a["ov"]), int(a["strand"]),
                int(a["passed"]), int(a["steps"]), int(a["flagged"]))
         assert got == exp, (rid, cid)
-    # the other statements of the same kernel (slices of 256 steps with compaction between launches; pair order; the scalar
+    # the other statements of the same kernel (one launch in length-sorted order; slices with compaction between launches = the default; pair order; the scalar
     # statement of xavier.h) give the same records, every field, every pair
     for variant in (0, 1, 2, 3):
         eng.set_tuning("xdrop_variant", variant)
