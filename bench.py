@@ -393,14 +393,14 @@ def main():
         if not a.no_xdrop:
             # configs[2]: the X-drop stage on the same candidate pairs (one pass, outside the SpGEMM timing)
             out["xdrop"] = xdrop_record(eng, "configs[2]: X-drop (xdrop=7) on the %d candidate pairs of the 10k set")
-            try:   # VALU issue rate of k_xdrop_sorted from the committed SQ counters (a profiling run) against the MEASURED issue rate of
+            try:   # VALU issue rate of the X-drop kernel (k_xdrop_slice) from the committed SQ counters (a profiling run) against the MEASURED issue rate of
                    # its instruction mix (tools/ubench/valu_rates.hip: v_pk_* / v_perm_b32 issue every 4.15 cycles per SIMD at ~2.4 GHz)
                 import re
                 for tag in ("r03", "r02"):
                     fn = os.path.join(ROOT, "profiles", "%s_xdrop_sq.txt" % tag)
                     if not os.path.exists(fn):
                         continue
-                    ln = [l for l in open(fn) if "k_xdrop_sorted" in l or "k_xdrop_refill" in l][0]
+                    ln = [l for l in open(fn) if "k_xdrop_slice" in l or "k_xdrop_sorted" in l][0]   # (the kernel of the default variant)
                     us = float(re.search(r"\| ([0-9.]+) us \|", ln).group(1))
                     valu = float(re.search(r"SQ_INSTS_VALU=([0-9.e+]+)", ln).group(1))
                     out["xdrop"]["valu_issue_frac"] = valu / (us * 1e-6 * 2.4e9 * 1024 / 4.15)
