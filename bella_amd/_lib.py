@@ -39,7 +39,13 @@ class Timings(C.Structure):
     _fields_ = [("assemble_ms", C.c_float), ("symbolic_ms", C.c_float), ("spgemm_ms", C.c_float), ("fold_ms", C.c_float),
                 ("compact_ms", C.c_float), ("xdrop_ms", C.c_float), ("overlap_total_ms", C.c_float), ("spgemm_launches", C.c_uint32),
                 ("kcount_ms", C.c_float), ("retry_columns", C.c_uint32), ("overflow_pairs", C.c_uint32), ("layout_ms", C.c_float),
-                ("rows_ms", C.c_float), ("lane_order", C.c_uint32)]
+                ("rows_ms", C.c_float), ("lane_order", C.c_uint32), ("expand_ms", C.c_float), ("numeric_passes", C.c_uint32),
+                ("symbolic_passes", C.c_uint32), ("pad", C.c_uint32), ("numeric_columns", C.c_uint64)]
+
+
+class Memory(C.Structure):
+    _fields_ = [("reads_bytes", C.c_uint64), ("matrix_bytes", C.c_uint64), ("layout_A_bytes", C.c_uint64), ("layout_B_bytes", C.c_uint64),
+                ("rowlist_bytes", C.c_uint64), ("pass_bytes", C.c_uint64), ("other_bytes", C.c_uint64), ("owned_nnz", C.c_uint64)]
 
 
 # every symbol include/bella_hip.h declares: (name, restype, argtypes)
@@ -69,6 +75,7 @@ SIGNATURES = [
     ("bella_hip_assemble_tuples", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint64, vp, vp, vp]),
     ("bella_hip_set_B", C.c_int, [vp, C.c_uint16, C.c_uint32, vp, vp, vp]),
     ("bella_hip_assemble_panel", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp]),
+    ("bella_hip_set_B_panel", C.c_int, [vp, C.c_uint16, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]),
     ("bella_hip_comm_id", C.c_int, [vp]),
     ("bella_hip_comm_init", C.c_int, [vp, C.c_int, C.c_int, vp]),
     ("bella_hip_comm_destroy", C.c_int, [vp]),
@@ -85,6 +92,7 @@ SIGNATURES = [
     ("bella_hip_set_partition", C.c_int, [vp, C.c_uint32, C.c_uint32]),
     ("bella_hip_set_column_range", C.c_int, [vp, C.c_uint32, C.c_uint32]),
     ("bella_hip_overlap", C.c_int, [vp, C.POINTER(Params), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("bella_hip_count_pairs", C.c_int, [vp, C.POINTER(Params), vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("bella_hip_get_pairs", C.c_int, [vp, vp, vp, vp]),
     ("bella_hip_align_pairs", C.c_int, [vp, C.POINTER(Params), C.POINTER(C.c_uint64)]),
     ("bella_hip_get_alignments", C.c_int, [vp, vp]),
@@ -94,6 +102,7 @@ SIGNATURES = [
     ("bella_hip_write_output", C.c_int, [C.c_char_p, C.POINTER(Params), C.c_int, C.c_uint32, vp, vp, vp, vp, C.c_uint64, C.c_int,
                                          C.POINTER(WriteStats)]),
     ("bella_hip_get_timings", C.c_int, [vp, C.POINTER(Timings)]),
+    ("bella_hip_get_memory", C.c_int, [vp, C.POINTER(Memory)]),
     ("bella_hip_set_debug", C.c_int, [vp, C.c_uint32]),
     ("bella_hip_set_tuning", C.c_int, [vp, C.c_uint32, vp, C.c_uint32]),
 ]

@@ -14,7 +14,7 @@ import sys
 import numpy as np
 
 from . import _lib
-from ._lib import ALN_DT, EXT_DT, PAIR_DT, SEED_DT, Params, Timings, WriteStats
+from ._lib import ALN_DT, EXT_DT, PAIR_DT, SEED_DT, Memory, Params, Timings, WriteStats
 
 
 class BellaHipError(RuntimeError):
@@ -150,6 +150,11 @@ class Engine:
         self._chk(self.lib.bella_hip_set_B(self.h, k, nkmers, colptr.ctypes.data, _p(rowids), _p(values)))
 
     # ---- multi-GPU assembly: row-block panels ----
+    def set_B_panel(self, k, nkmers, first_read, nreads_panel, colptr, rowids, values):
+        """bella_hip_set_B_panel: this context's row block of the reference's CSC of B (whole arrays given, the slice is uploaded)"""
+        colptr = np.ascontiguousarray(colptr, np.uint32); rowids = np.ascontiguousarray(rowids, np.uint32); values = np.ascontiguousarray(values, np.uint16)
+        self._chk(self.lib.bella_hip_set_B_panel(self.h, k, nkmers, first_read, nreads_panel, _p(colptr), _p(rowids), _p(values)))
+
     def assemble_panel(self, k, nkmers, first_read, nreads_panel, tk, tr, tp):
         tk = np.ascontiguousarray(tk, np.uint32); tr = np.ascontiguousarray(tr, np.uint32); tp = np.ascontiguousarray(tp, np.uint16)
         self._chk(self.lib.bella_hip_assemble_panel(self.h, k, nkmers, first_read, nreads_panel, len(tk), _p(tk), _p(tr), _p(tp)))
@@ -232,7 +237,7 @@ class Engine:
         self._chk(self.lib.bella_hip_set_debug(self.h, flags))
 
     # ---- HashSpGEMM ----
-    TUNE = {"lds_tiers": 0, "kcount_budget": 1, "wide_budget": 2, "xdrop_variant": 3}
+    TUNE = {"lds_tiers": 0, "kcount_budget": 1, "wide_budget": 2, "xdrop_variant": 3, "row_lists": 4}
 
     def set_tuning(self, what: str, *values):
         """bella_hip_set_tuning: per-context tuning parameters (tests, A/B measurements); no values = the default"""
@@ -245,6 +250,21 @@ class Engine:
         self._chk(self.lib.bella_hip_overlap(self.h, C.byref(cp), C.byref(n), C.byref(f)))
         self.npairs, self.flops = n.value, f.value
         return n.value, f.value
+
+    def count_pairs(self, pars: BellaPars):
+        """bella_hip_count_pairs: the symbolic phase alone (estimateFLOP + estimateNNZ_Hash + prefixsum) -> colptrC, nnz(C), products"""
+        n, f = C.c_uint64(0), C.c_uint64(0)
+        cp = pars.c()
+        colptrC = np.zeros(self.nreads + 1, np.uint64)
+        self._chk(self.lib.bella_hip_count_pairs(self.h, C.byref(cp), colptrC.ctypes.data, C.byref(n), C.byref(f)))
+        return colptrC, n.value, f.value
+
+    def count_flops(self, pars: BellaPars):
+        """estimateFLOP alone (bella_hip_count_pairs without the pair outputs): the products of the context's columns"""
+        f = C.c_uint64(0)
+        cp = pars.c()
+        self._chk(self.lib.bella_hip_count_pairs(self.h, C.byref(cp), None, None, C.byref(f)))
+        return f.value
 
     def get_pairs(self, ext=True):
         pairs = np.zeros(self.npairs, PAIR_DT)
@@ -275,6 +295,11 @@ class Engine:
         fn = self.lib.bella_hip_xdrop_batch_exact if exact else self.lib.bella_hip_xdrop_batch
         self._chk(fn(self.h, _p(seeds), len(seeds), C.byref(cp), _p(out)))
         return out
+
+    def memory(self) -> Memory:
+        m = Memory()
+        self._chk(self.lib.bella_hip_get_memory(self.h, C.byref(m)))
+        return m
 
     def timings(self) -> Timings:
         t = Timings()

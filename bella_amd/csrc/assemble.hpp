@@ -347,37 +347,68 @@ __device__ __forceinline__ void run_bounds(const uint32_t* skey, uint64_t nnz, u
 // radix pass on the top bits of e and k_layout_place then write B' region by region (the writes of a region meet in the caches).
 // by_kmer (the row-list layout, k_layout_rowlists below): the lists of A' stay in k-mer order = the sorted order itself -- no list
 // starts to scatter, scan and look up (k_layout_heads is not run), A' is written in place.
-__global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64_t nnz, const uint32_t* Bptr, const uint32_t* wscan,
+__global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64_t nnz, const uint32_t* Bptr, const uint32_t* Bloc, const uint32_t* wscan,
                               const uint32_t* packed, const uint64_t* roff, uint32_t k, uint32_t rmask, uint2* Aent, uint32_t* ekey, uint64_t* eval,
-                              uint32_t by_kmer, uint32_t* status) {
+                              uint32_t by_kmer, uint32_t own_first, uint32_t own_stride, uint32_t* counter, uint32_t* status) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= nnz) return;
-    uint64_t lo, hi;
-    run_bounds(skey, nnz, x, lo, hi);
-    const uint32_t dg = (uint32_t)(hi - lo), rk = (uint32_t)(x - lo);
-    const uint64_t vf = sval[lo], v = sval[x];
-    const uint32_t rf = (uint32_t)(vf >> 32) & rmask;
-    if (by_kmer && dg > 16383u && rk == 0) atomicOr(status, 64u);       // Bent's product count field holds 14 bits (k_layout_heads otherwise)
-    const uint32_t cs = by_kmer ? (uint32_t)lo : wscan[Bptr[rf] + ((uint32_t)vf >> 16)];
-    const uint32_t hiw = (uint32_t)(v >> 32), r = hiw & rmask, pos = (uint32_t)v & 0xFFFFu;
-    uint32_t pal;
-    if (rmask == 0x3FFFFFFFu) pal = (hiw >> 30) & 1u;
-    else {                                                                // (2^30 reads or more: from the sequence of the first occurrence)
-        const uint64_t le = kmer_le(packed, roff[rf] + ((uint32_t)vf & 0xFFFFu), k);
-        pal = kmer_fw_from_le(le, k) == kmer_rc_from_le(le, k) ? 1u : 0u;
+    bool mine = false;
+    uint32_t dstkey = 0;
+    uint64_t dstval = 0;
+    if (x < nnz) {
+        uint64_t lo, hi;
+        run_bounds(skey, nnz, x, lo, hi);
+        const uint32_t dg = (uint32_t)(hi - lo), rk = (uint32_t)(x - lo);
+        const uint64_t vf = sval[lo], v = sval[x];
+        const uint32_t rf = (uint32_t)(vf >> 32) & rmask;
+        if (dg > 16383u && rk == 0) atomicOr(status, 64u);                   // Bent's product count field holds 14 bits
+        // by_kmer: the list starts where its run starts; else at the scanned degree of the run's first entry (k_layout_heads: indexed
+        // by that entry's index in the WHOLE matrix)
+        const uint32_t cs = by_kmer ? (uint32_t)lo : wscan[Bptr[rf] + ((uint32_t)vf >> 16)];
+        const uint32_t hiw = (uint32_t)(v >> 32), r = hiw & rmask, pos = (uint32_t)v & 0xFFFFu;
+        uint32_t pal;
+        if (rmask == 0x3FFFFFFFu) pal = (hiw >> 30) & 1u;
+        else {                                                                // (2^30 reads or more: from the sequence of the first occurrence)
+            const uint64_t le = kmer_le(packed, roff[rf] + ((uint32_t)vf & 0xFFFFu), k);
+            pal = kmer_fw_from_le(le, k) == kmer_rc_from_le(le, k) ? 1u : 0u;
+        }
+        const uint32_t ori = pal ? 0u : hiw >> 31;                            // (palindromes count as canonical)
+        const uint32_t len = (uint32_t)(roff[r + 1] - roff[r]);
+        Aent[cs + rk] = make_uint2(r | (ori << 31), pos | (len << 16));
+        mine = own_stride == 1u || r % own_stride == own_first;               // B' entries only for the columns this context owns
+        dstkey = Bloc[r] + ((uint32_t)v >> 16);
+        dstval = (uint64_t)(cs + rk + 1) | ((uint64_t)(pos | ((dg - 1 - rk) << 16) | (pal << 30) | (ori << 31)) << 32);
     }
-    const uint32_t ori = pal ? 0u : hiw >> 31;                            // (palindromes count as canonical)
-    const uint32_t len = (uint32_t)(roff[r + 1] - roff[r]);
-    Aent[cs + rk] = make_uint2(r | (ori << 31), pos | (len << 16));
-    ekey[x] = Bptr[r] + ((uint32_t)v >> 16);
-    eval[x] = (uint64_t)(cs + rk + 1) | ((uint64_t)(pos | ((dg - 1 - rk) << 16) | (pal << 30) | (ori << 31)) << 32);
+    if (own_stride == 1u) {                                                   // every entry has a B' entry: it leaves at its sorted place
+        if (x < nnz) { ekey[x] = dstkey; eval[x] = dstval; }
+        return;
+    }
+    // partitioned: the owned entries leave compacted (one atomic per wavefront; their order does not matter, the partition pass and
+    // k_layout_place put every entry at its own index)
+    const unsigned long long mask = __ballot(mine);
+    if (mask == 0) return;
+    uint32_t base = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, __builtin_ctzll(mask), 64);
+    if (mine) {
+        const uint32_t o = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        ekey[o] = dstkey; eval[o] = dstval;
+    }
 }
 
-__global__ void k_layout_place(const uint32_t* ekey, const uint64_t* eval, uint64_t nnz, uint2* Bent) {
+__global__ void k_layout_place(const uint32_t* ekey, const uint64_t* eval, uint64_t n, uint2* Bent) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= nnz) return;
+    if (x >= n) return;
     const uint64_t v = eval[x];
     Bent[ekey[x]] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+
+// rows of B' of a partitioned context: column i keeps its entries when i % stride == first, else none (the exclusive scan of these
+// lengths is the context's own row pointer array, Bloc)
+__global__ void k_layout_own_lengths(const uint32_t* Bptr, uint32_t nreads, uint32_t own_first, uint32_t own_stride, uint32_t* len) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nreads) return;
+    len[i] = i < nreads && i % own_stride == own_first ? Bptr[i + 1] - Bptr[i] : 0u;
 }
 
 // the products of every entry once more, compact: estimateFLOP streams 2 B per nonzero

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cmath>
+#include <initializer_list>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -96,9 +98,12 @@ struct bella_ctx {
     uint32_t kc_bfirst = 0, kc_brows = 0; // the read block the device-resident tuples cover (all reads unless counted distributed)
     Buf kc_nk, kc_koff, kc_hist, kc_keys, kc_alt, kc_runlen, kc_flag, kc_slot, kc_nruns, kc_dcode, kc_dcount, kc_hkey, kc_hval, kc_found,
         kc_tstart, kc_cursor, kc_sel, kc_ringo, kc_ringp;
-    Buf Bptr, Bk, Bpos, Bent, Bcnt, Aent, Aent2, Aov, Arow;
+    Buf Bptr, Bk, Bpos, Bent, Bcnt, Aent, Aent2, Aov, Arow, Bloc;
     bool have_rowlists = false;          // Aent2 / Arow hold the row lists of the current layout
+    bool want_rowlists = false;          // BELLA_TUNE_ROW_LISTS: build them with the next layouts (when they fit)
     uint32_t part_first = 0, part_stride = 1;
+    uint32_t layout_first = 0, layout_stride = 1;   // the partition the current layout was built for (B' / row lists: owned columns only)
+    uint64_t owned_nnz = 0;              // B' entries of the current layout
     uint64_t sym_sig[6] = {};            // what flops / nnzC were last cleared for
     uint64_t layout_gen = 0;             // bumped by every build of the device layout
     uint32_t range_lo = 0, range_hi = 0xFFFFFFFFu;   // stage: the contiguous column range computed by the next passes
@@ -126,7 +131,7 @@ struct bella_ctx {
     uint64_t nalns = 0;
     Buf alns, seeds, xest, xest2, xids, xorder, xres, xstate, xlive, lg_res, lg_redo, lg_scratch;
     bella_timings tm{};
-    hipEvent_t ev[10]{};
+    hipEvent_t ev[12]{};
     uint32_t* pinned = nullptr;          // 128 host words the per-pass read backs land in
     Stager stager;                       // pinned bounce buffers of the large host <-> device copies
     bella_ingest_stats ingest{};         // of the last bella_hip_load_fastq
@@ -249,24 +254,51 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
     return ms;
 }
 
+// the row pointers the layout kernels and the passes index B' with: the matrix's own, or the partitioned context's (owned rows only)
+inline const uint32_t* layout_bptr(const bella_ctx* c) { return c->layout_stride > 1 ? ptr<uint32_t>(c->Bloc) : ptr<uint32_t>(c->Bptr); }
+
 // B (Bptr/Bk/Bpos on device) -> Bent / Aent   (see assemble.hpp): one stable radix sort of the entries by k-mer id (the runs are
 // the k-mer lists of A', ascending read id) and coalesced segmented passes; 32 B of temporaries per nonzero.
+// The layout follows the context's partition (bella_hip_set_partition): A' is whole, B' entries -- and the optional row lists --
+// exist for the owned columns only, so the per-column part of the work and of the memory is 1/stride of the whole.
 int build_layout(bella_ctx* c) {
     const uint64_t nnz = c->nnz;
     const uint32_t nk = c->nkmers;
+    const uint32_t pf = c->part_first, ps = c->part_stride;
     if (nnz >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "nnz(A) must be < 2^32 (KMERINDEX uint32, main.cpp:60)");
+    c->have_matrix = false;
+    c->have_rowlists = false;
+    c->tm.expand_ms = 0.f;
     ENSURE(c, c->lk_key, 4 * nnz);
     ENSURE(c, c->lk_key2, 4 * nnz);
     ENSURE(c, c->lk_val, 8 * nnz);
     ENSURE(c, c->lk_val2, 8 * nnz);
     ENSURE(c, c->w, 4 * (nnz + 1));
     ENSURE(c, c->wscan, 4 * (nnz + 1));
-    ENSURE(c, c->Bent, 8 * nnz);
-    ENSURE(c, c->Bcnt, 2 * nnz);
     ENSURE(c, c->Aent, 8 * nnz + 64);
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-    c->have_rowlists = false;
+    // the context's own row pointers: all rows, or the owned ones (the others keep no entries)
+    uint64_t nown_nnz = nnz;
+    c->layout_first = pf; c->layout_stride = ps;
+    if (ps > 1) {
+        ENSURE(c, c->Bloc, 4 * ((size_t)c->nreads + 2));
+        uint32_t* len = ptr<uint32_t>(c->w);
+        k_layout_own_lengths<<<nblk((uint64_t)c->nreads + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), c->nreads, pf, ps, len);
+        KCHK(c);
+        int rc = scan_u32(c, len, ptr<uint32_t>(c->Bloc), (uint64_t)c->nreads + 1);
+        if (rc) return rc;
+        uint32_t n32 = 0;
+        HIPCHK(c, hipMemcpyAsync(&n32, ptr<uint32_t>(c->Bloc) + c->nreads, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        nown_nnz = n32;
+    } else {
+        release(c->Bloc);
+    }
+    c->owned_nnz = nown_nnz;
+    const uint32_t* Bloc = layout_bptr(c);
+    ENSURE(c, c->Bent, 8 * nown_nnz);
+    ENSURE(c, c->Bcnt, 2 * nown_nnz);
     if (nnz) {
         k_layout_prep<<<nblk(c->nreads, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos), c->nreads,
                                                                         ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), c->kmer_size, nk,
@@ -290,10 +322,10 @@ int build_layout(bella_ctx* c) {
         const uint32_t* skey = dk.Current();
         const uint64_t* sval = dv.Current();
         const uint32_t rmask = c->nreads <= (1u << 30) ? 0x3FFFFFFFu : 0x7FFFFFFFu;   // read id field of the sort value
-        // the row-list layout (ready-made products, assemble.hpp) unless debug bit 10 asks for the expanding one (tests) or read ids need
-        // more than 30 bits; the products may also not fit (checked below, once their number is known: then the lists of A' stay in
-        // k-mer order and the pass expands from them -- correct, slower)
-        const uint32_t by_kmer = (c->debug & 1024u) == 0 && c->nreads <= (1u << 30) ? 1u : 0u;
+        // Default: the lists of A' stay in k-mer order (= the sorted order itself; nothing to scatter, scan or look up) and every pass
+        // expands B' x A' itself: the fastest ONE-SHOT call (layout + first pass).  debug bit 10 (tests): the lists in
+        // order of first appearance in B' (the owner row of a list streams it; three more random-access passes here).
+        const uint32_t by_kmer = (c->debug & 1024u) == 0 ? 1u : 0u;
         if (!by_kmer) {
             k_layout_heads<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), rmask, ptr<uint32_t>(c->w), ptr<uint32_t>(c->status));
             KCHK(c);
@@ -302,61 +334,85 @@ int build_layout(bella_ctx* c) {
         }
         uint32_t* ekey = dk.Alternate();                           // (the sort's other buffers are free now)
         uint64_t* eval = dv.Alternate();
-        k_layout_emit<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->wscan), ptr<uint32_t>(c->packed),
-                                                        ptr<uint64_t>(c->roff), c->kmer_size, rmask, ptr<uint2>(c->Aent), ekey, eval, by_kmer, ptr<uint32_t>(c->status));
+        uint32_t* counter = ptr<uint32_t>(c->status) + 7;
+        HIPCHK(c, hipMemsetAsync(counter, 0, 4, c->stream));
+        k_layout_emit<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), Bloc, ptr<uint32_t>(c->wscan), ptr<uint32_t>(c->packed),
+                                                        ptr<uint64_t>(c->roff), c->kmer_size, rmask, ptr<uint2>(c->Aent), ekey, eval, by_kmer, pf, ps, counter,
+                                                        ptr<uint32_t>(c->status));
         KCHK(c);
-        {   // one radix pass on the top 8 bits of the entry index: B' is then written region by region
+        {   // a k-mer in more than 16,383 reads overflows the count field of the B' entries: stop before anything trusts them
+            uint32_t st1 = 0;
+            int rc1 = read_status(c, &st1);
+            if (rc1) return rc1;
+            rc1 = status_to_error(c, st1);
+            if (rc1) return rc1;
+        }
+        if (nown_nnz) {   // one radix pass on the top 8 bits of the entry index: B' is then written region by region
             int ebits = 1;
-            while (ebits < 32 && (1ull << ebits) < nnz) ++ebits;
+            while (ebits < 32 && (1ull << ebits) < nown_nnz) ++ebits;
             hipcub::DoubleBuffer<uint32_t> ek(ekey, const_cast<uint32_t*>(skey));
             hipcub::DoubleBuffer<uint64_t> ev(eval, const_cast<uint64_t*>(sval));
             if (ebits > 12) {
                 size_t tb2 = 0;
-                HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, ek, ev, (uint64_t)nnz, ebits - 8, ebits, c->stream));
+                HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, ek, ev, (uint64_t)nown_nnz, ebits - 8, ebits, c->stream));
                 ENSURE(c, c->cubtmp, tb2);
-                HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb2, ek, ev, (uint64_t)nnz, ebits - 8, ebits, c->stream));
+                HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb2, ek, ev, (uint64_t)nown_nnz, ebits - 8, ebits, c->stream));
             }
-            k_layout_place<<<nblk(nnz), 256, 0, c->stream>>>(ek.Current(), ev.Current(), nnz, ptr<uint2>(c->Bent));
+            k_layout_place<<<nblk(nown_nnz), 256, 0, c->stream>>>(ek.Current(), ev.Current(), nown_nnz, ptr<uint2>(c->Bent));
+            KCHK(c);
+            k_layout_bcnt<<<nblk(nown_nnz), 256, 0, c->stream>>>(ptr<uint2>(c->Bent), nown_nnz, ptr<uint16_t>(c->Bcnt));
             KCHK(c);
         }
-        k_layout_bcnt<<<nblk(nnz), 256, 0, c->stream>>>(ptr<uint2>(c->Bent), nnz, ptr<uint16_t>(c->Bcnt));
-        KCHK(c);
-        c->have_rowlists = false;
-        if (by_kmer) {
-            // row lists: products per row -> row starts -> the tails of the lists copied in product order
-            ENSURE(c, c->Arow, 8 * ((size_t)c->nreads + 2));
-            uint32_t* rf = ptr<uint32_t>(c->w);                     // (w is free: k_layout_heads did not run)
-            k_layout_rowflops<<<nblk((uint64_t)c->nreads + 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint16_t>(c->Bcnt), c->nreads, rf);
-            KCHK(c);
-            int rc = scan_u32_to_u64(c, rf, ptr<uint64_t>(c->Arow), (uint64_t)c->nreads + 1);
-            if (rc) return rc;
+        if (by_kmer && c->want_rowlists && c->nreads <= (1u << 30)) {
+            // row lists (BELLA_TUNE_ROW_LISTS): products per owned row -> row starts -> the tails of the lists copied in product order.
+            // Optional in every respect: if they do not fit next to what a pass needs, or an allocation fails, the layout stands without them.
+            int rc = ensure_bytes(c, c->Arow, 8 * ((size_t)c->nreads + 2));
             uint64_t F = 0;
-            HIPCHK(c, hipMemcpyAsync(&F, ptr<uint64_t>(c->Arow) + c->nreads, 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (!rc) {
+                uint32_t* rf = ptr<uint32_t>(c->w);                 // (w is free: k_layout_heads did not run)
+                k_layout_rowflops<<<nblk((uint64_t)c->nreads + 1, kWaves), kBlock, 0, c->stream>>>(Bloc, ptr<uint16_t>(c->Bcnt), c->nreads, rf);
+                KCHK(c);
+                rc = scan_u32_to_u64(c, rf, ptr<uint64_t>(c->Arow), (uint64_t)c->nreads + 1);
+                if (rc) return rc;
+                HIPCHK(c, hipMemcpyAsync(&F, ptr<uint64_t>(c->Arow) + c->nreads, 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+            }
             size_t mfree = 0, mtotal = 0;
             HIPCHK(c, hipMemGetInfo(&mfree, &mtotal));
-            if (10 * F + 128 <= mfree / 2 && !(c->debug & 2048u)) {   // 10 bytes per product, and the pass needs room of its own (debug bit 11: tests, "no room")
-                ENSURE(c, c->Aent2, 8 * F + 64);
-                ENSURE(c, c->Aov, 2 * F + 64);
-                const uint32_t grid = c->nreads < 4096u ? c->nreads : 4096u;
-                if (grid) k_layout_rowlists<<<grid, kRowListBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint2>(c->Bent), ptr<uint2>(c->Aent), ptr<uint64_t>(c->Arow),
-                                                                                 ptr<uint64_t>(c->roff), c->nreads, ptr<uint2>(c->Aent2), ptr<uint16_t>(c->Aov));
-                KCHK(c);
-                c->have_rowlists = true;
+            // 10 bytes per product for the lists; a pass over all owned columns then needs about 60 more per product (records twice,
+            // product lists, scratch, diagnostics) -- the lists are only built when both fit (debug bit 11: tests, "no room")
+            const bool fits = (double)F * 70.0 + 1e8 <= (double)mfree && !(c->debug & 2048u);
+            if (!rc && fits) {
+                HIPCHK(c, hipEventRecord(c->ev[10], c->stream));
+                rc = ensure_bytes(c, c->Aent2, 8 * F + 64);
+                if (!rc) rc = ensure_bytes(c, c->Aov, 2 * F + 64);
+                if (!rc) {
+                    const uint32_t grid = c->nreads < 4096u ? c->nreads : 4096u;
+                    if (grid) k_layout_rowlists<<<grid, kRowListBlock, 0, c->stream>>>(Bloc, ptr<uint2>(c->Bent), ptr<uint2>(c->Aent), ptr<uint64_t>(c->Arow),
+                                                                                     ptr<uint64_t>(c->roff), c->nreads, ptr<uint2>(c->Aent2), ptr<uint16_t>(c->Aov));
+                    KCHK(c);
+                    HIPCHK(c, hipEventRecord(c->ev[11], c->stream));
+                    HIPCHK(c, hipEventSynchronize(c->ev[11]));
+                    c->tm.expand_ms = ev_ms(c->ev[10], c->ev[11]);
+                    c->have_rowlists = true;
+                }
             }
+            if (!c->have_rowlists) { release(c->Aent2); release(c->Aov); release(c->Arow); c->err.clear(); }
         }
     }
+    if (!c->have_rowlists) { release(c->Aent2); release(c->Aov); release(c->Arow); }
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-    // pairs/products on a sample of columns -> key-table budget of the LDS tiers (see k_sample_pair_ratio)
+    // pairs/products on a sample of (owned) columns -> key-table budget of the LDS tiers (see k_sample_pair_ratio)
     uint32_t ratio1024 = 1024;
     const size_t bitmap_bytes = 4 * (((size_t)c->nreads + 31) / 32);
-    if (nnz && bitmap_bytes <= 128 * 1024) {
+    if (nown_nnz && bitmap_bytes <= 128 * 1024) {
         HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 6, 0, 4, c->stream));
-        const uint32_t nsample = c->nreads < 512 ? c->nreads : 512;
-        const uint32_t stride = c->nreads / nsample ? c->nreads / nsample : 1;
+        const uint32_t ncols = c->nreads / ps + 1;                  // owned columns: first + j * stride
+        const uint32_t nsample = ncols < 512 ? ncols : 512;
+        const uint32_t step = (ncols / nsample ? ncols / nsample : 1) * ps;
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sample_pair_ratio, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bitmap_bytes));
-        k_sample_pair_ratio<<<nsample, kBlock, bitmap_bytes, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint2>(c->Bent), ptr<uint2>(c->Aent),
-                                                                         c->nreads, stride, ptr<uint32_t>(c->status) + 6);
+        k_sample_pair_ratio<<<nsample, kBlock, bitmap_bytes, c->stream>>>(Bloc, ptr<uint2>(c->Bent), ptr<uint2>(c->Aent),
+                                                                         c->nreads, pf, step, ptr<uint32_t>(c->status) + 6);
         KCHK(c);
         HIPCHK(c, hipMemcpyAsync(&ratio1024, ptr<uint32_t>(c->status) + 6, 4, hipMemcpyDeviceToHost, c->stream));
     }
@@ -467,7 +523,7 @@ void bella_hip_destroy(bella_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && c->api) { (void)c->api->CommDestroy(c->comm); c->comm = nullptr; }
     release(c->comm_meta);
-    Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Bcnt, &c->Aent, &c->Aent2, &c->Aov, &c->Arow, &c->t_kmer, &c->t_read, &c->t_pos,
+    Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Bcnt, &c->Aent, &c->Aent2, &c->Aov, &c->Arow, &c->Bloc, &c->t_kmer, &c->t_read, &c->t_pos,
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->asm_cls, &c->lk_key, &c->lk_key2, &c->lk_val, &c->lk_val2,
                   &c->w, &c->wscan, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC,
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
@@ -512,7 +568,14 @@ int bella_hip_set_tuning(bella_ctx* c, uint32_t what, const uint64_t* values, ui
         }
         case BELLA_TUNE_KCOUNT_BUDGET: c->kcount_budget = n && values[0] ? values[0] : (1ull << 30); return 0;
         case BELLA_TUNE_WIDE_BUDGET: c->wide_budget = n && values[0] ? values[0] : (1ull << 30); return 0;
-        case BELLA_TUNE_XDROP_VARIANT: c->xdrop_variant = n ? (uint32_t)values[0] : 1u; return c->xdrop_variant > 3 ? fail(c, BELLA_ERR_BAD_ARG, "x-drop variant 0..3") : 0;
+        case BELLA_TUNE_XDROP_VARIANT:
+            if (n && values[0] > 3) return fail(c, BELLA_ERR_BAD_ARG, "x-drop variant 0..3");   // (validated before it is stored)
+            c->xdrop_variant = n ? (uint32_t)values[0] : 1u;
+            return 0;
+        case BELLA_TUNE_ROW_LISTS:
+            if (n && values[0] > 1) return fail(c, BELLA_ERR_BAD_ARG, "row lists: 0 or 1");
+            c->want_rowlists = n && values[0] == 1;
+            return 0;
     }
     return fail(c, BELLA_ERR_BAD_ARG, "unknown tuning parameter %u", what);
 }
@@ -1102,7 +1165,21 @@ int bella_hip_count_kmers(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint
 int bella_hip_count_kmers_dist(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t selector, uint32_t window,
                                uint32_t first_read, uint32_t nreads_block, uint32_t* nkmers, uint64_t* ntuples, uint64_t* ndistinct) {
     if (!c) return BELLA_ERR_BAD_ARG;
-    if (selector > 2) return fail(c, BELLA_ERR_BAD_ARG, "selector: 0 = all k-mers, 1 = syncmers, 2 = minimizers");
+    if (!c->comm) return fail(c, BELLA_ERR_STATE, "bella_hip_comm_init first");
+    // argument and state errors are local: the rank still takes part in a status exchange, so that its peers leave the call with it
+    // instead of waiting for it in the dictionary exchange
+    int rc = 0;
+    if (selector > 2) rc = fail(c, BELLA_ERR_BAD_ARG, "selector: 0 = all k-mers, 1 = syncmers, 2 = minimizers");
+    else if (!c->have_reads) rc = fail(c, BELLA_ERR_STATE, "set_reads first");
+    else if (kmer_size < 1 || kmer_size > 32) rc = fail(c, BELLA_ERR_BAD_ARG, "k must be in [1,32]");
+    else if (lower < 2 || upper < lower || upper > 65535) rc = fail(c, BELLA_ERR_BAD_ARG, "need 2 <= lower <= upper <= 65535");
+    else if (selector == 2 && (window < 1 || window > 65535)) rc = fail(c, BELLA_ERR_BAD_ARG, "minimizer window must be in [1,65535]");
+    else if (selector == 1 && kmer_size <= kSmerLen) rc = fail(c, BELLA_ERR_BAD_ARG, "syncmer selection needs k > 5 (smerlen, syncmer.hpp:45)");
+    else if ((uint64_t)first_read + nreads_block > c->nreads) rc = fail(c, BELLA_ERR_BAD_ARG, "read block exceeds the read set");
+    if (hipSetDevice(c->device) != hipSuccess && !rc) rc = fail(c, BELLA_ERR_HIP, "hipSetDevice failed");
+    const std::string local_err = c->err;
+    rc = comm_agree(c, rc);
+    if (rc) { if (!local_err.empty()) c->err = local_err; return rc; }
     return count_kmers_impl(c, kmer_size, lower, upper, selector, window, nkmers, ntuples, ndistinct, true, first_read, nreads_block);
 }
 
@@ -1180,6 +1257,45 @@ int bella_hip_assemble_panel(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, 
     c->tm.assemble_ms = ev_ms(c->ev[0], c->ev[1]);
     c->tm.rows_ms = ev_ms(c->ev[0], c->ev[6]);
     release(c->t_kmer); release(c->t_read); release(c->t_pos); release(c->Bk_tmp); release(c->Bpos_tmp); release(c->asm_ws);
+    c->nkmers = nkmers;
+    c->kmer_size = kmer_size;
+    c->panel_first = first_read;
+    c->panel_rows = nreads_panel;
+    c->panel_nnz = nnz;
+    c->have_panel = true;
+    return 0;
+}
+
+// a row-block panel straight from the reference's CSC arrays of B (the caller holds the whole matrix on the host and gives every
+// context its block: the blocks then travel device to device, bella_hip_allgather_panels)
+int bella_hip_set_B_panel(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, uint32_t first_read, uint32_t nreads_panel, const uint32_t* colptr,
+                          const uint32_t* rowids, const uint16_t* values) {
+    if (!c || !colptr) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+    if (!c->have_reads) return fail(c, BELLA_ERR_STATE, "set_reads first");
+    if (kmer_size < 1 || kmer_size > 32) return fail(c, BELLA_ERR_BAD_ARG, "k must be in [1,32]");
+    if ((uint64_t)first_read + nreads_panel > c->nreads) return fail(c, BELLA_ERR_BAD_ARG, "panel exceeds the read set");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->have_matrix = c->have_pairs = c->have_alns = false;
+    c->have_panel = false;
+    c->have_tuples = false;
+    const uint32_t* cp = colptr + first_read;                      // colptr: the whole matrix's [nreads + 1]
+    std::vector<uint32_t> cnt((size_t)nreads_panel + 2, 0);
+    for (uint32_t r = 0; r < nreads_panel; ++r) {
+        if (cp[r + 1] < cp[r]) return fail(c, BELLA_ERR_BAD_ARG, "colptr must be non-decreasing (column %u)", first_read + r);
+        if (cp[r + 1] - cp[r] >= 65536u) return fail(c, BELLA_ERR_READ_TOO_LONG, "column %u has >= 65536 entries", first_read + r);
+        cnt[r] = cp[r + 1] - cp[r];
+    }
+    const uint64_t nnz = (uint64_t)cp[nreads_panel] - cp[0];
+    if (nnz && (!rowids || !values)) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+    ENSURE(c, c->rowcnt, 4 * ((size_t)nreads_panel + 2));
+    ENSURE(c, c->Bk, 4 * nnz);
+    ENSURE(c, c->Bpos, 2 * nnz);
+    HIPCHK(c, hipMemcpyAsync(c->rowcnt.p, cnt.data(), 4 * ((size_t)nreads_panel + 2), hipMemcpyHostToDevice, c->stream));
+    if (nnz) {
+        HIPCHK(c, c->stager.h2d(c->Bk.p, rowids + cp[0], 4 * nnz, c->stream));
+        HIPCHK(c, c->stager.h2d(c->Bpos.p, values + cp[0], 2 * nnz, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));                    // cnt is a host vector
     c->nkmers = nkmers;
     c->kmer_size = kmer_size;
     c->panel_first = first_read;
@@ -1619,6 +1735,18 @@ static int run_wide(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint3
     return 0;
 }
 
+// The pass's partition must lie inside the one the layout was built for (B' only holds the owned columns): a whole layout serves any
+// partition; otherwise the layout is rebuilt from the resident B for the partition now set.
+static int layout_for_partition(bella_ctx* c) {
+    if (c->layout_stride == 1 || (c->layout_stride == c->part_stride && c->layout_first == c->part_first)) return 0;
+    const bella_timings keep = c->tm;
+    int rc = build_layout(c);
+    const float lm = c->tm.layout_ms, em = c->tm.expand_ms;
+    c->tm = keep;
+    c->tm.layout_ms = lm; c->tm.expand_ms = em;
+    return rc;
+}
+
 static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out, int depth = 0) {
     const uint32_t nr = c->nreads;
     const bool force_global = (c->debug & 1u) != 0 || !c->lane_order_ok;   // (self-test failed: every column on the repairing path)
@@ -1703,14 +1831,14 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         k_row_flops_rl<<<nblk(nown), kBlock, 0, c->stream>>>(ptr<uint64_t>(c->Arow), i0, c->part_stride, nown, ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC), d_ctl);
         KCHK(c);
     } else if (nown) {
-        k_row_flops<<<nblk(nown, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint16_t>(c->Bcnt), i0, c->part_stride, nown,
+        k_row_flops<<<nblk(nown, kWaves), kBlock, 0, c->stream>>>(layout_bptr(c), ptr<uint16_t>(c->Bcnt), i0, c->part_stride, nown,
                                                                   ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC), d_ctl);
         KCHK(c);
     } else {
         HIPCHK(c, hipMemsetAsync(d_ctl, 0, 4 * kCtlWords, c->stream));
     }
     k_tier_lists<<<nblk(nown ? nown : 1), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->flopsr), nr, i0, c->part_stride, nown, ptr<uint32_t>(c->tiercaps), g_ntiers,
-                                                  ptr<uint32_t>(c->Bptr), ptr<uint64_t>(c->roff), ptr<uint4>(c->rowlists),
+                                                  layout_bptr(c), ptr<uint64_t>(c->roff), ptr<uint4>(c->rowlists),
                                                   (uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr), d_ctl + kCtlTierCnt,
                                                   (unsigned long long*)(d_ctl + kCtlTotals) + 1, ptr<uint64_t>(c->flopptr),
                                                   c->have_rowlists ? ptr<uint64_t>(c->Arow) : nullptr);
@@ -1741,7 +1869,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     EVREC(3);
 
     SpgemmArgs a;
-    a.Bptr = ptr<uint32_t>(c->Bptr);
+    a.Bptr = layout_bptr(c);
     a.Bent = ptr<uint2>(c->Bent);
     a.Aent = ptr<uint2>(c->Aent);
     a.Aent2 = c->have_rowlists ? ptr<uint2>(c->Aent2) : nullptr;
@@ -2036,20 +2164,155 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     return 0;
 }
 
+// the columns of this context under the current partition and stage: i0 + j * stride, j < nown
+static uint32_t owned_columns(const bella_ctx* c, uint32_t* i0_out) {
+    const uint32_t nr = c->nreads;
+    const uint32_t hi = c->range_hi < nr ? c->range_hi : nr;
+    uint32_t i0 = c->range_lo + (c->part_first + c->part_stride - c->range_lo % c->part_stride) % c->part_stride;
+    const uint32_t nown = i0 < hi ? (hi - i0 + c->part_stride - 1) / c->part_stride : 0;
+    if (!nown) i0 = 0;
+    if (i0_out) *i0_out = i0;
+    return nown;
+}
+
 int bella_hip_overlap(bella_ctx* c, const bella_params* p, uint64_t* npairs, uint64_t* flops) {
     if (!c) return BELLA_ERR_BAD_ARG;
     if (!c->have_matrix) return fail(c, BELLA_ERR_STATE, "set_B / assemble_tuples first");
     int rc = check_params(c, p);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    rc = layout_for_partition(c);
+    if (rc) return rc;
     uint32_t st = 0;
     rc = run_spgemm(c, p, &st);
+    if (rc == BELLA_ERR_NOMEM && c->have_rowlists) {
+        // the row lists are optional: give their memory to the pass and let it expand the products itself
+        (void)hipDeviceSynchronize();
+        release(c->Aent2); release(c->Aov); release(c->Arow);
+        c->have_rowlists = false;
+        c->layout_gen++;
+        c->pass_known = false;
+        rc = run_spgemm(c, p, &st);
+    }
     if (rc) { (void)hipDeviceSynchronize(); return rc; }     // side-stream kernels of the pass may still be in flight
     if (st & 1u) return fail(c, BELLA_ERR_BINS, "internal: > 16 bins without sort scratch");
     c->have_pairs = true;
     c->have_alns = false;
+    c->tm.numeric_passes++;
+    c->tm.numeric_columns += owned_columns(c, nullptr);
     if (npairs) *npairs = c->npairs;
     if (flops) *flops = c->flops;
+    return 0;
+}
+
+// the symbolic phase alone (spgemm.hpp: k_count_pairs)
+int bella_hip_count_pairs(bella_ctx* c, const bella_params* p, uint64_t* colptrC, uint64_t* npairs, uint64_t* flops) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    if (!c->have_matrix) return fail(c, BELLA_ERR_STATE, "set_B / assemble_tuples first");
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = layout_for_partition(c);
+    if (rc) return rc;
+    const uint32_t nr = c->nreads;
+    ENSURE(c, c->flopsr, 4 * ((size_t)nr + 2));
+    ENSURE(c, c->nnzC, 4 * ((size_t)nr + 2));
+    ENSURE(c, c->colptrC, 8 * ((size_t)nr + 2));
+    ENSURE(c, c->ctl, 4 * kCtlWords);
+    std::memset(c->sym_sig, 0, sizeof(c->sym_sig));          // (the next numeric pass clears flops / nnzC for itself)
+    c->have_pairs = c->have_alns = false;
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(c, hipMemsetAsync(c->flopsr.p, 0, 4 * ((size_t)nr + 2), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->nnzC.p, 0, 4 * ((size_t)nr + 2), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * kCtlWords, c->stream));
+    uint32_t i0 = 0;
+    const uint32_t nown = owned_columns(c, &i0);
+    if (!colptrC && !npairs) {
+        // estimateFLOP alone (overlap.hpp:157-202): the products per column are sums over the count stream, no gather at all
+        if (nown && c->have_rowlists) {
+            k_row_flops_rl<<<nblk(nown), kBlock, 0, c->stream>>>(ptr<uint64_t>(c->Arow), i0, c->part_stride, nown, ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC), ptr<uint32_t>(c->ctl));
+            KCHK(c);
+        } else if (nown) {
+            k_row_flops<<<nblk(nown, kWaves), kBlock, 0, c->stream>>>(layout_bptr(c), ptr<uint16_t>(c->Bcnt), i0, c->part_stride, nown, ptr<uint32_t>(c->flopsr),
+                                                                      ptr<uint32_t>(c->nnzC), ptr<uint32_t>(c->ctl));
+            KCHK(c);
+        }
+        hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> it(ptr<uint32_t>(c->flopsr), CastU64());
+        uint64_t* d_sum = ptr<uint64_t>(c->colptrC);
+        size_t tb = 0;
+        HIPCHK(c, hipcub::DeviceReduce::Sum(nullptr, tb, it, d_sum, (int)nr + 1, c->stream));
+        ENSURE(c, c->cubtmp, tb + 256);
+        tb = c->cubtmp.cap;
+        HIPCHK(c, hipcub::DeviceReduce::Sum(c->cubtmp.p, tb, it, d_sum, (int)nr + 1, c->stream));
+        uint64_t F = 0;
+        HIPCHK(c, hipMemcpyAsync(&F, d_sum, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (flops) *flops = F;
+        return 0;
+    }
+    if (nown) {
+        CountArgs a;
+        a.Bptr = layout_bptr(c); a.Bent = ptr<uint2>(c->Bent); a.Aent = ptr<uint2>(c->Aent);
+        a.Aent2 = c->have_rowlists ? ptr<uint2>(c->Aent2) : nullptr;
+        a.Arow = c->have_rowlists ? ptr<uint64_t>(c->Arow) : nullptr;
+        a.i0 = i0; a.stride = c->part_stride; a.nown = nown;
+        a.words = (nr + 31) / 32;
+        a.nnzC = ptr<uint32_t>(c->nnzC); a.flops = ptr<uint32_t>(c->flopsr);
+        a.totals = (unsigned long long*)(ptr<uint32_t>(c->ctl) + kCtlTotals);
+        const size_t map_bytes = 4 * (size_t)a.words;
+        const bool in_lds = map_bytes <= 150 * 1024 && !(c->debug & 8192u);   // debug bit 13: tests, bitmaps in global memory
+        if (in_lds) {
+            // as many workgroups per CU as the bitmaps allow (at most 4 x 512 threads)
+            const uint32_t per_cu = (uint32_t)std::min<size_t>(4, (160 * 1024) / (map_bytes + 64));
+            const uint32_t grid = std::min<uint32_t>(nown, 256u * (per_cu ? per_cu : 1u));
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_count_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)map_bytes));
+            a.gmap = nullptr;
+            k_count_pairs<true><<<grid, kCountBlock, map_bytes, c->stream>>>(a);
+        } else {
+            const uint32_t grid = std::min<uint32_t>(nown, 1024u);
+            ENSURE(c, c->ws, map_bytes * grid);
+            a.gmap = ptr<uint32_t>(c->ws);
+            k_count_pairs<false><<<grid, kCountBlock, 0, c->stream>>>(a);
+        }
+        KCHK(c);
+    }
+    {
+        hipcub::TransformInputIterator<uint64_t, CountU64, const uint32_t*> it(ptr<uint32_t>(c->nnzC), CountU64());
+        size_t tb = 0;
+        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, ptr<uint64_t>(c->colptrC), (int)nr + 1, c->stream));
+        ENSURE(c, c->cubtmp, tb + 256);
+        tb = c->cubtmp.cap;
+        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cubtmp.p, tb, it, ptr<uint64_t>(c->colptrC), (int)nr + 1, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    uint64_t tot[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(tot, ptr<uint32_t>(c->ctl) + kCtlTotals, 16, hipMemcpyDeviceToHost, c->stream));
+    if (colptrC) HIPCHK(c, hipMemcpyAsync(colptrC, c->colptrC.p, 8 * ((size_t)nr + 1), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tm.symbolic_ms = ev_ms(c->ev[2], c->ev[3]);
+    c->tm.symbolic_passes++;
+    if (npairs) *npairs = tot[0];
+    if (flops) *flops = tot[1];
+    return 0;
+}
+
+int bella_hip_get_memory(bella_ctx* c, bella_memory* m) {
+    if (!c || !m) return BELLA_ERR_BAD_ARG;
+    auto sum = [](std::initializer_list<const Buf*> l) { uint64_t t = 0; for (const Buf* b : l) t += b->cap; return t; };
+    m->reads_bytes = sum({&c->packed, &c->roff});
+    m->matrix_bytes = sum({&c->Bptr, &c->Bk, &c->Bpos});
+    m->layout_A_bytes = sum({&c->Aent});
+    m->layout_B_bytes = sum({&c->Bent, &c->Bcnt, &c->Bloc});
+    m->rowlist_bytes = sum({&c->Aent2, &c->Aov, &c->Arow});
+    m->pass_bytes = sum({&c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC, &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
+                         &c->cubtmp, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->orderlist, &c->order_ws, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx,
+                         &c->w_idx2, &c->w_hv, &c->w_ovfl, &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_redo, &c->w_segfirst, &c->w_toff, &c->w_table,
+                         &c->w_nruns, &c->w_desc, &c->w_gtab, &c->w_gcount, &c->w_gbase, &c->w_rfirst});
+    m->other_bytes = sum({&c->t_kmer, &c->t_read, &c->t_pos, &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->asm_cls, &c->lk_key, &c->lk_key2, &c->lk_val,
+                          &c->lk_val2, &c->w, &c->wscan, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen, &c->kc_flag, &c->kc_slot, &c->kc_nruns,
+                          &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->alns,
+                          &c->seeds, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch, &c->status, &c->comm_meta});
+    m->owned_nnz = c->have_matrix ? c->owned_nnz : 0;
     return 0;
 }
 
@@ -2185,9 +2448,30 @@ static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_se
             } else {
                 // slices (xdrop_packed.hpp): the state of the live extensions lives in HBM between launches of at most kXdropSlice steps;
                 // every launch runs full wavefronts of survivors.  Batches bound the state memory (288 B per extension).
-                const uint64_t capB = ne < (16ull << 20) ? ne : (16ull << 20);
-                ENSURE(c, c->xstate, 4 * (size_t)kXStateWords * capB);
-                ENSURE(c, c->xlive, 2 * 4 * capB + 64);
+                // (at most 16 M extensions = 4.8 GB, at most a quarter of the free device memory, at least 64 k; an allocation that
+                // fails all the same halves the batch, and below 64 k extensions the one-launch kernel, which needs no state, takes over)
+                uint64_t capB = ne < (16ull << 20) ? ne : (16ull << 20);
+                {
+                    size_t mfree = 0, mtotal = 0;
+                    if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
+                        const uint64_t held = c->xstate.cap + c->xlive.cap;
+                        const uint64_t fit = ((uint64_t)mfree + held) / 4 / (4 * (uint64_t)kXStateWords + 8);
+                        if (capB > fit) capB = fit;
+                    }
+                    if (capB < (64ull << 10)) capB = ne < (64ull << 10) ? ne : (64ull << 10);
+                }
+                bool have_state = false;
+                for (;;) {
+                    if (!ensure_bytes(c, c->xstate, 4 * (size_t)kXStateWords * capB) && !ensure_bytes(c, c->xlive, 2 * 4 * capB + 64)) { have_state = true; break; }
+                    if (capB <= (64ull << 10)) break;
+                    capB >>= 1;
+                }
+                if (!have_state) {
+                    c->err.clear();
+                    release(c->xstate); release(c->xlive);
+                    k_xdrop_sorted<<<nblk(ne, kXdropBlock), kXdropBlock, 0, c->stream>>>(sa);
+                    KCHK(c);
+                } else {
                 XdropSliceArgs xa;
                 xa.s = sa;
                 xa.state = ptr<uint32_t>(c->xstate);
@@ -2217,6 +2501,7 @@ static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_se
                         if (it > 4096) return fail(c, BELLA_ERR_STATE, "internal: X-drop slices do not terminate");
                     }
                 }
+                }   // have_state
             }
             k_xdrop_finish<<<nblk(n), 256, 0, c->stream>>>(sa);
             KCHK(c);

@@ -781,11 +781,11 @@ __global__ __launch_bounds__(64) void k_fold_overflow(FoldArgs a) {
 // the LDS tiers (cap/4 when at most ~1/5 of a column's products open a new pair, else cap/2).  One workgroup per sampled
 // column, the distinct row ids counted with a bitmap in LDS.  out[0] = max over the sample of 1024*d/F.
 __global__ __launch_bounds__(kBlock) void k_sample_pair_ratio(const uint32_t* Bptr, const uint2* Bent, const uint2* Aent, uint32_t nreads,
-                                                              uint32_t stride, uint32_t* out) {
+                                                              uint32_t first, uint32_t stride, uint32_t* out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* bits = (uint32_t*)smem;
     __shared__ uint32_t s_d, s_f;
-    const uint32_t i = blockIdx.x * stride;
+    const uint32_t i = first + blockIdx.x * stride;              // (a column the context owns: B' holds its entries)
     if (i >= nreads) return;
     const uint32_t words = (nreads + 31) / 32;
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) bits[w] = 0;
@@ -806,6 +806,77 @@ __global__ __launch_bounds__(kBlock) void k_sample_pair_ratio(const uint32_t* Bp
     atomicAdd(&s_f, f);
     __syncthreads();
     if (threadIdx.x == 0 && s_f >= 64) atomicMax(out, (uint32_t)(((uint64_t)s_d << 10) / s_f));
+}
+
+// ---- the symbolic phase alone: estimateFLOP + estimateNNZ_Hash (overlap.hpp:157-202, 205-276) -------------------------------------
+// Distinct row ids per output column, nothing else: no product lists, no fold, no records, no product-sized buffer.  The reference
+// inserts a column's keys into a hash table sized by its products; here the table is a BITMAP over the reads (one bit per possible
+// row id), in LDS when nreads bits fit (1.2 M reads) and in a per-workgroup slice of global memory above that: one atomic OR per
+// product, the pair count is the number of bits that were newly set.  Persistent workgroups over the columns of the context
+// (partition + stage); the bitmap is cleared after every column -- all of it when the column has more products than the bitmap has
+// words, else only the words its products touched (the products are read again: they are in the caches).
+constexpr int kCountBlock = 512;
+struct CountArgs {
+    const uint32_t* Bptr;        // row pointers of B' (the context's own: Bloc when partitioned)
+    const uint2* Bent;
+    const uint2* Aent;
+    const uint2* Aent2;          // row lists (nullptr: expand B' x A')
+    const uint64_t* Arow;
+    uint32_t i0, stride, nown;
+    uint32_t words;              // bitmap words = ceil(nreads / 32)
+    uint32_t* gmap;              // global bitmaps, `words` per workgroup (nullptr: LDS)
+    uint32_t* nnzC;              // [nreads + 1] out: pairs of the owned columns (the others are not touched)
+    uint32_t* flops;             // [nreads + 1] out: products
+    unsigned long long* totals;  // [2]: nnz(C), products (added)
+};
+template <bool LDSMAP>
+__global__ __launch_bounds__(kCountBlock) void k_count_pairs(CountArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t s_acc[2];
+    uint32_t* bits = LDSMAP ? (uint32_t*)smem : a.gmap + (size_t)blockIdx.x * a.words;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t w = tid; w < a.words; w += kCountBlock) bits[w] = 0;
+    if (tid < 2) s_acc[tid] = 0;
+    __syncthreads();
+    unsigned long long totP = 0, totF = 0;
+    for (uint32_t j = blockIdx.x; j < a.nown; j += gridDim.x) {
+        const uint32_t i = a.i0 + j * a.stride;
+        uint32_t d = 0, f = 0;
+        // one sweep over the column's products: mode 0 sets bits and counts, mode 1 clears the touched words
+        auto sweep = [&](const int mode) {
+            if (a.Aent2) {
+                const uint64_t p0 = a.Arow[i], p1 = a.Arow[i + 1];
+                for (uint64_t p = p0 + tid; p < p1; p += kCountBlock) {
+                    const uint32_t key = a.Aent2[p].x & 0x3FFFFFFFu;
+                    if (mode == 0) { const uint32_t bit = 1u << (key & 31u); if (!(atomicOr(&bits[key >> 5], bit) & bit)) d++; f++; }
+                    else bits[key >> 5] = 0;
+                }
+            } else {
+                for (uint32_t e = a.Bptr[i] + tid; e < a.Bptr[i + 1]; e += kCountBlock) {
+                    const uint2 be = a.Bent[e];
+                    const uint32_t cnt = (be.y >> 16) & 0x3FFFu;
+                    for (uint32_t t = 0; t < cnt; ++t) {
+                        const uint32_t key = a.Aent[(uint64_t)be.x + t].x & 0x7FFFFFFFu;
+                        if (mode == 0) { const uint32_t bit = 1u << (key & 31u); if (!(atomicOr(&bits[key >> 5], bit) & bit)) d++; }
+                        else bits[key >> 5] = 0;
+                    }
+                    if (mode == 0) f += cnt;
+                }
+            }
+        };
+        sweep(0);
+#pragma unroll
+        for (int dlt = 32; dlt > 0; dlt >>= 1) { d += __shfl_xor(d, dlt, 64); f += __shfl_xor(f, dlt, 64); }
+        if (lane_id() == 0) { if (d) atomicAdd(&s_acc[0], d); if (f) atomicAdd(&s_acc[1], f); }
+        __syncthreads();                                       // every bit of the column is set and counted
+        const uint32_t dcol = s_acc[0], fcol = s_acc[1];
+        if (fcol >= a.words) { for (uint32_t w = tid; w < a.words; w += kCountBlock) bits[w] = 0; }
+        else sweep(1);
+        __syncthreads();
+        if (tid == 0) { a.nnzC[i] = dcol; a.flops[i] = fcol; totP += dcol; totF += fcol; s_acc[0] = 0; s_acc[1] = 0; }
+        __syncthreads();
+    }
+    if (tid == 0) { if (totP) atomicAdd(a.totals, totP); if (totF) atomicAdd(a.totals + 1, totF); }
 }
 
 // estimateFLOP (overlap.hpp:157-202, lowtri): products of column i = sum of the suffix counts of its entries.

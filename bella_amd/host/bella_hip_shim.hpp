@@ -13,16 +13,18 @@
 //   errors: the reference returns void and prints; so does this (message on stderr, then abort(), as CSC.cpp:269 does).
 // The Kmer length is bpars.kmerSize (Kmer::set_k(bpars.kmerSize), main.cpp:183).
 //   bpars.numGPU (-g): as the reference's GPU build fans batches over the devices inside the call (loganGPU/functions.cuh:441-443,
-//       498-637; align.hpp:226-229), the call drives min(numGPU, devices) contexts from one host thread each: the host already
-//       holds all of B, so every context receives it, takes the output columns i % N == g and the results are merged back into
-//       the reference's column order (the multi-process path exchanges row-block panels with RCCL instead: bella_hip.h).
+//       498-637; align.hpp:226-229), the call drives min(numGPU, devices) contexts from one host thread each.  Reads are replicated;
+//       the matrix is 1D row-block partitioned: context g uploads ONLY the rows of B of its read block (bella_hip_set_B_panel), the
+//       blocks are exchanged device to device (bella_hip_allgather_panels on the in-process transport: the contexts share this
+//       process; across processes the same call runs on RCCL), and every context lays out B' for its own output columns i % N == g
+//       only (bella_hip_set_partition before the exchange).  The results are merged back into the reference's column order.
 //   bpars.totalMemory / userDefMem (-m): stage count and stage boundaries by the reference's own formula (estimateMemory,
 //       overlap.hpp:365-404; stages :682-710): ceil(1.5 * nnz(C) * (sizeof(spmatPtr_) + sizeof(uint32_t)) / free_memory), boundaries by
-//       upper_bound on colptrC.  With more than one stage the output is formed stage by stage (each pass holds its own columns
-//       only) and APPENDED -- the reference overwrites the file from offset 0 in every stage (overlap.hpp:613-636, a defect);
-//       the file written here is the single-stage one.  totalMemory shapes the OUTPUT stages only: the planning pass runs the SpGEMM
-//       over all columns on the device (device memory, not -m, bounds it: 24 bytes per product in flight) to obtain colptrC, and
-//       with more than one stage every stage is then computed again -- about twice the device work of a single-stage call.
+//       upper_bound on colptrC.  nnz(C) and colptrC come from the SYMBOLIC phase alone (bella_hip_count_pairs = estimateFLOP +
+//       estimateNNZ_Hash + prefixsum, as in the reference, overlap.hpp:667-679) -- and not even that when the product count, an upper
+//       bound of nnz(C), already fits one stage: every column is computed by the numeric phase exactly once.  With more than one
+//       stage the output is formed stage by stage (each pass holds its own columns only) and APPENDED -- the reference overwrites
+//       the file from offset 0 in every stage (overlap.hpp:613-636, a defect); the file written here is the single-stage one.
 // Also here, in namespace bella_hip (the reference defines functions of the same names and signatures, so these cannot be
 // overloads): bella_hip::xavierAlign -- include/align.hpp:152, same arguments, same xavierResult -- and bella_hip::alignXavier,
 // the batched form shaped like alignLogan (include/align.hpp:210-211), both forwarding to bella_hip_xdrop_batch.
@@ -35,6 +37,7 @@
 #include <cstdlib>
 #include <functional>
 #include <iostream>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -58,6 +61,16 @@ struct Worker {
     std::vector<bella_aln> alns;
     uint64_t nnzc = 0;
 };
+// what the last HashSpGEMM call of this process did (tests, logs): every column must be computed by the numeric phase exactly once
+struct CallStats {
+    uint64_t numeric_columns = 0;    // sum over the contexts of the columns their numeric passes computed
+    uint64_t numeric_passes = 0, symbolic_passes = 0;
+    uint64_t nreads = 0;
+    int stages = 0, contexts = 0;
+    uint64_t layout_B_bytes_max = 0, layout_B_bytes_sum = 0;   // B' per context: follows the partition
+    uint64_t host_upload_bytes = 0;  // matrix bytes that went host -> device, all contexts together
+};
+inline CallStats& last_call_stats() { static CallStats s; return s; }
 // the reference's printLog (include/common/common.h:40-44): "INFO:\tfile(line)\tname = value" on stderr
 #define BELLA_HIP_LOG(var) do { std::cerr << "INFO:\t" << "bella_hip_shim.hpp" << "(" << __LINE__ << ")\t" << #var << " = " << (var) << std::endl; } while (0)
 }  // namespace bella_hip_detail
@@ -93,15 +106,25 @@ void HashSpGEMM(const CSC<uint32_t, unsigned short>& A, const CSC<uint32_t, unsi
         for (int g = 0; g < N; ++g) th.emplace_back(fn, g);
         for (auto& t : th) t.join();
     };
+    uint8_t comm_id[BELLA_HIP_COMM_ID_BYTES];
+    if (N > 1) check(nullptr, bella_hip_comm_id_local(comm_id), "bella_hip_comm_id_local");
     on_all([&](int g) {
         Worker& w = W[(size_t)g];
         check(nullptr, bella_hip_init(g % ndev, &w.ctx), "bella_hip_init");
         check(w.ctx, bella_hip_set_reads(w.ctx, (const uint8_t*)flat.data(), offs.data(), nreads), "bella_hip_set_reads");
-        check(w.ctx, bella_hip_set_B(w.ctx, bpars.kmerSize, (uint32_t)B.rows, B.colptr, B.rowids, B.values), "bella_hip_set_B");
+        if (N == 1) {
+            check(w.ctx, bella_hip_set_B(w.ctx, bpars.kmerSize, (uint32_t)B.rows, B.colptr, B.rowids, B.values), "bella_hip_set_B");
+            return;
+        }
+        // row block g of B up, the other blocks from the peers' devices; the layout for the output columns i % N == g
+        const uint32_t lo = (uint32_t)((uint64_t)nreads * (uint64_t)g / (uint64_t)N), hi = (uint32_t)((uint64_t)nreads * (uint64_t)(g + 1) / (uint64_t)N);
         check(w.ctx, bella_hip_set_partition(w.ctx, (uint32_t)g, (uint32_t)N), "bella_hip_set_partition");
+        check(w.ctx, bella_hip_comm_init_local(w.ctx, N, g, comm_id), "bella_hip_comm_init_local");
+        check(w.ctx, bella_hip_set_B_panel(w.ctx, bpars.kmerSize, (uint32_t)B.rows, lo, hi - lo, B.colptr, B.rowids, B.values), "bella_hip_set_B_panel");
+        check(w.ctx, bella_hip_allgather_panels(w.ctx), "bella_hip_allgather_panels");
     });
     std::string().swap(flat);
-    auto do_overlap = [&](uint32_t lo, uint32_t hi) {                        // columns [lo, hi) on every context; colptrC only
+    auto do_overlap = [&](uint32_t lo, uint32_t hi) {                        // the numeric phase on the columns [lo, hi) of every context
         on_all([&](int g) {
             Worker& w = W[(size_t)g];
             check(w.ctx, bella_hip_set_column_range(w.ctx, lo, hi - lo), "bella_hip_set_column_range");
@@ -124,22 +147,44 @@ void HashSpGEMM(const CSC<uint32_t, unsigned short>& A, const CSC<uint32_t, unsi
             }
         });
     };
-    // first pass over all columns: nnz(C) and colptrC (what estimateNNZ_Hash + prefixsum give the reference, overlap.hpp:674-679)
+    auto merged_colptr = [&](std::vector<uint64_t>& colptrC) {               // column i lives on context i % N
+        colptrC.assign((size_t)nreads + 1, 0);
+        for (uint32_t i = 0; i < nreads; ++i) {
+            const Worker& w = W[(size_t)(i % (uint32_t)N)];
+            colptrC[i + 1] = colptrC[i] + (w.colptr[i + 1] - w.colptr[i]);
+        }
+    };
+    // Stage plan (overlap.hpp:365-404,682-710).  The products (estimateFLOP, a sum over a count stream) bound nnz(C) from above: if
+    // even they fit one stage the numeric phase runs at once over all columns; otherwise the symbolic phase (bella_hip_count_pairs =
+    // the reference's estimateNNZ_Hash + prefixsum, :674-679) gives the exact colptrC the boundaries are taken from.
     const double free_memory = bpars.totalMemory * 1024 * 1024;               // estimateMemory, overlap.hpp:365-404 (no LINUX/OSX define)
-    do_overlap(0, nreads);
+    const double safety_net = 1.5;                                            // overlap.hpp:92
+    const double per_nnz = (double)(sizeof(spmatPtr_) + sizeof(uint32_t));
+    std::vector<uint64_t> colptrC;
     uint64_t nnzc = 0;
-    std::vector<uint64_t> colptrC((size_t)nreads + 1, 0);                    // merged over the contexts: column i lives on context i % N
-    for (uint32_t i = 0; i < nreads; ++i) {
-        const Worker& w = W[(size_t)(i % (uint32_t)N)];
-        colptrC[i + 1] = colptrC[i] + (w.colptr[i + 1] - w.colptr[i]);
+    std::vector<uint64_t> wflops((size_t)N, 0);
+    on_all([&](int g) { check(W[(size_t)g].ctx, bella_hip_count_pairs(W[(size_t)g].ctx, &p, nullptr, nullptr, &wflops[(size_t)g]), "bella_hip_count_pairs (flops)"); });
+    uint64_t flops_all = 0;
+    for (uint64_t f : wflops) flops_all += f;
+    bool computed = false;                                                    // the numeric phase already ran over all columns
+    if (safety_net * (double)flops_all * per_nnz <= free_memory) {
+        do_overlap(0, nreads);
+        computed = true;
+    } else {
+        on_all([&](int g) {
+            Worker& w = W[(size_t)g];
+            w.colptr.assign((size_t)nreads + 1, 0);
+            uint64_t fl = 0;
+            check(w.ctx, bella_hip_count_pairs(w.ctx, &p, w.colptr.data(), &w.nnzc, &fl), "bella_hip_count_pairs");
+        });
     }
+    merged_colptr(colptrC);
     nnzc = colptrC[nreads];
     std::cout << nnzc << std::endl;                                           // overlap.hpp:686
-    const double safety_net = 1.5;                                            // overlap.hpp:92
-    const uint64_t required_memory = (uint64_t)(safety_net * nnzc * (sizeof(spmatPtr_) + sizeof(uint32_t)));
+    const uint64_t required_memory = (uint64_t)(safety_net * nnzc * per_nnz);
     int stages = (int)std::ceil((double)required_memory / free_memory);       // overlap.hpp:683
     if (stages < 1) stages = 1;
-    const uint64_t nnzcperstage = (uint64_t)(free_memory / (safety_net * (sizeof(spmatPtr_) + sizeof(uint32_t))));
+    const uint64_t nnzcperstage = (uint64_t)(free_memory / (safety_net * per_nnz));
     std::vector<uint32_t> colStart((size_t)stages + 1, 0);
     for (int i = 1; i < stages; ++i) {                                        // overlap.hpp:704-710
         auto upper = std::upper_bound(colptrC.begin(), colptrC.end(), (uint64_t)i * nnzcperstage);
@@ -154,7 +199,7 @@ void HashSpGEMM(const CSC<uint32_t, unsigned short>& A, const CSC<uint32_t, unsi
     for (int b = 0; b < stages; ++b) {
         const uint32_t lo = colStart[(size_t)b], hi = colStart[(size_t)b + 1];
         const auto t_stage = std::chrono::steady_clock::now();
-        if (stages > 1) do_overlap(lo, hi);                                   // a single stage reuses the first pass
+        if (!computed) do_overlap(lo, hi);                                    // (computed: one stage was certain, the pass over all columns ran above)
         fetch();
         const double aligntime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage).count();
         // the stage's records in the reference's column order (N contexts: column i lives on context i % N)
@@ -197,6 +242,22 @@ void HashSpGEMM(const CSC<uint32_t, unsigned short>& A, const CSC<uint32_t, unsi
         const std::string OutputtingTime = std::to_string(ws.seconds) + " seconds";
         BELLA_HIP_LOG(OutputtingTime);
     }
+    {
+        CallStats& cs = last_call_stats();
+        cs = CallStats();
+        cs.nreads = nreads; cs.stages = stages; cs.contexts = N;
+        for (auto& w : W) {
+            bella_timings tm;
+            bella_memory mm;
+            if (bella_hip_get_timings(w.ctx, &tm) == 0) { cs.numeric_columns += tm.numeric_columns; cs.numeric_passes += tm.numeric_passes; cs.symbolic_passes += tm.symbolic_passes; }
+            if (bella_hip_get_memory(w.ctx, &mm) == 0) { cs.layout_B_bytes_sum += mm.layout_B_bytes; cs.layout_B_bytes_max = std::max<uint64_t>(cs.layout_B_bytes_max, mm.layout_B_bytes); }
+        }
+        cs.host_upload_bytes = (uint64_t)6 * (uint64_t)B.colptr[nreads] + (uint64_t)4 * ((uint64_t)nreads + 1) * (uint64_t)(N == 1 ? 1 : 0);
+        const uint64_t NumericColumns = cs.numeric_columns, NumericPasses = cs.numeric_passes, SymbolicPasses = cs.symbolic_passes;
+        BELLA_HIP_LOG(NumericColumns);
+        BELLA_HIP_LOG(NumericPasses);
+        BELLA_HIP_LOG(SymbolicPasses);
+    }
     for (auto& w : W) bella_hip_destroy(w.ctx);
 }
 
@@ -208,6 +269,7 @@ struct ThreadCtx {                            // xavierAlign is called concurren
     bella_ctx* ctx = nullptr;
     ~ThreadCtx() { if (ctx) bella_hip_destroy(ctx); }
 };
+inline void thread_reads_invalidate();
 inline bella_ctx* thread_context() {
     static thread_local ThreadCtx t;
     if (!t.ctx) bella_hip_detail::check(nullptr, bella_hip_init(0, &t.ctx), "bella_hip_init");
@@ -234,6 +296,7 @@ inline void alignXavier(const std::vector<std::string>& target, const std::vecto
         flat += query[t];
     }
     check(ctx, bella_hip_set_reads(ctx, (const uint8_t*)flat.data(), offs.data(), (uint32_t)(2 * n)), "bella_hip_set_reads");
+    detail::thread_reads_invalidate();                                         // (the per-pair form re-uploads the registered read set)
     std::vector<bella_seed> sd(n);
     for (size_t t = 0; t < n; ++t) {
         sd[t].rid = (uint32_t)(2 * t);
@@ -260,11 +323,75 @@ inline void alignXavier(const std::vector<std::string>& target, const std::vecto
     }
 }
 
-// include/align.hpp:152.  One pair per call: both reads are uploaded and one extension pair is launched every time (a thread-local
-// context keeps it safe inside the reference's OpenMP pair loop, overlap.hpp:565, not fast): a caller with many pairs uses alignXavier
-// above, or the HashSpGEMM overload, which aligns all candidate pairs of a stage in one batch.
+// ---- include/align.hpp:152, per pair ------------------------------------------------------------------------------------------
+// The reference calls xavierAlign(seq1, seq2, seq1len, i, j, xDrop, kmerSize) from its OpenMP pair loop (overlap.hpp:565) with the
+// strings of two reads of the read set.  Uploading two strings per call is what makes a per-pair GPU call useless, so the per-pair
+// form here works on RESIDENT reads: use_reads(reads) once per run registers the read set (a pointer, nothing is copied), every
+// calling thread's context uploads it at its first call (one upload per thread and run), and
+//     xavierAlign(rid, cid, i, j, xDrop, kmerSize)
+// only sends the 12-byte seed and launches one extension pair.  Same xavierResult as the reference for reads[rid].seq / reads[cid].seq.
+// A maintainer who keeps RunPairWiseAlignments changes its call to pass the two read ids (they are at hand there: overlap.hpp:531-565).
+// Still ONE launch and one synchronisation per pair: a lane of this kernel runs one extension, so a lone pair takes milliseconds
+// where the batch takes microseconds per pair -- for throughput use alignXavier above, or the HashSpGEMM overload, which aligns all
+// candidate pairs of a stage in one batch.
+namespace detail {
+struct ResidentReads {
+    const readVector_* reads = nullptr;
+    uint64_t generation = 0;
+};
+inline ResidentReads& resident() { static ResidentReads r; return r; }
+struct ThreadReads { uint64_t generation = 0; };
+inline ThreadReads& thread_reads() { static thread_local ThreadReads t; return t; }
+inline void thread_reads_invalidate() { thread_reads().generation = 0; }
+}  // namespace detail
+
+// registers the read set the per-pair calls refer to (call once, before the pair loop; `reads` must outlive the loop)
+inline void use_reads(const readVector_& reads) {
+    detail::ResidentReads& r = detail::resident();
+    r.reads = &reads;
+    r.generation++;
+}
+
+inline xavierResult xavierAlign(uint32_t rid, uint32_t cid, int i, int j, int xDrop, int kmerSize) {
+    using bella_hip_detail::check;
+    detail::ResidentReads& rr = detail::resident();
+    if (!rr.reads) { std::cerr << "bella_hip::xavierAlign(rid, cid, ...): call bella_hip::use_reads(reads) first" << std::endl; std::abort(); }
+    bella_ctx* ctx = detail::thread_context();
+    detail::ThreadReads& tr = detail::thread_reads();
+    if (tr.generation != rr.generation) {                                      // this thread's context does not hold the read set yet
+        const readVector_& reads = *rr.reads;
+        std::vector<uint64_t> offs(reads.size() + 1, 0);
+        for (size_t r = 0; r < reads.size(); ++r) offs[r + 1] = offs[r] + reads[r].seq.size();
+        std::string flat;
+        flat.reserve(offs[reads.size()]);
+        for (size_t r = 0; r < reads.size(); ++r) flat += reads[r].seq;
+        check(ctx, bella_hip_set_reads(ctx, (const uint8_t*)flat.data(), offs.data(), (uint32_t)reads.size()), "bella_hip_set_reads");
+        tr.generation = rr.generation;
+    }
+    bella_seed sd;
+    sd.rid = rid; sd.cid = cid; sd.seedH = (uint16_t)i; sd.seedV = (uint16_t)j;
+    bella_params p;
+    p.kmer_size = (uint16_t)kmerSize; p.bin_size = 500; p.xdrop = (uint16_t)xDrop; p.skip_alignment = 0; p.error_rate = 0.15; p.delta_chernoff = 0.1;
+    bella_aln al;
+    check(ctx, bella_hip_xdrop_batch(ctx, &sd, 1, &p, &al), "bella_hip_xdrop_batch");
+    xavierResult out;
+    out.score = al.score;
+    out.strand = al.strand ? "c" : "n";
+    out.seed.beginPositionH = al.begH; out.seed.beginPositionV = al.begV;
+    out.seed.endPositionH = al.endH; out.seed.endPositionV = al.endV;
+    return out;
+}
+
+// The reference's own signature (two strings).  Kept so that an unchanged call site compiles and gives the reference's answers, but it is
+// the SLOW path -- both reads are uploaded at every call -- and says so once per process on stderr.
+[[deprecated("uploads both reads per call: register the reads with bella_hip::use_reads and call xavierAlign(rid, cid, i, j, xDrop, kmerSize), or batch with alignXavier")]]
 inline xavierResult xavierAlign(const std::string& row, const std::string& col, int rowLen, int i, int j, int xDrop, int kmerSize) {
     (void)rowLen;                                                              // == row.size() at the reference's call site (overlap.hpp:565)
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::cerr << "bella_hip::xavierAlign(row, col, ...): slow path -- both reads are uploaded at every call; use bella_hip::use_reads + "
+                     "xavierAlign(rid, cid, i, j, xDrop, kmerSize) for reads of the read set, alignXavier for batches" << std::endl;
+    });
     BELLApars bp;
     bp.kmerSize = (unsigned short)kmerSize;
     bp.xDrop = (unsigned short)xDrop;

@@ -112,28 +112,59 @@ def timed_passes(eng, pars, steps, warmup, sync):
     return acc
 
 
-def roofline_of(acc, nnz_share, copy_gbps, traffic_key):
+def roofline_of(acc, nnz_share, copy_gbps, traffic_key, expand_ms=0.0, layout="default"):
+    """HBM roofline of the SpGEMM numeric phase.  algorithmic bytes = 14*nnzA + 6*F + 16*P; the 14*nnzA term is the operand
+    traffic of the product expansion (B' entries + the gather of A's lists).  In the DEFAULT layout every pass does that expansion itself,
+    so frac == frac_incl_expansion by construction.  With BELLA_TUNE_ROW_LISTS the expansion runs once at assembly time (expand_ms,
+    bella_timings.expand_ms) and the pass streams ready-made products: frac_incl_expansion = bytes / (expansion + numeric phase) is the
+    like-for-like figure, frac alone over-credits the pass."""
     alg_bytes = 14.0 * nnz_share + 6.0 * float(acc["flops"]) + 16.0 * float(acc["npairs"])
     k_ms = (acc["rows"] + acc["fold"] + acc["comp"]) / acc["steps"]
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    incl = alg_bytes / ((k_ms + expand_ms) * 1e-3) / 1e9 if k_ms > 0 else 0.0
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-         "kernel": "SpGEMM numeric phase = k_spgemm_rows_lds (one launch set = the concurrent LDS-class launches of a pass) + k_fold_overflow "
-                   "+ k_order_wave/_block (the reference's slot order inside every column and the move of the records to their final place)",
+         "frac_incl_expansion": incl / HBM_PEAK_GBPS, "expansion_ms_outside_the_step": expand_ms, "layout": layout,
+         "kernel": "SpGEMM numeric phase = k_spgemm_rows_lds (one launch set = the concurrent LDS-class launches of a pass; in the default layout "
+                   "it expands B' x A' itself) + k_fold_overflow + k_order_wave/_block (the reference's slot order inside every column and the "
+                   "move of the records to their final place)",
          "kernel_ms_per_step": k_ms, "launches_per_step": acc["launches"] / acc["steps"], "algorithmic_bytes_per_step": alg_bytes,
          "columns_redone_on_global_path": acc.get("retry", 0),
          "measured_copy_ceiling_GBps": copy_gbps}
     # HBM traffic of the same kernels from the PMC counters (tools/collect_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes,
-    # gfx950 FETCH_SIZE x2 correction calibrated on our own stream): a profiling run, so read from the committed summary
-    for tag in ("r03", "r02"):
+    # gfx950 FETCH_SIZE x2 correction calibrated on our own stream): a separate profiling run, read from the committed summary and
+    # accepted only if it was taken on the same workload AND layout
+    for tag in ("r04",):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag)))[traffic_key]
-            if abs(tr["algorithmic_bytes"] - alg_bytes) < 1e-3 * alg_bytes:
+            if abs(tr["algorithmic_bytes"] - alg_bytes) < 1e-3 * alg_bytes and tr.get("layout", "default") == layout:
                 r["traffic"] = tr["hbm_bytes_corrected"]
-                r["traffic_source"] = "profiles/%s_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per step)" % tag
+                r["traffic_source"] = "profiles/%s_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per step; a separate profiled run)" % tag
                 break
         except Exception:
             pass
     return r
+
+
+def layout_ab_record(eng, pars, info, copy_gbps, sync, steps, traffic_key):
+    """The two device layouts side by side on the operands `eng` holds (counted tuples resident): for each, the layout time, the COLD
+    first pass (device time), their sum -- what a one-shot call pays -- and the warm step.  Justifies the default."""
+    out = {}
+    for name, rl in (("default", 0), ("row_lists", 1)):
+        eng.set_tuning("row_lists", rl)
+        eng.assemble_counted()
+        tm = eng.timings()
+        lay, exp_ms, rows_ms = tm.layout_ms, tm.expand_ms, tm.rows_ms
+        eng.overlap(pars)
+        cold = eng.timings().overlap_total_ms
+        acc = timed_passes(eng, pars, steps, 1, sync)
+        nnz = int(eng.get_B()[0][-1])
+        r = roofline_of(acc, nnz, copy_gbps, traffic_key, expand_ms=exp_ms, layout=name)
+        out[name] = {"layout_ms": lay, "expansion_ms": exp_ms, "rows_ms": rows_ms, "cold_pass_device_ms": cold, "cold_total_ms": lay + cold,
+                     "warm_ms_per_step": acc["elapsed"] * 1e3 / steps, "numeric_kernel_ms": r["kernel_ms_per_step"], "frac": r["frac"],
+                     "frac_incl_expansion": r["frac_incl_expansion"], "rowlist_bytes": int(eng.memory().rowlist_bytes)}
+    eng.set_tuning("row_lists")
+    out["default_chosen_by"] = "cold_total_ms (layout + first pass): HashSpGEMM is called once per run"
+    return out
 
 
 def phases_of(acc):
@@ -152,6 +183,18 @@ def assemble_record(info, nnz):
                          "algorithmic_bytes": alg, "kernel": "k_asm_rows_* + radix sort of the entries by k-mer + k_layout_* (one call)"}}
 
 
+def kcount_record(info, eng):
+    """k-mer counting + dictionary + tuples (bella_hip_count_kmers): HBM roofline on 8 B per k-mer position in and out of the sort key
+    array (emit + one read: 16 B / position) + 10 B per tuple written -- the bytes any counting-by-sorting of u64 words must move once"""
+    npos = float(info.get("npositions") or 0)
+    alg = 16.0 * npos + 10.0 * float(info["ntuples"])
+    ms = info["kcount_ms"]
+    ach = alg / (ms * 1e-3) / 1e9 if ms else 0.0
+    return {"ms": ms, "positions": int(npos), "tuples": int(info["ntuples"]),
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "algorithmic_bytes": alg,
+                         "kernel": "k_emit_codes + radix sort of the canonical words + run/dictionary/tuple passes (one call)"}}
+
+
 def xdrop_record(eng, workload):
     """RunPairWiseAlignments on the candidate pairs the engine holds (one pass, outside the SpGEMM timing)"""
     from bella_amd import BellaPars
@@ -164,8 +207,8 @@ def xdrop_record(eng, workload):
     rec = {"workload": workload % len(al), "pairs": int(len(al)), "passed": int(npass), "ms": xms,
            "pairs_per_s": len(al) / (xms * 1e-3) if xms else None, "antidiagonal_steps": steps_tot,
            "gcups": 31 * steps_tot / (xms * 1e-3) / 1e9 if xms else None, "flagged": int(al["flagged"].sum()),
-           "bound": "VALU issue: packed-i16 / v_perm band updates issue one wavefront-instruction per SIMD every 4 cycles "
-                    "(profiles/r03_valu_rates.txt)"}
+           "bound": "VALU issue: packed-i16 / v_perm band updates issue one wavefront-instruction per SIMD every ~4 cycles "
+                    "(profiles/r03_valu_rates.txt; the instruction counts of this kernel are in profiles/r04_xdrop_sq.txt, a separate profiled run)"}
     del al
     return rec
 
@@ -187,6 +230,7 @@ def dropin_call_record(rs, Bhost, nk, device):
     rec["set_B_device_layout_ms"] = eng.timings().layout_ms
     t0 = time.perf_counter(); npairs, flops = eng.overlap(pars); rec["cold_overlap_ms"] = (time.perf_counter() - t0) * 1e3
     rec["cold_overlap_device_ms"] = eng.timings().overlap_total_ms
+    rec["spgemm_cold_device_ms"] = rec["set_B_device_layout_ms"] + rec["cold_overlap_device_ms"]     # layout + first pass: what the ONE call of a run pays on the device
     t0 = time.perf_counter(); pairs, _, colptr = eng.get_pairs(ext=False); rec["get_pairs_ms"] = (time.perf_counter() - t0) * 1e3
     with tempfile.TemporaryDirectory() as tmp:
         f = os.path.join(tmp, "out.out")
@@ -247,6 +291,7 @@ def main():
     ap.add_argument("--no-xdrop", action="store_true", help="N=1: skip the X-drop records (configs[2]; configs[3]'s alignment stage)")
     ap.add_argument("--no-hifi", action="store_true", help="N=1: skip the config_hifi sub-record (configs[4]'s regime, 10k HiFi reads)")
     ap.add_argument("--no-dropin", action="store_true", help="N=1: skip the dropin_call records (the shim's call sequence, cold, wall clock)")
+    ap.add_argument("--no-layout-ab", action="store_true", help="N=1: skip the layout A/B records (default layout vs row lists: layout + cold pass + warm step)")
     ap.add_argument("--debug-flags", type=int, default=0, help="extra bella_hip_set_debug bits (development A/B)")
     ap.add_argument("--cpu-baseline-child", default=None)
     ap.add_argument("--threads", type=int, default=0)
@@ -293,6 +338,7 @@ def main():
         t1 = time.time()
         eng = Engine(local)
         eng.set_reads(rs)                                   # reads are replicated (2 bit/base)
+        t_setup = time.time()
         have_comm = False
         if world > 1:
             from bella_amd import dist as bd
@@ -318,7 +364,7 @@ def main():
             nk, nt, ndistinct = eng.count_kmers(17, 2, 8)
         else:
             have_dist_count = True
-        info = {"rs": rs, "nk": nk, "ntuples": nt, "kcount_ms": eng.timings().kcount_ms, "xchg_ms": None, "xchg_path": None, "have_comm": have_comm,
+        info = {"rs": rs, "nk": nk, "ntuples": nt, "npositions": int(np.maximum(rs.lengths.astype(np.int64) - 16, 0).sum()), "kcount_ms": eng.timings().kcount_ms, "xchg_ms": None, "xchg_path": None, "have_comm": have_comm,
                 "kcount_path": "bella_hip_count_kmers_dist (code space split over the ranks)" if have_dist_count else "bella_hip_count_kmers (every rank, all reads)"}
         info["tup"] = synth.Tuples(*eng.get_tuples(), nk) if want_host_tuples else None
         if rank == 0:
@@ -332,6 +378,7 @@ def main():
         else:
             eng.assemble_counted_panel(lo, npanel)             # from the device-resident tuples of this rank's read block
             info["asm_ms"] = eng.timings().assemble_ms
+            eng.set_partition(rank, world)                     # BEFORE the exchange: the layout it ends with holds B' for this rank's columns only
             sync()
             tx = time.perf_counter()
             xok = False
@@ -345,8 +392,13 @@ def main():
             if not xok:
                 info["xchg_path"] = bd.exchange_panels(eng, local, backend, have_comm=False)
             sync()
-            info["xchg_ms"] = (time.perf_counter() - tx) * 1e3
+            info["xchg_ms"] = (time.perf_counter() - tx) * 1e3               # exchange + device layout (wall, barrier to barrier)
+            info["layout_ms"] = eng.timings().layout_ms
             info["asm_ms"] += eng.timings().assemble_ms
+            mem = eng.memory()
+            info["mem"] = {"layout_B_bytes": int(mem.layout_B_bytes), "layout_A_bytes": int(mem.layout_A_bytes), "matrix_bytes": int(mem.matrix_bytes),
+                           "owned_nnz": int(mem.owned_nnz)}
+        info["setup_wall_ms"] = (time.time() - t_setup) * 1e3                     # reads on the device -> operands laid out (count + assemble + exchange + layout)
         return eng, info
 
     # measured device-copy ceiling: 1 GiB device-to-device, read + write bytes per second
@@ -390,25 +442,12 @@ def main():
             "kcount_ms": info["kcount_ms"], "assemble_ms": info["asm_ms"], "panel_allgather_ms": None,
         }
         out["assemble"] = assemble_record(info, nnz)
+        out["kcount"] = kcount_record(info, eng)
+        if not a.no_layout_ab:
+            out["layout_ab"] = layout_ab_record(eng, pars, info, copy_gbps, sync, 5, "10k")
         if not a.no_xdrop:
             # configs[2]: the X-drop stage on the same candidate pairs (one pass, outside the SpGEMM timing)
             out["xdrop"] = xdrop_record(eng, "configs[2]: X-drop (xdrop=7) on the %d candidate pairs of the 10k set")
-            try:   # VALU issue rate of the X-drop kernel (k_xdrop_slice) from the committed SQ counters (a profiling run) against the MEASURED issue rate of
-                   # its instruction mix (tools/ubench/valu_rates.hip: v_pk_* / v_perm_b32 issue every 4.15 cycles per SIMD at ~2.4 GHz)
-                import re
-                for tag in ("r03", "r02"):
-                    fn = os.path.join(ROOT, "profiles", "%s_xdrop_sq.txt" % tag)
-                    if not os.path.exists(fn):
-                        continue
-                    ln = [l for l in open(fn) if "k_xdrop_slice" in l or "k_xdrop_sorted" in l][0]   # (the kernel of the default variant)
-                    us = float(re.search(r"\| ([0-9.]+) us \|", ln).group(1))
-                    valu = float(re.search(r"SQ_INSTS_VALU=([0-9.e+]+)", ln).group(1))
-                    out["xdrop"]["valu_issue_frac"] = valu / (us * 1e-6 * 2.4e9 * 1024 / 4.15)
-                    out["xdrop"]["valu_issue_frac_source"] = ("profiles/%s_xdrop_sq.txt: SQ_INSTS_VALU / (kernel time x 2.4 GHz x 1024 SIMDs / 4.15 "
-                                                              "cycles per packed/perm wavefront-instruction, profiles/r03_valu_rates.txt)" % tag)
-                    break
-            except Exception:
-                pass
         Bhost = eng.get_B() if not a.no_dropin else None
         if not a.no_cpu_baseline:
             tup = info["tup"]
@@ -432,7 +471,16 @@ def main():
                    "ms_per_step": acc["elapsed"] * 1e3 / 5, "value": acc["npairs"] / (acc["elapsed"] / 5), "unit": "pairs/s",
                    "reads": BIG_READS, "nkmers": info["nk"], "nnzA": nnz, "flops": int(acc["flops"]), "pairs": int(acc["npairs"]),
                    "roofline": roofline_of(acc, nnz, copy_gbps, "100k"), "phases_ms_per_step": phases_of(acc),
-                   "kcount_ms": info["kcount_ms"], "assemble_ms": info["asm_ms"], "assemble": assemble_record(info, nnz)}
+                   "kcount_ms": info["kcount_ms"], "assemble_ms": info["asm_ms"], "assemble": assemble_record(info, nnz), "kcount": kcount_record(info, eng)}
+            if not a.no_layout_ab:
+                sub["layout_ab"] = layout_ab_record(eng, pars, info, copy_gbps, sync, 3, "100k")
+            # (the driver's parser keeps the top-level roofline object: the 100k figures travel there too)
+            out["roofline"]["frac_100k"] = sub["roofline"]["frac"]
+            out["roofline"]["frac_100k_incl_expansion"] = sub["roofline"]["frac_incl_expansion"]
+            out["roofline"]["kernel_ms_per_step_100k"] = sub["roofline"]["kernel_ms_per_step"]
+            if "layout_ab" in sub:
+                out["roofline"]["row_lists_100k"] = {k2: sub["layout_ab"]["row_lists"][k2] for k2 in ("frac", "frac_incl_expansion", "expansion_ms", "numeric_kernel_ms", "cold_total_ms")}
+                out["roofline"]["default_100k_cold_total_ms"] = sub["layout_ab"]["default"]["cold_total_ms"]
             if not a.no_xdrop:
                 # configs[3] is SpGEMM + alignment: the X-drop stage on ALL candidate pairs of the 100k set
                 sub["xdrop"] = xdrop_record(eng, "configs[3]'s alignment stage on one GPU: X-drop (xdrop=7) on the %d candidate pairs of the 100k set")
@@ -444,6 +492,8 @@ def main():
                 cut = int(rs.offsets[SAMPLE_READS])
                 cb = run_cpu_baseline(rs.codes[:cut], rs.offsets[:SAMPLE_READS + 1], tk[keep], tr[keep], tp[keep], info["nk"],
                                       "bounded sample: reads 0..%d of the 100k set with the set's own k-mer dictionary" % (SAMPLE_READS - 1))
+                cb["note"] = ("a SAMPLE of the set: %d pairs over %d reads; the full set has %d pairs over %d reads (pairs per read grow with the "
+                              "set), so this pairs/s is not comparable with the GPU line's, only with a GPU run of the same sample" % (cb["pairs"] or 0, SAMPLE_READS, int(acc["npairs"]), BIG_READS))
                 cb.pop("pairs")
                 sub["cpu_baseline"] = cb
                 del tk, tr, tp, keep
@@ -490,12 +540,15 @@ def main():
         eng.set_partition(rank, n_gpus)
         eng.set_debug(2 | a.debug_flags)
         acc = timed_passes(eng, pars, a.steps, a.warmup, sync)
+        mem = info.get("mem") or {}
         tt = torch.tensor([acc["elapsed"], acc["rows"] + acc["fold"] + acc["comp"], info["kcount_ms"], info["asm_ms"], info["xchg_ms"] or 0.0,
-                           float(acc["npairs"]), float(acc["flops"])], dtype=torch.float64, device=tdev)
+                           float(acc["npairs"]), float(acc["flops"]), info["setup_wall_ms"], info.get("layout_ms") or 0.0,
+                           float(mem.get("layout_B_bytes", 0)), float(mem.get("owned_nnz", 0))], dtype=torch.float64, device=tdev)
         mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         return {"acc": acc, "elapsed": float(mx[0]), "kernel_ms": float(mx[1]) / a.steps, "kcount_ms_max": float(mx[2]), "assemble_ms_max": float(mx[3]),
-                "xchg_ms_max": float(mx[4]), "pairs": float(sm[5]), "flops": float(sm[6])}
+                "xchg_ms_max": float(mx[4]), "pairs": float(sm[5]), "flops": float(sm[6]), "setup_ms_max": float(mx[7]), "layout_ms_max": float(mx[8]),
+                "layout_B_bytes_max": float(mx[9]), "layout_B_bytes_sum": float(sm[9]), "owned_nnz_max": float(mx[10]), "owned_nnz_sum": float(sm[10])}
 
     eng, info = prepare(nreads, False)                       # set-up through torch.distributed (every rank counts all reads)
     mA = measure(eng, info)
@@ -514,14 +567,28 @@ def main():
               "largest_rank_share": float(xm[1]) / max(float(xs[1]), 1.0)}
         eng.set_debug(2 | a.debug_flags)
     single = None
-    if rank == 0:
-        # the same workload on ONE GPU (rank 0 holds all operands): the denominator of the speed-up
-        eng.set_partition(0, 1)
-        acc1 = timed_passes(eng, pars, 3, 1, torch.cuda.synchronize)
-        single = {"ms_per_step": acc1["elapsed"] * 1e3 / 3, "value": acc1["npairs"] / (acc1["elapsed"] / 3), "pairs": int(acc1["npairs"])}
-    dist.barrier()
     colptr, _, _ = eng.get_B()
     nnz = int(colptr[-1])
+    if rank == 0:
+        # the same workload on ONE GPU, set-up included (a fresh context on rank 0's device): the denominator of the speed-ups
+        e1 = Engine(local)
+        t0 = time.perf_counter()
+        e1.set_reads(info["rs"])
+        t1 = time.perf_counter()
+        e1.count_kmers(17, 2, 8)
+        e1.assemble_counted()
+        setup1 = (time.perf_counter() - t1) * 1e3
+        e1.set_debug(2 | a.debug_flags)
+        acc1 = timed_passes(e1, pars, 3, 1, torch.cuda.synchronize)
+        single = {"ms_per_step": acc1["elapsed"] * 1e3 / 3, "value": acc1["npairs"] / (acc1["elapsed"] / 3), "pairs": int(acc1["npairs"]),
+                  "setup_ms": setup1, "kcount_ms": e1.timings().kcount_ms, "assemble_ms": e1.timings().assemble_ms, "xdrop_ms": None}
+        if not a.no_xdrop:
+            e1.set_debug(a.debug_flags)
+            e1.overlap(BellaPars())
+            e1.align_pairs(BellaPars())
+            single["xdrop_ms"] = e1.timings().xdrop_ms
+        e1.close()
+    dist.barrier()
 
     def line(m, setup):
         elapsed = m["elapsed"]
@@ -536,9 +603,17 @@ def main():
             "roofline": roofline_of(m["acc"], nnz / n_gpus, copy_gbps, "none"),
             "phases_ms_per_step": phases_of(m["acc"]),
             "kcount_ms_max": m["kcount_ms_max"], "assemble_ms_max": m["assemble_ms_max"], "panel_allgather_ms": m["xchg_ms_max"],
+            # the set-up of the step (reads resident -> operands laid out: count + assemble + exchange + device layout), wall clock, max over ranks
+            "setup_ms_max_over_ranks": m["setup_ms_max"], "layout_ms_max_over_ranks": m["layout_ms_max"],
+            "per_rank_layout": {"B_bytes_max": m["layout_B_bytes_max"], "B_bytes_sum": m["layout_B_bytes_sum"], "owned_nnz_max": m["owned_nnz_max"],
+                                "owned_nnz_sum": m["owned_nnz_sum"], "nnz": nnz,
+                                "note": "B' (10 B per entry) exists for the rank's own columns only; A' (8 B per entry) and the exchanged matrix (6 B) are whole on every rank"},
             "xdrop": xd,
             "single_gpu_same_workload": single,
             "speedup_vs_single_gpu": (single["ms_per_step"] / (elapsed * 1e3 / a.steps)) if single else None,
+            # the figure that counts for a run: set-up + one step + the alignment stage, N GPUs against one
+            "speedup_setup_step_xdrop": ((single["setup_ms"] + single["ms_per_step"] + (single["xdrop_ms"] or 0.0)) /
+                                         (m["setup_ms_max"] + elapsed * 1e3 / a.steps + ((xd or {}).get("ms_max_over_ranks") or 0.0))) if single else None,
             "pairs_match_single_gpu": (single["pairs"] == int(m["pairs"])) if single else None,
         }
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define BELLA_HIP_ABI_VERSION 4
+#define BELLA_HIP_ABI_VERSION 5
 
 enum {
     BELLA_OK = 0,
@@ -111,6 +111,13 @@ typedef struct {
     uint32_t lane_order;      /* init-time self-test of the LDS-atomic lane order the LDS tiers rely on (phase S):
                                  1 = holds; 2 = does not hold on this device/driver: every column takes the repairing
                                  global-workspace path (correct, slower)                                                 */
+    float expand_ms;          /* part of layout_ms: the product expansion done at assembly time (the row lists of
+                                 BELLA_TUNE_ROW_LISTS; 0 in the default layout, where every pass expands B' x A' itself)   */
+    uint32_t numeric_passes;  /* since bella_hip_init: calls of bella_hip_overlap that ran the numeric phase ...          */
+    uint32_t symbolic_passes; /* ... and calls of bella_hip_count_pairs (symbolic phase only)                            */
+    uint32_t pad;
+    uint64_t numeric_columns; /* since bella_hip_init: output columns the numeric phase computed (a staged run that computes
+                                 every column once ends at nreads)                                                        */
 } bella_timings;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */
@@ -192,9 +199,9 @@ int bella_hip_assemble_tuples(bella_ctx* ctx, uint16_t kmer_size, uint32_t nkmer
  * colptr[nreads+1], rowids = k-mer ids in MergeDuplicates slot order, values = positions.
  * A = spmat is derived on device (ascending read ids per k-mer = the reference's 1-thread Transpose).
  * Every call that installs operands (this one, the assemble_* calls, bella_hip_allgather_panels) also lays them out for the passes:
- * B', A', and -- when 10 bytes per product of the whole SpGEMM fit in half of the free device memory and read ids need at most 30
- * bits -- the row lists (the two operand entries of every product side by side in product order), which a pass streams instead of
- * expanding B' x A' itself.  Same results either way. */
+ * A' (whole) and B' (the columns of the context's partition, bella_hip_set_partition); every pass expands B' x A' itself.  With
+ * BELLA_TUNE_ROW_LISTS (callers that run several passes over the same columns) also the row lists -- the two operand entries of every
+ * product side by side in product order, 10 bytes per product -- when they fit.  Same results either way. */
 int bella_hip_set_B(bella_ctx* ctx, uint16_t kmer_size, uint32_t nkmers, const uint32_t* colptr,
                     const uint32_t* rowids, const uint16_t* values);
 /* Multi-GPU assembly: rank r builds only the rows of B of ITS reads (a row-block panel) from their tuples (global read ids,
@@ -203,6 +210,11 @@ int bella_hip_set_B(bella_ctx* ctx, uint16_t kmer_size, uint32_t nkmers, const u
  * rowids = k-mer ids in MergeDuplicates slot order (u32), values = positions (u16). */
 int bella_hip_assemble_panel(bella_ctx* ctx, uint16_t kmer_size, uint32_t nkmers, uint32_t first_read, uint32_t nreads_panel,
                              uint64_t ntuples, const uint32_t* t_kmer, const uint32_t* t_read, const uint16_t* t_pos);
+/* The same panel from the reference's CSC arrays of B (colptr[nreads + 1], rowids, values: the WHOLE matrix on the host; only the
+ * block's slice is uploaded).  A host program that holds B and drives several GPUs gives every context its block this way and lets
+ * bella_hip_allgather_panels move the blocks device to device, instead of uploading the whole matrix once per GPU. */
+int bella_hip_set_B_panel(bella_ctx* ctx, uint16_t kmer_size, uint32_t nkmers, uint32_t first_read, uint32_t nreads_panel,
+                          const uint32_t* colptr, const uint32_t* rowids, const uint16_t* values);
 int bella_hip_panel_device_ptrs(bella_ctx* ctx, uint32_t* first_read, uint32_t* nreads_panel, uint64_t* nnz,
                                 const void** d_rowcnt, const void** d_rowids, const void** d_values);
 /* As bella_hip_set_B, from DEVICE pointers (colptr[nreads+1], rowids[nnz], values[nnz]); copied, the caller keeps ownership. */
@@ -212,7 +224,10 @@ int bella_hip_set_B_device(bella_ctx* ctx, uint16_t kmer_size, uint32_t nkmers, 
 int bella_hip_get_B(bella_ctx* ctx, uint64_t* nnz, uint32_t* colptr, uint32_t* rowids, uint16_t* values);
 
 /* Multi-GPU (one context per GPU/process): this context computes output columns i with
- * i % stride == first.  Default (0,1) = all columns.  Every rank holds the full operands. */
+ * i % stride == first.  Default (0,1) = all columns.  The device layout follows the partition: operands installed AFTER this call
+ * get B' entries (and row lists) for the OWNED columns only -- per-column layout work and memory are 1/stride of the whole; A' (the
+ * k-mer -> reads lists every column gathers from) and the exchanged reference-layout B stay whole.  Changing the partition of a
+ * context whose layout was built for another one rebuilds the layout from the resident B at the next pass. */
 int bella_hip_set_partition(bella_ctx* ctx, uint32_t first, uint32_t stride);
 /* Stages (the reference forms the output in stages of consecutive columns when it does not fit the -m budget:
  * estimateMemory, overlap.hpp:365-404, stage loop :682-789): the next passes compute only the output columns
@@ -222,6 +237,14 @@ int bella_hip_set_column_range(bella_ctx* ctx, uint32_t first, uint32_t count);
 
 /* ---- HashSpGEMM (overlap.hpp:650-789): estimateFLOP + estimateNNZ_Hash + LocalSpGEMM ---------------- */
 int bella_hip_overlap(bella_ctx* ctx, const bella_params* p, uint64_t* npairs, uint64_t* flops);
+/* The symbolic phase alone: estimateFLOP (overlap.hpp:157-202) + estimateNNZ_Hash (:205-276) + prefixsum (:110-146) over the
+ * columns of the current partition and column range -- distinct row ids per output column, no product lists, no fold, no records,
+ * and no product-sized buffers (a bitmap over the reads per workgroup).  colptrC[nreads + 1] (host, nullable): exclusive prefix sums
+ * of the per-column pair counts (columns outside the partition / range count 0); *npairs = nnz(C), *flops = products.  This is what
+ * the reference knows BEFORE its numeric phase and sizes its stages from (overlap.hpp:674-710); the shim's stage planner uses it
+ * so that no column is computed twice.  With colptrC == NULL and npairs == NULL only estimateFLOP runs (*flops; sums over the
+ * count stream, no gather): an upper bound of nnz(C) that lets a planner skip the symbolic phase when one stage is certain. */
+int bella_hip_count_pairs(bella_ctx* ctx, const bella_params* p, uint64_t* colptrC, uint64_t* npairs, uint64_t* flops);
 /* pairs[npairs]; ext (nullable) [npairs]; colptrC (nullable) [nreads+1] */
 int bella_hip_get_pairs(bella_ctx* ctx, bella_pair* pairs, bella_pair_ext* ext, uint64_t* colptrC);
 
@@ -237,9 +260,11 @@ int bella_hip_xdrop_batch(bella_ctx* ctx, const bella_seed* seeds, uint64_t n, c
  * p->skip_alignment (overlap.hpp:577-588), else the passed alignments as BELLA's 12 columns (:472-473) or PAF (paf != 0,
  * :476-489) -- and APPENDS the text to `path` (the reference opens its file in append mode, :613).  names[nreads]: NUL-terminated
  * read names (readType_::nametag); lens[nreads]: read lengths; alns may be NULL when p->skip_alignment.  nthreads host threads
- * (0 = all hardware threads) each measure a contiguous share (exact bytes), the file is grown and mapped, and every thread formats
- * its share at its offset of the mapping (through buffers and offset writes where the file cannot be mapped).
- * Plain host code: no context, usable from any thread.  stats (nullable): what RunPairWiseAlignments returns (:644) + timings. */
+ * (0 = min(hardware threads, 16): more threads into ONE file are slower, the writes serialise on the inode) first measure contiguous
+ * shares (exact bytes, no formatting), then format pieces of about 1 MB into private buffers and pwrite() each at its offset behind
+ * the file's size at entry (fstat, not O_APPEND: ONE writer per file at a time is assumed; mapping the file was measured and
+ * rejected, page faults).  Plain host code: no context, usable from any thread.  stats (nullable): what RunPairWiseAlignments
+ * returns (:644) + timings. */
 typedef struct {
     uint64_t lines;            /* outputted                                                       */
     uint64_t bytes;
@@ -294,6 +319,18 @@ int bella_hip_count_kmers_dist(bella_ctx* ctx, uint16_t kmer_size, uint32_t lowe
 
 /* ---- measurement --------------------------------------------------------------------------------- */
 int bella_hip_get_timings(bella_ctx* ctx, bella_timings* t);
+/* Device memory the context holds right now, by role (multi-GPU: what is replicated and what follows the partition). */
+typedef struct {
+    uint64_t reads_bytes;      /* packed reads + offsets: replicated                                                     */
+    uint64_t matrix_bytes;     /* B in the reference's layout (colptr / rowids / values): what the all-gather delivers     */
+    uint64_t layout_A_bytes;   /* A' (k-mer -> reads lists): whole on every context                                        */
+    uint64_t layout_B_bytes;   /* B' entries + their count stream: owned columns only                                      */
+    uint64_t rowlist_bytes;    /* row lists (BELLA_TUNE_ROW_LISTS) + row pointers: owned columns only                      */
+    uint64_t pass_bytes;       /* buffers of the passes (records, product lists, workspaces): follow the pass's products   */
+    uint64_t other_bytes;      /* counting / assembly / alignment buffers still held                                        */
+    uint64_t owned_nnz;        /* B' entries laid out (= nnz of the owned columns)                                         */
+} bella_memory;
+int bella_hip_get_memory(bella_ctx* ctx, bella_memory* m);
 /* 0 = default; bit0 = force the global-memory row path (tests); bit1 = no pair_ext output; bit2 = tests: treat every fifth
  * column as if its product lists had come out of order (the LDS tiers verify the order and fall back to the repairing path);
  * bit3 = tests: 512-thread workgroups in every LDS class (default: 1024 threads where a CU holds one or two columns);
@@ -301,9 +338,10 @@ int bella_hip_get_timings(bella_ctx* ctx, bella_timings* t);
  * LDS tiers takes the sort-based path of the wide columns (default: from 16 such columns in a pass on); bit6 = tests: that path
  * sorts on 64-bit keys on any input (default: 32-bit keys when column bits + read-id bits fit); bit8 = tests: the exact X-drop mode
  * launches its extensions in chunks of 1,000 (default 2^24: grid x block stays below 2^32 threads); bit10 (read when the operands are
- * assembled) = tests: no row lists -- the layout that inputs whose products do not fit in memory (10 bytes each) fall back to: every pass
- * expands the products from B' and A' itself; bit11 (same moment) = tests: as if the row lists did not fit (A' in k-mer order, no row lists);
- * bit12 = tests: the columns above the LDS tiers are grouped by the radix sort also when the row lists would allow grouping in LDS */
+ * assembled) = tests: the lists of A' in order of first appearance in B' (default: k-mer order), no row lists; bit11 (same moment) =
+ * tests: as if the row lists BELLA_TUNE_ROW_LISTS asks for did not fit in memory (the layout stands without them);
+ * bit12 = tests: the columns above the LDS tiers are grouped by the radix sort also when the row lists would allow grouping in LDS;
+ * bit13 = tests: the symbolic phase (bella_hip_count_pairs) keeps its bitmaps in global memory also when they fit in LDS */
 int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
 /* Per-context tuning parameters (tests and A/B measurements; nothing here changes results).  what:
  *   BELLA_TUNE_LDS_TIERS      values = ascending product capacities of the row kernels' LDS tiers, each in [64, 11008] (n = 0: defaults)
@@ -311,8 +349,14 @@ int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
  *   BELLA_TUNE_WIDE_BUDGET    values[0] = products per batch of the sort-based path of the wide columns (default 2^30)
  *   BELLA_TUNE_XDROP_VARIANT  values[0] = 0 one launch in length-sorted order, 1 (default; n = 0) slices of 512 steps with compaction of
  *                             the live extensions between launches, 2 packed kernel in pair order, 3 the scalar statement of xavier.h.
- *                             Same results in every variant. */
-enum { BELLA_TUNE_LDS_TIERS = 0, BELLA_TUNE_KCOUNT_BUDGET = 1, BELLA_TUNE_WIDE_BUDGET = 2, BELLA_TUNE_XDROP_VARIANT = 3 };
+ *                             Same results in every variant.
+ *   BELLA_TUNE_ROW_LISTS      values[0] = 1: operands installed from now on also get ROW LISTS -- the two operand entries of every product
+ *                             of the owned columns side by side in product order (10 bytes per product, written once at assembly time)
+ *                             -- when they fit next to what a pass needs; the numeric phase then streams its products instead of
+ *                             expanding B' x A'.  For callers that run SEVERAL passes over the same columns (parameter sweeps): the
+ *                             expansion is paid once instead of per pass.  Default 0 (n = 0): a one-shot call is faster without them
+ *                             (layout + first pass); bella_timings.expand_ms reports the expansion when they are built. */
+enum { BELLA_TUNE_LDS_TIERS = 0, BELLA_TUNE_KCOUNT_BUDGET = 1, BELLA_TUNE_WIDE_BUDGET = 2, BELLA_TUNE_XDROP_VARIANT = 3, BELLA_TUNE_ROW_LISTS = 4 };
 int bella_hip_set_tuning(bella_ctx* ctx, uint32_t what, const uint64_t* values, uint32_t n);
 
 #ifdef __cplusplus

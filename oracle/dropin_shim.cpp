@@ -115,7 +115,32 @@ extern "C" int bella_dropin_hashspgemm(uint32_t nreads, uint32_t nkmers, uint64_
                                     outputPaf, errorRate, deltaChernoff, 1, 400000.0, outfile, stdout_log, stdout_cap);
 }
 
+// what the shim's last HashSpGEMM did: {numeric columns, numeric passes, symbolic passes, nreads, stages, contexts, B' bytes max, B' bytes sum, host upload bytes}
+extern "C" int bella_dropin_last_stats(uint64_t* out) {
+    const bella_hip_detail::CallStats& s = bella_hip_detail::last_call_stats();
+    out[0] = s.numeric_columns; out[1] = s.numeric_passes; out[2] = s.symbolic_passes; out[3] = s.nreads; out[4] = (uint64_t)s.stages;
+    out[5] = (uint64_t)s.contexts; out[6] = s.layout_B_bytes_max; out[7] = s.layout_B_bytes_sum; out[8] = s.host_upload_bytes;
+    return 0;
+}
+
+// the per-pair form on RESIDENT reads (bella_hip::use_reads once, then read ids): n calls on the same read set
+extern "C" int bella_dropin_xavier_align_resident(uint32_t nreads, const char* const* seqs, int n, const uint32_t* rids, const uint32_t* cids, const int* is,
+                                                  const int* js, int xDrop, int kmerSize, int* out, char* strands) {
+    readVector_ reads(nreads);
+    for (uint32_t r = 0; r < nreads; ++r) { reads[r].seq = seqs[r]; reads[r].readid = r; }
+    bella_hip::use_reads(reads);
+    for (int t = 0; t < n; ++t) {
+        xavierResult res = bella_hip::xavierAlign(rids[t], cids[t], is[t], js[t], xDrop, kmerSize);
+        out[5 * t] = res.score; out[5 * t + 1] = res.seed.beginPositionH; out[5 * t + 2] = res.seed.endPositionH;
+        out[5 * t + 3] = res.seed.beginPositionV; out[5 * t + 4] = res.seed.endPositionV;
+        strands[t] = res.strand[0];
+    }
+    return 0;
+}
+
 // the align.hpp call surface through the shim: out = {score, begH, endH, begV, endV}, strand = "n" / "c"
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Wdeprecated-declarations"
 extern "C" int bella_dropin_xavier_align(const char* row, const char* col, int i, int j, int xDrop, int kmerSize, int* out, char* strand) {
     const std::string r(row), c(col);
     xavierResult res = bella_hip::xavierAlign(r, c, (int)r.size(), i, j, xDrop, kmerSize);
@@ -123,6 +148,7 @@ extern "C" int bella_dropin_xavier_align(const char* row, const char* col, int i
     strand[0] = res.strand[0]; strand[1] = 0;
     return 0;
 }
+#pragma GCC diagnostic pop
 
 // the batched form (alignLogan's shape, align.hpp:210-211): n pairs at once
 extern "C" int bella_dropin_align_batch(int n, const char* const* rows, const char* const* cols, const int* is, const int* js, int xDrop,

@@ -21,13 +21,48 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == {s[0] for s in _lib.SIGNATURES}
-    assert lib.bella_hip_abi_version() == 4
+    assert lib.bella_hip_abi_version() == 5
 
 
 def test_struct_layouts_match_header():
     assert _lib.PAIR_DT.itemsize == 16 and _lib.EXT_DT.itemsize == 8 and _lib.ALN_DT.itemsize == 32 and _lib.SEED_DT.itemsize == 12
     import ctypes
-    assert ctypes.sizeof(_lib.Params) == 24 and ctypes.sizeof(_lib.Timings) == 56 and ctypes.sizeof(_lib.WriteStats) == 80 and ctypes.sizeof(_lib.IngestStats) == 40
+    assert ctypes.sizeof(_lib.Params) == 24 and ctypes.sizeof(_lib.Timings) == 80 and ctypes.sizeof(_lib.WriteStats) == 80 and ctypes.sizeof(_lib.IngestStats) == 40
+    assert ctypes.sizeof(_lib.Memory) == 64
+
+
+def test_ctypes_structs_equal_the_headers_as_a_c_compiler_sees_them(tmp_path):
+    """sizeof / offsetof of every struct of include/bella_hip.h, from gcc, against the ctypes mirrors"""
+    import ctypes
+    import subprocess
+    structs = {"bella_params": _lib.Params, "bella_timings": _lib.Timings, "bella_write_stats": _lib.WriteStats, "bella_ingest_stats": _lib.IngestStats,
+               "bella_memory": _lib.Memory}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "bella_hip.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        src.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            src.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    for cname, dt in (("bella_pair", _lib.PAIR_DT), ("bella_pair_ext", _lib.EXT_DT), ("bella_aln", _lib.ALN_DT), ("bella_seed", _lib.SEED_DT)):
+        src.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname in dt.names:
+            src.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    src.append('return 0; }')
+    cfile = tmp_path / "layout.c"
+    cfile.write_text("\n".join(src))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(cfile), "-o", exe])
+    got = {}
+    for ln in subprocess.check_output([exe]).decode().splitlines():
+        a, b, v = ln.split()
+        got[(a, b)] = int(v)
+    for cname, cls in structs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+    for cname, dt in (("bella_pair", _lib.PAIR_DT), ("bella_pair_ext", _lib.EXT_DT), ("bella_aln", _lib.ALN_DT), ("bella_seed", _lib.SEED_DT)):
+        assert got[(cname, "size")] == dt.itemsize, cname
+        for fname in dt.names:
+            assert got[(cname, fname)] == dt.fields[fname][1], (cname, fname)
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -48,14 +48,18 @@ def test_assembly_matches_reference_layout(eng, golden):
         assert np.array_equal(a, b)           # colptr, k-mer ids in MergeDuplicates slot order, positions
 
 
-@pytest.mark.parametrize("debug", [0, 1, 1024, 1025, 2048])
-def test_spgemm_pairs_bit_exact(eng, golden, debug):
+@pytest.mark.parametrize("debug,rowlists", [(0, 0), (1, 0), (1024, 0), (1025, 0), (0, 1), (1, 1), (2048, 1)])
+def test_spgemm_pairs_bit_exact(eng, golden, debug, rowlists):
     g = golden
-    eng.set_debug(debug)                       # 1 = force the global-workspace row path; 1024 = the layout without the row lists
-                                               # (the pass expands B' x A' itself); 2048 = as if the row lists did not fit in memory
+    eng.set_debug(debug)                       # 1 = force the global-workspace row path; 1024 = the lists of A' in order of first appearance
+                                               # (default: k-mer order); 2048 = as if the row lists asked for did not fit in memory
+    eng.set_tuning("row_lists", rowlists)      # 1 = the products ready-made at assembly time (callers with repeated passes); default: every
+                                               # pass expands B' x A' itself
     try:
         eng.set_reads(g.rs)
         eng.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
+        assert (eng.timings().expand_ms > 0) == (rowlists == 1 and debug != 2048 and len(g.tk) > 0)
+        assert (eng.memory().rowlist_bytes > 0) == (rowlists == 1 and debug != 2048 and len(g.tk) > 0)
         n, flops = eng.overlap(BellaPars(skipAlignment=True, kmerSize=g.k))
         pairs, ext, colptrC = eng.get_pairs()
         _, flop, ecol, exp = oracle_pairs(g.rs, g.seqs, g.nkmers, g.tk, g.tr, g.tp, g.k)
@@ -64,6 +68,47 @@ def test_spgemm_pairs_bit_exact(eng, golden, debug):
         check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
     finally:
         eng.set_debug(0)
+        eng.set_tuning("row_lists")
+
+
+@pytest.mark.parametrize("debug,rowlists", [(0, 0), (8192, 0), (0, 1)])
+def test_symbolic_phase_alone_matches_oracle(eng, golden, debug, rowlists):
+    """bella_hip_count_pairs = estimateFLOP + estimateNNZ_Hash + prefixsum (overlap.hpp:157-276,110-146): colptrC, nnz(C) and the products
+    without a numeric pass -- whole, per stage (column range) and per partition; then the numeric phase on the same context"""
+    g = golden
+    eng.set_debug(debug)                       # 8192: the bitmaps of the symbolic phase in global memory
+    eng.set_tuning("row_lists", rowlists)
+    try:
+        eng.set_reads(g.rs)
+        eng.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
+        pars = BellaPars(skipAlignment=True, kmerSize=g.k)
+        _, flop, ecol, exp = oracle_pairs(g.rs, g.seqs, g.nkmers, g.tk, g.tr, g.tp, g.k)
+        ecnt = np.diff(ecol.astype(np.int64))
+        t0 = eng.timings()
+        colptrC, n, flops = eng.count_pairs(pars)
+        assert n == len(exp) and flops == int(flop.sum()) and np.array_equal(colptrC, ecol.astype(np.uint64))
+        assert eng.count_flops(pars) == int(flop.sum())
+        t1 = eng.timings()
+        assert t1.symbolic_passes == t0.symbolic_passes + 1 and t1.numeric_passes == t0.numeric_passes and t1.numeric_columns == t0.numeric_columns
+        nr = g.rs.nreads
+        lo, hi = nr // 3, nr // 3 + max(1, nr // 2)
+        eng.set_column_range(lo, hi - lo)
+        eng.set_partition(1, 2)
+        colptrC, n, flops = eng.count_pairs(pars)
+        own = np.zeros(nr, bool); own[lo:min(hi, nr)] = True; own &= (np.arange(nr) % 2 == 1)
+        assert np.array_equal(np.diff(colptrC.astype(np.int64)), np.where(own, ecnt, 0)) and n == int(ecnt[own].sum()) and flops == int(flop[own].sum())
+        eng.set_column_range(0, 0xFFFFFFFF)
+        eng.set_partition(0, 1)
+        n, flops = eng.overlap(pars)           # the numeric phase still starts from clean arrays
+        pairs, ext, colptrC = eng.get_pairs()
+        assert n == len(exp) and np.array_equal(colptrC, ecol.astype(np.uint64))
+        check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
+        assert eng.timings().numeric_columns == t1.numeric_columns + nr
+    finally:
+        eng.set_debug(0)
+        eng.set_tuning("row_lists")
+        eng.set_column_range(0, 0xFFFFFFFF)
+        eng.set_partition(0, 1)
 
 
 def test_set_B_boundary_equals_tuple_assembly(eng, golden):
@@ -373,6 +418,7 @@ def test_dropin_shim_stages_and_gpus_from_bellapars(eng, tmp_path, monkeypatch):
     lib.bella_dropin_hashspgemm2.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, u32p, u32p, u16p, C.POINTER(C.c_char_p),
                                              C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                              C.c_double, C.c_int, C.c_double, C.c_char_p, C.c_char_p, C.c_size_t]
+    lib.bella_dropin_last_stats.argtypes = [C.POINTER(C.c_uint64)]
     g = load_golden("toy120")
     n = g.rs.nreads
     sarr = (C.c_char_p * n)(*g.seqs)
@@ -389,6 +435,13 @@ def test_dropin_shim_stages_and_gpus_from_bellapars(eng, tmp_path, monkeypatch):
             nums = so.value.decode().split()
             assert nums[:3] == g.stdout[key][:3]
             assert open(f, "rb").read() == g.out[key], (ngpu, stages, key)
+            st = (C.c_uint64 * 9)()
+            lib.bella_dropin_last_stats(st)
+            # every column is computed by the numeric phase exactly ONCE; the symbolic phase runs only when one stage is not certain
+            assert st[0] == n and st[3] == n and st[4] == stages and st[5] == ngpu, list(st)
+            assert st[2] == (ngpu if stages > 1 else 0) and st[1] == ngpu * stages, list(st)
+            if ngpu > 1:   # B' follows the partition: no context holds (much) more than its share of the entries
+                assert st[6] <= 1.3 * st[7] / ngpu + 2048, list(st)
             if not skip:
                 assert len(nums) == 3 + stages and sum(int(x) for x in nums[3:]) == int(g.stdout["align"][3])   # outputted per stage (:771)
 
@@ -410,6 +463,29 @@ def test_dropin_shim_align_call_surface(eng):
         lib.bella_dropin_xavier_align(kat["row"].encode(), kat["col"].encode(), kat["i"], kat["j"], kat["x"], kat["k"], out, st)
         if not fl:
             assert list(out) == kat["expect"] and st.value.decode() == kat["strand"], kat["name"]
+    # the per-pair form on RESIDENT reads: use_reads once, then read ids and seeds only (the reads are uploaded once per thread and run)
+    g = load_golden("toy120")
+    Bc, Br, Bv = O.build_B(g.rs.nreads, g.tk, g.tr, g.tp)
+    _, _, op = O.spgemm(g.seqs, g.nkmers, Bc, Br, Bv, g.k)
+    sel = op[:: max(1, len(op) // 40)][:40]
+    m = len(sel)
+    u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+    i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+    lib.bella_dropin_xavier_align_resident.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), C.c_int, u32p, u32p, i32p, i32p, C.c_int, C.c_int, i32p, C.c_char_p]
+    sarr = (C.c_char_p * g.rs.nreads)(*g.seqs)
+    res = np.zeros(5 * m, np.int32)
+    stb = C.create_string_buffer(m + 1)
+    lib.bella_dropin_xavier_align_resident(g.rs.nreads, sarr, m, np.ascontiguousarray(sel["rid"], np.uint32), np.ascontiguousarray(sel["cid"], np.uint32),
+                                           np.ascontiguousarray(sel["seedH"], np.int32), np.ascontiguousarray(sel["seedV"], np.int32), g.xdrop, g.k, res, stb)
+    nchk = 0
+    for t, pr in enumerate(sel):
+        e = O.xavier_align(g.seqs[int(pr["rid"])], g.seqs[int(pr["cid"])], int(pr["seedH"]), int(pr["seedV"]), g.xdrop, g.k)
+        if e["flagged"]:
+            continue
+        assert list(res[5 * t:5 * t + 5]) == [int(e["score"]), int(e["begH"]), int(e["endH"]), int(e["begV"]), int(e["endV"])], t
+        assert stb.raw[t:t + 1] == (b"c" if e["strand"] else b"n")
+        nchk += 1
+    assert nchk >= 20
     same = [k for k in kats if (k["x"], k["k"]) == (kats[0]["x"], kats[0]["k"])]
     n = len(same)
     rows = (C.c_char_p * n)(*[k["row"].encode() for k in same])
@@ -844,12 +920,14 @@ def test_file_to_file_pipeline_reproduces_reference_up_to_kmer_labels(eng, tmp_p
 
 # ---- columns with >= 65,536 products (wide.hpp) -----------------------------------------------------------------------------
 
-@pytest.mark.parametrize("budget,layout,passdbg", [(0, 0, 0), (300000, 0, 0), (0, 1024, 0), (300000, 2048, 0), (0, 0, 4096), (300000, 0, 4096)])
-def test_wide_columns_bit_exact(eng, budget, layout, passdbg):
+@pytest.mark.parametrize("budget,layout,passdbg,rowlists", [(0, 0, 0, 1), (300000, 0, 0, 1), (0, 1024, 0, 0), (300000, 0, 0, 0), (0, 0, 4096, 1), (300000, 0, 4096, 1),
+                                                             (0, 2048, 0, 1)])
+def test_wide_columns_bit_exact(eng, budget, layout, passdbg, rowlists):
     """70 near-identical reads with -u 80: every k-mer is shared by all of them, column 0 has ~200k products (the row kernels
     index products with 16 bits); strands mixed, two reads carry a 700-base deletion plus a random tail (a second overlap bin)"""
     eng.set_tuning("wide_budget", budget)                            # 300000: several batches of wide columns
-    eng.set_debug(layout)                                            # 1024 / 2048: the layouts without row lists (the pass expands the products)
+    eng.set_debug(layout)                                            # 1024: A' in order of first appearance; 2048: the row lists asked for "do not fit"
+    eng.set_tuning("row_lists", rowlists)                            # 1: grouping of the wide columns in LDS from the row lists; 0 (default): the sort-based path
     rng = np.random.default_rng(17)
     base = rng.integers(0, 4, size=3000, dtype=np.uint8)
     comp = (3 - base)[::-1]
@@ -867,6 +945,7 @@ def test_wide_columns_bit_exact(eng, budget, layout, passdbg):
     eng.set_debug(passdbg)                                           # 4096: the sort-based grouping of the wide columns also with row lists
     n, flops = eng.overlap(BellaPars(skipAlignment=True))
     eng.set_debug(0)
+    eng.set_tuning("row_lists")
     pairs, ext, colptrC = eng.get_pairs()
     _, flop, ecol, exp = oracle_pairs(rs, rs.seqs(), nk, tk, tr, tp, 17)
     assert int(flop.max()) >= 65536 and flops == int(flop.sum()) and n == len(exp)
@@ -1173,20 +1252,40 @@ def test_collectives_with_several_ranks_on_the_in_process_transport(bounds):
         nk_r, _, _ = e.count_kmers_dist(lo, n, 17, 2, 8)
         dic = e.get_dictionary()
         e.assemble_counted_panel(lo, n)
+        e.set_partition(r, nranks)             # BEFORE the exchange: the layout it ends with holds B' for the owned columns only
         e.allgather_panels()
         B = e.get_B()
-        e.set_partition(r, nranks)
+        mem = e.memory()
         e.overlap(BellaPars(skipAlignment=True))
-        return nk_r, dic, B, e.get_pairs()
+        own = e.get_pairs()
+        # another partition on a context laid out for (r, nranks): the layout is rebuilt from the resident B
+        e.set_partition((r + 1) % nranks, nranks)
+        e.overlap(BellaPars(skipAlignment=True))
+        other = e.get_pairs()
+        e.set_partition(0, 1)
+        e.overlap(BellaPars(skipAlignment=True))
+        whole = e.get_pairs()
+        return nk_r, dic, B, own, mem, other, whole
     out, err = _run_ranks(nranks, body)
     assert not err, err
+    nnz = int(B1[0][-1])
+    rowlen = np.diff(B1[0].astype(np.int64))
     for r in range(nranks):
-        nk_r, dic, B, _ = out[r]
+        nk_r, dic, B, _, mem, _, whole = out[r]
         assert nk_r == nk
         assert np.array_equal(dic[0], d0[0]) and np.array_equal(dic[1], d0[1])
         for a, b in zip(B, B1):
             assert np.array_equal(a, b)
+        # per-column layout memory follows the partition: B' entries exactly for the owned columns, 10 bytes each (+ row pointers, + the
+        # allocator's slack of 1/16 + 256 bytes per array); A' and the exchanged matrix are whole
+        owned = int(rowlen[r::nranks].sum())
+        assert mem.owned_nnz == owned and owned <= 1.3 * nnz / nranks
+        assert mem.layout_B_bytes <= 1.3 * (10 * nnz / nranks) + 4 * (rs.nreads + 2) * 1.07 + 3 * 300
+        assert mem.layout_A_bytes >= 8 * nnz and mem.matrix_bytes >= 6 * nnz and mem.rowlist_bytes == 0
+        assert np.array_equal(whole[0], p1[0])
     merged = bd.merge_in_reference_order([out[r][3][0] for r in range(nranks)])
+    assert np.array_equal(merged, p1[0])
+    merged = bd.merge_in_reference_order([out[(r - 1) % nranks][5][0] for r in range(nranks)])
     assert np.array_equal(merged, p1[0])
     for e in engines:
         e.comm_destroy()
@@ -1213,6 +1312,13 @@ def test_a_failing_rank_takes_all_ranks_out_of_the_collective():
         return True
     out, err = _run_ranks(3, body, timeout=120)
     assert sorted(r for r, _ in err) == [0, 1, 2] and all(isinstance(e, BellaHipError) for _, e in err)
+
+    def body2(r):                              # a rank with a bad ARGUMENT (k = 40) takes part in the agreement too: nobody waits for its dictionary
+        engines[r].count_kmers_dist(bounds[r], bounds[r + 1] - bounds[r], 40 if r == 2 else 17, 2, 8)
+        return True
+    out, err = _run_ranks(3, body2, timeout=120)
+    assert sorted(r for r, _ in err) == [0, 1, 2] and all(isinstance(e, BellaHipError) for _, e in err)
+    assert [e.code for r, e in sorted(err, key=lambda t: t[0])] == [-7, -7, -3]
     for e in engines:
         e.comm_destroy()
         e.close()
