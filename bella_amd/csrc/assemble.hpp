@@ -347,6 +347,7 @@ __device__ __forceinline__ void run_bounds(const uint32_t* skey, uint64_t nnz, u
 // radix pass on the top bits of e and k_layout_place then write B' region by region (the writes of a region meet in the caches).
 // by_kmer (the row-list layout, k_layout_rowlists below): the lists of A' stay in k-mer order = the sorted order itself -- no list
 // starts to scatter, scan and look up (k_layout_heads is not run), A' is written in place.
+constexpr int kLayoutEmitPartBlock = 1024;      // workgroup of the partitioned launch (own_stride > 1); any size otherwise
 __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64_t nnz, const uint32_t* Bptr, const uint32_t* Bloc, const uint32_t* wscan,
                               const uint32_t* packed, const uint64_t* roff, uint32_t k, uint32_t rmask, uint2* Aent, uint32_t* ekey, uint64_t* eval,
                               uint32_t by_kmer, uint32_t own_first, uint32_t own_stride, uint32_t* counter, uint32_t* status) {
@@ -382,18 +383,16 @@ __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64
         if (x < nnz) { ekey[x] = dstkey; eval[x] = dstval; }
         return;
     }
-    // partitioned: the owned entries leave compacted (one atomic per wavefront; their order does not matter, the partition pass and
-    // k_layout_place put every entry at its own index)
-    const unsigned long long mask = __ballot(mine);
-    if (mask == 0) return;
-    uint32_t base = 0;
-    const uint32_t lane = threadIdx.x & 63u;
-    if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = (uint32_t)__shfl((int)base, __builtin_ctzll(mask), 64);
-    if (mine) {
-        const uint32_t o = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        ekey[o] = dstkey; eval[o] = dstval;
-    }
+    // partitioned: the owned entries leave compacted, ONE atomic per workgroup of 1,024 entries on the shared counter (a counter takes
+    // about 90 atomics per microsecond: one per wavefront would be 3 M of them at 100k reads); their order does not matter, the
+    // partition pass and k_layout_place put every entry at its own index
+    __shared__ uint32_t scr[16];
+    __shared__ uint32_t s_base;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan<16>(mine ? 1u : 0u, scr, &tot);
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(counter, tot) : 0u;
+    __syncthreads();
+    if (mine) { const uint32_t o = s_base + ex; ekey[o] = dstkey; eval[o] = dstval; }
 }
 
 __global__ void k_layout_place(const uint32_t* ekey, const uint64_t* eval, uint64_t n, uint2* Bent) {
@@ -411,10 +410,40 @@ __global__ void k_layout_own_lengths(const uint32_t* Bptr, uint32_t nreads, uint
     len[i] = i < nreads && i % own_stride == own_first ? Bptr[i + 1] - Bptr[i] : 0u;
 }
 
-// the products of every entry once more, compact: estimateFLOP streams 2 B per nonzero
-__global__ void k_layout_bcnt(const uint2* Bent, uint64_t nnz, uint16_t* Bcnt) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < nnz) Bcnt[e] = (uint16_t)((Bent[e].y >> 16) & 0x3FFFu);
+// ---- packed rows: B' keeps only the entries that have products ---------------------------------------------------------------------
+// An entry whose k-mer occurs in no LATER read (cnt = 0: the read is the last of the k-mer's list -- 38 % of the entries of a 30x read
+// set, nearly all entries of the last columns) contributes no product to the strictly lower triangle.  The passes stream a row's
+// entries, so B' is stored without them: same products in the same order (the entries that remain keep their slot order).
+// one wavefront per row: entries with products
+__global__ __launch_bounds__(kBlock) void k_layout_nzcount(const uint32_t* Bloc, const uint2* Bent, uint32_t nreads, uint32_t* nz) {
+    const uint32_t r = blockIdx.x * kWaves + wave_id();
+    if (r > nreads) return;
+    uint32_t s = 0;
+    if (r < nreads) for (uint32_t e = Bloc[r] + lane_id(); e < Bloc[r + 1]; e += 64) s += ((Bent[e].y >> 16) & 0x3FFFu) ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane_id() == 0) nz[r] = s;                                           // (nz[nreads] = 0: the scan's last element)
+}
+// one wavefront per row: the entries with products, in order, to the packed arrays (+ their counts once more as u16: estimateFLOP
+// streams 2 B per entry)
+__global__ __launch_bounds__(kBlock) void k_layout_pack(const uint32_t* Bloc, const uint2* Bent, const uint32_t* Bpk, uint32_t nreads, uint2* Bent2,
+                                                        uint16_t* Bcnt2) {
+    const uint32_t r = blockIdx.x * kWaves + wave_id();
+    if (r >= nreads) return;
+    const uint32_t b0 = Bloc[r], b1 = Bloc[r + 1];
+    uint32_t o = Bpk[r];
+    for (uint32_t e0 = b0; e0 < b1; e0 += 64) {
+        const uint32_t e = e0 + lane_id();
+        uint2 be = make_uint2(0u, 0u);
+        if (e < b1) be = Bent[e];
+        const uint32_t cnt = (be.y >> 16) & 0x3FFFu;
+        const unsigned long long m = __ballot(cnt != 0);
+        if (cnt) {
+            const uint32_t d = o + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+            Bent2[d] = be; Bcnt2[d] = (uint16_t)cnt;
+        }
+        o += (uint32_t)__popcll(m);
+    }
 }
 
 // ---- row lists: the products of every column, ready-made, in product order -----------------------------------------------------
@@ -435,43 +464,60 @@ __global__ __launch_bounds__(kBlock) void k_layout_rowflops(const uint32_t* Bptr
     for (int dlt = 32; dlt > 0; dlt >>= 1) s += __shfl_xor(s, dlt, 64);
     if (lane_id() == 0) rowflops[i] = s;                            // (rowflops[nreads] = 0: the scan's last element)
 }
-// one workgroup per row (grid-stride), its entries in rounds of 1024: block scan of the counts, then product-parallel copy (product q of
-// the round belongs to the last entry whose first product is <= q: binary search over the round's offsets in LDS)
+// one workgroup per row (grid-stride), its entries in rounds of 1024: block scan of the counts, then groups of L lanes copy the tail
+// of one entry's list each (L = 1, 4 or 16 by the round's products per entry: short lists -- PacBio-like input, less than one later
+// read per entry -- one lane per entry, four independent loads in flight; long lists -- HiFi-like input, tens of later reads -- a
+// group per entry, so that a store instruction writes runs of L neighbouring products).  The tails are contiguous in A', the
+// products of neighbouring entries are neighbours in the output.  cols == nullptr: all rows, row i starts at starts[i] (= Arow);
+// else the rows cols[0 .. nrows), row cols[x] starts at starts[x] (the wide columns of a batch expanded into a temporary list, wide.hpp).
 constexpr int kRowListBlock = 1024;
-__global__ __launch_bounds__(kRowListBlock) void k_layout_rowlists(const uint32_t* Bptr, const uint2* Bent, const uint2* Aent, const uint64_t* Arow,
-                                                                   const uint64_t* roff, uint32_t nreads, uint2* Aent2, uint16_t* Aov) {
+__global__ __launch_bounds__(kRowListBlock) void k_layout_rowlists(const uint32_t* Bptr, const uint2* Bent, const uint2* Aent, const uint64_t* starts,
+                                                                   const uint64_t* roff, const uint32_t* cols, uint32_t nrows, uint2* Aent2, uint16_t* Aov) {
     __shared__ uint32_t scr[kRowListBlock / 64];
-    __shared__ uint32_t s_off[kRowListBlock + 1];
+    __shared__ uint32_t s_off[kRowListBlock];
     __shared__ uint2 s_be[kRowListBlock];
-    for (uint32_t i = blockIdx.x; i < nreads; i += gridDim.x) {
+    for (uint32_t x = blockIdx.x; x < nrows; x += gridDim.x) {
+        const uint32_t i = cols ? cols[x] : x;
         const uint32_t b0 = Bptr[i], n = Bptr[i + 1] - b0;
-        const uint64_t o = Arow[i];
+        const uint64_t o = starts[x];
         uint64_t running = 0;
         for (uint32_t jb = 0; jb < n; jb += kRowListBlock) {
             const uint32_t j = jb + threadIdx.x;
+            const uint32_t nround = n - jb < (uint32_t)kRowListBlock ? n - jb : (uint32_t)kRowListBlock;
             uint2 be = make_uint2(0u, 0u);
             if (j < n) be = Bent[b0 + j];
             const uint32_t cnt = (be.y >> 16) & 0x3FFFu;
             uint32_t tot;
             const uint32_t ex = block_excl_scan<kRowListBlock / 64>(cnt, scr, &tot);
-            s_off[threadIdx.x] = ex; s_be[threadIdx.x] = be;
-            if (threadIdx.x == 0) s_off[kRowListBlock] = tot;
-            __syncthreads();
-            for (uint32_t q = threadIdx.x; q < tot; q += kRowListBlock) {
-                uint32_t lo = 0, hi = kRowListBlock;                // s_off[lo] <= q < s_off[hi]
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (s_off[mid] <= q) lo = mid; else hi = mid;
+            const uint32_t L = tot <= 2u * nround ? 1u : tot <= 12u * nround ? 4u : 16u;   // (uniform over the workgroup)
+            auto copy_tail = [&](const uint2 eb, const uint32_t ecnt, const uint64_t dst, const uint32_t t_first, const uint32_t t_step) {
+                const uint32_t posV = eb.y & 0xFFFFu, pal = (eb.y >> 30) & 1u, oriB = eb.y >> 31;
+                for (uint32_t t0 = t_first; t0 < ecnt; t0 += 4 * t_step) {
+                    uint2 ae[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) { ae[u] = make_uint2(0u, 0u); if (t0 + u * t_step < ecnt) ae[u] = Aent[(uint64_t)eb.x + t0 + u * t_step]; }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t t = t0 + u * t_step;
+                        if (t >= ecnt) continue;
+                        const uint32_t posH = ae[u].y & 0xFFFFu, lenH = ae[u].y >> 16;
+                        const bool oriented = (ae[u].x >> 31) == oriB;
+                        Aent2[dst + t] = make_uint2((ae[u].x & 0x3FFFFFFFu) | (pal << 30) | (oriented ? 0x80000000u : 0u), posH | (posV << 16));
+                        Aov[dst + t] = (uint16_t)lenH;
+                    }
                 }
-                const uint2 eb = s_be[lo];
-                const uint2 ae = Aent[(uint64_t)eb.x + (q - s_off[lo])];
-                const uint32_t posV = eb.y & 0xFFFFu, pal = (eb.y >> 30) & 1u;
-                const uint32_t posH = ae.y & 0xFFFFu, lenH = ae.y >> 16;
-                const bool oriented = (ae.x >> 31) == (eb.y >> 31);
-                Aent2[o + running + q] = make_uint2((ae.x & 0x3FFFFFFFu) | (pal << 30) | (oriented ? 0x80000000u : 0u), posH | (posV << 16));
-                Aov[o + running + q] = (uint16_t)lenH;
+            };
+            if (L == 1u) {
+                copy_tail(be, cnt, o + running + ex, 0u, 1u);
+            } else {
+                s_off[threadIdx.x] = ex; s_be[threadIdx.x] = be;
+                __syncthreads();
+                for (uint32_t e = threadIdx.x / L; e < nround; e += kRowListBlock / L) {
+                    const uint2 eb = s_be[e];
+                    copy_tail(eb, (eb.y >> 16) & 0x3FFFu, o + running + s_off[e], threadIdx.x % L, L);
+                }
+                __syncthreads();
             }
-            __syncthreads();
             running += tot;
         }
     }

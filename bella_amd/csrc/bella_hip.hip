@@ -70,6 +70,9 @@ constexpr uint32_t kAsmGrid = 128;
 struct CastU64 {
     __host__ __device__ uint64_t operator()(const uint32_t& v) const { return (uint64_t)v; }
 };
+struct CastU8 {
+    __host__ __device__ uint32_t operator()(const uint8_t& v) const { return (uint32_t)v; }
+};
 struct CountU64 {                                        // pair counts: without the "already in slot order" mark
     __host__ __device__ uint64_t operator()(const uint32_t& v) const { return (uint64_t)(v & ~kOrderedBit); }
 };
@@ -97,8 +100,8 @@ struct bella_ctx {
     uint32_t kc_nkmers = 0, kc_k = 0;
     uint32_t kc_bfirst = 0, kc_brows = 0; // the read block the device-resident tuples cover (all reads unless counted distributed)
     Buf kc_nk, kc_koff, kc_hist, kc_keys, kc_alt, kc_runlen, kc_flag, kc_slot, kc_nruns, kc_dcode, kc_dcount, kc_hkey, kc_hval, kc_found,
-        kc_tstart, kc_cursor, kc_sel, kc_ringo, kc_ringp;
-    Buf Bptr, Bk, Bpos, Bent, Bcnt, Aent, Aent2, Aov, Arow, Bloc;
+        kc_tstart, kc_cursor, kc_sel, kc_ringo, kc_ringp, kc_ids;
+    Buf Bptr, Bk, Bpos, Bent, Bcnt, Aent, Aent2, Aov, Arow, Bloc, Bpk;
     bool have_rowlists = false;          // Aent2 / Arow hold the row lists of the current layout
     bool want_rowlists = false;          // BELLA_TUNE_ROW_LISTS: build them with the next layouts (when they fit)
     uint32_t part_first = 0, part_stride = 1;
@@ -123,7 +126,7 @@ struct bella_ctx {
         status, cubtmp, plist_hv, overflow, ctl, retry, orderlist, order_ws;
     bool order_attr = false;
     Buf w_f, w_off, w_key, w_key2, w_idx, w_idx2, w_hv, w_ovfl, w_plist, w_scr, w_rlen, w_rstart, w_rrank, w_redo, w_segfirst,
-        w_toff, w_table, w_nruns, w_desc, w_gtab, w_gcount, w_gbase, w_rfirst;
+        w_toff, w_table, w_nruns, w_desc, w_gtab, w_gcount, w_gbase, w_rfirst, w_aent2, w_aov;
     uint32_t n_wide = 0;
     uint32_t n_retry = 0;
     uint32_t n_overflow = 0;
@@ -254,8 +257,8 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
     return ms;
 }
 
-// the row pointers the layout kernels and the passes index B' with: the matrix's own, or the partitioned context's (owned rows only)
-inline const uint32_t* layout_bptr(const bella_ctx* c) { return c->layout_stride > 1 ? ptr<uint32_t>(c->Bloc) : ptr<uint32_t>(c->Bptr); }
+// the row pointers the passes index B' with: the packed rows of the context's own columns (build_layout)
+inline const uint32_t* layout_bptr(const bella_ctx* c) { return ptr<uint32_t>(c->Bloc); }
 
 // B (Bptr/Bk/Bpos on device) -> Bent / Aent   (see assemble.hpp): one stable radix sort of the entries by k-mer id (the runs are
 // the k-mer lists of A', ascending read id) and coalesced segmented passes; 32 B of temporaries per nonzero.
@@ -281,8 +284,9 @@ int build_layout(bella_ctx* c) {
     // the context's own row pointers: all rows, or the owned ones (the others keep no entries)
     uint64_t nown_nnz = nnz;
     c->layout_first = pf; c->layout_stride = ps;
+    ENSURE(c, c->Bloc, 4 * ((size_t)c->nreads + 2));
+    ENSURE(c, c->Bpk, 4 * ((size_t)c->nreads + 2));
     if (ps > 1) {
-        ENSURE(c, c->Bloc, 4 * ((size_t)c->nreads + 2));
         uint32_t* len = ptr<uint32_t>(c->w);
         k_layout_own_lengths<<<nblk((uint64_t)c->nreads + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), c->nreads, pf, ps, len);
         KCHK(c);
@@ -293,12 +297,11 @@ int build_layout(bella_ctx* c) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         nown_nnz = n32;
     } else {
-        release(c->Bloc);
+        HIPCHK(c, hipMemcpyAsync(c->Bloc.p, c->Bptr.p, 4 * ((size_t)c->nreads + 1), hipMemcpyDeviceToDevice, c->stream));
     }
-    c->owned_nnz = nown_nnz;
-    const uint32_t* Bloc = layout_bptr(c);
+    c->owned_nnz = 0;
+    const uint32_t* Bloc = ptr<uint32_t>(c->Bloc);                 // dense rows of the owned columns (every entry) until they are packed below
     ENSURE(c, c->Bent, 8 * nown_nnz);
-    ENSURE(c, c->Bcnt, 2 * nown_nnz);
     if (nnz) {
         k_layout_prep<<<nblk(c->nreads, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos), c->nreads,
                                                                         ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), c->kmer_size, nk,
@@ -336,7 +339,7 @@ int build_layout(bella_ctx* c) {
         uint64_t* eval = dv.Alternate();
         uint32_t* counter = ptr<uint32_t>(c->status) + 7;
         HIPCHK(c, hipMemsetAsync(counter, 0, 4, c->stream));
-        k_layout_emit<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), Bloc, ptr<uint32_t>(c->wscan), ptr<uint32_t>(c->packed),
+        k_layout_emit<<<nblk(nnz, ps > 1 ? kLayoutEmitPartBlock : 256), ps > 1 ? kLayoutEmitPartBlock : 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), Bloc, ptr<uint32_t>(c->wscan), ptr<uint32_t>(c->packed),
                                                         ptr<uint64_t>(c->roff), c->kmer_size, rmask, ptr<uint2>(c->Aent), ekey, eval, by_kmer, pf, ps, counter,
                                                         ptr<uint32_t>(c->status));
         KCHK(c);
@@ -360,8 +363,30 @@ int build_layout(bella_ctx* c) {
             }
             k_layout_place<<<nblk(nown_nnz), 256, 0, c->stream>>>(ek.Current(), ev.Current(), nown_nnz, ptr<uint2>(c->Bent));
             KCHK(c);
-            k_layout_bcnt<<<nblk(nown_nnz), 256, 0, c->stream>>>(ptr<uint2>(c->Bent), nown_nnz, ptr<uint16_t>(c->Bcnt));
+        }
+        {   // packed rows (assemble.hpp): only the entries with products stay, in their order; the row pointers become Bpk
+            uint32_t* nz = ptr<uint32_t>(c->wscan);                 // (free: k_layout_emit is done with it)
+            k_layout_nzcount<<<nblk((uint64_t)c->nreads + 1, kWaves), kBlock, 0, c->stream>>>(Bloc, ptr<uint2>(c->Bent), c->nreads, nz);
             KCHK(c);
+            int rc = scan_u32(c, nz, ptr<uint32_t>(c->Bpk), (uint64_t)c->nreads + 1);
+            if (rc) return rc;
+            uint32_t n32 = 0;
+            HIPCHK(c, hipMemcpyAsync(&n32, ptr<uint32_t>(c->Bpk) + c->nreads, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            Buf packed_ent;
+            rc = ensure_bytes(c, packed_ent, 8 * (size_t)n32);
+            if (rc) return rc;
+            rc = ensure_bytes(c, c->Bcnt, 2 * (size_t)n32);
+            if (rc) { release(packed_ent); return rc; }
+            k_layout_pack<<<nblk(c->nreads ? c->nreads : 1, kWaves), kBlock, 0, c->stream>>>(Bloc, ptr<uint2>(c->Bent), ptr<uint32_t>(c->Bpk), c->nreads, ptr<uint2>(packed_ent),
+                                                                                     ptr<uint16_t>(c->Bcnt));
+            KCHK(c);
+            HIPCHK(c, hipStreamSynchronize(c->stream));              // (the dense rows are released next)
+            release(c->Bent);
+            c->Bent = packed_ent;
+            std::swap(c->Bloc, c->Bpk);
+            Bloc = ptr<uint32_t>(c->Bloc);
+            c->owned_nnz = n32;
         }
         if (by_kmer && c->want_rowlists && c->nreads <= (1u << 30)) {
             // row lists (BELLA_TUNE_ROW_LISTS): products per owned row -> row starts -> the tails of the lists copied in product order.
@@ -389,7 +414,7 @@ int build_layout(bella_ctx* c) {
                 if (!rc) {
                     const uint32_t grid = c->nreads < 4096u ? c->nreads : 4096u;
                     if (grid) k_layout_rowlists<<<grid, kRowListBlock, 0, c->stream>>>(Bloc, ptr<uint2>(c->Bent), ptr<uint2>(c->Aent), ptr<uint64_t>(c->Arow),
-                                                                                     ptr<uint64_t>(c->roff), c->nreads, ptr<uint2>(c->Aent2), ptr<uint16_t>(c->Aov));
+                                                                                     ptr<uint64_t>(c->roff), nullptr, c->nreads, ptr<uint2>(c->Aent2), ptr<uint16_t>(c->Aov));
                     KCHK(c);
                     HIPCHK(c, hipEventRecord(c->ev[11], c->stream));
                     HIPCHK(c, hipEventSynchronize(c->ev[11]));
@@ -401,11 +426,13 @@ int build_layout(bella_ctx* c) {
         }
     }
     if (!c->have_rowlists) { release(c->Aent2); release(c->Aov); release(c->Arow); }
+    if (!nnz) HIPCHK(c, hipMemsetAsync(c->Bloc.p, 0, 4 * ((size_t)c->nreads + 2), c->stream));
+    release(c->Bpk);
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     // pairs/products on a sample of (owned) columns -> key-table budget of the LDS tiers (see k_sample_pair_ratio)
     uint32_t ratio1024 = 1024;
     const size_t bitmap_bytes = 4 * (((size_t)c->nreads + 31) / 32);
-    if (nown_nnz && bitmap_bytes <= 128 * 1024) {
+    if (c->owned_nnz && bitmap_bytes <= 128 * 1024) {
         HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 6, 0, 4, c->stream));
         const uint32_t ncols = c->nreads / ps + 1;                  // owned columns: first + j * stride
         const uint32_t nsample = ncols < 512 ? ncols : 512;
@@ -523,13 +550,13 @@ void bella_hip_destroy(bella_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && c->api) { (void)c->api->CommDestroy(c->comm); c->comm = nullptr; }
     release(c->comm_meta);
-    Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Bcnt, &c->Aent, &c->Aent2, &c->Aov, &c->Arow, &c->Bloc, &c->t_kmer, &c->t_read, &c->t_pos,
+    Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Bcnt, &c->Aent, &c->Aent2, &c->Aov, &c->Arow, &c->Bloc, &c->Bpk, &c->t_kmer, &c->t_read, &c->t_pos,
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->asm_cls, &c->lk_key, &c->lk_key2, &c->lk_val, &c->lk_val2,
                   &c->w, &c->wscan, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC,
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
                   &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->orderlist, &c->order_ws, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx, &c->w_idx2, &c->w_hv, &c->w_ovfl,
-                  &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_redo, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->w_desc, &c->w_gtab, &c->w_gcount, &c->w_gbase, &c->w_rfirst, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
-                  &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch};
+                  &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_redo, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->w_desc, &c->w_gtab, &c->w_gcount, &c->w_gbase, &c->w_rfirst, &c->w_aent2, &c->w_aov, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
+                  &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->kc_ids, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& st : c->side) (void)hipStreamDestroy(st);
@@ -927,6 +954,8 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     // so that all ranks leave the call together instead of waiting for it in the dictionary exchange.
     const uint8_t* d_sel = nullptr;
     uint64_t nk_total = 0, ndistinct = 0;
+    bool fast = false, one_pass_all = false;
+    uint32_t pb = 0;
     int rc = [&]() -> int {
     const unsigned rgrid = nr < 16384u ? (nr ? nr : 1u) : 16384u;
     ENSURE(c, c->kc_nk, 4 * ((size_t)nr + 2));
@@ -958,16 +987,35 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
         d_sel = ptr<uint8_t>(c->kc_sel);
         release(c->kc_ringo); release(c->kc_ringp);
     }
+    // Words with their positions (kcount.hpp): when the word's 2k bits and a global position index fit 64 bits together -- and the
+    // positions that make tuples are the positions that are counted (not so in syncmer mode) -- every sorted word still knows where it
+    // came from and the reliable ones hand their id to their position directly: no hash table over the dictionary, no look-up per
+    // position (which was a third of this call).  Not across ranks (a rank only sorts its share of the words).
+    {
+        int posbits = 1;
+        while (posbits < 63 && (1ull << posbits) < ntot) ++posbits;
+        fast = NR == 1 && mode != 1 && 2 * (int)k + posbits <= 64 && !(c->debug & 16384u);   // debug bit 14: tests, the look-up path
+        pb = fast ? (uint32_t)posbits : 0u;
+    }
+    if (fast) {
+        ENSURE(c, c->kc_ids, 4 * ntot + 16);
+        HIPCHK(c, hipMemsetAsync(c->kc_ids.p, 0xFF, 4 * ntot + 16, c->stream));
+    }
+    uint64_t budget = c->kcount_budget;
+    if (budget > 0x7FFF0000ull) budget = 0x7FFF0000ull;               // rocPRIM item counts are 32-bit
+    uint64_t hist[kCountBins] = {};
+    if (mode == 0 && NR == 1 && ntot <= budget) {
+        hist[0] = ntot;                                                // one pass over every position: no histogram needed to size it
+        one_pass_all = true;
+    } else {
     HIPCHK(c, hipMemsetAsync(c->kc_hist.p, 0, 8 * kCountBins, c->stream));
     k_code_hist<<<rgrid, kBlock, 0, c->stream>>>(ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), ptr<uint32_t>(c->kc_nk), nr, k, mode,
                                                  ptr<uint64_t>(c->kc_koff), d_sel, (unsigned long long*)c->kc_hist.p);
     KCHK(c);
-    uint64_t hist[kCountBins];
     HIPCHK(c, hipMemcpyAsync(hist, c->kc_hist.p, sizeof(hist), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     // passes = runs of consecutive bins holding at most `budget` k-mers (28 bytes of HBM per k-mer in flight)
-    uint64_t budget = c->kcount_budget;
-    if (budget > 0x7FFF0000ull) budget = 0x7FFF0000ull;               // rocPRIM item counts are 32-bit
     // this rank's bins: consecutive, balanced by their word counts (every rank derives the same split from the same histogram)
     uint32_t bin_lo = 0, bin_hi = kCountBins;
     if (NR > 1) {
@@ -987,6 +1035,8 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     }
     std::vector<uint32_t> pass_lo, pass_hi;
     std::vector<uint64_t> pass_n;
+    if (one_pass_all) { pass_lo.push_back(0); pass_hi.push_back(kCountBins); pass_n.push_back(ntot); }
+    else
     for (uint32_t b = bin_lo; b < bin_hi;) {
         uint64_t n = hist[b];
         if (n > 0x7FFF0000ull) return fail(c, BELLA_ERR_NOMEM, "k-mer counting: one bin of canonical k-mers holds %llu words", (unsigned long long)n);
@@ -1007,14 +1057,53 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
         if (!single) HIPCHK(c, hipMemsetAsync(c->kc_cursor.p, 0, 8, c->stream));
         k_emit_codes<<<rgrid, kBlock, 0, c->stream>>>(ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), ptr<uint32_t>(c->kc_nk),
                                                       ptr<uint64_t>(c->kc_koff), nr, k, mode, pass_lo[p], pass_hi[p], d_sel, ptr<uint64_t>(c->kc_keys),
-                                                      single ? nullptr : (unsigned long long*)c->kc_cursor.p);
+                                                      single ? nullptr : (unsigned long long*)c->kc_cursor.p, pb);
         KCHK(c);
         hipcub::DoubleBuffer<uint64_t> db(ptr<uint64_t>(c->kc_keys), ptr<uint64_t>(c->kc_alt));
         size_t tb = 0;
-        HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, db, (int)np, 0, 2 * (int)k, c->stream));
+        HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, db, (int)np, (int)pb, (int)pb + 2 * (int)k, c->stream));
         ENSURE(c, c->cubtmp, tb);
-        HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(c->cubtmp.p, tb, db, (int)np, 0, 2 * (int)k, c->stream));
+        HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(c->cubtmp.p, tb, db, (int)np, (int)pb, (int)pb + 2 * (int)k, c->stream));
         uint64_t* sorted = db.Current();
+        if (fast) {
+            // runs of equal words -> reliable flags -> their scan = the ids of this pass -> every reliable word's id to its position
+            uint8_t* flag8 = ptr<uint8_t>(c->kc_flag);
+            uint32_t* slot = ptr<uint32_t>(c->kc_slot);
+            const unsigned nfb = nblk(np + 1, kRunFlagsPerBlock);
+            uint32_t* heads = ptr<uint32_t>(c->kc_runlen);           // (one count per block of 4,096 words; 4 (np + 1) bytes are there)
+            k_run_flags<<<nfb, 256, 0, c->stream>>>(sorted, np, pb, lower, upper, mode != 0, flag8, heads);
+            KCHK(c);
+            {
+                hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> hit(heads, CastU64());
+                size_t tb4 = 0;
+                HIPCHK(c, hipcub::DeviceReduce::Sum(nullptr, tb4, hit, ptr<uint64_t>(c->kc_cursor), (int)nfb, c->stream));
+                ENSURE(c, c->cubtmp, tb4);
+                HIPCHK(c, hipcub::DeviceReduce::Sum(c->cubtmp.p, tb4, hit, ptr<uint64_t>(c->kc_cursor), (int)nfb, c->stream));
+            }
+            {
+                hipcub::TransformInputIterator<uint32_t, CastU8, const uint8_t*> it(flag8, CastU8());
+                size_t tb3 = 0;
+                HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, it, slot, (int)(np + 1), c->stream));
+                ENSURE(c, c->cubtmp, tb3);
+                HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cubtmp.p, tb3, it, slot, (int)(np + 1), c->stream));
+            }
+            uint32_t nrel = 0;
+            uint64_t nruns = 0;
+            HIPCHK(c, hipMemcpyAsync(&nrel, slot + np, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&nruns, c->kc_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (nk_total + nrel >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "more than 2^32 reliable k-mers");
+            rc = grow_keep(c, c->kc_dcode, 8 * (nk_total + nrel), 8 * nk_total);
+            if (rc) return rc;
+            rc = grow_keep(c, c->kc_dcount, 2 * (nk_total + nrel), 2 * nk_total);
+            if (rc) return rc;
+            k_run_ids<<<nblk(np), 256, 0, c->stream>>>(sorted, np, pb, lower, upper, mode != 0, slot, (uint32_t)nk_total, 0ull, ntot, ptr<uint32_t>(c->kc_ids),
+                                                       ptr<uint64_t>(c->kc_dcode) + nk_total, ptr<uint16_t>(c->kc_dcount) + nk_total);
+            KCHK(c);
+            nk_total += nrel;
+            ndistinct += nruns;
+            continue;
+        }
         uint64_t* run_code = sorted == ptr<uint64_t>(c->kc_keys) ? ptr<uint64_t>(c->kc_alt) : ptr<uint64_t>(c->kc_keys);
         size_t tb2 = 0;
         HIPCHK(c, hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, sorted, run_code, ptr<uint32_t>(c->kc_runlen),
@@ -1101,6 +1190,18 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
         nk_total = off[NR];
         ndistinct = nd_all;
     }
+    uint32_t* ids_rel = nullptr;
+    const unsigned bgrid = brows < 16384u ? (brows ? brows : 1u) : 16384u;
+    if (fast) {
+        // the ids are where they belong already (k_run_ids): count the tuples per read
+        release(c->kc_keys);
+        ids_rel = ptr<uint32_t>(c->kc_ids);                           // (indexed by the absolute position koff[r] + j, all reads)
+        if (brows) {
+            k_count_found<<<nblk(brows, kWaves), kBlock, 0, c->stream>>>(ids_rel, ptr<uint32_t>(c->kc_nk) + bfirst, ptr<uint64_t>(c->kc_koff) + bfirst, brows,
+                                                                       ptr<uint32_t>(c->kc_found));
+            KCHK(c);
+        }
+    } else {
     // countsreliable: open addressing at load factor <= 1/2
     uint64_t slots = 1024;
     while (slots < 2 * nk_total) slots <<= 1;
@@ -1120,13 +1221,13 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const uint64_t nblockpos = kb[1] - kb[0];
     ENSURE(c, c->kc_keys, 4 * nblockpos);
-    uint32_t* ids_rel = ptr<uint32_t>(c->kc_keys) - kb[0];            // the kernels index ids with the absolute position koff[r] + j
+    ids_rel = ptr<uint32_t>(c->kc_keys) - kb[0];                      // the kernels index ids with the absolute position koff[r] + j
     const uint8_t* sel_rel = d_sel;
-    const unsigned bgrid = brows < 16384u ? (brows ? brows : 1u) : 16384u;
     k_lookup_ids<<<bgrid, kBlock, 0, c->stream>>>(ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff) + bfirst, ptr<uint32_t>(c->kc_nk) + bfirst,
                                                   ptr<uint64_t>(c->kc_koff) + bfirst, brows, k, ptr<uint64_t>(c->kc_hkey), ptr<uint32_t>(c->kc_hval),
                                                   slots - 1, sel_rel, ids_rel, ptr<uint32_t>(c->kc_found));
     KCHK(c);
+    }
     HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->kc_found) + brows, 0, 4, c->stream));
     rc = scan_u32_to_u64(c, ptr<uint32_t>(c->kc_found), ptr<uint64_t>(c->kc_tstart), (uint64_t)brows + 1);
     if (rc) return rc;
@@ -1144,7 +1245,7 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev[1]));
     c->tm.kcount_ms = ev_ms(c->ev[0], c->ev[1]);
-    release(c->kc_keys); release(c->kc_hkey); release(c->kc_hval); release(c->kc_sel);
+    release(c->kc_keys); release(c->kc_hkey); release(c->kc_hval); release(c->kc_sel); release(c->kc_ids);
     c->kc_ntuples = nt;
     c->kc_nkmers = (uint32_t)nk_total;
     c->kc_k = k;
@@ -1565,18 +1666,13 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (T >= 0x7FFF0000ull) return fail(c, BELLA_ERR_ROW_TOO_LARGE, "the columns with >= 65536 products hold %llu products together (limit 2^31)",
                                         (unsigned long long)T);
-    ENSURE(c, c->w_key, 8 * T); ENSURE(c, c->w_key2, 8 * T);
-    ENSURE(c, c->w_idx, 4 * T); ENSURE(c, c->w_idx2, 4 * T);
-    ENSURE(c, c->w_hv, 8 * T);
     ENSURE(c, c->w_plist, 8 * (T + 64)); ENSURE(c, c->w_scr, 2 * T);
-    ENSURE(c, c->w_rlen, 4 * (T + 1)); ENSURE(c, c->w_rstart, 4 * (T + 2)); ENSURE(c, c->w_rrank, 4 * T);
     ENSURE(c, c->w_segfirst, 4 * ((size_t)nw + 2));
     ENSURE(c, c->w_toff, 8 * ((size_t)nw + 2));
     WideArgs a{};
     a.cols = d_cols; a.nw = nw; a.woff = ptr<uint64_t>(c->w_off);
     a.Bptr = sa.Bptr; a.Bent = sa.Bent; a.Aent = sa.Aent; a.Aent2 = sa.Aent2; a.Aov = sa.Aov; a.Arow = sa.Arow; a.roff = sa.roff; a.packed = sa.packed; a.flopptr = sa.flopptr;
     a.k = sa.k; a.binSize = sa.binSize;
-    a.W_key = c->w_key.p; a.W_idx = ptr<uint32_t>(c->w_idx); a.W_rec = ptr<uint2>(c->w_hv);
     a.plist = ptr<uint2>(c->w_plist); a.plist_pad = T; a.sort_scratch = ptr<uint16_t>(c->w_scr);
     a.tmp_pairs = sa.tmp_pairs; a.tmp_ext = sa.tmp_ext; a.nnzC = sa.nnzC; a.status = sa.ctl + kCtlStatus;
     int rbits = 1;
@@ -1588,9 +1684,24 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     a.R_first = nullptr;
     uint32_t np = 0;
     bool grouped = false;
-    // wide columns with few partners (HiFi-like input): group in LDS, two streaming passes over the row lists (wide.hpp) -- unless a
-    // column's partners do not fit the table, the lane-order self-test failed, or debug bit 12 asks for the sort-based path (tests)
-    if (c->have_rowlists && c->lane_order_ok && !(c->debug & 4096u)) {
+    // wide columns with few partners (HiFi-like input): group in LDS, two streaming passes over the columns' products (wide.hpp) --
+    // unless a column's partners do not fit the table, the lane-order self-test failed, or debug bit 12 asks for the sort-based path
+    // (tests).  The products are read from the row lists; a layout without them (the default) expands the BATCH's columns into a
+    // temporary list first (10 bytes per product of the batch, k_layout_rowlists on the batch's columns).
+    bool lists = c->have_rowlists;
+    if (!lists && c->lane_order_ok && !(c->debug & 4096u) && c->nreads <= (1u << 30)) {
+        if (!ensure_bytes(c, c->w_aent2, 8 * T + 64) && !ensure_bytes(c, c->w_aov, 2 * T + 64)) {
+            k_layout_rowlists<<<nw < 4096u ? nw : 4096u, kRowListBlock, 0, c->stream>>>(sa.Bptr, sa.Bent, sa.Aent, ptr<uint64_t>(c->w_off), sa.roff, d_cols, nw,
+                                                                                        ptr<uint2>(c->w_aent2), ptr<uint16_t>(c->w_aov));
+            KCHK(c);
+            a.Aent2 = ptr<uint2>(c->w_aent2); a.Aov = ptr<uint16_t>(c->w_aov); a.Arow = nullptr;
+            lists = true;
+        } else {
+            c->err.clear();                                        // (no room: the sort-based path expands for itself)
+            release(c->w_aent2); release(c->w_aov);
+        }
+    }
+    if (lists && c->lane_order_ok && !(c->debug & 4096u)) {
         ENSURE(c, c->w_gtab, sizeof(uint4) * 2 * (size_t)nw * kWideGroupSlots);
         ENSURE(c, c->w_gcount, 4 * ((size_t)nw + 4));
         ENSURE(c, c->w_gbase, 4 * ((size_t)nw + 4));
@@ -1622,6 +1733,12 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
         }
     }
     if (!grouped) {
+        // the sort-based path: 38 bytes per product of the batch in flight (only allocated when this path runs)
+        ENSURE(c, c->w_key, 8 * T); ENSURE(c, c->w_key2, 8 * T);
+        ENSURE(c, c->w_idx, 4 * T); ENSURE(c, c->w_idx2, 4 * T);
+        ENSURE(c, c->w_hv, 8 * T);
+        ENSURE(c, c->w_rlen, 4 * (T + 1)); ENSURE(c, c->w_rstart, 4 * (T + 2)); ENSURE(c, c->w_rrank, 4 * T);
+        a.W_key = c->w_key.p; a.W_idx = ptr<uint32_t>(c->w_idx); a.W_rec = ptr<uint2>(c->w_hv);
         k_wide_expand<<<nw < 2048u ? nw : 2048u, kWideExpandBlock, 0, c->stream>>>(a);
         KCHK(c);
         // sort by (column, partner read) over the meaningful bits, run-length encode into pairs; u32 keys when they fit
@@ -2307,10 +2424,10 @@ int bella_hip_get_memory(bella_ctx* c, bella_memory* m) {
     m->pass_bytes = sum({&c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC, &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
                          &c->cubtmp, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->orderlist, &c->order_ws, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx,
                          &c->w_idx2, &c->w_hv, &c->w_ovfl, &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_redo, &c->w_segfirst, &c->w_toff, &c->w_table,
-                         &c->w_nruns, &c->w_desc, &c->w_gtab, &c->w_gcount, &c->w_gbase, &c->w_rfirst});
+                         &c->w_nruns, &c->w_desc, &c->w_gtab, &c->w_gcount, &c->w_gbase, &c->w_rfirst, &c->w_aent2, &c->w_aov});
     m->other_bytes = sum({&c->t_kmer, &c->t_read, &c->t_pos, &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->asm_cls, &c->lk_key, &c->lk_key2, &c->lk_val,
                           &c->lk_val2, &c->w, &c->wscan, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen, &c->kc_flag, &c->kc_slot, &c->kc_nruns,
-                          &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->alns,
+                          &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->kc_ids, &c->alns,
                           &c->seeds, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch, &c->status, &c->comm_meta});
     m->owned_nnz = c->have_matrix ? c->owned_nnz : 0;
     return 0;

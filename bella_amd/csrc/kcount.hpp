@@ -135,9 +135,11 @@ __global__ __launch_bounds__(kBlock) void k_code_hist(const uint32_t* packed, co
 
 // the canonical words of the bins [b0, b1) of one pass.  Single pass (cursor == nullptr): word j of read r goes to koff[r] + j.
 // Otherwise the order is irrelevant (the words are sorted next): a workgroup reserves room for 1024 positions at a time.
+// pb > 0: the word leaves as (word << pb) | global position index (koff[r] + j): the sort then runs on the word's bits only and every
+// sorted word still knows where it came from -- the reliable ones hand their id straight to their position, no dictionary look-up.
 __global__ __launch_bounds__(kBlock) void k_emit_codes(const uint32_t* packed, const uint64_t* roff, const uint32_t* nk,
                                                        const uint64_t* koff, uint32_t nreads, uint32_t k, uint32_t mode, uint32_t b0,
-                                                       uint32_t b1, const uint8_t* sel, uint64_t* out, unsigned long long* cursor) {
+                                                       uint32_t b1, const uint8_t* sel, uint64_t* out, unsigned long long* cursor, uint32_t pb) {
     __shared__ uint32_t scr[kWaves];
     __shared__ unsigned long long s_base;
     __shared__ uint64_t tab[kSmerCount];
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_codes(const uint32_t* packed, c
         const uint64_t g0 = roff[r], o = koff[r];
         const uint32_t n = nk[r];
         if (!cursor) {
-            for (uint32_t j = threadIdx.x; j < n; j += kBlock) out[o + j] = canonical_word(packed, g0 + j, k);
+            for (uint32_t j = threadIdx.x; j < n; j += kBlock) out[o + j] = (canonical_word(packed, g0 + j, k) << pb) | (pb ? o + j : 0ull);
             continue;
         }
         for (uint32_t base = 0; base < n; base += 4 * kBlock) {
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_codes(const uint32_t* packed, c
             __syncthreads();
             uint64_t wo = s_base + ex;
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) if (take & (1u << u)) out[wo++] = w[u];
+            for (uint32_t u = 0; u < 4; ++u) if (take & (1u << u)) out[wo++] = (w[u] << pb) | (pb ? o + base + u * kBlock + threadIdx.x : 0ull);
             __syncthreads();
         }
     }
@@ -191,6 +193,96 @@ __global__ void k_write_dict(const uint64_t* run_code, const uint32_t* run_len, 
     if (i >= nruns || !flag[i]) return;
     dict_code[slot[i]] = run_code[i];
     dict_count[slot[i]] = (uint16_t)count16(run_len[i], saturate);
+}
+
+// ---- the sorted words with their positions in the low pb bits (k_emit_codes, pb > 0) ------------------------------------------------
+// first / one-past-last place of the run of equal WORDS around x (reliable runs are short; long ones by bisection)
+__device__ __forceinline__ void word_run_bounds(const uint64_t* s, uint64_t n, uint64_t x, uint32_t pb, uint64_t& lo, uint64_t& hi) {
+    const uint64_t w = s[x] >> pb;
+    uint64_t a = x;
+    uint32_t j = 0;
+    while (a > 0 && j < 16 && (s[a - 1] >> pb) == w) { --a; ++j; }
+    if (j == 16 && a > 0 && (s[a - 1] >> pb) == w) {
+        uint64_t l = 0, h = a;
+        while (l < h) { const uint64_t m = (l + h) >> 1; if ((s[m] >> pb) < w) l = m + 1; else h = m; }
+        a = l;
+    }
+    uint64_t b = x + 1;
+    j = 0;
+    while (b < n && j < 16 && (s[b] >> pb) == w) { ++b; ++j; }
+    if (j == 16 && b < n && (s[b] >> pb) == w) {
+        uint64_t l = b, h = n;
+        while (l < h) { const uint64_t m = (l + h) >> 1; if ((s[m] >> pb) <= w) l = m + 1; else h = m; }
+        b = l;
+    }
+    lo = a; hi = b;
+}
+// flag[x] = 1 where a RELIABLE run starts (their exclusive scan numbers the dictionary); heads[block] = runs that start in the
+// block's 4,096 words (their sum = the distinct words; one number per block, no atomics on a shared counter)
+constexpr uint32_t kRunFlagsPerBlock = 4096;
+__global__ __launch_bounds__(256) void k_run_flags(const uint64_t* s, uint64_t n, uint32_t pb, uint32_t lower, uint32_t upper, uint32_t saturate,
+                                                   uint8_t* flag, uint32_t* heads) {
+    __shared__ uint32_t s_heads;
+    if (threadIdx.x == 0) s_heads = 0;
+    __syncthreads();
+    uint32_t head = 0;
+    const uint64_t x0 = (uint64_t)blockIdx.x * kRunFlagsPerBlock;
+#pragma unroll 4
+    for (uint32_t u = 0; u < kRunFlagsPerBlock / 256; ++u) {
+        const uint64_t x = x0 + u * 256 + threadIdx.x;
+        if (x > n) break;                                                      // (flag[n] = 0: the scan's last element)
+        uint32_t f = 0;
+        if (x < n) {
+            const uint64_t w = s[x] >> pb;
+            if (x == 0 || (s[x - 1] >> pb) != w) {
+                head++;
+                if (x + 1 < n && (s[x + 1] >> pb) == w) {                      // (a singleton is never reliable: lower >= 2)
+                    uint64_t lo, hi;
+                    word_run_bounds(s, n, x, pb, lo, hi);
+                    const uint32_t c = count16((uint32_t)(hi - lo), saturate);
+                    f = (c >= lower && c <= upper) ? 1u : 0u;
+                }
+            }
+        }
+        flag[x] = (uint8_t)f;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) head += __shfl_xor(head, d, 64);
+    if (lane_id() == 0 && head) atomicAdd(&s_heads, head);
+    __syncthreads();
+    if (threadIdx.x == 0) heads[blockIdx.x] = s_heads;
+}
+// every word of a reliable run: ids[its position] = the run's id; the run's first word also writes the dictionary entry.
+// slot[x] = reliable runs before x (the scan of k_run_flags' flags); pos_lo / pos_hi: the positions ids[] covers
+__global__ __launch_bounds__(256) void k_run_ids(const uint64_t* s, uint64_t n, uint32_t pb, uint32_t lower, uint32_t upper, uint32_t saturate,
+                                                 const uint32_t* slot, uint32_t id_base, uint64_t pos_lo, uint64_t pos_hi, uint32_t* ids,
+                                                 uint64_t* dict_code, uint16_t* dict_count) {
+    const uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= n) return;
+    const uint64_t v = s[x];
+    // (a singleton -- most words of an error-rich read set -- needs no bounds: lower >= 2)
+    const bool same_l = x > 0 && (s[x - 1] >> pb) == (v >> pb), same_r = x + 1 < n && (s[x + 1] >> pb) == (v >> pb);
+    if (!same_l && !same_r) return;
+    uint64_t lo, hi;
+    word_run_bounds(s, n, x, pb, lo, hi);
+    const uint32_t c = count16((uint32_t)(hi - lo), saturate);
+    if (c < lower || c > upper) return;
+    const uint32_t local = slot[lo];
+    const uint64_t gp = v & ((1ull << pb) - 1ull);
+    if (gp >= pos_lo && gp < pos_hi) ids[gp - pos_lo] = id_base + local;
+    if (x == lo) { dict_code[local] = v >> pb; dict_count[local] = (uint16_t)c; }
+}
+// tuples per read from the ids of its positions (what k_lookup_ids counts on the look-up path)
+__global__ __launch_bounds__(kBlock) void k_count_found(const uint32_t* ids, const uint32_t* nk, const uint64_t* koff, uint32_t nreads, uint32_t* found_per_read) {
+    const uint32_t r = blockIdx.x * kWaves + wave_id();
+    if (r >= nreads) return;
+    const uint64_t o = koff[r];
+    const uint32_t n = nk[r];
+    uint32_t mine = 0;
+    for (uint32_t j = lane_id(); j < n; j += 64) mine += ids[o + j] != 0xFFFFFFFFu;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if (lane_id() == 0) found_per_read[r] = mine;
 }
 
 // countsreliable (a CuckooDict in the reference, main.cpp:410 `find`): open addressing over the dictionary, value = id

@@ -27,7 +27,7 @@ struct WideArgs {
     const uint2* Aent;
     const uint2* Aent2;          // ready-made products (assemble.hpp: k_layout_rowlists; nullptr: expand from B' x A')
     const uint16_t* Aov;
-    const uint64_t* Arow;
+    const uint64_t* Arow;        // nullptr: the lists are the batch's own (column cols[s] starts at woff[s]; bella_hip.hip: run_wide_batch)
     const uint64_t* roff;
     const uint32_t* packed;
     const uint64_t* flopptr;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
         const uint32_t b0 = a.Bptr[i], n = a.Bptr[i + 1] - b0;
         const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
         const uint64_t o = a.woff[s];
-        const uint64_t arow = a.Aent2 ? a.Arow[i] : 0ull;
+        const uint64_t arow = a.Aent2 ? (a.Arow ? a.Arow[i] : o) : 0ull;
         if (a.Aent2) {                                          // ready-made products: a stream copy into the sort's input
             const uint64_t Fc = a.woff[s + 1] - o;
             for (uint64_t q = threadIdx.x; q < Fc; q += kWideExpandBlock) {
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kWideGroup1Block) void k_wide_group1(WideArgs a) {
     const uint32_t tid = threadIdx.x;
     for (uint32_t s = blockIdx.x; s < a.nw; s += gridDim.x) {
         const uint32_t i = a.cols[s];
-        const uint64_t F = a.woff[s + 1] - a.woff[s], arow = a.Arow[i];
+        const uint64_t F = a.woff[s + 1] - a.woff[s], arow = a.Arow ? a.Arow[i] : a.woff[s];
         const uint32_t RB = wide_group_range(F);
         for (uint32_t h = tid; h < kWideGroupSlots; h += kWideGroup1Block) {
             s_key[h] = 0xFFFFFFFFu; s_first[h] = 0xFFFFFFFFu;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kWideGroup2Block) void k_wide_group2(WideArgs a) {
     const uint32_t tid = threadIdx.x;
     for (uint32_t s = blockIdx.x; s < a.nw; s += gridDim.x) {
         const uint32_t i = a.cols[s];
-        const uint64_t wo = a.woff[s], F = a.woff[s + 1] - wo, arow = a.Arow[i];
+        const uint64_t wo = a.woff[s], F = a.woff[s + 1] - wo, arow = a.Arow ? a.Arow[i] : wo;
         const uint32_t RB = wide_group_range(F);
         const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
         const uint4* G = a.gtab + (size_t)s * kWideGroupSlots;

@@ -41,16 +41,19 @@ __device__ __forceinline__ uint32_t rev2_32(uint32_t x) {      // reverse the or
     return __builtin_bswap32(x);
 }
 
-// One sequence as the extension reads it (element t = base g0 + dir*t, complemented if comp), through a register window.
+// One sequence as the extension reads it (element t = base g0 + dir*t, complemented if comp), through a 64-bit SHIFT REGISTER: bits 1:0
+// of `hs` are the next base the lane will read; consuming it is a funnel shift by two bits (by zero for the stream that does not move:
+// no select).  Up to 16 bases are consumed between two checkpoints (every 16 steps, all lanes at once); a checkpoint tops the register
+// up to 32 bases again from the block fetched one period ahead: no lane ever makes the wavefront wait on its own reload.
 struct SeqWin {
     const uint32_t* packed;
     int64_t g0;
     int32_t dir;
     uint32_t comp;       // 0 or 0xFFFFFFFF (complement = bitwise not of the 2-bit codes)
     uint32_t len;
-    uint32_t wp;         // stream index of the first base in the window
-    uint64_t x0, x1;     // bases [wp, wp+32), [wp+32, wp+64), base i at bits 2(i%32)
-    uint32_t nw;         // prefetched block [wp+64, wp+80)
+    uint32_t tp;         // stream index the register held at bits 1:0 at the last checkpoint
+    uint32_t lo, hi;     // bases [t, t + 32): base t + i at bits 2i of hi:lo
+    uint32_t nw;         // prefetched block [tp + 32, tp + 48)
 
     // 16 consecutive stream elements starting at t0, element j at bits 2j
     __device__ __forceinline__ uint32_t block16(uint32_t t0) const {
@@ -68,25 +71,33 @@ struct SeqWin {
         return v ^ comp;
     }
     __device__ __forceinline__ void init(uint32_t t0) {
-        wp = t0;
-        x0 = (uint64_t)block16(t0) | ((uint64_t)block16(t0 + 16) << 32);
-        x1 = (uint64_t)block16(t0 + 32) | ((uint64_t)block16(t0 + 48) << 32);
-        nw = block16(t0 + 64);
+        tp = t0;
+        lo = block16(t0);
+        hi = block16(t0 + 16);
+        nw = block16(t0 + 32);
     }
-    // wave-uniform checkpoint (every 16 steps): t = next element this lane will read
+    // wave-uniform checkpoint (every 16 steps): t = next element this lane will read (t - tp <= 16 were consumed since the last one)
     __device__ __forceinline__ void checkpoint(uint32_t t) {
-        if (t - wp >= 16u) {
-            x0 = (x0 >> 32) | (x1 << 32);
-            x1 = (x1 >> 32) | ((uint64_t)nw << 32);
-            wp += 16;
-            nw = block16(wp + 64);
+        const uint32_t c = t - tp;                                 // 0 .. 16 bases to top up: they enter at bit 2 * (32 - c)
+        if (c) {
+            // the register holds 32 - c valid bases; the c new ones are the first c elements of nw
+            const uint64_t add = (uint64_t)nw << (2u * (32u - c));  // (c == 16: bits 32..63; smaller c: the top bits fall off, they are re-fetched)
+            lo |= (uint32_t)add;
+            hi |= (uint32_t)(add >> 32);
+            tp = t;
+            nw = block16(t + 32);
         }
     }
+    // the base at stream index t = the register's bits 1:0 (t must be the lane's current read position)
     __device__ __forceinline__ int code(uint32_t t) const {
-        if (t >= len) return t == len ? kCodeNul : kCodePad;
-        const uint32_t off = t - wp;
-        const uint64_t x = off < 32u ? x0 : x1;
-        return (int)((x >> ((off & 31u) * 2u)) & 3ull);
+        const int c = (int)(lo & 3u);
+        return t >= len ? (t == len ? kCodeNul : kCodePad) : c;
+    }
+    // consume one base if `take` (funnel shift by 2 or 0 bits)
+    __device__ __forceinline__ void advance(bool take) {
+        const uint32_t sh = take ? 2u : 0u;
+        lo = __builtin_amdgcn_alignbit(hi, lo, sh);
+        hi >>= sh;
     }
 };
 
@@ -150,22 +161,25 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
     V.init((uint32_t)kXLW);
     const s2 one = splat2(kXScale), mone = splat2(-kXScale), ninf = splat2(kXNinf * kXScale), top = splat2(kXTop), q1 = splat2(kQScale);
 
-// CLAMP = 0 leaves out the upper clamp of adds_epi8 (one v_pk_min_i16 per word): exact whenever no cell of antiDiag1 holds 127, which
-// the caller knows from the bounds it tracks (h1 below); antiDiag3 cells above CUTOFF = 102 are rebased away, so in practice always.
-#define BELLA_PSTEP(CLAMP)                                                                                          \
+// The upper clamp of adds_epi8 (127) is DEFERRED: the 16-bit add saturates at 32767 = 127 * 256 + 255, so a cell that would have been
+// clamped is exactly 0x7FFF -- the largest value there is -- and the arg-max key, which is computed anyway, shows it: a key above
+// 0x7F1F (127 << 8 | 31) means some cell overflowed, and only then are the sixteen v_pk_min_i16 of the clamp executed and the key taken
+// again (BELLA_PFIX).  Cells above CUTOFF = 102 are rebased away, so in practice never; exact on any input.
+#define BELLA_PSTEP()                                                                                               \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                 \
         const s2 xr = s2_of(u32_of(qh[i]) ^ u32_of(qv[i]));                       /* 0 iff the bases match, else >= 512 */ \
         const s2 mt = one - pmin(xr, q1);                                         /* +1 match, -1 mismatch (x 256) */    \
-        const s2 a1s = adds2(a1[i], mt);                                          /* adds_epi8 */                        \
-        const s2 a1f = (CLAMP) ? pmin(a1s, top) : a1s;                                                                \
+        const s2 a1s = adds2(a1[i], mt);                                          /* adds_epi8, upper clamp deferred */  \
         const s2 shv = shl_cell(a2[i], i < 15 ? a2[i < 15 ? i + 1 : 15] : ninf);  /* shiftLeft(antiDiag2) */            \
         const s2 a2f = adds2(pmax(shv, a2[i]), mone);                             /* lower clamp = NINF exactly */       \
-        a3[i] = pmax(a1f, a2f);                                                                                       \
+        a3[i] = pmax(a1s, a2f);                                                                                       \
     }                                                                                                                 \
     a3[15].y = (short)(kXNinf * kXScale);
-// the step with the clamp only where some lane of the wavefront may need it (h1 = upper bound of this lane's antiDiag1 cells)
-#define BELLA_PSTEP_AUTO()                                                                                          \
-    if (__builtin_amdgcn_ballot_w64(h1 >= 127) != 0ull) { BELLA_PSTEP(1) } else { BELLA_PSTEP(0) }
+#define BELLA_PFIX(key)                                                                                              \
+    if ((key) > 0x7F1F) {                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) a3[i] = pmin(a3[i], top);                                      \
+        BELLA_PKEY(key)                                                                                               \
+    }
 
 // arg-max key: value in the upper byte (the lower byte of a cell is zero), 31 - cell in the lower one: first maximum wins.
 // (the position goes in with an OR -- full rate -- not a packed add: the byte it lands in is zero)
@@ -176,13 +190,23 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
         keyout = imax_((int)kk.x, (int)kk.y);                                                                         \
     }
 
-#define BELLA_PREBASE()                                                                                              \
+// rebase (xavier.h:152-158): antiDiag2 / antiDiag3 -= min of cells 0..30, saturating.  With a minimum >= 0 (the usual case: the band
+// is full of real scores) nothing can saturate upwards, so the upper clamp is left out, and every cell that is not at the lower bound
+// moves by the same amount: the arg-max stays where it is and the key follows by subtraction (keyio -= mn << 8) -- no second arg-max.
+// A negative minimum (cells near NINF inside the logical width) takes the clamped form and the key is taken again.
+#define BELLA_PREBASE(keyio, want_key)                                                                               \
     {                                                                                                                 \
         s2 mn2 = a3[0];                                                                                               \
         _Pragma("unroll") for (int i = 1; i < 15; ++i) mn2 = pmin(mn2, a3[i]);                                        \
         const int mn = imin_(imin_((int)mn2.x, (int)mn2.y), (int)a3[15].x) >> 8; /* cells 0..30 (LOGICALWIDTH) */      \
         const s2 mnv = splat2(mn * kXScale);                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) { a2[i] = pmin(subs2(a2[i], mnv), top); a3[i] = pmin(subs2(a3[i], mnv), top); } \
+        if (mn >= 0) {                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) { a2[i] = subs2(a2[i], mnv); a3[i] = subs2(a3[i], mnv); }  \
+            keyio -= mn * kXScale;                                                                                    \
+        } else {                                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) { a2[i] = pmin(subs2(a2[i], mnv), top); a3[i] = pmin(subs2(a3[i], mnv), top); } \
+            if (want_key) { BELLA_PKEY(keyio) }                                                                       \
+        }                                                                                                             \
         off += mn;                                                                                                    \
     }
 
@@ -212,27 +236,21 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
     // ---- Phase 2 (xavier.h:105-183)
     int maxpos = 0;
     int endH = hoff, endV = voff;
-    // upper bounds (cell values) of this lane's antiDiag1 / antiDiag2: antiDiag1 of a step is the antiDiag2 of the step before, which is
-    // the antiDiag3 of the step before that (moves only shift cells); a rebase subtracts mn from antiDiag2 and antiDiag3
-    int h1 = DPmax, h2 = DPmax;
     bool first = true;
     uint32_t tick = 0;
     bool dropped = false;
     while (hoff < hl && voff < vl) {
         if ((tick & 15u) == 0u) { H.checkpoint((uint32_t)hoff); V.checkpoint((uint32_t)voff); }
         ++tick;
-        BELLA_PSTEP_AUTO()
+        BELLA_PSTEP()
         int key;
         BELLA_PKEY(key)
+        BELLA_PFIX(key)
         const int adb = key >> 8;
         const int curr = adb + off;
         if (curr < best - X) { dropped = true; break; }        // xavier.h:128-135: X-drop termination
-        h1 = h2; h2 = adb;                                      // (what the move below makes of antiDiag2 / antiDiag3)
         if (adb > kXCutoff) {
-            const int off0 = off;
-            BELLA_PREBASE()
-            BELLA_PKEY(key)
-            h1 = imin_(h1 - (off - off0), 127); h2 = imin_(h2 - (off - off0), 127);
+            BELLA_PREBASE(key, true)
         }
         if (curr > best) best = curr;
         if ((key >> 8) > 0) maxpos = 31 - (key & 31);
@@ -241,6 +259,7 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
         endH = hoff; endV = voff;
         const bool right = maxpos > kXMiddle;
         const int c = right ? H.code((uint32_t)hoff) : V.code((uint32_t)voff);
+        H.advance(right); V.advance(!right);
         hoff += right ? 1 : 0;
         voff += right ? 0 : 1;
         BELLA_PMOVE(right, c)
@@ -250,22 +269,21 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
     int dir = hoff >= hl ? 1 : 0;
     H.checkpoint((uint32_t)hoff); V.checkpoint((uint32_t)voff);      // 28 more steps: at most 14 per stream, inside the window
     for (int it = 0; it < kXLW - 3; ++it) {
-        BELLA_PSTEP_AUTO()
+        BELLA_PSTEP()
         int key;
         BELLA_PKEY(key)
+        BELLA_PFIX(key)
         const int adb = key >> 8;
         const int curr = adb + off;
         if (curr < best - X) break;
-        h1 = h2; h2 = adb;
         if (adb > kXCutoff) {
-            const int off0 = off;
-            BELLA_PREBASE()
-            h1 = imin_(h1 - (off - off0), 127); h2 = imin_(h2 - (off - off0), 127);
+            BELLA_PREBASE(key, false)
         }
         if (curr > best) best = curr;
         const int next = dir ^ 1;
         const bool right = next == 0;
         const int c = right ? H.code((uint32_t)hoff) : V.code((uint32_t)voff);
+        H.advance(right); V.advance(!right);
         hoff += right ? 1 : 0;
         voff += right ? 0 : 1;
         BELLA_PMOVE(right, c)
@@ -273,7 +291,7 @@ __device__ __forceinline__ void xavier_one_direction_packed(const SeqAcc& Hacc, 
     }
     r.best = best; r.endH = endH; r.endV = endV; r.steps = (hoff - kXLW) + (voff - kXLW);
 #undef BELLA_PSTEP
-#undef BELLA_PSTEP_AUTO
+#undef BELLA_PFIX
 #undef BELLA_PKEY
 #undef BELLA_PREBASE
 #undef BELLA_PMOVE
@@ -542,30 +560,40 @@ __global__ __launch_bounds__(kXdropBlock, BELLA_XSLICE_WAVES) void k_xdrop_slice
     const int X = a.xdrop;
     const s2 one = splat2(kXScale), mone = splat2(-kXScale), ninf = splat2(kXNinf * kXScale), top = splat2(kXTop), q1 = splat2(kQScale);
 
-#define BELLA_PSTEP(CLAMP)                                                                                          \
+#define BELLA_PSTEP()                                                                                               \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                 \
         const s2 xr = s2_of(u32_of(qh[i]) ^ u32_of(qv[i]));                                                           \
         const s2 mt = one - pmin(xr, q1);                                                                             \
-        const s2 a1s = adds2(a1[i], mt);                                                                              \
-        const s2 a1f = (CLAMP) ? pmin(a1s, top) : a1s;                                                                \
+        const s2 a1s = adds2(a1[i], mt);                          /* upper clamp deferred: see xavier_one_direction_packed */ \
         const s2 shv = shl_cell(a2[i], i < 15 ? a2[i < 15 ? i + 1 : 15] : ninf);                                      \
         const s2 a2f = adds2(pmax(shv, a2[i]), mone);                                                                 \
-        a3[i] = pmax(a1f, a2f);                                                                                       \
+        a3[i] = pmax(a1s, a2f);                                                                                       \
     }                                                                                                                 \
     a3[15].y = (short)(kXNinf * kXScale);
+#define BELLA_PFIX(key)                                                                                              \
+    if ((key) > 0x7F1F) {                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) a3[i] = pmin(a3[i], top);                                      \
+        BELLA_PKEY(key)                                                                                               \
+    }
 #define BELLA_PKEY(keyout)                                                                                           \
     {                                                                                                                 \
         s2 kk = s2_of(u32_of(a3[0]) | (31u | (30u << 16)));                                                           \
         _Pragma("unroll") for (int i = 1; i < 16; ++i) kk = pmax(kk, s2_of(u32_of(a3[i]) | ((uint32_t)(31 - 2 * i) | ((uint32_t)(30 - 2 * i) << 16)))); \
         keyout = imax_((int)kk.x, (int)kk.y);                                                                         \
     }
-#define BELLA_PREBASE()                                                                                              \
+#define BELLA_PREBASE(keyio, want_key)                                  /* see xavier_one_direction_packed */        \
     {                                                                                                                 \
         s2 mn2 = a3[0];                                                                                               \
         _Pragma("unroll") for (int i = 1; i < 15; ++i) mn2 = pmin(mn2, a3[i]);                                        \
         const int mn = imin_(imin_((int)mn2.x, (int)mn2.y), (int)a3[15].x) >> 8;                                      \
         const s2 mnv = splat2(mn * kXScale);                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) { a2[i] = pmin(subs2(a2[i], mnv), top); a3[i] = pmin(subs2(a3[i], mnv), top); } \
+        if (mn >= 0) {                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) { a2[i] = subs2(a2[i], mnv); a3[i] = subs2(a3[i], mnv); }  \
+            keyio -= mn * kXScale;                                                                                    \
+        } else {                                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) { a2[i] = pmin(subs2(a2[i], mnv), top); a3[i] = pmin(subs2(a3[i], mnv), top); } \
+            if (want_key) { BELLA_PKEY(keyio) }                                                                       \
+        }                                                                                                             \
         off += mn;                                                                                                    \
     }
 #define BELLA_PMOVE(right, c)                                                                                        \
@@ -594,9 +622,10 @@ __global__ __launch_bounds__(kXdropBlock, BELLA_XSLICE_WAVES) void k_xdrop_slice
     for (int step = 0; step < xa.steps; ++step) {
         if (!__ballot(active && !done)) break;                    // (wave-uniform)
         if ((step & 15) == 0) { H.checkpoint((uint32_t)hoff); V.checkpoint((uint32_t)voff); }
-        BELLA_PSTEP(1)                                           // (always with the upper clamp: two variants of the step do not fit 128 VGPRs)
+        BELLA_PSTEP()
         int key;
         BELLA_PKEY(key)
+        BELLA_PFIX(key)                                          // (the deferred upper clamp: sixteen more instructions only when a cell overflowed)
         const int adb = key >> 8;
         const int curr = adb + off;
         const bool live = active && !done;
@@ -608,8 +637,7 @@ __global__ __launch_bounds__(kXdropBlock, BELLA_XSLICE_WAVES) void k_xdrop_slice
         }
         if (live && !drop) {
             if (adb > kXCutoff) {
-                BELLA_PREBASE()
-                if (!mode4) BELLA_PKEY(key)
+                BELLA_PREBASE(key, !mode4)
             }
             if (curr > best) best = curr;
             bool right;
@@ -624,6 +652,7 @@ __global__ __launch_bounds__(kXdropBlock, BELLA_XSLICE_WAVES) void k_xdrop_slice
                 right = dir == 0;
             }
             const int c = right ? H.code((uint32_t)hoff) : V.code((uint32_t)voff);
+            H.advance(right); V.advance(!right);
             hoff += right ? 1 : 0;
             voff += right ? 0 : 1;
             BELLA_PMOVE(right, c)
@@ -636,6 +665,7 @@ __global__ __launch_bounds__(kXdropBlock, BELLA_XSLICE_WAVES) void k_xdrop_slice
         }
     }
 #undef BELLA_PSTEP
+#undef BELLA_PFIX
 #undef BELLA_PKEY
 #undef BELLA_PREBASE
 #undef BELLA_PMOVE

@@ -341,7 +341,9 @@ int bella_hip_get_memory(bella_ctx* ctx, bella_memory* m);
  * assembled) = tests: the lists of A' in order of first appearance in B' (default: k-mer order), no row lists; bit11 (same moment) =
  * tests: as if the row lists BELLA_TUNE_ROW_LISTS asks for did not fit in memory (the layout stands without them);
  * bit12 = tests: the columns above the LDS tiers are grouped by the radix sort also when the row lists would allow grouping in LDS;
- * bit13 = tests: the symbolic phase (bella_hip_count_pairs) keeps its bitmaps in global memory also when they fit in LDS */
+ * bit13 = tests: the symbolic phase (bella_hip_count_pairs) keeps its bitmaps in global memory also when they fit in LDS;
+ * bit14 = tests: k-mer counting looks every position up in a hash table over the dictionary (the path of syncmer mode, of k-mers too
+ * long to share a 64-bit sort key with their position, and of the distributed count) also where the sorted words carry their positions */
 int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
 /* Per-context tuning parameters (tests and A/B measurements; nothing here changes results).  what:
  *   BELLA_TUNE_LDS_TIERS      values = ascending product capacities of the row kernels' LDS tiers, each in [64, 11008] (n = 0: defaults)

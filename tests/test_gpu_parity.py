@@ -665,7 +665,8 @@ def test_baseline_config3_100k_read_set_parity(eng):
       * every column's product count and pair count (colptrC) against the oracle's symbolic phase (all 100k columns, host cores),
       * every record of a quarter of the columns (every fourth column and the 200 pair-richest) against the oracle's numeric phase,
       * size-independent properties of all ~50 M records,
-      * X-drop on ALL pairs, 20,000 of them (mostly chance pairs) against the oracle's scalar Xavier."""
+      * X-drop on ALL pairs, 200,000 of them (mostly chance pairs) against the oracle's scalar Xavier;
+      * the engine's tuples against the test kit's independent counter."""
     import time
     t0 = time.time()
     rs = synth.make_reads(100000, read_len=10000, coverage=30.0, err=0.15, seed=1)
@@ -673,6 +674,11 @@ def test_baseline_config3_100k_read_set_parity(eng):
     eng.set_reads(rs)
     nk, nt, _ = eng.count_kmers(17, 2, 8)
     tk, tr, tp = eng.get_tuples()
+    # the tuples the oracle is fed come from the engine's own counter: the test kit's independent (torch) counter must agree with
+    # it tuple for tuple at this size too (ids = ranks of the canonical k-mers)
+    t2 = synth.count_and_tuples(rs, 17, 2, 8, device="cuda:0")
+    assert nk == t2.nkmers and np.array_equal(tk, t2.kmer) and np.array_equal(tr, t2.read) and np.array_equal(tp, t2.pos)
+    del t2
     eng.assemble_counted()
     pars = BellaPars()
     n, flops = eng.overlap(pars)
@@ -703,13 +709,13 @@ def test_baseline_config3_100k_read_set_parity(eng):
     alns = eng.get_alignments()
     assert 0 < npass < n
     rng = np.random.default_rng(11)
-    pick = np.sort(rng.choice(n, size=20000, replace=False))
+    pick = np.sort(rng.choice(n, size=200000, replace=False))                        # 0.4 % of the pairs, mostly chance pairs
     global _XSEQS
     _XSEQS = seqs
     import multiprocessing as mp
-    jobs = [(int(pairs["rid"][i]), int(pairs["cid"][i]), int(pairs["seedH"][i]), int(pairs["seedV"][i])) for i in pick]
-    with mp.get_context("fork").Pool(min(64, os.cpu_count() or 1)) as pool:
-        res = pool.map(_xavier_job, jobs, chunksize=64)
+    jobs = list(zip(pairs["rid"][pick].tolist(), pairs["cid"][pick].tolist(), pairs["seedH"][pick].tolist(), pairs["seedV"][pick].tolist()))
+    with mp.get_context("fork").Pool(min(128, os.cpu_count() or 1)) as pool:
+        res = pool.map(_xavier_job, jobs, chunksize=256)
     bad = 0
     for i, e in zip(pick, res):
         al = alns[i]
@@ -720,6 +726,7 @@ def test_baseline_config3_100k_read_set_parity(eng):
 
 
 _XSEQS = None
+_BIG_SETS = {}
 
 
 def _xavier_job(job):
@@ -759,13 +766,22 @@ def test_count_kmers_matches_oracle_and_reference_dump(eng, golden):
 def test_count_kmers_parameter_sweep(eng, k, lower, upper):
     rs = synth.make_reads(70, read_len=900, coverage=12.0, err=0.1, seed=11)
     eng.set_reads(rs)
-    nk, nt, nd = eng.count_kmers(k, lower, upper)
     codes, counts, tk, tr, tp, ndist = O.count_kmers(rs.seqs(), k, lower, upper)
-    assert (nk, nt, nd) == (len(codes), len(tk), ndist)
-    dc, dn = eng.get_dictionary()
-    gk, gr, gp = eng.get_tuples()
-    assert np.array_equal(dc, codes) and np.array_equal(dn, counts)
-    assert np.array_equal(gk, tk) and np.array_equal(gr, tr) and np.array_equal(gp, tp)
+    # the sorted words carry their positions where word + position index fit 64 bits (all of these but k = 32); debug bit 14 takes the
+    # hash-table look-up path that the other cases use; one pass over all words, then several passes over the bins
+    for dbg, budget in ((0, 0), (16384, 0), (0, 9000), (16384, 9000)):
+        eng.set_debug(dbg)
+        eng.set_tuning("kcount_budget", budget)
+        try:
+            nk, nt, nd = eng.count_kmers(k, lower, upper)
+        finally:
+            eng.set_debug(0)
+            eng.set_tuning("kcount_budget")
+        assert (nk, nt, nd) == (len(codes), len(tk), ndist)
+        dc, dn = eng.get_dictionary()
+        gk, gr, gp = eng.get_tuples()
+        assert np.array_equal(dc, codes) and np.array_equal(dn, counts)
+        assert np.array_equal(gk, tk) and np.array_equal(gr, tr) and np.array_equal(gp, tp)
 
 
 @pytest.mark.parametrize("k,lower,upper", [(17, 2, 8), (6, 2, 60000), (11, 2, 30), (21, 2, 4), (32, 2, 8), (7, 3, 65535)])
@@ -795,9 +811,13 @@ def test_count_minimizers_parameter_sweep(eng, k, window, lower, upper):
     rs = synth.make_reads(60, read_len=1200, coverage=10.0, err=0.02, seed=29, mix=(1 / 3, 1 / 3, 1 / 3))
     eng.set_reads(rs)
     codes, counts, tk, tr, tp, ndist = O.count_kmers(rs.seqs(), k, lower, upper, False, window)
-    for budget in (0, 2000):
+    for budget, dbg in ((0, 0), (2000, 0), (0, 16384)):                # (debug bit 14: the look-up path instead of positions in the sort keys)
         eng.set_tuning("kcount_budget", budget)
-        nk, nt, nd = eng.count_kmers(k, lower, upper, False, window)
+        eng.set_debug(dbg)
+        try:
+            nk, nt, nd = eng.count_kmers(k, lower, upper, False, window)
+        finally:
+            eng.set_debug(0)
         assert (nk, nt, nd) == (len(codes), len(tk), ndist)
         dc, dn = eng.get_dictionary()
         gk, gr, gp = eng.get_tuples()
@@ -921,13 +941,13 @@ def test_file_to_file_pipeline_reproduces_reference_up_to_kmer_labels(eng, tmp_p
 # ---- columns with >= 65,536 products (wide.hpp) -----------------------------------------------------------------------------
 
 @pytest.mark.parametrize("budget,layout,passdbg,rowlists", [(0, 0, 0, 1), (300000, 0, 0, 1), (0, 1024, 0, 0), (300000, 0, 0, 0), (0, 0, 4096, 1), (300000, 0, 4096, 1),
-                                                             (0, 2048, 0, 1)])
+                                                             (0, 2048, 0, 1), (0, 0, 4096, 0)])
 def test_wide_columns_bit_exact(eng, budget, layout, passdbg, rowlists):
     """70 near-identical reads with -u 80: every k-mer is shared by all of them, column 0 has ~200k products (the row kernels
     index products with 16 bits); strands mixed, two reads carry a 700-base deletion plus a random tail (a second overlap bin)"""
     eng.set_tuning("wide_budget", budget)                            # 300000: several batches of wide columns
     eng.set_debug(layout)                                            # 1024: A' in order of first appearance; 2048: the row lists asked for "do not fit"
-    eng.set_tuning("row_lists", rowlists)                            # 1: grouping of the wide columns in LDS from the row lists; 0 (default): the sort-based path
+    eng.set_tuning("row_lists", rowlists)                            # 1: grouping of the wide columns in LDS from the row lists; 0 (default): from a list expanded per batch
     rng = np.random.default_rng(17)
     base = rng.integers(0, 4, size=3000, dtype=np.uint8)
     comp = (3 - base)[::-1]
@@ -1005,7 +1025,7 @@ def test_baseline_config4_hifi_10k_reads_parity(eng, upper):
     nk, nt, _ = eng.count_kmers(17, 2, upper, syncmer=True)
     tk, tr, tp = eng.get_tuples()
     eng.assemble_counted()
-    pars = BellaPars(errorRate=0.005, skipAlignment=True)
+    pars = BellaPars(errorRate=0.005)                                                # the full pipeline: SpGEMM + X-drop + the pass test
     n, flops = eng.overlap(pars)
     pairs, ext, colptrC = eng.get_pairs()
     assert n > 1000
@@ -1024,8 +1044,102 @@ def test_baseline_config4_hifi_10k_reads_parity(eng, upper):
     got_idx = np.concatenate([np.arange(int(colptrC[c]), int(colptrC[c + 1])) for c in sample])
     exp = np.concatenate([per_col[int(c)] for c in sample])
     check_pairs(pairs[got_idx], ext[got_idx], exp, rs.lengths, 17)
-    print("HiFi 10k reads -u %d: %d reliable syncmers, %d tuples, %d products, %d pairs, %d records compared"
-          % (upper, nk, nt, flops, n, len(exp)))
+    # configs[4] aligns: X-drop on all pairs (HiFi: true overlaps of up to 15 kb per direction), 6,000 of them against the oracle's scalar
+    # Xavier and PostAlignDecision (errorRate 0.005)
+    npass = eng.align_pairs(pars)
+    alns = eng.get_alignments()
+    assert 0 < npass <= n
+    pick = np.sort(np.random.default_rng(13).choice(n, size=min(6000, n), replace=False))
+    global _XSEQS
+    _XSEQS = seqs
+    import multiprocessing as mp
+    jobs = list(zip(pairs["rid"][pick].tolist(), pairs["cid"][pick].tolist(), pairs["seedH"][pick].tolist(), pairs["seedV"][pick].tolist()))
+    with mp.get_context("fork").Pool(min(128, os.cpu_count() or 1)) as pool:
+        res = pool.map(_xavier_job, jobs, chunksize=16)
+    phi = O.slope(0.005)
+    bad = 0
+    for i, e in zip(pick, res):
+        al = alns[i]
+        bad += (int(al["score"]), int(al["begH"]), int(al["endH"]), int(al["begV"]), int(al["endV"])) != e
+        ok, ov = O.post_align(e[0], e[3], e[4], e[1], e[2], int(rs.lengths[pairs["rid"][i]]), int(rs.lengths[pairs["cid"][i]]), phi)
+        bad += (int(al["passed"]), int(al["ov"])) != (int(ok), int(ov))
+    assert bad == 0, bad
+    print("HiFi 10k reads -u %d: %d reliable syncmers, %d tuples, %d products, %d pairs (%d pass), %d records and %d alignments compared"
+          % (upper, nk, nt, flops, n, npass, len(exp), len(pick)))
+
+
+@pytest.mark.parametrize("upper,stages", [(8, 1), (40, 4)])
+def test_baseline_config4_hifi_100k_reads(eng, upper, stages):
+    """BASELINE configs[4]'s regime at 100,000 HiFi reads (15 kb, 0.5 % error, 30x; a tenth of the configuration's 1M reads, one GPU),
+    syncmer selection, -u 8 and -u 40.  With -u 40 that is ~3e9 products: the expanding default layout and the path of the columns
+    above the LDS tiers at a size where they are the product, formed in four column stages as a -m budget would (the symbolic phase
+    alone gives the boundaries).  Every column's product and pair count against the symbolic phase of the engine AND of the oracle,
+    every record of > 2 % of the columns against the oracle's numeric phase, size-independent properties of all records, X-drop on a
+    stage's pairs with 3,000 of them against the oracle."""
+    import time
+    t0 = time.time()
+    if "hifi100k" not in _BIG_SETS:                                                  # (both parameter sets run on the same reads)
+        _BIG_SETS.clear()
+        r_ = synth.make_reads(100000, read_len=15000, coverage=30.0, err=0.005, seed=2, mix=(1 / 3, 1 / 3, 1 / 3))
+        _BIG_SETS["hifi100k"] = (r_, r_.seqs())
+    rs, seqs = _BIG_SETS["hifi100k"]
+    t1 = time.time()
+    eng.set_reads(rs)
+    nk, nt, _ = eng.count_kmers(17, 2, upper, syncmer=True)
+    tk, tr, tp = eng.get_tuples()
+    eng.assemble_counted()
+    pars = BellaPars(errorRate=0.005)
+    colS, nS, fS = eng.count_pairs(pars)                                             # estimateFLOP + estimateNNZ_Hash + prefixsum
+    bounds = [0] + [int(np.searchsorted(colS, np.uint64(b * int(nS) // stages), side="right")) - 1 for b in range(1, stages)] + [rs.nreads]
+    parts, exts, alns_last, n, flops = [], [], None, 0, 0
+    try:
+        for b in range(stages):
+            eng.set_column_range(bounds[b], bounds[b + 1] - bounds[b])
+            nb, fb = eng.overlap(pars)
+            p, e, cp = eng.get_pairs()
+            assert nb == int(colS[bounds[b + 1]] - colS[bounds[b]])
+            parts.append(p); exts.append(e); n += nb; flops += fb
+            if b == stages - 1:                                                          # the alignment stage on the last stage's pairs
+                npass = eng.align_pairs(pars)
+                alns_last = eng.get_alignments()
+                assert 0 < npass <= nb
+    finally:
+        eng.set_column_range(0, 0xFFFFFFFF)
+    t2 = time.time()
+    pairs, ext = np.concatenate(parts), np.concatenate(exts)
+    assert n == nS == len(pairs) and flops == fS and n > 10000
+    assert (pairs["rid"] > pairs["cid"]).all() and (np.diff(pairs["cid"].astype(np.int64)) >= 0).all()
+    key = pairs["cid"].astype(np.uint64) << np.uint64(32) | pairs["rid"].astype(np.uint64)
+    assert (np.diff(key) != 0).all() and len(np.unique(key)) == len(key)
+    del key
+    assert np.array_equal(np.bincount(pairs["cid"], minlength=rs.nreads), np.diff(colS.astype(np.int64)))
+    assert ((ext["nbins"] >= 1) & (ext["support"] >= 1)).all()
+    Bc, Br, Bv = O.build_B(rs.nreads, tk, tr, tp)
+    for a_, b_ in zip(eng.get_B(), (Bc, Br, Bv)):
+        assert np.array_equal(a_, b_)
+    per_row = np.diff(colS.astype(np.int64))
+    sample = np.unique(np.concatenate([np.arange(0, rs.nreads, 45), np.argsort(per_row)[-100:]])).astype(np.uint32)
+    assert len(sample) >= rs.nreads // 50
+    flop, nnzc, per_col = O.spgemm_parallel(seqs, nk, Bc, Br, Bv, sample, 17)
+    t3 = time.time()
+    assert flops == int(flop.astype(np.int64).sum())
+    assert np.array_equal(per_row, nnzc.astype(np.int64))
+    got_idx = np.concatenate([np.arange(int(colS[c]), int(colS[c + 1])) for c in sample])
+    exp = np.concatenate([per_col[int(c)] for c in sample])
+    check_pairs(pairs[got_idx], ext[got_idx], exp, rs.lengths, 17)
+    last = parts[-1]
+    pick = np.sort(np.random.default_rng(3).choice(len(last), size=min(3000, len(last)), replace=False))
+    global _XSEQS
+    _XSEQS = seqs
+    import multiprocessing as mp
+    jobs = list(zip(last["rid"][pick].tolist(), last["cid"][pick].tolist(), last["seedH"][pick].tolist(), last["seedV"][pick].tolist()))
+    with mp.get_context("fork").Pool(min(128, os.cpu_count() or 1)) as pool:
+        res = pool.map(_xavier_job, jobs, chunksize=16)
+    bad = sum((int(alns_last[i]["score"]), int(alns_last[i]["begH"]), int(alns_last[i]["endH"]), int(alns_last[i]["begV"]), int(alns_last[i]["endV"])) != e
+              for i, e in zip(pick, res))
+    assert bad == 0, bad
+    print("HiFi 100k reads -u %d: %d reliable syncmers, %d tuples, %d products, %d pairs in %d stages, %d records compared; reads %.0f s, engine %.0f s, oracle %.0f s, total %.0f s"
+          % (upper, nk, nt, flops, n, stages, len(exp), t1 - t0, t2 - t1, t3 - t2, time.time() - t0))
 
 
 @pytest.mark.parametrize("name,dbg", [("toy120", 32), ("toyrep90", 32), ("toyhifi50", 32), ("toysync60", 32), ("toyrep90", 32 | 64)])
@@ -1278,8 +1392,8 @@ def test_collectives_with_several_ranks_on_the_in_process_transport(bounds):
             assert np.array_equal(a, b)
         # per-column layout memory follows the partition: B' entries exactly for the owned columns, 10 bytes each (+ row pointers, + the
         # allocator's slack of 1/16 + 256 bytes per array); A' and the exchanged matrix are whole
-        owned = int(rowlen[r::nranks].sum())
-        assert mem.owned_nnz == owned and owned <= 1.3 * nnz / nranks
+        owned = int(rowlen[r::nranks].sum())                # (B' keeps the entries that have products: at most the owned rows' entries)
+        assert 0 < mem.owned_nnz <= owned and owned <= 1.3 * nnz / nranks
         assert mem.layout_B_bytes <= 1.3 * (10 * nnz / nranks) + 4 * (rs.nreads + 2) * 1.07 + 3 * 300
         assert mem.layout_A_bytes >= 8 * nnz and mem.matrix_bytes >= 6 * nnz and mem.rowlist_bytes == 0
         assert np.array_equal(whole[0], p1[0])
