@@ -101,7 +101,7 @@ struct bella_ctx {
     uint32_t kc_bfirst = 0, kc_brows = 0; // the read block the device-resident tuples cover (all reads unless counted distributed)
     Buf kc_nk, kc_koff, kc_hist, kc_keys, kc_alt, kc_runlen, kc_flag, kc_slot, kc_nruns, kc_dcode, kc_dcount, kc_hkey, kc_hval, kc_found,
         kc_tstart, kc_cursor, kc_sel, kc_ringo, kc_ringp, kc_ids;
-    Buf Bptr, Bk, Bpos, Bent, Bcnt, Aent, Aent2, Aov, Arow, Bloc, Bpk;
+    Buf Bptr, Bk, Bpos, Bent, Bcnt, Aent, Aent2, Aov, Arow, Bloc;
     bool have_rowlists = false;          // Aent2 / Arow hold the row lists of the current layout
     bool want_rowlists = false;          // BELLA_TUNE_ROW_LISTS: build them with the next layouts (when they fit)
     uint32_t part_first = 0, part_stride = 1;
@@ -257,7 +257,7 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
     return ms;
 }
 
-// the row pointers the passes index B' with: the packed rows of the context's own columns (build_layout)
+// the row pointers the passes index B' with: the rows of the context's own columns (build_layout; the other rows are empty)
 inline const uint32_t* layout_bptr(const bella_ctx* c) { return ptr<uint32_t>(c->Bloc); }
 
 // B (Bptr/Bk/Bpos on device) -> Bent / Aent   (see assemble.hpp): one stable radix sort of the entries by k-mer id (the runs are
@@ -285,7 +285,6 @@ int build_layout(bella_ctx* c) {
     uint64_t nown_nnz = nnz;
     c->layout_first = pf; c->layout_stride = ps;
     ENSURE(c, c->Bloc, 4 * ((size_t)c->nreads + 2));
-    ENSURE(c, c->Bpk, 4 * ((size_t)c->nreads + 2));
     if (ps > 1) {
         uint32_t* len = ptr<uint32_t>(c->w);
         k_layout_own_lengths<<<nblk((uint64_t)c->nreads + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), c->nreads, pf, ps, len);
@@ -300,7 +299,7 @@ int build_layout(bella_ctx* c) {
         HIPCHK(c, hipMemcpyAsync(c->Bloc.p, c->Bptr.p, 4 * ((size_t)c->nreads + 1), hipMemcpyDeviceToDevice, c->stream));
     }
     c->owned_nnz = 0;
-    const uint32_t* Bloc = ptr<uint32_t>(c->Bloc);                 // dense rows of the owned columns (every entry) until they are packed below
+    const uint32_t* Bloc = ptr<uint32_t>(c->Bloc);                 // the rows of the owned columns
     ENSURE(c, c->Bent, 8 * nown_nnz);
     if (nnz) {
         k_layout_prep<<<nblk(c->nreads, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos), c->nreads,
@@ -364,30 +363,13 @@ int build_layout(bella_ctx* c) {
             k_layout_place<<<nblk(nown_nnz), 256, 0, c->stream>>>(ek.Current(), ev.Current(), nown_nnz, ptr<uint2>(c->Bent));
             KCHK(c);
         }
-        {   // packed rows (assemble.hpp): only the entries with products stay, in their order; the row pointers become Bpk
-            uint32_t* nz = ptr<uint32_t>(c->wscan);                 // (free: k_layout_emit is done with it)
-            k_layout_nzcount<<<nblk((uint64_t)c->nreads + 1, kWaves), kBlock, 0, c->stream>>>(Bloc, ptr<uint2>(c->Bent), c->nreads, nz);
-            KCHK(c);
-            int rc = scan_u32(c, nz, ptr<uint32_t>(c->Bpk), (uint64_t)c->nreads + 1);
+        if (nown_nnz) {
+            int rc = ensure_bytes(c, c->Bcnt, 2 * nown_nnz);
             if (rc) return rc;
-            uint32_t n32 = 0;
-            HIPCHK(c, hipMemcpyAsync(&n32, ptr<uint32_t>(c->Bpk) + c->nreads, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            Buf packed_ent;
-            rc = ensure_bytes(c, packed_ent, 8 * (size_t)n32);
-            if (rc) return rc;
-            rc = ensure_bytes(c, c->Bcnt, 2 * (size_t)n32);
-            if (rc) { release(packed_ent); return rc; }
-            k_layout_pack<<<nblk(c->nreads ? c->nreads : 1, kWaves), kBlock, 0, c->stream>>>(Bloc, ptr<uint2>(c->Bent), ptr<uint32_t>(c->Bpk), c->nreads, ptr<uint2>(packed_ent),
-                                                                                     ptr<uint16_t>(c->Bcnt));
+            k_layout_bcnt<<<nblk(nown_nnz), 256, 0, c->stream>>>(ptr<uint2>(c->Bent), nown_nnz, ptr<uint16_t>(c->Bcnt));
             KCHK(c);
-            HIPCHK(c, hipStreamSynchronize(c->stream));              // (the dense rows are released next)
-            release(c->Bent);
-            c->Bent = packed_ent;
-            std::swap(c->Bloc, c->Bpk);
-            Bloc = ptr<uint32_t>(c->Bloc);
-            c->owned_nnz = n32;
         }
+        c->owned_nnz = nown_nnz;
         if (by_kmer && c->want_rowlists && c->nreads <= (1u << 30)) {
             // row lists (BELLA_TUNE_ROW_LISTS): products per owned row -> row starts -> the tails of the lists copied in product order.
             // Optional in every respect: if they do not fit next to what a pass needs, or an allocation fails, the layout stands without them.
@@ -427,7 +409,6 @@ int build_layout(bella_ctx* c) {
     }
     if (!c->have_rowlists) { release(c->Aent2); release(c->Aov); release(c->Arow); }
     if (!nnz) HIPCHK(c, hipMemsetAsync(c->Bloc.p, 0, 4 * ((size_t)c->nreads + 2), c->stream));
-    release(c->Bpk);
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     // pairs/products on a sample of (owned) columns -> key-table budget of the LDS tiers (see k_sample_pair_ratio)
     uint32_t ratio1024 = 1024;
@@ -550,7 +531,7 @@ void bella_hip_destroy(bella_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && c->api) { (void)c->api->CommDestroy(c->comm); c->comm = nullptr; }
     release(c->comm_meta);
-    Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Bcnt, &c->Aent, &c->Aent2, &c->Aov, &c->Arow, &c->Bloc, &c->Bpk, &c->t_kmer, &c->t_read, &c->t_pos,
+    Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Bcnt, &c->Aent, &c->Aent2, &c->Aov, &c->Arow, &c->Bloc, &c->t_kmer, &c->t_read, &c->t_pos,
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->asm_cls, &c->lk_key, &c->lk_key2, &c->lk_val, &c->lk_val2,
                   &c->w, &c->wscan, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC,
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,

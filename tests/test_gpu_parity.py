@@ -1392,8 +1392,8 @@ def test_collectives_with_several_ranks_on_the_in_process_transport(bounds):
             assert np.array_equal(a, b)
         # per-column layout memory follows the partition: B' entries exactly for the owned columns, 10 bytes each (+ row pointers, + the
         # allocator's slack of 1/16 + 256 bytes per array); A' and the exchanged matrix are whole
-        owned = int(rowlen[r::nranks].sum())                # (B' keeps the entries that have products: at most the owned rows' entries)
-        assert 0 < mem.owned_nnz <= owned and owned <= 1.3 * nnz / nranks
+        owned = int(rowlen[r::nranks].sum())
+        assert mem.owned_nnz == owned and owned <= 1.3 * nnz / nranks
         assert mem.layout_B_bytes <= 1.3 * (10 * nnz / nranks) + 4 * (rs.nreads + 2) * 1.07 + 3 * 300
         assert mem.layout_A_bytes >= 8 * nnz and mem.matrix_bytes >= 6 * nnz and mem.rowlist_bytes == 0
         assert np.array_equal(whole[0], p1[0])
