@@ -1047,30 +1047,27 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
         HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(c->cubtmp.p, tb, db, (int)np, (int)pb, (int)pb + 2 * (int)k, c->stream));
         uint64_t* sorted = db.Current();
         if (fast) {
-            // runs of equal words -> reliable flags -> their scan = the ids of this pass -> every reliable word's id to its position
-            uint8_t* flag8 = ptr<uint8_t>(c->kc_flag);
-            uint32_t* slot = ptr<uint32_t>(c->kc_slot);
-            const unsigned nfb = nblk(np + 1, kRunFlagsPerBlock);
-            uint32_t* heads = ptr<uint32_t>(c->kc_runlen);           // (one count per block of 4,096 words; 4 (np + 1) bytes are there)
-            k_run_flags<<<nfb, 256, 0, c->stream>>>(sorted, np, pb, lower, upper, mode != 0, flag8, heads);
+            // runs of equal words, tile by tile: reliable runs per tile -> scan over the tiles = the ids of this pass -> every reliable
+            // word's id to its position, the dictionary entries from the runs' first words (kcount.hpp)
+            const unsigned ntile = nblk(np, kRunTile);
+            uint32_t* tile_rel = ptr<uint32_t>(c->kc_runlen);       // (ntile + 1 each; 4 (np + 1) bytes are there)
+            uint32_t* tile_heads = ptr<uint32_t>(c->kc_flag);
+            uint32_t* tile_base = ptr<uint32_t>(c->kc_slot);
+            HIPCHK(c, hipMemsetAsync(tile_rel + ntile, 0, 4, c->stream));
+            k_run_count<<<ntile, kRunBlock, 0, c->stream>>>(sorted, np, pb, lower, upper, mode != 0, tile_rel, tile_heads);
             KCHK(c);
+            rc = scan_u32(c, tile_rel, tile_base, (uint64_t)ntile + 1);
+            if (rc) return rc;
             {
-                hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> hit(heads, CastU64());
+                hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> hit(tile_heads, CastU64());
                 size_t tb4 = 0;
-                HIPCHK(c, hipcub::DeviceReduce::Sum(nullptr, tb4, hit, ptr<uint64_t>(c->kc_cursor), (int)nfb, c->stream));
+                HIPCHK(c, hipcub::DeviceReduce::Sum(nullptr, tb4, hit, ptr<uint64_t>(c->kc_cursor), (int)ntile, c->stream));
                 ENSURE(c, c->cubtmp, tb4);
-                HIPCHK(c, hipcub::DeviceReduce::Sum(c->cubtmp.p, tb4, hit, ptr<uint64_t>(c->kc_cursor), (int)nfb, c->stream));
-            }
-            {
-                hipcub::TransformInputIterator<uint32_t, CastU8, const uint8_t*> it(flag8, CastU8());
-                size_t tb3 = 0;
-                HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, it, slot, (int)(np + 1), c->stream));
-                ENSURE(c, c->cubtmp, tb3);
-                HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cubtmp.p, tb3, it, slot, (int)(np + 1), c->stream));
+                HIPCHK(c, hipcub::DeviceReduce::Sum(c->cubtmp.p, tb4, hit, ptr<uint64_t>(c->kc_cursor), (int)ntile, c->stream));
             }
             uint32_t nrel = 0;
             uint64_t nruns = 0;
-            HIPCHK(c, hipMemcpyAsync(&nrel, slot + np, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&nrel, tile_base + ntile, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(&nruns, c->kc_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (nk_total + nrel >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "more than 2^32 reliable k-mers");
@@ -1078,8 +1075,8 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
             if (rc) return rc;
             rc = grow_keep(c, c->kc_dcount, 2 * (nk_total + nrel), 2 * nk_total);
             if (rc) return rc;
-            k_run_ids<<<nblk(np), 256, 0, c->stream>>>(sorted, np, pb, lower, upper, mode != 0, slot, (uint32_t)nk_total, 0ull, ntot, ptr<uint32_t>(c->kc_ids),
-                                                       ptr<uint64_t>(c->kc_dcode) + nk_total, ptr<uint16_t>(c->kc_dcount) + nk_total);
+            k_run_assign<<<ntile, kRunBlock, 0, c->stream>>>(sorted, np, pb, lower, upper, mode != 0, tile_base, (uint32_t)nk_total, 0ull, ntot, ptr<uint32_t>(c->kc_ids),
+                                                             ptr<uint64_t>(c->kc_dcode) + nk_total, ptr<uint16_t>(c->kc_dcount) + nk_total);
             KCHK(c);
             nk_total += nrel;
             ndistinct += nruns;

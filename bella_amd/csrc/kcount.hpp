@@ -196,82 +196,109 @@ __global__ void k_write_dict(const uint64_t* run_code, const uint32_t* run_len, 
 }
 
 // ---- the sorted words with their positions in the low pb bits (k_emit_codes, pb > 0) ------------------------------------------------
-// first / one-past-last place of the run of equal WORDS around x (reliable runs are short; long ones by bisection)
-__device__ __forceinline__ void word_run_bounds(const uint64_t* s, uint64_t n, uint64_t x, uint32_t pb, uint64_t& lo, uint64_t& hi) {
-    const uint64_t w = s[x] >> pb;
-    uint64_t a = x;
-    uint32_t j = 0;
-    while (a > 0 && j < 16 && (s[a - 1] >> pb) == w) { --a; ++j; }
-    if (j == 16 && a > 0 && (s[a - 1] >> pb) == w) {
-        uint64_t l = 0, h = a;
-        while (l < h) { const uint64_t m = (l + h) >> 1; if ((s[m] >> pb) < w) l = m + 1; else h = m; }
-        a = l;
-    }
-    uint64_t b = x + 1;
-    j = 0;
-    while (b < n && j < 16 && (s[b] >> pb) == w) { ++b; ++j; }
-    if (j == 16 && b < n && (s[b] >> pb) == w) {
-        uint64_t l = b, h = n;
-        while (l < h) { const uint64_t m = (l + h) >> 1; if ((s[m] >> pb) <= w) l = m + 1; else h = m; }
-        b = l;
-    }
-    lo = a; hi = b;
-}
-// flag[x] = 1 where a RELIABLE run starts (their exclusive scan numbers the dictionary); heads[block] = runs that start in the
-// block's 4,096 words (their sum = the distinct words; one number per block, no atomics on a shared counter)
-constexpr uint32_t kRunFlagsPerBlock = 4096;
-__global__ __launch_bounds__(256) void k_run_flags(const uint64_t* s, uint64_t n, uint32_t pb, uint32_t lower, uint32_t upper, uint32_t saturate,
-                                                   uint8_t* flag, uint32_t* heads) {
-    __shared__ uint32_t s_heads;
-    if (threadIdx.x == 0) s_heads = 0;
+// The runs of equal words, tile by tile (2,048 sorted words of a workgroup in LDS + 32 words of look-ahead): a run belongs to the tile
+// that holds its first word.  Two passes over the sorted words with a scan over the TILES in between -- no per-word flag or slot arrays:
+//   k_run_count   per tile: runs that start in it (-> distinct words) and reliable runs that start in it (-> ids of the tile's runs)
+//   k_run_assign  per tile: the same runs again; a reliable run's first word writes the dictionary entry and hands the id to the
+//                 position of every word of the run (reliable runs are at most `upper` words long)
+constexpr uint32_t kRunTile = 2048, kRunHalo = 32, kRunBlock = 256;
+struct RunTile {
+    uint64_t w[kRunTile + kRunHalo];       // the tile's words and the look-ahead
+    unsigned long long bm[kRunTile / 64];  // reliable run heads, one bit per word of the tile
+    uint32_t pre[kRunTile / 64 + 1];       // reliable heads before each group of 64 words
+    uint64_t prev;                         // the word before the tile (its WORD bits; ~0 for the first tile)
+};
+// loads the tile, finds the heads and the length of the runs that start in it; calls fn(u, e, len, count16) for every head (e = u * 256
+// + thread: place in the tile); returns the number of heads of this thread
+template <class Fn>
+__device__ __forceinline__ uint32_t run_tile_heads(RunTile& T, const uint64_t* s, uint64_t n, uint32_t pb, uint32_t saturate, Fn&& fn) {
+    const uint64_t x0 = (uint64_t)blockIdx.x * kRunTile;
+    const uint32_t have = (uint32_t)(n - x0 < kRunTile + kRunHalo ? n - x0 : kRunTile + kRunHalo);
+    for (uint32_t e = threadIdx.x; e < kRunTile + kRunHalo; e += kRunBlock) T.w[e] = e < have ? s[x0 + e] : ~0ull;
+    if (threadIdx.x == 0) T.prev = x0 ? s[x0 - 1] >> pb : ~0ull;
     __syncthreads();
-    uint32_t head = 0;
-    const uint64_t x0 = (uint64_t)blockIdx.x * kRunFlagsPerBlock;
-#pragma unroll 4
-    for (uint32_t u = 0; u < kRunFlagsPerBlock / 256; ++u) {
-        const uint64_t x = x0 + u * 256 + threadIdx.x;
-        if (x > n) break;                                                      // (flag[n] = 0: the scan's last element)
-        uint32_t f = 0;
-        if (x < n) {
-            const uint64_t w = s[x] >> pb;
-            if (x == 0 || (s[x - 1] >> pb) != w) {
-                head++;
-                if (x + 1 < n && (s[x + 1] >> pb) == w) {                      // (a singleton is never reliable: lower >= 2)
-                    uint64_t lo, hi;
-                    word_run_bounds(s, n, x, pb, lo, hi);
-                    const uint32_t c = count16((uint32_t)(hi - lo), saturate);
-                    f = (c >= lower && c <= upper) ? 1u : 0u;
-                }
-            }
-        }
-        flag[x] = (uint8_t)f;
-    }
+    const uint32_t nt = have < kRunTile ? have : kRunTile;      // words of the tile itself
+    uint32_t heads = 0;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) head += __shfl_xor(head, d, 64);
-    if (lane_id() == 0 && head) atomicAdd(&s_heads, head);
+    for (uint32_t u = 0; u < kRunTile / kRunBlock; ++u) {
+        const uint32_t e = u * kRunBlock + threadIdx.x;
+        if (e >= nt) continue;
+        const uint64_t w = T.w[e] >> pb;
+        const uint64_t before = e ? T.w[e - 1] >> pb : T.prev;
+        if (before == w && (e || x0)) continue;                   // not the first word of its run
+        heads++;
+        uint32_t len = 1;
+        while (e + len < have && (T.w[e + len] >> pb) == w) ++len;
+        uint64_t run = len;
+        if (e + len == have && x0 + have < n) {                   // the run leaves the look-ahead: its end by bisection in the sorted array
+            uint64_t l = x0 + have, h = n;
+            while (l < h) { const uint64_t m = (l + h) >> 1; if ((s[m] >> pb) <= w) l = m + 1; else h = m; }
+            run = l - (x0 + e);
+        }
+        fn(u, e, run, count16((uint32_t)(run > 0xFFFFFFFFull ? 0xFFFFFFFFull : run), saturate));
+    }
+    return heads;
+}
+__global__ __launch_bounds__(kRunBlock) void k_run_count(const uint64_t* s, uint64_t n, uint32_t pb, uint32_t lower, uint32_t upper, uint32_t saturate,
+                                                         uint32_t* tile_rel, uint32_t* tile_heads) {
+    __shared__ RunTile T;
+    __shared__ uint32_t s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    uint32_t rel = 0;
+    uint32_t heads = run_tile_heads(T, s, n, pb, saturate, [&](uint32_t, uint32_t, uint64_t, uint32_t c) { rel += (c >= lower && c <= upper) ? 1u : 0u; });
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { rel += __shfl_xor(rel, d, 64); heads += __shfl_xor(heads, d, 64); }
+    if (lane_id() == 0) { if (rel) atomicAdd(&s_cnt[0], rel); if (heads) atomicAdd(&s_cnt[1], heads); }
     __syncthreads();
-    if (threadIdx.x == 0) heads[blockIdx.x] = s_heads;
+    if (threadIdx.x == 0) { tile_rel[blockIdx.x] = s_cnt[0]; tile_heads[blockIdx.x] = s_cnt[1]; }
 }
-// every word of a reliable run: ids[its position] = the run's id; the run's first word also writes the dictionary entry.
-// slot[x] = reliable runs before x (the scan of k_run_flags' flags); pos_lo / pos_hi: the positions ids[] covers
-__global__ __launch_bounds__(256) void k_run_ids(const uint64_t* s, uint64_t n, uint32_t pb, uint32_t lower, uint32_t upper, uint32_t saturate,
-                                                 const uint32_t* slot, uint32_t id_base, uint64_t pos_lo, uint64_t pos_hi, uint32_t* ids,
-                                                 uint64_t* dict_code, uint16_t* dict_count) {
-    const uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (x >= n) return;
-    const uint64_t v = s[x];
-    // (a singleton -- most words of an error-rich read set -- needs no bounds: lower >= 2)
-    const bool same_l = x > 0 && (s[x - 1] >> pb) == (v >> pb), same_r = x + 1 < n && (s[x + 1] >> pb) == (v >> pb);
-    if (!same_l && !same_r) return;
-    uint64_t lo, hi;
-    word_run_bounds(s, n, x, pb, lo, hi);
-    const uint32_t c = count16((uint32_t)(hi - lo), saturate);
-    if (c < lower || c > upper) return;
-    const uint32_t local = slot[lo];
-    const uint64_t gp = v & ((1ull << pb) - 1ull);
-    if (gp >= pos_lo && gp < pos_hi) ids[gp - pos_lo] = id_base + local;
-    if (x == lo) { dict_code[local] = v >> pb; dict_count[local] = (uint16_t)c; }
+// tile_base[t] = reliable runs that start before tile t (exclusive scan of k_run_count's tile_rel); pos_lo / pos_hi: the positions ids[] covers
+__global__ __launch_bounds__(kRunBlock) void k_run_assign(const uint64_t* s, uint64_t n, uint32_t pb, uint32_t lower, uint32_t upper, uint32_t saturate,
+                                                          const uint32_t* tile_base, uint32_t id_base, uint64_t pos_lo, uint64_t pos_hi, uint32_t* ids,
+                                                          uint64_t* dict_code, uint16_t* dict_count) {
+    __shared__ RunTile T;
+    const uint64_t x0 = (uint64_t)blockIdx.x * kRunTile;
+    // pass 1 over the heads: which of them are reliable (one bit per word of the tile)
+    uint32_t myrel = 0;                                            // bit u: this thread's word of round u starts a reliable run
+    uint32_t mylen[kRunTile / kRunBlock];
+#pragma unroll
+    for (uint32_t u = 0; u < kRunTile / kRunBlock; ++u) mylen[u] = 0;
+    run_tile_heads(T, s, n, pb, saturate, [&](uint32_t u, uint32_t, uint64_t run, uint32_t c) {
+        if (c >= lower && c <= upper) { myrel |= 1u << u; mylen[u] = (uint32_t)(run > 0xFFFFFFFFull ? 0xFFFFFFFFull : run); }
+    });
+#pragma unroll
+    for (uint32_t u = 0; u < kRunTile / kRunBlock; ++u) {          // words u * 256 + w * 64 + lane: one ballot per group of 64 words
+        const unsigned long long m = __ballot((myrel >> u) & 1u);
+        if (lane_id() == 0) T.bm[u * (kRunBlock / 64) + wave_id()] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                                        // reliable heads before each group (32 groups: one wavefront)
+        const uint32_t c = threadIdx.x < kRunTile / 64 ? (uint32_t)__popcll(T.bm[threadIdx.x]) : 0u;
+        const uint32_t inc = wave_incl_scan(c);
+        if (threadIdx.x < kRunTile / 64) T.pre[threadIdx.x] = inc - c;
+    }
+    __syncthreads();
+    const uint32_t base = tile_base[blockIdx.x];
+    const uint64_t pmask = (1ull << pb) - 1ull;
+    const uint32_t have = (uint32_t)(n - x0 < kRunTile + kRunHalo ? n - x0 : kRunTile + kRunHalo);
+#pragma unroll
+    for (uint32_t u = 0; u < kRunTile / kRunBlock; ++u) {
+        if (!((myrel >> u) & 1u)) continue;
+        const uint32_t e = u * kRunBlock + threadIdx.x;
+        const uint32_t g = e / 64;
+        const uint32_t local = base + T.pre[g] + (uint32_t)__popcll(T.bm[g] & ((1ull << (e & 63u)) - 1ull));
+        const uint64_t w = T.w[e] >> pb;
+        const uint32_t len = mylen[u];
+        dict_code[local] = w;
+        dict_count[local] = (uint16_t)count16(len, saturate);
+        for (uint32_t m2 = 0; m2 < len; ++m2) {                    // (len <= upper unless the 16-bit count wrapped: then the run is long and this loop is too)
+            const uint64_t v = e + m2 < have ? T.w[e + m2] : s[x0 + e + m2];
+            const uint64_t gp = v & pmask;
+            if (gp >= pos_lo && gp < pos_hi) ids[gp - pos_lo] = id_base + local;
+        }
+    }
 }
+
 // tuples per read from the ids of its positions (what k_lookup_ids counts on the look-up path)
 __global__ __launch_bounds__(kBlock) void k_count_found(const uint32_t* ids, const uint32_t* nk, const uint64_t* koff, uint32_t nreads, uint32_t* found_per_read) {
     const uint32_t r = blockIdx.x * kWaves + wave_id();

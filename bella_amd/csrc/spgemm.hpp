@@ -186,7 +186,13 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 
     // the B' entries of the first round travel while the tables are initialised (their load is the second of two dependent HBM
     // round trips at the head of every column: descriptor, then entries)
-    constexpr uint32_t RMAX = kRowBlock >= 1024 ? 4 : 8;      // B' entries per thread and round (registers: 1024-thread workgroups run at 64 VGPRs)
+#ifndef BELLA_RMAX_SMALL
+#define BELLA_RMAX_SMALL 8
+#endif
+    // B' entries per thread and round (registers: 1024-thread workgroups run at 64 VGPRs).  A read of the PacBio-like sets has ~2,050
+    // entries: a workgroup of 256 threads covers them in one round with ten entries per thread and needs a second round -- one more
+    // dependent trip to HBM, one more scan -- with eight
+    constexpr uint32_t RMAX = kRowBlock >= 1024 ? 4 : kRowBlock >= 512 ? 8 : BELLA_RMAX_SMALL;
     uint2 be0[RMAX];
     if (!RL) {
         const uint32_t nn = n < RMAX * kRowBlock ? n : RMAX * kRowBlock;
