@@ -237,7 +237,7 @@ class Engine:
         self._chk(self.lib.bella_hip_set_debug(self.h, flags))
 
     # ---- HashSpGEMM ----
-    TUNE = {"lds_tiers": 0, "kcount_budget": 1, "wide_budget": 2, "xdrop_variant": 3, "row_lists": 4}
+    TUNE = {"lds_tiers": 0, "kcount_budget": 1, "wide_budget": 2, "xdrop_variant": 3, "row_lists": 4, "xdrop_class_min": 5}
 
     def set_tuning(self, what: str, *values):
         """bella_hip_set_tuning: per-context tuning parameters (tests, A/B measurements); no values = the default"""

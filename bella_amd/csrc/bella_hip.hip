@@ -153,6 +153,7 @@ struct bella_ctx {
     bool tiers_from_env = false;         // custom tier table (bella_hip_set_tuning)
     uint64_t kcount_budget = 1ull << 30, wide_budget = 1ull << 30;   // items per pass of the counting sort / of the wide-column path
     bool lane_order_ok = true;           // k_lane_order_selftest at init
+    uint64_t xdrop_class_min = 4ull * 4096 * 64;   // extensions of a batch from which on the slices run it as four classes (BELLA_TUNE_XDROP_CLASS_MIN)
     uint32_t xdrop_variant = 1;          // 0: one launch in length-sorted order; 1 (default): slices with compaction; 2: packed kernel in pair order; 3: scalar statement
     size_t lds_attr[18] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
     hipStream_t side[kNumTiers + 1]{};   // independent tier launches / fold instances run concurrently
@@ -300,6 +301,9 @@ int build_layout(bella_ctx* c) {
     }
     c->owned_nnz = 0;
     const uint32_t* Bloc = ptr<uint32_t>(c->Bloc);                 // the rows of the owned columns
+    // (buffers only ever grow; a context that goes from a whole layout to a partition's gives the difference back)
+    if (c->Bent.cap > 16 * nown_nnz + (1u << 20)) release(c->Bent);
+    if (c->Bcnt.cap > 4 * nown_nnz + (1u << 20)) release(c->Bcnt);
     ENSURE(c, c->Bent, 8 * nown_nnz);
     if (nnz) {
         k_layout_prep<<<nblk(c->nreads, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos), c->nreads,
@@ -580,6 +584,7 @@ int bella_hip_set_tuning(bella_ctx* c, uint32_t what, const uint64_t* values, ui
             if (n && values[0] > 3) return fail(c, BELLA_ERR_BAD_ARG, "x-drop variant 0..3");   // (validated before it is stored)
             c->xdrop_variant = n ? (uint32_t)values[0] : 1u;
             return 0;
+        case BELLA_TUNE_XDROP_CLASS_MIN: c->xdrop_class_min = n ? values[0] : 4ull * 4096 * 64; return 0;
         case BELLA_TUNE_ROW_LISTS:
             if (n && values[0] > 1) return fail(c, BELLA_ERR_BAD_ARG, "row lists: 0 or 1");
             c->want_rowlists = n && values[0] == 1;
@@ -2567,34 +2572,83 @@ static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_se
                     k_xdrop_sorted<<<nblk(ne, kXdropBlock), kXdropBlock, 0, c->stream>>>(sa);
                     KCHK(c);
                 } else {
+                // Classes: the extensions are sorted by their step estimate, longest first.  Advanced together -- one slice per ROUND of
+                // the whole batch -- the longest ones would finish alone, one wavefront per SIMD, long after everybody else (a quarter of the
+                // stage at 10k reads: 41 rounds, the last 25 of them on a fifth of the machine).  So a big batch is cut, in sorted order, into
+                // four classes -- 1/16, 2/16, 4/16 of the extensions and the rest -- and the three classes of long extensions run their own
+                // slices back to back on side streams, at a higher wave priority (s_setprio) and queue priority, while the bulk fills the
+                // machine: every class ends within lenH + lenV steps, so it gets that many launches and the empty ones return at once.
                 XdropSliceArgs xa;
                 xa.s = sa;
-                xa.state = ptr<uint32_t>(c->xstate);
                 xa.cap = capB;
-                uint32_t* const lists[2] = {ptr<uint32_t>(c->xlive), ptr<uint32_t>(c->xlive) + capB};
-                uint32_t* const counts = ptr<uint32_t>(c->xlive) + 2 * capB;     // two counters
+                xa.steps = kXdropSlice;                              // (64 / 128 steps for the first two slices: 3.41 s against 3.35 s on the 100k set)
+                uint32_t* const L = ptr<uint32_t>(c->xlive);         // per class: two lists of its slots, back to back; then two counters per class
+                uint32_t* const counters = L + 2 * capB;
+                uint32_t longest = 0;
+                for (uint32_t l : c->host_lens) longest = l > longest ? l : longest;
+                const int nsl_bound = (int)((2u * longest) / (uint32_t)kXdropSlice) + 3;
                 for (uint64_t first = 0; first < ne; first += capB) {
+                    const uint64_t count = ne - first < capB ? ne - first : capB;
+                    xa.state = ptr<uint32_t>(c->xstate);
                     xa.first = first;
-                    xa.count = ne - first < capB ? ne - first : capB;
-                    k_xdrop_begin<<<nblk(xa.count, kXdropBlock), kXdropBlock, 0, c->stream>>>(xa);
+                    xa.count = count;
+                    xa.live_in = nullptr; xa.nlive_in = nullptr; xa.live_out = nullptr; xa.nlive_out = nullptr; xa.prio = 0;
+                    k_xdrop_begin<<<nblk(count, kXdropBlock), kXdropBlock, 0, c->stream>>>(xa);
                     KCHK(c);
-                    uint64_t live = xa.count;
-                    xa.live_in = nullptr; xa.nlive_in = nullptr;
-                    for (int it = 0; live; ++it) {
-                        const int o = it & 1;
-                        xa.live_out = lists[o]; xa.nlive_out = counts + o;
-                        HIPCHK(c, hipMemsetAsync(xa.nlive_out, 0, 4, c->stream));
-                        xa.steps = kXdropSlice;                      // (64 / 128 steps for the first two slices: 3.41 s against 3.35 s on the 100k set)
-                        k_xdrop_slice<<<nblk(live, kXdropBlock), kXdropBlock, 0, c->stream>>>(xa);   // (live: an upper bound; the kernel reads the count)
-                        KCHK(c);
-                        if ((it & 3) == 3 || live <= 4096) {          // the survivor count comes back every fourth slice: it only ever shrinks
-                            HIPCHK(c, hipMemcpyAsync(c->pinned + 100, xa.nlive_out, 4, hipMemcpyDeviceToHost, c->stream));
-                            HIPCHK(c, hipStreamSynchronize(c->stream));
-                            live = c->pinned[100];
+                    // class boundaries (slots of the batch, sorted order): only a batch several times the machine's 4,096 resident wavefronts
+                    // is worth cutting
+                    uint64_t cb[5] = {0, 0, 0, 0, count};
+                    const bool classes = count >= c->xdrop_class_min && count >= 1024 && c->xdrop_variant == 1;
+                    if (classes) { cb[1] = (count / 16) & ~63ull; cb[2] = (3 * count / 16) & ~63ull; cb[3] = (7 * count / 16) & ~63ull; }
+                    if (classes) HIPCHK(c, hipEventRecord(c->fork, c->stream));
+                    int nside = 0;
+                    for (int k2 = 0; k2 < 3 && classes; ++k2) {      // the long classes: fixed number of launches, no host round trip
+                        const uint64_t c0 = cb[k2], cn = cb[k2 + 1] - cb[k2];
+                        if (!cn) continue;
+                        hipStream_t sst = c->side[k2];
+                        HIPCHK(c, hipStreamWaitEvent(sst, c->fork, 0));
+                        XdropSliceArgs ya = xa;
+                        ya.state = ptr<uint32_t>(c->xstate) + c0;     // (word w of slot t at state[w * cap + t]: the class's slots start at c0)
+                        ya.count = cn;
+                        ya.prio = 3 - k2;
+                        uint32_t* const lists[2] = {L + 2 * c0, L + 2 * c0 + cn};
+                        uint32_t* const cnts = counters + 2 * (k2 + 1);
+                        ya.live_in = nullptr; ya.nlive_in = nullptr;
+                        for (int s2 = 0; s2 < nsl_bound; ++s2) {
+                            ya.live_out = lists[s2 & 1]; ya.nlive_out = cnts + (s2 & 1);
+                            HIPCHK(c, hipMemsetAsync(ya.nlive_out, 0, 4, sst));
+                            k_xdrop_slice<<<nblk(cn, kXdropBlock), kXdropBlock, 0, sst>>>(ya);
+                            KCHK(c);
+                            ya.live_in = ya.live_out; ya.nlive_in = ya.nlive_out;
                         }
-                        xa.live_in = xa.live_out; xa.nlive_in = xa.nlive_out;
-                        if (it > 4096) return fail(c, BELLA_ERR_STATE, "internal: X-drop slices do not terminate");
+                        HIPCHK(c, hipEventRecord(c->join[k2], sst));
+                        nside = k2 + 1;
                     }
+                    {   // the bulk (or the whole batch): as many launches as it takes, the survivor count read back every fourth slice
+                        const uint64_t c0 = cb[3], cn = cb[4] - cb[3];
+                        XdropSliceArgs za = xa;
+                        za.state = ptr<uint32_t>(c->xstate) + c0;
+                        za.count = cn;
+                        uint32_t* const lists[2] = {L + 2 * c0, L + 2 * c0 + cn};
+                        uint64_t live = cn;
+                        za.live_in = nullptr; za.nlive_in = nullptr;
+                        for (int it = 0; live; ++it) {
+                            const int o = it & 1;
+                            za.live_out = lists[o]; za.nlive_out = counters + o;
+                            HIPCHK(c, hipMemsetAsync(za.nlive_out, 0, 4, c->stream));
+                            k_xdrop_slice<<<nblk(live, kXdropBlock), kXdropBlock, 0, c->stream>>>(za);   // (live: an upper bound; the kernel reads the count)
+                            KCHK(c);
+                            if ((it & 3) == 3 || live <= 4096) {          // the survivor count comes back every fourth slice: it only ever shrinks
+                                HIPCHK(c, hipMemcpyAsync(c->pinned + 100, za.nlive_out, 4, hipMemcpyDeviceToHost, c->stream));
+                                HIPCHK(c, hipStreamSynchronize(c->stream));
+                                live = c->pinned[100];
+                            }
+                            za.live_in = za.live_out; za.nlive_in = za.nlive_out;
+                            if (it > 4096) return fail(c, BELLA_ERR_STATE, "internal: X-drop slices do not terminate");
+                        }
+                    }
+                    for (int k2 = 0; k2 < nside; ++k2)              // (the next batch reuses the state slots and the lists; k_xdrop_finish reads every result)
+                        HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[k2], 0));
                 }
                 }   // have_state
             }

@@ -421,6 +421,7 @@ struct XdropSliceArgs {
     uint32_t* live_out;          // survivors
     uint32_t* nlive_out;
     int steps;                   // anti-diagonal steps of this launch (a multiple of 16, at most kXdropSlice)
+    int prio;                    // wave priority of this launch (0 .. 3): the classes of the longest extensions run ahead (bella_hip.hip: run_xdrop)
 };
 
 // flags word: maxpos (5 bits) | first << 5 | flagged << 6 | mode4 << 7 | dir << 8 | it4 << 9 (5 bits) | dead << 15
@@ -513,6 +514,9 @@ __global__ __launch_bounds__(kXdropBlock, BELLA_XSLICE_WAVES) void k_xdrop_slice
     const uint64_t x = (uint64_t)blockIdx.x * kXdropBlock + threadIdx.x;
     const uint64_t nlive = xa.live_in ? (uint64_t)*xa.nlive_in : xa.count;
     const uint64_t cap = xa.cap;
+    if (xa.prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (xa.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (xa.prio == 1) __builtin_amdgcn_s_setprio(1);
     bool active = x < nlive;
     uint64_t t = 0;
     uint32_t flags = 1u << 15;

@@ -357,8 +357,12 @@ int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
  *                             -- when they fit next to what a pass needs; the numeric phase then streams its products instead of
  *                             expanding B' x A'.  For callers that run SEVERAL passes over the same columns (parameter sweeps): the
  *                             expansion is paid once instead of per pass.  Default 0 (n = 0): a one-shot call is faster without them
- *                             (layout + first pass); bella_timings.expand_ms reports the expansion when they are built. */
-enum { BELLA_TUNE_LDS_TIERS = 0, BELLA_TUNE_KCOUNT_BUDGET = 1, BELLA_TUNE_WIDE_BUDGET = 2, BELLA_TUNE_XDROP_VARIANT = 3, BELLA_TUNE_ROW_LISTS = 4 };
+ *                             (layout + first pass); bella_timings.expand_ms reports the expansion when they are built.
+ *   BELLA_TUNE_XDROP_CLASS_MIN values[0] = extensions of a batch from which on the slices of variant 1 run the batch as four classes by step
+ *                             estimate, the three classes of long extensions on streams of their own at a higher priority (default 2^20:
+ *                             four times the wavefronts the device holds at once; tests set it low, UINT64_MAX = never) */
+enum { BELLA_TUNE_LDS_TIERS = 0, BELLA_TUNE_KCOUNT_BUDGET = 1, BELLA_TUNE_WIDE_BUDGET = 2, BELLA_TUNE_XDROP_VARIANT = 3, BELLA_TUNE_ROW_LISTS = 4,
+       BELLA_TUNE_XDROP_CLASS_MIN = 5 };
 int bella_hip_set_tuning(bella_ctx* ctx, uint32_t what, const uint64_t* values, uint32_t n);
 
 #ifdef __cplusplus

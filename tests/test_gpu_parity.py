@@ -176,6 +176,15 @@ def test_alignments_match_oracle_fieldwise(eng, golden):
         finally:
             eng.set_tuning("xdrop_variant")
         assert np.array_equal(other, alns), variant
+    # the slices with the batch cut into four classes by step estimate (the long extensions on streams of their own, at a higher wave
+    # priority): the default for batches of a million extensions, forced here
+    eng.set_tuning("xdrop_class_min", 1024)
+    try:
+        assert eng.align_pairs(pars) == npass
+        other = eng.get_alignments()
+    finally:
+        eng.set_tuning("xdrop_class_min")
+    assert np.array_equal(other, alns)
 
 
 def test_xavier_known_answers_on_gpu(eng):

@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/traffic
 mkdir -p "$OUT"; rm -rf "$OUT/$KEY"_*
 STEPS=4
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/${KEY}_$C" -o t -- python "$R/bench.py" --steps $STEPS --warmup 1 --no-cpu-baseline --no-100k --no-xdrop --no-dropin --no-hifi "$@" > "$OUT/${KEY}_bench_$C.json" 2> "$OUT/${KEY}_bench_$C.err" || true
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/${KEY}_$C" -o t -- python "$R/bench.py" --steps $STEPS --warmup 1 --no-cpu-baseline --no-100k --no-xdrop --no-dropin --no-hifi --no-layout-ab "$@" > "$OUT/${KEY}_bench_$C.json" 2> "$OUT/${KEY}_bench_$C.err" || true
 done
 python - <<PY
 import csv, collections, json, glob
@@ -30,12 +30,12 @@ def tot(c, pred):
     return sum(v["sum_kb"] for k, v in out.get(c, {}).items() if pred(k)) * 1024 / passes
 sp = lambda k: "k_spgemm_rows" in k or "k_fold" in k or "k_order" in k
 fetch, write = tot("FETCH_SIZE", sp), tot("WRITE_SIZE", sp)
-# calibration of FETCH_SIZE on our own coalesced stream: k_layout_bcnt (assembly, one dispatch in the run) reads the 8-byte B' entry
-# of every nonzero once
+# calibration of FETCH_SIZE on our own coalesced stream: k_layout_bcnt (assembly; the bench counts twice, assembles once: one dispatch
+# in the run) reads the 8-byte B' entry of every nonzero once
 nnz = bench["config"]["nnzA"]
 rf = sum(v["sum_kb"] for k, v in out.get("FETCH_SIZE", {}).items() if "k_layout_bcnt" in k) * 1024
 summary = {
- "workload": "%d reads, 1 GPU" % bench["config"]["reads"],
+ "workload": "%d reads, 1 GPU" % bench["config"]["reads"], "layout": bench["roofline"].get("layout", "default"),
  "kernels": "k_spgemm_rows_lds (all LDS classes) + k_fold_overflow + k_order_wave/_block", "per": "step (= one launch set)",
  "FETCH_SIZE_raw_bytes": fetch, "WRITE_SIZE_raw_bytes": write,
  "fetch_calibration": {"kernel": "k_layout_bcnt", "expected_bytes": 8 * nnz, "ratio_measured_over_expected": rf / (8.0 * nnz),

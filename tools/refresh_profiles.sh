@@ -1,16 +1,16 @@
 #!/usr/bin/env bash
 # Regenerates the judged artefacts of a round on the GPU box: the bench line, rocprofv3 kernel stats + the step timeline of the
-# same commands (10k and 100k reads), HBM traffic (PMC) and SQ counters.  usage: bash tools/refresh_profiles.sh r03
+# same commands (10k and 100k reads), HBM traffic (PMC) and SQ counters.  usage: bash tools/refresh_profiles.sh r04
 # (outputs under gpurun_out/refresh/; copy into profiles/)
 set -uo pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/refresh; rm -rf $OUT; mkdir -p $OUT
 cd $R
 python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 for KEY in 10k 100k; do
   if [ $KEY = 10k ]; then ARGS="--steps 20 --warmup 3"; else ARGS="--reads 100000 --steps 5 --warmup 2"; fi
-  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$KEY -o s -- python $R/bench.py $ARGS --no-cpu-baseline --no-100k --no-xdrop --no-dropin --no-hifi > $OUT/${TAG}_bench_under_rocprof_$KEY.json 2>/dev/null )
+  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$KEY -o s -- python $R/bench.py $ARGS --no-cpu-baseline --no-100k --no-xdrop --no-dropin --no-hifi --no-layout-ab > $OUT/${TAG}_bench_under_rocprof_$KEY.json 2>/dev/null )
   python tools/summarize_rocprof.py $OUT/prof_$KEY/s_kernel_stats.csv 30 > $OUT/${TAG}_kernel_stats_$KEY.txt
   cp $OUT/prof_$KEY/s_kernel_stats.csv $OUT/${TAG}_kernel_stats_$KEY.csv
   python tools/timeline.py $OUT/prof_$KEY/s_kernel_trace.csv > $OUT/${TAG}_step_timeline_$KEY.txt
@@ -32,4 +32,7 @@ hipcc --offload-arch=gfx950 -O3 -w -o /tmp/lds_ops tools/ubench/lds_ops.hip && /
 # the HiFi-like probe (columns above the LDS tiers on the sort-based path) and one rank's share of the strong-scaling run
 ( python tools/hifi_probe2.py 3000 40 1 2>&1 | tail -1; bash tools/hifi_trace.sh 3000 40 1 2>&1 | tail -18 ) > $OUT/${TAG}_hifi_probe.txt
 python tools/rank_probe.py 2 4 8 2>&1 | tail -8 > $OUT/${TAG}_rank_probe_100k.txt
+# the front end kernel by kernel, and the N > 1 branch of bench.py end to end on this one GPU (two ranks, gloo rendezvous)
+bash tools/frontend_trace.sh 100000 > $OUT/${TAG}_frontend_100k.txt 2>&1
+BELLA_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 > $OUT/${TAG}_bench_gloo2_one_gpu.json 2> $OUT/${TAG}_bench_gloo2_one_gpu.err
 tail -n 2 $OUT/traffic_10k.log; tail -n 2 $OUT/traffic_100k.log; cat $OUT/${TAG}_bench.json | cut -c1-600; cat $OUT/${TAG}_step_timeline_10k.txt | tail -3
