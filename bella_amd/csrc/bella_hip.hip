@@ -2249,7 +2249,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     {
         unsigned long long ph[10 * kNumTiers];
         HIPCHK(c, hipMemcpy(ph, c->prof.p, sizeof(ph), hipMemcpyDeviceToHost));
-        static const char* nm[9] = {"expand", "gather+insert", "count-scan", "scatter+singles", "rank/overlay", "parents", "walks", "emit", "-"};
+        static const char* nm[9] = {"expand", "gather+insert", "count-scan", "scatter+singles", "rank/overlay", "parents", "walks", "emit", "head (descriptor + first entries + table init)"};
         for (int l = 0; l < nl; ++l) {
             const unsigned long long* q = ph + 10 * l;
             if (!q[9]) continue;

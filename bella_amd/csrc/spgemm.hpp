@@ -207,6 +207,9 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     for (uint32_t s = tid; s < H1; s += kRowBlock) { m.T1key[s] = kEmpty; m.T1first[s] = 0; m.T1cnt[s] = 0; }
     if (tid == 0) { *s_chunk = 0; *s_fail = 0; *s_np = 0; }
     __syncthreads();
+#ifdef BELLA_DEV_PROF                                          // the head of the column: descriptor + first B' entries arrived, tables initialised
+    { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long t2_ = clock64(); if (tid == 0 && a.prof) atomicAdd(a.prof + 8, (unsigned long long)(t2_ - tc_)); tc_ = t2_; }
+#endif
 
     // ---- X: expand products in reference order, group keys --------------------------------------------
     // X1/X2: each thread owns a CONTIGUOUS run of B' entries (so one block scan orders all products); it only records,
