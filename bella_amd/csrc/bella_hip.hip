@@ -300,6 +300,7 @@ int build_layout(bella_ctx* c) {
         HIPCHK(c, hipMemcpyAsync(c->Bloc.p, c->Bptr.p, 4 * ((size_t)c->nreads + 1), hipMemcpyDeviceToDevice, c->stream));
     }
     c->owned_nnz = 0;
+    uint32_t ratio1024 = 1024;
     const uint32_t* Bloc = ptr<uint32_t>(c->Bloc);                 // the rows of the owned columns
     // (buffers only ever grow; a context that goes from a whole layout to a partition's gives the difference back)
     if (c->Bent.cap > 16 * nown_nnz + (1u << 20)) release(c->Bent);
@@ -374,7 +375,28 @@ int build_layout(bella_ctx* c) {
             KCHK(c);
         }
         c->owned_nnz = nown_nnz;
-        if (by_kmer && c->want_rowlists && c->nreads <= (1u << 30)) {
+        // pairs/products on a sample of (owned) columns -> key-table budget of the LDS tiers (see k_sample_pair_ratio), and: is this a
+        // long-list input (HiFi-like: at most one pair in 64 products)?
+        const size_t bitmap_bytes = 4 * (((size_t)c->nreads + 31) / 32);
+        uint32_t samp[2] = {0, 0};
+        if (c->owned_nnz && bitmap_bytes <= 128 * 1024) {
+            HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 6, 0, 16, c->stream));   // [6] max ratio, [8] pairs, [9] products / 64 of the sample
+            const uint32_t ncols = c->nreads / ps + 1;                  // owned columns: first + j * stride
+            const uint32_t nsample = ncols < 512 ? ncols : 512;
+            const uint32_t step = (ncols / nsample ? ncols / nsample : 1) * ps;
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_sample_pair_ratio, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bitmap_bytes));
+            k_sample_pair_ratio<<<nsample, kBlock, bitmap_bytes, c->stream>>>(Bloc, ptr<uint2>(c->Bent), ptr<uint2>(c->Aent),
+                                                                             c->nreads, pf, step, ptr<uint32_t>(c->status) + 6);
+            KCHK(c);
+            HIPCHK(c, hipMemcpyAsync(&ratio1024, ptr<uint32_t>(c->status) + 6, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(samp, ptr<uint32_t>(c->status) + 8, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        // Long-list inputs send most of their columns to the path above the LDS tiers, which groups a column's products in LDS from a
+        // product list -- expanded per batch and per pass when the layout has none.  The same expansion once, here, costs a one-shot
+        // call nothing and every further pass less: such inputs get the row lists whenever they fit.
+        const bool auto_lists = samp[1] > 0 && samp[0] <= samp[1] && !(c->debug & 1u) && c->lane_order_ok;   // >= 64 products per pair on the sample
+        if (by_kmer && (c->want_rowlists || auto_lists) && c->nreads <= (1u << 30)) {
             // row lists (BELLA_TUNE_ROW_LISTS): products per owned row -> row starts -> the tails of the lists copied in product order.
             // Optional in every respect: if they do not fit next to what a pass needs, or an allocation fails, the layout stands without them.
             int rc = ensure_bytes(c, c->Arow, 8 * ((size_t)c->nreads + 2));
@@ -414,20 +436,6 @@ int build_layout(bella_ctx* c) {
     if (!c->have_rowlists) { release(c->Aent2); release(c->Aov); release(c->Arow); }
     if (!nnz) HIPCHK(c, hipMemsetAsync(c->Bloc.p, 0, 4 * ((size_t)c->nreads + 2), c->stream));
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-    // pairs/products on a sample of (owned) columns -> key-table budget of the LDS tiers (see k_sample_pair_ratio)
-    uint32_t ratio1024 = 1024;
-    const size_t bitmap_bytes = 4 * (((size_t)c->nreads + 31) / 32);
-    if (c->owned_nnz && bitmap_bytes <= 128 * 1024) {
-        HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->status) + 6, 0, 4, c->stream));
-        const uint32_t ncols = c->nreads / ps + 1;                  // owned columns: first + j * stride
-        const uint32_t nsample = ncols < 512 ? ncols : 512;
-        const uint32_t step = (ncols / nsample ? ncols / nsample : 1) * ps;
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_sample_pair_ratio, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bitmap_bytes));
-        k_sample_pair_ratio<<<nsample, kBlock, bitmap_bytes, c->stream>>>(Bloc, ptr<uint2>(c->Bent), ptr<uint2>(c->Aent),
-                                                                         c->nreads, pf, step, ptr<uint32_t>(c->status) + 6);
-        KCHK(c);
-        HIPCHK(c, hipMemcpyAsync(&ratio1024, ptr<uint32_t>(c->status) + 6, 4, hipMemcpyDeviceToHost, c->stream));
-    }
     uint32_t st = 0;
     int rc = read_status(c, &st);
     if (rc) return rc;
@@ -1047,9 +1055,12 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
         KCHK(c);
         hipcub::DoubleBuffer<uint64_t> db(ptr<uint64_t>(c->kc_keys), ptr<uint64_t>(c->kc_alt));
         size_t tb = 0;
-        HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, db, (int)np, (int)pb, (int)pb + 2 * (int)k, c->stream));
+        // (with the positions in the keys the run kernels handle groups of four neighbouring words: the sort may leave out the word's
+        // two lowest bits, and does when that saves it a pass of eight bits -- 32 instead of 34 bits for k = 17)
+        const uint32_t gb = fast && 2 * k >= 10 && (2 * k + 7) / 8 > (2 * k - 2 + 7) / 8 ? 2u : 0u;
+        HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, db, (int)np, (int)(pb + gb), (int)pb + 2 * (int)k, c->stream));
         ENSURE(c, c->cubtmp, tb);
-        HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(c->cubtmp.p, tb, db, (int)np, (int)pb, (int)pb + 2 * (int)k, c->stream));
+        HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(c->cubtmp.p, tb, db, (int)np, (int)(pb + gb), (int)pb + 2 * (int)k, c->stream));
         uint64_t* sorted = db.Current();
         if (fast) {
             // runs of equal words, tile by tile: reliable runs per tile -> scan over the tiles = the ids of this pass -> every reliable
@@ -1059,7 +1070,7 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
             uint32_t* tile_heads = ptr<uint32_t>(c->kc_flag);
             uint32_t* tile_base = ptr<uint32_t>(c->kc_slot);
             HIPCHK(c, hipMemsetAsync(tile_rel + ntile, 0, 4, c->stream));
-            k_run_count<<<ntile, kRunBlock, 0, c->stream>>>(sorted, np, pb, lower, upper, mode != 0, tile_rel, tile_heads);
+            k_run_count<<<ntile, kRunBlock, 0, c->stream>>>(sorted, np, pb, gb, lower, upper, mode != 0, tile_rel, tile_heads);
             KCHK(c);
             rc = scan_u32(c, tile_rel, tile_base, (uint64_t)ntile + 1);
             if (rc) return rc;
@@ -1080,7 +1091,7 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
             if (rc) return rc;
             rc = grow_keep(c, c->kc_dcount, 2 * (nk_total + nrel), 2 * nk_total);
             if (rc) return rc;
-            k_run_assign<<<ntile, kRunBlock, 0, c->stream>>>(sorted, np, pb, lower, upper, mode != 0, tile_base, (uint32_t)nk_total, 0ull, ntot, ptr<uint32_t>(c->kc_ids),
+            k_run_assign<<<ntile, kRunBlock, 0, c->stream>>>(sorted, np, pb, gb, lower, upper, mode != 0, tile_base, (uint32_t)nk_total, 0ull, ntot, ptr<uint32_t>(c->kc_ids),
                                                              ptr<uint64_t>(c->kc_dcode) + nk_total, ptr<uint16_t>(c->kc_dcount) + nk_total);
             KCHK(c);
             nk_total += nrel;

@@ -196,56 +196,79 @@ __global__ void k_write_dict(const uint64_t* run_code, const uint32_t* run_len, 
 }
 
 // ---- the sorted words with their positions in the low pb bits (k_emit_codes, pb > 0) ------------------------------------------------
-// The runs of equal words, tile by tile (2,048 sorted words of a workgroup in LDS + 32 words of look-ahead): a run belongs to the tile
-// that holds its first word.  Two passes over the sorted words with a scan over the TILES in between -- no per-word flag or slot arrays:
+// The runs of equal words, tile by tile (2,048 sorted words of a workgroup in LDS + 32 words of look-ahead).  The radix sort leaves
+// out the word's lowest `gb` bits when that saves it a pass (gb = 2: 32 instead of 34 bits for k = 17 -- four passes instead of five):
+// the sorted array is then ordered by GROUP = word >> gb, and the up to 2^gb words of a group stand interleaved, each in position
+// order.  A group is handled by the thread of its first word: it counts the group's words per value of the low bits, which gives the
+// group's runs in ascending word order without moving anything.  A group belongs to the tile that holds its first word.  Two passes
+// over the sorted words with a scan over the TILES in between -- no per-word flag or slot arrays:
 //   k_run_count   per tile: runs that start in it (-> distinct words) and reliable runs that start in it (-> ids of the tile's runs)
-//   k_run_assign  per tile: the same runs again; a reliable run's first word writes the dictionary entry and hands the id to the
-//                 position of every word of the run (reliable runs are at most `upper` words long)
-constexpr uint32_t kRunTile = 2048, kRunHalo = 32, kRunBlock = 256;
+//   k_run_assign  per tile: the same groups again; every reliable run gets its id (tile's first id + reliable runs before it), writes
+//                 its dictionary entry and hands the id to the position of every word of the run (`ids[position]`)
+constexpr uint32_t kRunTile = 2048, kRunHalo = 32, kRunBlock = 256, kRunGroupMax = 4;
 struct RunTile {
-    uint64_t w[kRunTile + kRunHalo];       // the tile's words and the look-ahead
-    unsigned long long bm[kRunTile / 64];  // reliable run heads, one bit per word of the tile
-    uint32_t pre[kRunTile / 64 + 1];       // reliable heads before each group of 64 words
-    uint64_t prev;                         // the word before the tile (its WORD bits; ~0 for the first tile)
+    uint64_t w[kRunTile + kRunHalo];          // the tile's words and the look-ahead
+    unsigned long long bm[3][kRunTile / 64];  // reliable runs of the group that starts at a word (0 .. 4), as three bit planes
+    uint32_t pre[kRunTile / 64 + 1];          // reliable runs before each group of 64 words
+    uint64_t prev;                            // the GROUP of the word before the tile (~0 for the first tile)
 };
-// loads the tile, finds the heads and the length of the runs that start in it; calls fn(u, e, len, count16) for every head (e = u * 256
-// + thread: place in the tile); returns the number of heads of this thread
+struct RunGroup {                             // what the first word of a group learns about it
+    uint64_t len;                             // words of the group
+    uint32_t cnt[kRunGroupMax];               // ... per value of the low bits
+};
+// loads the tile and finds the groups that start in it; fn(u, e, group) for every group head (e = u * 256 + thread: place in the tile)
 template <class Fn>
-__device__ __forceinline__ uint32_t run_tile_heads(RunTile& T, const uint64_t* s, uint64_t n, uint32_t pb, uint32_t saturate, Fn&& fn) {
+__device__ __forceinline__ void run_tile_groups(RunTile& T, const uint64_t* s, uint64_t n, uint32_t pb, uint32_t gb, Fn&& fn) {
     const uint64_t x0 = (uint64_t)blockIdx.x * kRunTile;
     const uint32_t have = (uint32_t)(n - x0 < kRunTile + kRunHalo ? n - x0 : kRunTile + kRunHalo);
     for (uint32_t e = threadIdx.x; e < kRunTile + kRunHalo; e += kRunBlock) T.w[e] = e < have ? s[x0 + e] : ~0ull;
-    if (threadIdx.x == 0) T.prev = x0 ? s[x0 - 1] >> pb : ~0ull;
+    if (threadIdx.x == 0) T.prev = x0 ? s[x0 - 1] >> (pb + gb) : ~0ull;
     __syncthreads();
     const uint32_t nt = have < kRunTile ? have : kRunTile;      // words of the tile itself
-    uint32_t heads = 0;
+    const uint32_t lowmask = (1u << gb) - 1u;
 #pragma unroll
     for (uint32_t u = 0; u < kRunTile / kRunBlock; ++u) {
         const uint32_t e = u * kRunBlock + threadIdx.x;
         if (e >= nt) continue;
-        const uint64_t w = T.w[e] >> pb;
-        const uint64_t before = e ? T.w[e - 1] >> pb : T.prev;
-        if (before == w && (e || x0)) continue;                   // not the first word of its run
-        heads++;
-        uint32_t len = 1;
-        while (e + len < have && (T.w[e + len] >> pb) == w) ++len;
-        uint64_t run = len;
-        if (e + len == have && x0 + have < n) {                   // the run leaves the look-ahead: its end by bisection in the sorted array
-            uint64_t l = x0 + have, h = n;
-            while (l < h) { const uint64_t m = (l + h) >> 1; if ((s[m] >> pb) <= w) l = m + 1; else h = m; }
-            run = l - (x0 + e);
+        const uint64_t g = T.w[e] >> (pb + gb);
+        const uint64_t before = e ? T.w[e - 1] >> (pb + gb) : T.prev;
+        if (before == g && (e || x0)) continue;                   // not the first word of its group
+        RunGroup G;
+#pragma unroll
+        for (uint32_t v = 0; v < kRunGroupMax; ++v) G.cnt[v] = 0;
+        uint32_t len = 0;
+        while (e + len < have && (T.w[e + len] >> (pb + gb)) == g) {
+            const uint32_t v = (uint32_t)(T.w[e + len] >> pb) & lowmask;
+            G.cnt[0] += v == 0; G.cnt[1] += v == 1; G.cnt[2] += v == 2; G.cnt[3] += v == 3;
+            ++len;
         }
-        fn(u, e, run, count16((uint32_t)(run > 0xFFFFFFFFull ? 0xFFFFFFFFull : run), saturate));
+        G.len = len;
+        if (e + len == have && x0 + have < n) {                   // the group leaves the look-ahead: its end by bisection, its words one by one
+            uint64_t l = x0 + have, h = n;
+            while (l < h) { const uint64_t m = (l + h) >> 1; if ((s[m] >> (pb + gb)) <= g) l = m + 1; else h = m; }
+            for (uint64_t y = x0 + have; y < l; ++y) {
+                const uint32_t v = (uint32_t)(s[y] >> pb) & lowmask;
+                G.cnt[0] += v == 0; G.cnt[1] += v == 1; G.cnt[2] += v == 2; G.cnt[3] += v == 3;   // (u32: a word with >= 2^32 copies is beyond every limit here)
+            }
+            G.len = l - (x0 + e);
+        }
+        fn(u, e, G);
     }
-    return heads;
 }
-__global__ __launch_bounds__(kRunBlock) void k_run_count(const uint64_t* s, uint64_t n, uint32_t pb, uint32_t lower, uint32_t upper, uint32_t saturate,
-                                                         uint32_t* tile_rel, uint32_t* tile_heads) {
+__global__ __launch_bounds__(kRunBlock) void k_run_count(const uint64_t* s, uint64_t n, uint32_t pb, uint32_t gb, uint32_t lower, uint32_t upper,
+                                                         uint32_t saturate, uint32_t* tile_rel, uint32_t* tile_heads) {
     __shared__ RunTile T;
     __shared__ uint32_t s_cnt[2];
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-    uint32_t rel = 0;
-    uint32_t heads = run_tile_heads(T, s, n, pb, saturate, [&](uint32_t, uint32_t, uint64_t, uint32_t c) { rel += (c >= lower && c <= upper) ? 1u : 0u; });
+    uint32_t rel = 0, heads = 0;
+    run_tile_groups(T, s, n, pb, gb, [&](uint32_t, uint32_t, const RunGroup& G) {
+#pragma unroll
+        for (uint32_t v = 0; v < kRunGroupMax; ++v) {
+            const uint32_t c = count16(G.cnt[v], saturate);
+            heads += G.cnt[v] ? 1u : 0u;
+            rel += (G.cnt[v] && c >= lower && c <= upper) ? 1u : 0u;
+        }
+    });
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { rel += __shfl_xor(rel, d, 64); heads += __shfl_xor(heads, d, 64); }
     if (lane_id() == 0) { if (rel) atomicAdd(&s_cnt[0], rel); if (heads) atomicAdd(&s_cnt[1], heads); }
@@ -253,48 +276,77 @@ __global__ __launch_bounds__(kRunBlock) void k_run_count(const uint64_t* s, uint
     if (threadIdx.x == 0) { tile_rel[blockIdx.x] = s_cnt[0]; tile_heads[blockIdx.x] = s_cnt[1]; }
 }
 // tile_base[t] = reliable runs that start before tile t (exclusive scan of k_run_count's tile_rel); pos_lo / pos_hi: the positions ids[] covers
-__global__ __launch_bounds__(kRunBlock) void k_run_assign(const uint64_t* s, uint64_t n, uint32_t pb, uint32_t lower, uint32_t upper, uint32_t saturate,
-                                                          const uint32_t* tile_base, uint32_t id_base, uint64_t pos_lo, uint64_t pos_hi, uint32_t* ids,
-                                                          uint64_t* dict_code, uint16_t* dict_count) {
+__global__ __launch_bounds__(kRunBlock) void k_run_assign(const uint64_t* s, uint64_t n, uint32_t pb, uint32_t gb, uint32_t lower, uint32_t upper,
+                                                          uint32_t saturate, const uint32_t* tile_base, uint32_t id_base, uint64_t pos_lo, uint64_t pos_hi,
+                                                          uint32_t* ids, uint64_t* dict_code, uint16_t* dict_count) {
     __shared__ RunTile T;
     const uint64_t x0 = (uint64_t)blockIdx.x * kRunTile;
-    // pass 1 over the heads: which of them are reliable (one bit per word of the tile)
-    uint32_t myrel = 0;                                            // bit u: this thread's word of round u starts a reliable run
-    uint32_t mylen[kRunTile / kRunBlock];
+    // pass 1 over the group heads: how many reliable runs each group has (0 .. 4) and which
+    uint32_t relmask[kRunTile / kRunBlock];                       // bits 0..3: value v of the low bits is a reliable run of my group of round u
+    uint32_t glen[kRunTile / kRunBlock];
+    uint32_t gcnt[kRunTile / kRunBlock][kRunGroupMax];
 #pragma unroll
-    for (uint32_t u = 0; u < kRunTile / kRunBlock; ++u) mylen[u] = 0;
-    run_tile_heads(T, s, n, pb, saturate, [&](uint32_t u, uint32_t, uint64_t run, uint32_t c) {
-        if (c >= lower && c <= upper) { myrel |= 1u << u; mylen[u] = (uint32_t)(run > 0xFFFFFFFFull ? 0xFFFFFFFFull : run); }
+    for (uint32_t u = 0; u < kRunTile / kRunBlock; ++u) { relmask[u] = 0; glen[u] = 0; }
+    run_tile_groups(T, s, n, pb, gb, [&](uint32_t u, uint32_t, const RunGroup& G) {
+        uint32_t mk = 0;
+#pragma unroll
+        for (uint32_t v = 0; v < kRunGroupMax; ++v) {
+            const uint32_t c = count16(G.cnt[v], saturate);
+            mk |= (G.cnt[v] && c >= lower && c <= upper) ? 1u << v : 0u;
+            gcnt[u][v] = G.cnt[v];
+        }
+        relmask[u] = mk;
+        glen[u] = (uint32_t)(G.len > 0xFFFFFFFFull ? 0xFFFFFFFFull : G.len);
     });
 #pragma unroll
-    for (uint32_t u = 0; u < kRunTile / kRunBlock; ++u) {          // words u * 256 + w * 64 + lane: one ballot per group of 64 words
-        const unsigned long long m = __ballot((myrel >> u) & 1u);
-        if (lane_id() == 0) T.bm[u * (kRunBlock / 64) + wave_id()] = m;
+    for (uint32_t u = 0; u < kRunTile / kRunBlock; ++u) {          // words u * 256 + w * 64 + lane: three ballots per group of 64 words
+        const uint32_t nr = (uint32_t)__popc(relmask[u]);
+#pragma unroll
+        for (uint32_t b = 0; b < 3; ++b) {
+            const unsigned long long m = __ballot((nr >> b) & 1u);
+            if (lane_id() == 0) T.bm[b][u * (kRunBlock / 64) + wave_id()] = m;
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 64) {                                        // reliable heads before each group (32 groups: one wavefront)
-        const uint32_t c = threadIdx.x < kRunTile / 64 ? (uint32_t)__popcll(T.bm[threadIdx.x]) : 0u;
+    if (threadIdx.x < 64) {                                        // reliable runs before each group of 64 words (32 groups: one wavefront)
+        uint32_t c = 0;
+        if (threadIdx.x < kRunTile / 64)
+            c = (uint32_t)__popcll(T.bm[0][threadIdx.x]) + 2u * (uint32_t)__popcll(T.bm[1][threadIdx.x]) + 4u * (uint32_t)__popcll(T.bm[2][threadIdx.x]);
         const uint32_t inc = wave_incl_scan(c);
         if (threadIdx.x < kRunTile / 64) T.pre[threadIdx.x] = inc - c;
     }
     __syncthreads();
     const uint32_t base = tile_base[blockIdx.x];
     const uint64_t pmask = (1ull << pb) - 1ull;
+    const uint32_t lowmask = (1u << gb) - 1u;
     const uint32_t have = (uint32_t)(n - x0 < kRunTile + kRunHalo ? n - x0 : kRunTile + kRunHalo);
 #pragma unroll
     for (uint32_t u = 0; u < kRunTile / kRunBlock; ++u) {
-        if (!((myrel >> u) & 1u)) continue;
+        if (!relmask[u]) continue;
         const uint32_t e = u * kRunBlock + threadIdx.x;
-        const uint32_t g = e / 64;
-        const uint32_t local = base + T.pre[g] + (uint32_t)__popcll(T.bm[g] & ((1ull << (e & 63u)) - 1ull));
-        const uint64_t w = T.w[e] >> pb;
-        const uint32_t len = mylen[u];
-        dict_code[local] = w;
-        dict_count[local] = (uint16_t)count16(len, saturate);
-        for (uint32_t m2 = 0; m2 < len; ++m2) {                    // (len <= upper unless the 16-bit count wrapped: then the run is long and this loop is too)
-            const uint64_t v = e + m2 < have ? T.w[e + m2] : s[x0 + e + m2];
-            const uint64_t gp = v & pmask;
-            if (gp >= pos_lo && gp < pos_hi) ids[gp - pos_lo] = id_base + local;
+        const uint32_t q = e / 64;
+        const unsigned long long below = (1ull << (e & 63u)) - 1ull;
+        const uint32_t first = base + T.pre[q] + (uint32_t)__popcll(T.bm[0][q] & below) + 2u * (uint32_t)__popcll(T.bm[1][q] & below) +
+                               4u * (uint32_t)__popcll(T.bm[2][q] & below);
+        const uint64_t g = T.w[e] >> (pb + gb);
+        uint32_t idv[kRunGroupMax];                               // local id of the group's run with low bits v (if reliable)
+        uint32_t nxt = first;
+#pragma unroll
+        for (uint32_t v = 0; v < kRunGroupMax; ++v) {
+            idv[v] = nxt;
+            if ((relmask[u] >> v) & 1u) {
+                dict_code[nxt] = (g << gb) | v;
+                dict_count[nxt] = (uint16_t)count16(gcnt[u][v], saturate);
+                ++nxt;
+            }
+        }
+        for (uint32_t m2 = 0; m2 < glen[u]; ++m2) {                // (a reliable run is at most `upper` words unless its 16-bit count wrapped)
+            const uint64_t wv = e + m2 < have ? T.w[e + m2] : s[x0 + e + m2];
+            const uint32_t v = (uint32_t)(wv >> pb) & lowmask;
+            if (!((relmask[u] >> v) & 1u)) continue;
+            const uint64_t gp = wv & pmask;
+            const uint32_t id = v == 0 ? idv[0] : v == 1 ? idv[1] : v == 2 ? idv[2] : idv[3];
+            if (gp >= pos_lo && gp < pos_hi) ids[gp - pos_lo] = id_base + id;
         }
     }
 }

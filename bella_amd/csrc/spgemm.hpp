@@ -815,6 +815,8 @@ __global__ __launch_bounds__(kBlock) void k_sample_pair_ratio(const uint32_t* Bp
     atomicAdd(&s_f, f);
     __syncthreads();
     if (threadIdx.x == 0 && s_f >= 64) atomicMax(out, (uint32_t)(((uint64_t)s_d << 10) / s_f));
+    // out[2], out[3]: pairs and products / 64 over the whole sample (the average list length: long-list inputs get row lists, bella_hip.hip)
+    if (threadIdx.x == 0) { atomicAdd(out + 2, s_d); atomicAdd(out + 3, (s_f >> 6) < (1u << 20) ? (s_f >> 6) : (1u << 20)); }
 }
 
 // ---- the symbolic phase alone: estimateFLOP + estimateNNZ_Hash (overlap.hpp:157-202, 205-276) -------------------------------------

@@ -531,13 +531,15 @@ def main():
                 kc = eng.timings().kcount_ms
                 eng.assemble_counted()
                 asm_ms = eng.timings().assemble_ms
+                exp_ms = eng.timings().expand_ms                     # long-list inputs get the row lists at layout time: their expansion counts
                 eng.set_debug(2 | a.debug_flags)
                 acc = timed_passes(eng, hp, 5, 2, sync)
                 colptr, _, _ = eng.get_B()
                 nnz = int(colptr[-1])
                 hifi["u%d" % upper] = {"upper": upper, "nkmers": nk, "nnzA": nnz, "flops": int(acc["flops"]), "pairs": int(acc["npairs"]),
                                        "ms_per_step": acc["elapsed"] * 1e3 / 5, "products_per_s": acc["flops"] / (acc["elapsed"] / 5),
-                                       "pairs_per_s": acc["npairs"] / (acc["elapsed"] / 5), "roofline": roofline_of(acc, nnz, copy_gbps, "hifi_u%d" % upper),
+                                       "pairs_per_s": acc["npairs"] / (acc["elapsed"] / 5), "roofline": roofline_of(acc, nnz, copy_gbps, "hifi_u%d" % upper, expand_ms=exp_ms, layout="row_lists" if exp_ms else "default"),
+                                       "expansion_ms_at_layout": exp_ms,
                                        "phases_ms_per_step": phases_of(acc), "kcount_ms": kc, "assemble_ms": asm_ms}
                 eng.close()
             out["config_hifi"] = hifi
