@@ -45,7 +45,7 @@ constexpr uint32_t kScatterChunk = 64;                    // phase S appends one
 #define BELLA_WALK_W 8
 #endif
 #ifndef BELLA_GATHER_BATCH
-#define BELLA_GATHER_BATCH(blk) 4u                          // (8 for the <= 512-thread classes measured 8 % slower)
+#define BELLA_GATHER_BATCH(blk) 2u                          // (round 4, expanding pass at 100k reads: 1 / 2 / 3 / 4 / 8 loads in flight per lane = 4.06 / 4.00 / 4.04 / 4.07 / 4.19 ms)
 #endif
 #ifndef BELLA_SCATTER_CHUNKS
 #define BELLA_SCATTER_CHUNKS 8
