@@ -34,5 +34,5 @@ hipcc --offload-arch=gfx950 -O3 -w -o /tmp/lds_ops tools/ubench/lds_ops.hip && /
 python tools/rank_probe.py 2 4 8 2>&1 | tail -8 > $OUT/${TAG}_rank_probe_100k.txt
 # the front end kernel by kernel, and the N > 1 branch of bench.py end to end on this one GPU (two ranks, gloo rendezvous)
 bash tools/frontend_trace.sh 100000 > $OUT/${TAG}_frontend_100k.txt 2>&1
-BELLA_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 > $OUT/${TAG}_bench_gloo2_one_gpu.json 2> $OUT/${TAG}_bench_gloo2_one_gpu.err
+BELLA_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 2> $OUT/${TAG}_bench_gloo2_one_gpu.err | grep "^{" > $OUT/${TAG}_bench_gloo2_one_gpu.json
 tail -n 2 $OUT/traffic_10k.log; tail -n 2 $OUT/traffic_100k.log; cat $OUT/${TAG}_bench.json | cut -c1-600; cat $OUT/${TAG}_step_timeline_10k.txt | tail -3
