@@ -141,8 +141,9 @@ def roofline_of(acc, nnz_share, copy_gbps, traffic_key, expand_ms=0.0, layout="d
                 r["traffic_uncorrected"] = tr["FETCH_SIZE_raw_bytes"] + tr["WRITE_SIZE_raw_bytes"]
                 r["traffic_source"] = ("profiles/%s_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes per step; a separate "
                                        "profiled run).  traffic = 2 x FETCH_SIZE + WRITE_SIZE: the gfx950 correction of the guide, calibrated on our own "
-                                       "coalesced stream (0.500); it over-counts the random 64-byte gathers of A', which the counter tallies at face "
-                                       "value -- the true figure lies between traffic_uncorrected and traffic" % tag)
+                                       "coalesced stream (0.500).  profiles/%s_mem_counters_100k.txt shows every L2 miss of these kernels leaving as a 128-byte "
+                                       "fabric request (TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ), so the correction holds for the random gathers of A' too: "
+                                       "the traffic above the algorithmic bytes is whole lines fetched for 8 ... 24-byte list tails" % (tag, tag))
                 break
         except Exception:
             pass
