@@ -31,6 +31,20 @@
 #define I_LSHR(r) "v_lshrrev_b32 " #r ", 1, " #r "\n"
 #define I_ADD3(r) "v_add3_u32 " #r ", " #r ", %8, %9\n"
 #define I_MOVDPP(r) "v_mov_b32_dpp " #r ", " #r " row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define I_CNDMASK64(r) "v_cndmask_b32_e64 " #r ", " #r ", %8, s[20:21]\n"
+#define I_PKMAD(r) "v_pk_mad_i16 " #r ", " #r ", %8, %9\n"
+#define I_BFI(r) "v_bfi_b32 " #r ", %9, " #r ", %8\n"
+#define I_AND(r) "v_and_b32 " #r ", " #r ", %8\n"
+#define I_OR(r) "v_or_b32 " #r ", " #r ", %8\n"
+#define I_ANDLIT(r) "v_and_b32 " #r ", 0x00010001, " #r "\n"
+#define I_PKMAXSEL(r) "v_pk_max_i16 " #r ", " #r ", " #r " op_sel:[0,1] op_sel_hi:[1,0]\n"
+#define I_ALIGNBIT(r) "v_alignbit_b32 " #r ", " #r ", %8, 16\n"
+#define I_LSHLOR(r) "v_lshl_or_b32 " #r ", " #r ", 15, %8\n"
+#define I_CMPI16(r) "v_cmp_gt_i16 vcc, " #r ", %8\n"
+#define I_MOV(r) "v_mov_b32 " #r ", %8\n"
+#define I_LSHL(r) "v_lshlrev_b32 " #r ", 1, " #r "\n"
+#define I_SUB(r) "v_sub_u32 " #r ", " #r ", %8\n"
+#define I_MAXI32(r) "v_max_i32 " #r ", " #r ", %8\n"
 #define I_READLANE(r) "v_readfirstlane_b32 s20, " #r "\n"
 
 template <int OP>
@@ -57,6 +71,20 @@ __global__ void k(uint32_t* out, int iters, unsigned long long* cyc) {
         else if (OP == 15) { REP8(BODY(I_LSHR);) }
         else if (OP == 16) { REP8(BODY(I_ADD3);) }
         else if (OP == 17) { REP8(BODY(I_MOVDPP);) }
+        else if (OP == 18) { REP8(BODY(I_CNDMASK64);) }
+        else if (OP == 19) { REP8(BODY(I_PKMAD);) }
+        else if (OP == 20) { REP8(BODY(I_BFI);) }
+        else if (OP == 21) { REP8(BODY(I_AND);) }
+        else if (OP == 22) { REP8(BODY(I_OR);) }
+        else if (OP == 23) { REP8(BODY(I_ANDLIT);) }
+        else if (OP == 24) { REP8(BODY(I_PKMAXSEL);) }
+        else if (OP == 25) { REP8(BODY(I_ALIGNBIT);) }
+        else if (OP == 26) { REP8(BODY(I_LSHLOR);) }
+        else if (OP == 27) { REP8(BODY(I_CMPI16);) }
+        else if (OP == 28) { REP8(BODY(I_MOV);) }
+        else if (OP == 29) { REP8(BODY(I_LSHL);) }
+        else if (OP == 30) { REP8(BODY(I_SUB);) }
+        else if (OP == 31) { REP8(BODY(I_MAXI32);) }
     }
     const long long t1 = clock64();
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = (unsigned long long)(t1 - t0);
@@ -103,5 +131,19 @@ int main() {
     run<15>("v_lshrrev_b32", d, dc);
     run<16>("v_add3_u32", d, dc);
     run<17>("v_mov_b32_dpp", d, dc);
+    run<18>("v_cndmask_b32 sgpr", d, dc);
+    run<19>("v_pk_mad_i16", d, dc);
+    run<20>("v_bfi_b32", d, dc);
+    run<21>("v_and_b32", d, dc);
+    run<22>("v_or_b32", d, dc);
+    run<23>("v_and_b32 literal", d, dc);
+    run<24>("v_pk_max_i16 op_sel", d, dc);
+    run<25>("v_alignbit_b32", d, dc);
+    run<26>("v_lshl_or_b32", d, dc);
+    run<27>("v_cmp_gt_i16", d, dc);
+    run<28>("v_mov_b32", d, dc);
+    run<29>("v_lshlrev_b32", d, dc);
+    run<30>("v_sub_u32", d, dc);
+    run<31>("v_max_i32", d, dc);
     return 0;
 }
