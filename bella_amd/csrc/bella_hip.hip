@@ -100,7 +100,7 @@ struct bella_ctx {
     uint32_t kc_nkmers = 0, kc_k = 0;
     uint32_t kc_bfirst = 0, kc_brows = 0; // the read block the device-resident tuples cover (all reads unless counted distributed)
     Buf kc_nk, kc_koff, kc_hist, kc_keys, kc_alt, kc_runlen, kc_flag, kc_slot, kc_nruns, kc_dcode, kc_dcount, kc_hkey, kc_hval, kc_found,
-        kc_tstart, kc_cursor, kc_sel, kc_ringo, kc_ringp, kc_ids;
+        kc_tstart, kc_cursor, kc_sel, kc_ringo, kc_ringp, kc_opos, kc_oid, kc_opos2, kc_oid2;
     Buf Bptr, Bk, Bpos, Bent, Bcnt, Aent, Aent2, Aov, Arow, Bloc;
     bool have_rowlists = false;          // Aent2 / Arow hold the row lists of the current layout
     bool want_rowlists = false;          // BELLA_TUNE_ROW_LISTS: build them with the next layouts (when they fit)
@@ -549,7 +549,7 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
                   &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->orderlist, &c->order_ws, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx, &c->w_idx2, &c->w_hv, &c->w_ovfl,
                   &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_redo, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->w_desc, &c->w_gtab, &c->w_gcount, &c->w_gbase, &c->w_rfirst, &c->w_aent2, &c->w_aov, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
-                  &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->kc_ids, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch};
+                  &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->kc_opos, &c->kc_oid, &c->kc_opos2, &c->kc_oid2, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch};
     for (Buf* b : all) release(*b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& st : c->side) (void)hipStreamDestroy(st);
@@ -940,6 +940,15 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     HIPCHK(c, hipSetDevice(c->device));
     c->have_tuples = false;
     const uint32_t nr = c->nreads, k = kmer_size;
+    static const bool dev_marks = getenv("BELLA_DEV_KCMARKS") != nullptr;
+    auto tmark0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!dev_marks) return;
+        (void)hipStreamSynchronize(c->stream);
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[kc] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tmark0).count());
+        tmark0 = t;
+    };
     const int NR = dist ? c->comm_ranks : 1, me = dist ? c->comm_rank : 0;
     if (dist && !c->comm) return fail(c, BELLA_ERR_STATE, "bella_hip_comm_init first");
     if (brows == 0xFFFFFFFFu) { bfirst = 0; brows = nr; }
@@ -947,7 +956,8 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     // Local phase (histogram, sort passes, partial dictionary): a rank that fails here still takes part in the status exchange below,
     // so that all ranks leave the call together instead of waiting for it in the dictionary exchange.
     const uint8_t* d_sel = nullptr;
-    uint64_t nk_total = 0, ndistinct = 0;
+    uint64_t nk_total = 0, ndistinct = 0, nocc = 0;                // reliable k-mers, distinct k-mers, occurrences of reliable k-mers so far
+    uint32_t *occ_pos = nullptr, *occ_id = nullptr, *occ_pos2 = nullptr, *occ_id2 = nullptr;   // the list of occurrences and what it is sorted against
     bool fast = false, one_pass_all = false;
     uint32_t pb = 0;
     int rc = [&]() -> int {
@@ -983,17 +993,13 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     }
     // Words with their positions (kcount.hpp): when the word's 2k bits and a global position index fit 64 bits together -- and the
     // positions that make tuples are the positions that are counted (not so in syncmer mode) -- every sorted word still knows where it
-    // came from and the reliable ones hand their id to their position directly: no hash table over the dictionary, no look-up per
-    // position (which was a third of this call).  Not across ranks (a rank only sorts its share of the words).
+    // came from and the reliable ones leave (position, id) on a list that one more sort turns into the tuples: no hash table over the
+    // dictionary, no look-up per position (which was a third of this call).  Not across ranks (a rank only sorts its share of the words).
     {
         int posbits = 1;
         while (posbits < 63 && (1ull << posbits) < ntot) ++posbits;
-        fast = NR == 1 && mode != 1 && 2 * (int)k + posbits <= 64 && !(c->debug & 16384u);   // debug bit 14: tests, the look-up path
+        fast = NR == 1 && mode != 1 && 2 * (int)k + posbits <= 64 && posbits <= 32 && !(c->debug & 16384u);   // debug bit 14: tests, the look-up path
         pb = fast ? (uint32_t)posbits : 0u;
-    }
-    if (fast) {
-        ENSURE(c, c->kc_ids, 4 * ntot + 16);
-        HIPCHK(c, hipMemsetAsync(c->kc_ids.p, 0xFF, 4 * ntot + 16, c->stream));
     }
     uint64_t budget = c->kcount_budget;
     if (budget > 0x7FFF0000ull) budget = 0x7FFF0000ull;               // rocPRIM item counts are 32-bit
@@ -1045,14 +1051,15 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
         if (!np) continue;
         ENSURE(c, c->kc_keys, 8 * np);
         ENSURE(c, c->kc_alt, 8 * np);
-        ENSURE(c, c->kc_runlen, 4 * (np + 1));
-        ENSURE(c, c->kc_flag, 4 * (np + 2));
-        ENSURE(c, c->kc_slot, 4 * (np + 2));
+        ENSURE(c, c->kc_runlen, 4 * (np + 64));                    // (fast path: per-tile arrays, two of ntile + 8 words each -- np / 2048 tiles)
+        ENSURE(c, c->kc_flag, 4 * (np + 64));
+        ENSURE(c, c->kc_slot, 4 * (np + 64));
         if (!single) HIPCHK(c, hipMemsetAsync(c->kc_cursor.p, 0, 8, c->stream));
         k_emit_codes<<<rgrid, kBlock, 0, c->stream>>>(ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), ptr<uint32_t>(c->kc_nk),
                                                       ptr<uint64_t>(c->kc_koff), nr, k, mode, pass_lo[p], pass_hi[p], d_sel, ptr<uint64_t>(c->kc_keys),
                                                       single ? nullptr : (unsigned long long*)c->kc_cursor.p, pb);
         KCHK(c);
+        mark("alloc + emit codes");
         hipcub::DoubleBuffer<uint64_t> db(ptr<uint64_t>(c->kc_keys), ptr<uint64_t>(c->kc_alt));
         size_t tb = 0;
         // (with the positions in the keys the run kernels handle groups of four neighbouring words: the sort may leave out the word's
@@ -1062,17 +1069,23 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
         ENSURE(c, c->cubtmp, tb);
         HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(c->cubtmp.p, tb, db, (int)np, (int)(pb + gb), (int)pb + 2 * (int)k, c->stream));
         uint64_t* sorted = db.Current();
+        mark("sort");
         if (fast) {
             // runs of equal words, tile by tile: reliable runs per tile -> scan over the tiles = the ids of this pass -> every reliable
             // word's id to its position, the dictionary entries from the runs' first words (kcount.hpp)
             const unsigned ntile = nblk(np, kRunTile);
-            uint32_t* tile_rel = ptr<uint32_t>(c->kc_runlen);       // (ntile + 1 each; 4 (np + 1) bytes are there)
+            uint32_t* tile_rel = ptr<uint32_t>(c->kc_runlen);       // (ntile + 1 each; 4 (np + 64) bytes are there)
+            uint32_t* tile_words = tile_rel + ntile + 8;
             uint32_t* tile_heads = ptr<uint32_t>(c->kc_flag);
             uint32_t* tile_base = ptr<uint32_t>(c->kc_slot);
+            uint32_t* tile_wbase = tile_base + ntile + 8;
             HIPCHK(c, hipMemsetAsync(tile_rel + ntile, 0, 4, c->stream));
-            k_run_count<<<ntile, kRunBlock, 0, c->stream>>>(sorted, np, pb, gb, lower, upper, mode != 0, tile_rel, tile_heads);
+            HIPCHK(c, hipMemsetAsync(tile_words + ntile, 0, 4, c->stream));
+            k_run_count<<<ntile, kRunBlock, 0, c->stream>>>(sorted, np, pb, gb, lower, upper, mode != 0, tile_rel, tile_heads, tile_words);
             KCHK(c);
             rc = scan_u32(c, tile_rel, tile_base, (uint64_t)ntile + 1);
+            if (rc) return rc;
+            rc = scan_u32(c, tile_words, tile_wbase, (uint64_t)ntile + 1);
             if (rc) return rc;
             {
                 hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> hit(tile_heads, CastU64());
@@ -1081,19 +1094,41 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
                 ENSURE(c, c->cubtmp, tb4);
                 HIPCHK(c, hipcub::DeviceReduce::Sum(c->cubtmp.p, tb4, hit, ptr<uint64_t>(c->kc_cursor), (int)ntile, c->stream));
             }
-            uint32_t nrel = 0;
+            uint32_t nrel = 0, nwords = 0;
             uint64_t nruns = 0;
             HIPCHK(c, hipMemcpyAsync(&nrel, tile_base + ntile, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&nwords, tile_wbase + ntile, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(&nruns, c->kc_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            mark("run count + scans");
             if (nk_total + nrel >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "more than 2^32 reliable k-mers");
+            if (nocc + nwords >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "tuple count must be < 2^32");
             rc = grow_keep(c, c->kc_dcode, 8 * (nk_total + nrel), 8 * nk_total);
             if (rc) return rc;
             rc = grow_keep(c, c->kc_dcount, 2 * (nk_total + nrel), 2 * nk_total);
             if (rc) return rc;
-            k_run_assign<<<ntile, kRunBlock, 0, c->stream>>>(sorted, np, pb, gb, lower, upper, mode != 0, tile_base, (uint32_t)nk_total, 0ull, ntot, ptr<uint32_t>(c->kc_ids),
+            // the list of occurrences: with one pass (the usual case) it goes into the sort's free buffer (8 np bytes: positions, then
+            // ids) and is later sorted against the buffer of the sorted words, which nobody reads after this kernel -- no allocation;
+            // with several passes it grows in buffers of its own
+            uint32_t *op = nullptr, *oi = nullptr;
+            if (pass_n.size() == 1) {
+                uint64_t* freebuf = sorted == ptr<uint64_t>(c->kc_keys) ? ptr<uint64_t>(c->kc_alt) : ptr<uint64_t>(c->kc_keys);
+                op = (uint32_t*)freebuf; oi = op + np;
+                occ_pos = op; occ_id = oi; occ_pos2 = (uint32_t*)sorted; occ_id2 = occ_pos2 + np;
+            } else {
+                rc = grow_keep(c, c->kc_opos, 4 * (nocc + nwords) + 16, 4 * nocc);
+                if (rc) return rc;
+                rc = grow_keep(c, c->kc_oid, 4 * (nocc + nwords) + 16, 4 * nocc);
+                if (rc) return rc;
+                op = ptr<uint32_t>(c->kc_opos) + nocc; oi = ptr<uint32_t>(c->kc_oid) + nocc;
+                occ_pos = ptr<uint32_t>(c->kc_opos); occ_id = ptr<uint32_t>(c->kc_oid); occ_pos2 = nullptr; occ_id2 = nullptr;
+            }
+            mark("grow dict + list");
+            k_run_assign<<<ntile, kRunBlock, 0, c->stream>>>(sorted, np, pb, gb, lower, upper, mode != 0, tile_base, tile_wbase, (uint32_t)nk_total, op, oi,
                                                              ptr<uint64_t>(c->kc_dcode) + nk_total, ptr<uint16_t>(c->kc_dcount) + nk_total);
             KCHK(c);
+            mark("run assign");
+            nocc += nwords;
             nk_total += nrel;
             ndistinct += nruns;
             continue;
@@ -1132,7 +1167,9 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     }();
     if (NR > 1) rc = comm_agree(c, rc);
     if (rc) return rc;
-    release(c->kc_alt); release(c->kc_runlen); release(c->kc_flag); release(c->kc_slot);
+    if (!(fast && occ_pos2)) release(c->kc_alt);                  // (fast path, one pass: the sort's two buffers hold the list of occurrences)
+    release(c->kc_runlen); release(c->kc_flag); release(c->kc_slot);
+    mark("release sort buffers");
     if (NR > 1) {
         // partial dictionaries -> the whole dictionary on every rank
         ENSURE(c, c->comm_meta, 8 * 4 * ((size_t)NR + 1));
@@ -1186,13 +1223,39 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     }
     uint32_t* ids_rel = nullptr;
     const unsigned bgrid = brows < 16384u ? (brows ? brows : 1u) : 16384u;
+    uint64_t nt = 0;
     if (fast) {
-        // the ids are where they belong already (k_run_ids): count the tuples per read
-        release(c->kc_keys);
-        ids_rel = ptr<uint32_t>(c->kc_ids);                           // (indexed by the absolute position koff[r] + j, all reads)
-        if (brows) {
-            k_count_found<<<nblk(brows, kWaves), kBlock, 0, c->stream>>>(ids_rel, ptr<uint32_t>(c->kc_nk) + bfirst, ptr<uint64_t>(c->kc_koff) + bfirst, brows,
-                                                                       ptr<uint32_t>(c->kc_found));
+        // the list of occurrences, sorted by position = the tuples in the reference's order (main.cpp:393-416); where each read's begin
+        if (!occ_pos2) release(c->kc_keys);
+        const uint32_t* spos = occ_pos;
+        const uint32_t* sid = occ_id;
+        if (nocc) {
+            if (!occ_pos2) {
+                ENSURE(c, c->kc_opos2, 4 * nocc + 16);
+                ENSURE(c, c->kc_oid2, 4 * nocc + 16);
+                occ_pos2 = ptr<uint32_t>(c->kc_opos2); occ_id2 = ptr<uint32_t>(c->kc_oid2);
+            }
+            hipcub::DoubleBuffer<uint32_t> dk(occ_pos, occ_pos2);
+            hipcub::DoubleBuffer<uint32_t> dv(occ_id, occ_id2);
+            size_t tb = 0;
+            HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (uint64_t)nocc, 0, (int)pb, c->stream));
+            ENSURE(c, c->cubtmp, tb);
+            HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb, dk, dv, (uint64_t)nocc, 0, (int)pb, c->stream));
+            spos = dk.Current();
+            sid = dv.Current();
+            mark("sort occurrences");
+        }
+        uint32_t* first = ptr<uint32_t>(c->kc_found);              // (nr + 2 words)
+        k_occ_bounds<<<nblk((uint64_t)brows + 1), 256, 0, c->stream>>>(spos, nocc, ptr<uint64_t>(c->kc_koff) + bfirst, brows, first, ptr<uint64_t>(c->kc_tstart));
+        KCHK(c);
+        HIPCHK(c, hipMemcpyAsync(&nt, ptr<uint64_t>(c->kc_tstart) + brows, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        ENSURE(c, c->t_kmer, 4 * nt);
+        ENSURE(c, c->t_read, 4 * nt);
+        ENSURE(c, c->t_pos, 2 * nt);
+        if (brows && nt) {
+            k_write_tuples_sorted<<<bgrid, kBlock, 0, c->stream>>>(spos, sid, ptr<uint64_t>(c->kc_koff) + bfirst, first, brows, bfirst, ptr<uint32_t>(c->t_kmer),
+                                                                   ptr<uint32_t>(c->t_read), ptr<uint16_t>(c->t_pos));
             KCHK(c);
         }
     } else {
@@ -1221,11 +1284,9 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
                                                   ptr<uint64_t>(c->kc_koff) + bfirst, brows, k, ptr<uint64_t>(c->kc_hkey), ptr<uint32_t>(c->kc_hval),
                                                   slots - 1, sel_rel, ids_rel, ptr<uint32_t>(c->kc_found));
     KCHK(c);
-    }
     HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->kc_found) + brows, 0, 4, c->stream));
     rc = scan_u32_to_u64(c, ptr<uint32_t>(c->kc_found), ptr<uint64_t>(c->kc_tstart), (uint64_t)brows + 1);
     if (rc) return rc;
-    uint64_t nt = 0;
     HIPCHK(c, hipMemcpyAsync(&nt, ptr<uint64_t>(c->kc_tstart) + brows, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (nt >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "tuple count must be < 2^32");
@@ -1236,10 +1297,13 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
                                                     ptr<uint64_t>(c->kc_tstart), brows, bfirst, ptr<uint32_t>(c->t_kmer), ptr<uint32_t>(c->t_read),
                                                     ptr<uint16_t>(c->t_pos));
     KCHK(c);
+    }
+    mark("tuples");
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev[1]));
     c->tm.kcount_ms = ev_ms(c->ev[0], c->ev[1]);
-    release(c->kc_keys); release(c->kc_hkey); release(c->kc_hval); release(c->kc_sel); release(c->kc_ids);
+    release(c->kc_keys); release(c->kc_alt); release(c->kc_hkey); release(c->kc_hval); release(c->kc_sel);
+    release(c->kc_opos); release(c->kc_oid); release(c->kc_opos2); release(c->kc_oid2);
     c->kc_ntuples = nt;
     c->kc_nkmers = (uint32_t)nk_total;
     c->kc_k = k;
@@ -2421,7 +2485,7 @@ int bella_hip_get_memory(bella_ctx* c, bella_memory* m) {
                          &c->w_nruns, &c->w_desc, &c->w_gtab, &c->w_gcount, &c->w_gbase, &c->w_rfirst, &c->w_aent2, &c->w_aov});
     m->other_bytes = sum({&c->t_kmer, &c->t_read, &c->t_pos, &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->asm_cls, &c->lk_key, &c->lk_key2, &c->lk_val,
                           &c->lk_val2, &c->w, &c->wscan, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen, &c->kc_flag, &c->kc_slot, &c->kc_nruns,
-                          &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->kc_ids, &c->alns,
+                          &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->kc_opos, &c->kc_oid, &c->kc_opos2, &c->kc_oid2, &c->alns,
                           &c->seeds, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch, &c->status, &c->comm_meta});
     m->owned_nnz = c->have_matrix ? c->owned_nnz : 0;
     return 0;

@@ -202,9 +202,13 @@ __global__ void k_write_dict(const uint64_t* run_code, const uint32_t* run_len, 
 // order.  A group is handled by the thread of its first word: it counts the group's words per value of the low bits, which gives the
 // group's runs in ascending word order without moving anything.  A group belongs to the tile that holds its first word.  Two passes
 // over the sorted words with a scan over the TILES in between -- no per-word flag or slot arrays:
-//   k_run_count   per tile: runs that start in it (-> distinct words) and reliable runs that start in it (-> ids of the tile's runs)
+//   k_run_count   per tile: runs that start in it (-> distinct words), reliable runs that start in it (-> ids of the tile's runs) and
+//                 their words (-> the tile's place in the list of occurrences)
 //   k_run_assign  per tile: the same groups again; every reliable run gets its id (tile's first id + reliable runs before it), writes
-//                 its dictionary entry and hands the id to the position of every word of the run (`ids[position]`)
+//                 its dictionary entry and appends (position, id) of every word of the run to the list of occurrences -- compact,
+//                 sequential writes; one radix sort of that list by position (a fifth of the words) then IS the tuple list in the
+//                 reference's order.  (Handing the id to `ids[position]` directly was 205 M random 4-byte writes into a 4 GB
+//                 array at 100k reads: 12.7 ms, and three more passes over that array.)
 constexpr uint32_t kRunTile = 2048, kRunHalo = 32, kRunBlock = 256, kRunGroupMax = 4;
 struct RunTile {
     uint64_t w[kRunTile + kRunHalo];          // the tile's words and the look-ahead
@@ -256,51 +260,67 @@ __device__ __forceinline__ void run_tile_groups(RunTile& T, const uint64_t* s, u
     }
 }
 __global__ __launch_bounds__(kRunBlock) void k_run_count(const uint64_t* s, uint64_t n, uint32_t pb, uint32_t gb, uint32_t lower, uint32_t upper,
-                                                         uint32_t saturate, uint32_t* tile_rel, uint32_t* tile_heads) {
+                                                         uint32_t saturate, uint32_t* tile_rel, uint32_t* tile_heads, uint32_t* tile_words) {
     __shared__ RunTile T;
-    __shared__ uint32_t s_cnt[2];
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-    uint32_t rel = 0, heads = 0;
+    __shared__ uint32_t s_cnt[3];
+    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+    uint32_t rel = 0, heads = 0, words = 0;
     run_tile_groups(T, s, n, pb, gb, [&](uint32_t, uint32_t, const RunGroup& G) {
 #pragma unroll
         for (uint32_t v = 0; v < kRunGroupMax; ++v) {
             const uint32_t c = count16(G.cnt[v], saturate);
+            const bool r = G.cnt[v] && c >= lower && c <= upper;
             heads += G.cnt[v] ? 1u : 0u;
-            rel += (G.cnt[v] && c >= lower && c <= upper) ? 1u : 0u;
+            rel += r ? 1u : 0u;
+            words += r ? G.cnt[v] : 0u;                           // (at most the words of the pass: < 2^31)
         }
     });
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { rel += __shfl_xor(rel, d, 64); heads += __shfl_xor(heads, d, 64); }
-    if (lane_id() == 0) { if (rel) atomicAdd(&s_cnt[0], rel); if (heads) atomicAdd(&s_cnt[1], heads); }
+    for (int d = 32; d > 0; d >>= 1) { rel += __shfl_xor(rel, d, 64); heads += __shfl_xor(heads, d, 64); words += __shfl_xor(words, d, 64); }
+    if (lane_id() == 0) { if (rel) atomicAdd(&s_cnt[0], rel); if (heads) atomicAdd(&s_cnt[1], heads); if (words) atomicAdd(&s_cnt[2], words); }
     __syncthreads();
-    if (threadIdx.x == 0) { tile_rel[blockIdx.x] = s_cnt[0]; tile_heads[blockIdx.x] = s_cnt[1]; }
+    if (threadIdx.x == 0) { tile_rel[blockIdx.x] = s_cnt[0]; tile_heads[blockIdx.x] = s_cnt[1]; tile_words[blockIdx.x] = s_cnt[2]; }
 }
-// tile_base[t] = reliable runs that start before tile t (exclusive scan of k_run_count's tile_rel); pos_lo / pos_hi: the positions ids[] covers
+// tile_base[t] = reliable runs that start before tile t, tile_wbase[t] = their words (exclusive scans of k_run_count's tile_rel /
+// tile_words); occ_pos / occ_id: this pass's part of the list of occurrences (the order inside a tile's part is arbitrary: the list is
+// sorted by position afterwards, and positions are unique)
 __global__ __launch_bounds__(kRunBlock) void k_run_assign(const uint64_t* s, uint64_t n, uint32_t pb, uint32_t gb, uint32_t lower, uint32_t upper,
-                                                          uint32_t saturate, const uint32_t* tile_base, uint32_t id_base, uint64_t pos_lo, uint64_t pos_hi,
-                                                          uint32_t* ids, uint64_t* dict_code, uint16_t* dict_count) {
+                                                          uint32_t saturate, const uint32_t* tile_base, const uint32_t* tile_wbase, uint32_t id_base,
+                                                          uint32_t* occ_pos, uint32_t* occ_id, uint64_t* dict_code, uint16_t* dict_count) {
     __shared__ RunTile T;
+    __shared__ uint32_t s_words, s_nrec;
+    // the groups with a reliable run, collected: {place in the tile | reliable runs << 16, words of the group, words of its reliable runs}.
+    // One in twelve group heads has one; handled where they stand, eight rounds of 256 threads would each run as long as their
+    // longest group with a handful of lanes busy (10.6 ms at 100k reads); collected, they fill the lanes of one round.
+    __shared__ uint32_t s_rec[kRunTile / 2][3];                   // (a reliable group has at least two words: at most 1,024 start in a tile)
+    if (threadIdx.x == 0) { s_words = 0; s_nrec = 0; }
     const uint64_t x0 = (uint64_t)blockIdx.x * kRunTile;
-    // pass 1 over the group heads: how many reliable runs each group has (0 .. 4) and which
-    uint32_t relmask[kRunTile / kRunBlock];                       // bits 0..3: value v of the low bits is a reliable run of my group of round u
-    uint32_t glen[kRunTile / kRunBlock];
-    uint32_t gcnt[kRunTile / kRunBlock][kRunGroupMax];
+    uint32_t relcnt[kRunTile / kRunBlock];                        // reliable runs of my group of round u (0 .. 4)
 #pragma unroll
-    for (uint32_t u = 0; u < kRunTile / kRunBlock; ++u) { relmask[u] = 0; glen[u] = 0; }
-    run_tile_groups(T, s, n, pb, gb, [&](uint32_t u, uint32_t, const RunGroup& G) {
-        uint32_t mk = 0;
+    for (uint32_t u = 0; u < kRunTile / kRunBlock; ++u) relcnt[u] = 0;
+    run_tile_groups(T, s, n, pb, gb, [&](uint32_t u, uint32_t e, const RunGroup& G) {
+        uint32_t mk = 0, words = 0;
 #pragma unroll
         for (uint32_t v = 0; v < kRunGroupMax; ++v) {
             const uint32_t c = count16(G.cnt[v], saturate);
-            mk |= (G.cnt[v] && c >= lower && c <= upper) ? 1u << v : 0u;
-            gcnt[u][v] = G.cnt[v];
+            const bool r = G.cnt[v] && c >= lower && c <= upper;
+            mk |= r ? 1u << v : 0u;
+            words += r ? G.cnt[v] : 0u;
         }
-        relmask[u] = mk;
-        glen[u] = (uint32_t)(G.len > 0xFFFFFFFFull ? 0xFFFFFFFFull : G.len);
+        relcnt[u] = (uint32_t)__popc(mk);
+        // (all group heads of a round arrive here together: one LDS atomic for the lanes that have something to append)
+        const unsigned long long bal = __ballot(mk != 0u);
+        if (bal) {
+            const int leader = __ffsll((long long)bal) - 1;
+            uint32_t at = 0;
+            if ((int)lane_id() == leader) at = atomicAdd(&s_nrec, (uint32_t)__popcll(bal));
+            at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(bal & ((1ull << lane_id()) - 1ull));
+            if (mk) { s_rec[at][0] = e | (mk << 16); s_rec[at][1] = (uint32_t)(G.len > 0xFFFFFFFFull ? 0xFFFFFFFFull : G.len); s_rec[at][2] = words; }
+        }
     });
 #pragma unroll
     for (uint32_t u = 0; u < kRunTile / kRunBlock; ++u) {          // words u * 256 + w * 64 + lane: three ballots per group of 64 words
-        const uint32_t nr = (uint32_t)__popc(relmask[u]);
+        const uint32_t nr = relcnt[u];
 #pragma unroll
         for (uint32_t b = 0; b < 3; ++b) {
             const unsigned long long m = __ballot((nr >> b) & 1u);
@@ -317,51 +337,68 @@ __global__ __launch_bounds__(kRunBlock) void k_run_assign(const uint64_t* s, uin
     }
     __syncthreads();
     const uint32_t base = tile_base[blockIdx.x];
+    const uint32_t wbase = tile_wbase[blockIdx.x];
     const uint64_t pmask = (1ull << pb) - 1ull;
     const uint32_t lowmask = (1u << gb) - 1u;
     const uint32_t have = (uint32_t)(n - x0 < kRunTile + kRunHalo ? n - x0 : kRunTile + kRunHalo);
-#pragma unroll
-    for (uint32_t u = 0; u < kRunTile / kRunBlock; ++u) {
-        if (!relmask[u]) continue;
-        const uint32_t e = u * kRunBlock + threadIdx.x;
+    const uint32_t nrec = s_nrec;
+    for (uint32_t r0 = 0; r0 < nrec; r0 += kRunBlock) {
+        const uint32_t r = r0 + threadIdx.x;
+        const bool valid = r < nrec;
+        const uint32_t r0w = valid ? s_rec[r][0] : 0u, glen = valid ? s_rec[r][1] : 0u, mywords = valid ? s_rec[r][2] : 0u;
+        // this group's place in the tile's part of the list: one LDS atomic per wavefront (a same-address atomic per lane serialises)
+        const uint32_t inc = wave_incl_scan(mywords);
+        uint32_t w0 = 0;
+        if (lane_id() == 63 && inc) w0 = atomicAdd(&s_words, inc);
+        w0 = (uint32_t)__shfl((int)w0, 63, 64);
+        if (!valid) continue;
+        const uint32_t e = r0w & 0xFFFFu, mk = r0w >> 16;
         const uint32_t q = e / 64;
         const unsigned long long below = (1ull << (e & 63u)) - 1ull;
         const uint32_t first = base + T.pre[q] + (uint32_t)__popcll(T.bm[0][q] & below) + 2u * (uint32_t)__popcll(T.bm[1][q] & below) +
                                4u * (uint32_t)__popcll(T.bm[2][q] & below);
         const uint64_t g = T.w[e] >> (pb + gb);
-        uint32_t idv[kRunGroupMax];                               // local id of the group's run with low bits v (if reliable)
+        uint32_t idv[kRunGroupMax], cnt[kRunGroupMax];            // local id of the group's run with low bits v (if reliable), its words
         uint32_t nxt = first;
 #pragma unroll
-        for (uint32_t v = 0; v < kRunGroupMax; ++v) {
-            idv[v] = nxt;
-            if ((relmask[u] >> v) & 1u) {
-                dict_code[nxt] = (g << gb) | v;
-                dict_count[nxt] = (uint16_t)count16(gcnt[u][v], saturate);
-                ++nxt;
-            }
-        }
-        for (uint32_t m2 = 0; m2 < glen[u]; ++m2) {                // (a reliable run is at most `upper` words unless its 16-bit count wrapped)
+        for (uint32_t v = 0; v < kRunGroupMax; ++v) { idv[v] = nxt; cnt[v] = 0; nxt += (mk >> v) & 1u; }
+        uint32_t w = wbase + w0 + inc - mywords;
+        for (uint32_t m2 = 0; m2 < glen; ++m2) {                   // (a reliable run is at most `upper` words unless its 16-bit count wrapped)
             const uint64_t wv = e + m2 < have ? T.w[e + m2] : s[x0 + e + m2];
             const uint32_t v = (uint32_t)(wv >> pb) & lowmask;
-            if (!((relmask[u] >> v) & 1u)) continue;
-            const uint64_t gp = wv & pmask;
+            if (!((mk >> v) & 1u)) continue;
             const uint32_t id = v == 0 ? idv[0] : v == 1 ? idv[1] : v == 2 ? idv[2] : idv[3];
-            if (gp >= pos_lo && gp < pos_hi) ids[gp - pos_lo] = id_base + id;
+            cnt[0] += v == 0; cnt[1] += v == 1; cnt[2] += v == 2; cnt[3] += v == 3;
+            occ_pos[w] = (uint32_t)(wv & pmask);
+            occ_id[w] = id_base + id;
+            ++w;
         }
+#pragma unroll
+        for (uint32_t v = 0; v < kRunGroupMax; ++v)
+            if ((mk >> v) & 1u) { dict_code[idv[v]] = (g << gb) | v; dict_count[idv[v]] = (uint16_t)count16(cnt[v], saturate); }
     }
 }
 
-// tuples per read from the ids of its positions (what k_lookup_ids counts on the look-up path)
-__global__ __launch_bounds__(kBlock) void k_count_found(const uint32_t* ids, const uint32_t* nk, const uint64_t* koff, uint32_t nreads, uint32_t* found_per_read) {
-    const uint32_t r = blockIdx.x * kWaves + wave_id();
-    if (r >= nreads) return;
-    const uint64_t o = koff[r];
-    const uint32_t n = nk[r];
-    uint32_t mine = 0;
-    for (uint32_t j = lane_id(); j < n; j += 64) mine += ids[o + j] != 0xFFFFFFFFu;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
-    if (lane_id() == 0) found_per_read[r] = mine;
+// the list of occurrences sorted by position: where the tuples of each read of the block begin (first[r] = the first occurrence at or
+// after the read's first position, r = 0 .. nreads) and, relative to the block's first tuple, tstart
+__global__ void k_occ_bounds(const uint32_t* spos, uint64_t nocc, const uint64_t* koff, uint32_t nreads, uint32_t* first, uint64_t* tstart) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nreads) return;
+    auto lower = [&](uint64_t key) -> uint64_t { uint64_t l = 0, h = nocc; while (l < h) { const uint64_t m = (l + h) >> 1; if ((uint64_t)spos[m] < key) l = m + 1; else h = m; } return l; };
+    const uint64_t me = lower(koff[r]);
+    first[r] = (uint32_t)me;
+    tstart[r] = me - lower(koff[0]);
+}
+// tuples (id, read, position) from the sorted list: the reference's generation order -- read by read, positions ascending (main.cpp:393-416)
+__global__ __launch_bounds__(kBlock) void k_write_tuples_sorted(const uint32_t* spos, const uint32_t* sid, const uint64_t* koff, const uint32_t* first,
+                                                                uint32_t nreads, uint32_t read_base, uint32_t* t_kmer, uint32_t* t_read, uint16_t* t_pos) {
+    for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
+        const uint32_t f0 = first[0], lo = first[r], hi = first[r + 1];
+        const uint64_t o = koff[r];
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+            t_kmer[i - f0] = sid[i]; t_read[i - f0] = read_base + r; t_pos[i - f0] = (uint16_t)((uint64_t)spos[i] - o);
+        }
+    }
 }
 
 // countsreliable (a CuckooDict in the reference, main.cpp:410 `find`): open addressing over the dictionary, value = id
