@@ -265,7 +265,16 @@ inline const uint32_t* layout_bptr(const bella_ctx* c) { return ptr<uint32_t>(c-
 // the k-mer lists of A', ascending read id) and coalesced segmented passes; 32 B of temporaries per nonzero.
 // The layout follows the context's partition (bella_hip_set_partition): A' is whole, B' entries -- and the optional row lists --
 // exist for the owned columns only, so the per-column part of the work and of the memory is 1/stride of the whole.
+// The large working buffers of k-mer counting (the sort's two key arrays and the tile arrays: 29 GB at 100k reads) stay with the context
+// when the call returns and go when the next stage starts (assembly, device layout): a second count finds them in place, a pipeline's
+// peak is what it was -- and no call frees tens of GB only for the next one to ask for them again at once (hipMalloc right after a
+// hipFree of that size was measured at ~1 s on ROCm 7.2, against microseconds otherwise).
+void release_count_scratch(bella_ctx* c) {
+    release(c->kc_keys); release(c->kc_alt); release(c->kc_runlen); release(c->kc_flag); release(c->kc_slot);
+}
+
 int build_layout(bella_ctx* c) {
+    release_count_scratch(c);
     const uint64_t nnz = c->nnz;
     const uint32_t nk = c->nkmers;
     const uint32_t pf = c->part_first, ps = c->part_stride;
@@ -769,6 +778,7 @@ int bella_hip_set_B(bella_ctx* c, uint16_t kmer_size, uint32_t nkmers, const uin
 // t_kmer == nullptr: the tuples are already on the device (bella_hip_count_kmers), `toff` tuples into the buffers
 static int assemble_rows_device(bella_ctx* c, uint32_t first, uint32_t nr, uint64_t ntuples, const uint32_t* t_kmer,
                                 const uint32_t* t_read, const uint16_t* t_pos, uint64_t* nnz_out, uint64_t toff = 0) {
+    release_count_scratch(c);
     if (t_kmer || !ntuples) {
         ENSURE(c, c->t_kmer, 4 * ntuples);
         ENSURE(c, c->t_read, 4 * ntuples);
@@ -940,11 +950,11 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     HIPCHK(c, hipSetDevice(c->device));
     c->have_tuples = false;
     const uint32_t nr = c->nreads, k = kmer_size;
-    static const bool dev_marks = getenv("BELLA_DEV_KCMARKS") != nullptr;
+    static const int dev_marks = getenv("BELLA_DEV_KCMARKS") ? atoi(getenv("BELLA_DEV_KCMARKS")) : 0;   // 1: stage times (synchronising), 2: host time only
     auto tmark0 = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
         if (!dev_marks) return;
-        (void)hipStreamSynchronize(c->stream);
+        if (dev_marks == 1) (void)hipStreamSynchronize(c->stream);
         const auto t = std::chrono::steady_clock::now();
         fprintf(stderr, "[kc] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tmark0).count());
         tmark0 = t;
@@ -1167,9 +1177,7 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     }();
     if (NR > 1) rc = comm_agree(c, rc);
     if (rc) return rc;
-    if (!(fast && occ_pos2)) release(c->kc_alt);                  // (fast path, one pass: the sort's two buffers hold the list of occurrences)
-    release(c->kc_runlen); release(c->kc_flag); release(c->kc_slot);
-    mark("release sort buffers");
+    mark("passes");
     if (NR > 1) {
         // partial dictionaries -> the whole dictionary on every rank
         ENSURE(c, c->comm_meta, 8 * 4 * ((size_t)NR + 1));
@@ -1226,7 +1234,6 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     uint64_t nt = 0;
     if (fast) {
         // the list of occurrences, sorted by position = the tuples in the reference's order (main.cpp:393-416); where each read's begin
-        if (!occ_pos2) release(c->kc_keys);
         const uint32_t* spos = occ_pos;
         const uint32_t* sid = occ_id;
         if (nocc) {
@@ -1302,7 +1309,7 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev[1]));
     c->tm.kcount_ms = ev_ms(c->ev[0], c->ev[1]);
-    release(c->kc_keys); release(c->kc_alt); release(c->kc_hkey); release(c->kc_hval); release(c->kc_sel);
+    release(c->kc_hkey); release(c->kc_hval); release(c->kc_sel);
     release(c->kc_opos); release(c->kc_oid); release(c->kc_opos2); release(c->kc_oid2);
     c->kc_ntuples = nt;
     c->kc_nkmers = (uint32_t)nk_total;

