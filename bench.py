@@ -213,7 +213,7 @@ def xdrop_record(eng, workload):
            "pairs_per_s": len(al) / (xms * 1e-3) if xms else None, "antidiagonal_steps": steps_tot,
            "gcups": 31 * steps_tot / (xms * 1e-3) / 1e9 if xms else None, "flagged": int(al["flagged"].sum()),
            "bound": "VALU issue: packed-i16 / v_perm band updates issue one wavefront-instruction per SIMD every ~4 cycles "
-                    "(profiles/r03_valu_rates.txt; the instruction counts of this kernel are in profiles/r04_xdrop_sq.txt, a separate profiled run)"}
+                    "(profiles/r04_valu_rates.txt; 264 VALU instructions per anti-diagonal of 64 extensions: profiles/r04_xdrop_sq.txt, a separate profiled run)"}
     del al
     return rec
 
