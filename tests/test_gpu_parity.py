@@ -218,6 +218,60 @@ def test_xavier_known_answers_on_gpu(eng):
             assert ("c" if a["strand"] else "n") == kat["strand"]
 
 
+def test_xdrop_sequence_ends_short_reads_both_strands(eng):
+    """The band on and past the sequence ends (xavier.h:185-251, the terminator / pad codes of simdutils.h:191-195): many short pairs --
+    40 .. 400 bases, seeds anywhere including the very ends, identical / noisy / unrelated flanks, both strands, unequal lengths -- so
+    that every extension reaches Phase 4 within a few dozen steps.  Every field of every record against the oracle, all kernel
+    variants (the slices forced into classes as well)."""
+    rng = np.random.default_rng(20240)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    k, x = 17, 7
+    seqs, seeds = [], []
+    for n in range(900):
+        L = int(rng.integers(40, 400))
+        tpl = rng.integers(0, 4, L).astype(np.uint8)
+        s0 = int(rng.integers(0, L - k + 1)) if n % 5 else (0 if n % 2 else L - k)          # every fifth seed at an end of the row
+        noise = (0.0, 0.03, 0.15, 0.6)[n % 4]
+        cut_l = int(rng.integers(0, s0 + 1)) if n % 3 else 0                                 # the column starts later / ends earlier than the row
+        cut_r = int(rng.integers(s0 + k, L + 1)) if n % 3 == 1 else L
+        col = tpl[cut_l:cut_r].copy()
+        sj = s0 - cut_l
+        mut = rng.random(len(col)) < noise
+        mut[sj:sj + k] = False                                                              # the seed k-mer stays
+        col[mut] = (col[mut] + rng.integers(1, 4, int(mut.sum()))) % 4
+        row_b = bytes(b"ACGT"[c] for c in tpl)
+        col_b = bytes(b"ACGT"[c] for c in col)
+        if n % 2:                                                                           # the column as its reverse complement
+            col_b = col_b.translate(comp)[::-1]
+            sj = len(col_b) - k - sj
+        if len(col_b) < k or len(row_b) < k:
+            continue
+        seqs += [row_b, col_b]
+        seeds.append((len(seqs) - 2, len(seqs) - 1, s0, sj))
+    rs = synth.readset_from_seqs(seqs)
+    eng.set_reads(rs)
+    sd = np.zeros(len(seeds), api.SEED_DT)
+    for t, q in enumerate(seeds):
+        sd[t] = q
+    pars = BellaPars(kmerSize=k, xDrop=x)
+    ref = eng.xdrop_batch(sd, pars)
+    for (rid, cid, i, j), a in zip(seeds, ref):
+        o = O.xavier_align(seqs[rid], seqs[cid], i, j, x, k)
+        got = (int(a["score"]), int(a["begH"]), int(a["endH"]), int(a["begV"]), int(a["endV"]), int(a["strand"]), int(a["steps"]), int(a["flagged"]))
+        exp = (int(o["score"]), int(o["begH"]), int(o["endH"]), int(o["begV"]), int(o["endV"]), int(o["strand"]), int(o["steps"]), int(o["flagged"]))
+        assert got == exp, (rid, cid, i, j, len(seqs[rid]), len(seqs[cid]))
+    for variant, cmin in ((0, None), (1, 64), (2, None), (3, None)):
+        eng.set_tuning("xdrop_variant", variant)
+        if cmin:
+            eng.set_tuning("xdrop_class_min", cmin)
+        try:
+            other = eng.xdrop_batch(sd, pars)
+        finally:
+            eng.set_tuning("xdrop_variant")
+            eng.set_tuning("xdrop_class_min")
+        assert np.array_equal(other, ref), variant
+
+
 def test_exact_xdrop_mode_matches_logan_oracle_and_seqan_answers(eng):
     """the LOGAN-equivalent scoring kernel (logan.hpp): the reference's alignSeqAn known answers, and a golden read set's candidate
     pairs (Xavier's seeds) field by field against the oracle's restatement of loganGPU/functions.cuh + PostAlignDecisionGPU"""
