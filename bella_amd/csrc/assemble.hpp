@@ -350,7 +350,7 @@ __device__ __forceinline__ void run_bounds(const uint32_t* skey, uint64_t nnz, u
 constexpr int kLayoutEmitPartBlock = 1024;      // workgroup of the partitioned launch (own_stride > 1); any size otherwise
 __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64_t nnz, const uint32_t* Bptr, const uint32_t* Bloc, const uint32_t* wscan,
                               const uint32_t* packed, const uint64_t* roff, uint32_t k, uint32_t rmask, uint2* Aent, uint32_t* ekey, uint64_t* eval,
-                              uint32_t by_kmer, uint32_t own_first, uint32_t own_stride, uint32_t* counter, uint32_t* status) {
+                              uint32_t by_kmer, uint32_t own_first, uint32_t own_stride, uint32_t* counter, uint32_t* status, uint32_t inl) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool mine = false;
     uint32_t dstkey = 0;
@@ -378,6 +378,11 @@ __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64
         mine = own_stride == 1u || r % own_stride == own_first;               // B' entries only for the columns this context owns
         dstkey = Bloc[r] + ((uint32_t)v >> 16);
         dstval = (uint64_t)(cs + rk + 1) | ((uint64_t)(pos | ((dg - 1 - rk) << 16) | (pal << 30) | (ori << 31)) << 32);
+        if (inl && dg == 2u && rk == 0u && !pal) {                            // exactly one later read: the entry carries it (util.hpp: INLINE form)
+            const uint64_t v1 = sval[lo + 1];
+            const uint32_t hi1 = (uint32_t)(v1 >> 32);
+            dstval = (uint64_t)((hi1 & rmask) | ((hi1 >> 31) == ori ? 1u << 30 : 0u) | (1u << 31)) | ((uint64_t)(pos | (((uint32_t)v1 & 0xFFFFu) << 16)) << 32);
+        }
     }
     if (own_stride == 1u) {                                                   // every entry has a B' entry: it leaves at its sorted place
         if (x < nnz) { ekey[x] = dstkey; eval[x] = dstval; }
@@ -413,9 +418,9 @@ __global__ void k_layout_own_lengths(const uint32_t* Bptr, uint32_t nreads, uint
 // the products of every entry once more, compact: estimateFLOP streams 2 B per nonzero
 // (Measured and not kept, round 4: B' without the entries that have no later read -- 38 % of the entries at 30x, nearly all entries of
 // the last columns: two more streaming passes at layout time, +0.9 ms at 100k reads, for 0.13 ms per pass.)
-__global__ void k_layout_bcnt(const uint2* Bent, uint64_t nnz, uint16_t* Bcnt) {
+__global__ void k_layout_bcnt(const uint2* Bent, uint64_t nnz, uint16_t* Bcnt, uint32_t inl) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < nnz) Bcnt[e] = (uint16_t)((Bent[e].y >> 16) & 0x3FFFu);
+    if (e < nnz) Bcnt[e] = (uint16_t)bent_count(Bent[e], inl);
 }
 
 // ---- row lists: the products of every column, ready-made, in product order -----------------------------------------------------
@@ -444,7 +449,8 @@ __global__ __launch_bounds__(kBlock) void k_layout_rowflops(const uint32_t* Bptr
 // else the rows cols[0 .. nrows), row cols[x] starts at starts[x] (the wide columns of a batch expanded into a temporary list, wide.hpp).
 constexpr int kRowListBlock = 1024;
 __global__ __launch_bounds__(kRowListBlock) void k_layout_rowlists(const uint32_t* Bptr, const uint2* Bent, const uint2* Aent, const uint64_t* starts,
-                                                                   const uint64_t* roff, const uint32_t* cols, uint32_t nrows, uint2* Aent2, uint16_t* Aov) {
+                                                                   const uint64_t* roff, const uint32_t* cols, uint32_t nrows, uint2* Aent2, uint16_t* Aov,
+                                                                   uint32_t inl) {
     __shared__ uint32_t scr[kRowListBlock / 64];
     __shared__ uint32_t s_off[kRowListBlock];
     __shared__ uint2 s_be[kRowListBlock];
@@ -458,11 +464,19 @@ __global__ __launch_bounds__(kRowListBlock) void k_layout_rowlists(const uint32_
             const uint32_t nround = n - jb < (uint32_t)kRowListBlock ? n - jb : (uint32_t)kRowListBlock;
             uint2 be = make_uint2(0u, 0u);
             if (j < n) be = Bent[b0 + j];
-            const uint32_t cnt = (be.y >> 16) & 0x3FFFu;
+            const uint32_t cnt = bent_count(be, inl);
             uint32_t tot;
             const uint32_t ex = block_excl_scan<kRowListBlock / 64>(cnt, scr, &tot);
             const uint32_t L = tot <= 2u * nround ? 1u : tot <= 12u * nround ? 4u : 16u;   // (uniform over the workgroup)
             auto copy_tail = [&](const uint2 eb, const uint32_t ecnt, const uint64_t dst, const uint32_t t_first, const uint32_t t_step) {
+                if (bent_is_inline(eb, inl)) {                                // the one product is in the entry
+                    if (t_first == 0u) {
+                        const BProduct pr = bent_product(eb, 0u, Aent, roff, inl);
+                        Aent2[dst] = make_uint2(pr.key | (pr.oriented ? 0x80000000u : 0u), pr.posH | (pr.posV << 16));
+                        Aov[dst] = (uint16_t)pr.lenH;
+                    }
+                    return;
+                }
                 const uint32_t posV = eb.y & 0xFFFFu, pal = (eb.y >> 30) & 1u, oriB = eb.y >> 31;
                 for (uint32_t t0 = t_first; t0 < ecnt; t0 += 4 * t_step) {
                     uint2 ae[4];
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(kRowListBlock) void k_layout_rowlists(const uint32_
                 __syncthreads();
                 for (uint32_t e = threadIdx.x / L; e < nround; e += kRowListBlock / L) {
                     const uint2 eb = s_be[e];
-                    copy_tail(eb, (eb.y >> 16) & 0x3FFFu, o + running + s_off[e], threadIdx.x % L, L);
+                    copy_tail(eb, bent_count(eb, inl), o + running + s_off[e], threadIdx.x % L, L);
                 }
                 __syncthreads();
             }

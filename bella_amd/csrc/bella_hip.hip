@@ -154,6 +154,7 @@ struct bella_ctx {
     uint64_t kcount_budget = 1ull << 30, wide_budget = 1ull << 30;   // items per pass of the counting sort / of the wide-column path
     bool lane_order_ok = true;           // k_lane_order_selftest at init
     uint64_t xdrop_class_min = 4ull * 4096 * 64;   // extensions of a batch from which on the slices run it as four classes (BELLA_TUNE_XDROP_CLASS_MIN)
+    uint32_t layout_inline = 0;          // the device layout holds B' entries in the INLINE form (util.hpp); 0 / 1
     uint32_t xdrop_variant = 1;          // 0: one launch in length-sorted order; 1 (default): slices with compaction; 2: packed kernel in pair order; 3: scalar statement
     size_t lds_attr[18] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
     hipStream_t side[kNumTiers + 1]{};   // independent tier launches / fold instances run concurrently
@@ -281,6 +282,7 @@ int build_layout(bella_ctx* c) {
     if (nnz >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "nnz(A) must be < 2^32 (KMERINDEX uint32, main.cpp:60)");
     c->have_matrix = false;
     c->have_rowlists = false;
+    c->layout_inline = 0;
     c->tm.expand_ms = 0.f;
     ENSURE(c, c->lk_key, 4 * nnz);
     ENSURE(c, c->lk_key2, 4 * nnz);
@@ -342,6 +344,14 @@ int build_layout(bella_ctx* c) {
         // expands B' x A' itself: the fastest ONE-SHOT call (layout + first pass).  debug bit 10 (tests): the lists in
         // order of first appearance in B' (the owner row of a list streams it; three more random-access passes here).
         const uint32_t by_kmer = (c->debug & 1024u) == 0 ? 1u : 0u;
+        // entries whose k-mer has exactly one later read carry that read (util.hpp: INLINE form) when bit 31 of the list index and bit 30
+        // of a read id are free -- and when A' is larger than the last-level cache (256 MB): the form saves a line from HBM per such
+        // entry and pass (row kernels 4.03 -> 3.69 ms at 100k reads, A' = 1.6 GB), but where the gather is a cache hit it only adds a
+        // branch (10k reads, A' = 92 MB: 0.360 -> 0.367 ms per step).  debug bit 15 (tests): the plain form everywhere, as for inputs
+        // beyond those bounds; bit 16: the inline form on any size
+        const bool inl_pays = 8ull * nnz > (192ull << 20) || (c->debug & 65536u);
+        const uint32_t inl = by_kmer && rmask == 0x3FFFFFFFu && nnz < 0x80000000ull && inl_pays && !(c->debug & 32768u) ? 1u : 0u;
+        c->layout_inline = inl;
         if (!by_kmer) {
             k_layout_heads<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), rmask, ptr<uint32_t>(c->w), ptr<uint32_t>(c->status));
             KCHK(c);
@@ -354,7 +364,7 @@ int build_layout(bella_ctx* c) {
         HIPCHK(c, hipMemsetAsync(counter, 0, 4, c->stream));
         k_layout_emit<<<nblk(nnz, ps > 1 ? kLayoutEmitPartBlock : 256), ps > 1 ? kLayoutEmitPartBlock : 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), Bloc, ptr<uint32_t>(c->wscan), ptr<uint32_t>(c->packed),
                                                         ptr<uint64_t>(c->roff), c->kmer_size, rmask, ptr<uint2>(c->Aent), ekey, eval, by_kmer, pf, ps, counter,
-                                                        ptr<uint32_t>(c->status));
+                                                        ptr<uint32_t>(c->status), inl);
         KCHK(c);
         {   // a k-mer in more than 16,383 reads overflows the count field of the B' entries: stop before anything trusts them
             uint32_t st1 = 0;
@@ -380,7 +390,7 @@ int build_layout(bella_ctx* c) {
         if (nown_nnz) {
             int rc = ensure_bytes(c, c->Bcnt, 2 * nown_nnz);
             if (rc) return rc;
-            k_layout_bcnt<<<nblk(nown_nnz), 256, 0, c->stream>>>(ptr<uint2>(c->Bent), nown_nnz, ptr<uint16_t>(c->Bcnt));
+            k_layout_bcnt<<<nblk(nown_nnz), 256, 0, c->stream>>>(ptr<uint2>(c->Bent), nown_nnz, ptr<uint16_t>(c->Bcnt), inl);
             KCHK(c);
         }
         c->owned_nnz = nown_nnz;
@@ -395,7 +405,7 @@ int build_layout(bella_ctx* c) {
             const uint32_t step = (ncols / nsample ? ncols / nsample : 1) * ps;
             HIPCHK(c, hipFuncSetAttribute((const void*)k_sample_pair_ratio, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bitmap_bytes));
             k_sample_pair_ratio<<<nsample, kBlock, bitmap_bytes, c->stream>>>(Bloc, ptr<uint2>(c->Bent), ptr<uint2>(c->Aent),
-                                                                             c->nreads, pf, step, ptr<uint32_t>(c->status) + 6);
+                                                                             c->nreads, pf, step, ptr<uint32_t>(c->status) + 6, inl);
             KCHK(c);
             HIPCHK(c, hipMemcpyAsync(&ratio1024, ptr<uint32_t>(c->status) + 6, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(samp, ptr<uint32_t>(c->status) + 8, 8, hipMemcpyDeviceToHost, c->stream));
@@ -431,7 +441,7 @@ int build_layout(bella_ctx* c) {
                 if (!rc) {
                     const uint32_t grid = c->nreads < 4096u ? c->nreads : 4096u;
                     if (grid) k_layout_rowlists<<<grid, kRowListBlock, 0, c->stream>>>(Bloc, ptr<uint2>(c->Bent), ptr<uint2>(c->Aent), ptr<uint64_t>(c->Arow),
-                                                                                     ptr<uint64_t>(c->roff), nullptr, c->nreads, ptr<uint2>(c->Aent2), ptr<uint16_t>(c->Aov));
+                                                                                     ptr<uint64_t>(c->roff), nullptr, c->nreads, ptr<uint2>(c->Aent2), ptr<uint16_t>(c->Aov), inl);
                     KCHK(c);
                     HIPCHK(c, hipEventRecord(c->ev[11], c->stream));
                     HIPCHK(c, hipEventSynchronize(c->ev[11]));
@@ -1736,7 +1746,7 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     ENSURE(c, c->w_toff, 8 * ((size_t)nw + 2));
     WideArgs a{};
     a.cols = d_cols; a.nw = nw; a.woff = ptr<uint64_t>(c->w_off);
-    a.Bptr = sa.Bptr; a.Bent = sa.Bent; a.Aent = sa.Aent; a.Aent2 = sa.Aent2; a.Aov = sa.Aov; a.Arow = sa.Arow; a.roff = sa.roff; a.packed = sa.packed; a.flopptr = sa.flopptr;
+    a.Bptr = sa.Bptr; a.Bent = sa.Bent; a.inl = sa.inl; a.Aent = sa.Aent; a.Aent2 = sa.Aent2; a.Aov = sa.Aov; a.Arow = sa.Arow; a.roff = sa.roff; a.packed = sa.packed; a.flopptr = sa.flopptr;
     a.k = sa.k; a.binSize = sa.binSize;
     a.plist = ptr<uint2>(c->w_plist); a.plist_pad = T; a.sort_scratch = ptr<uint16_t>(c->w_scr);
     a.tmp_pairs = sa.tmp_pairs; a.tmp_ext = sa.tmp_ext; a.nnzC = sa.nnzC; a.status = sa.ctl + kCtlStatus;
@@ -1757,7 +1767,7 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     if (!lists && c->lane_order_ok && !(c->debug & 4096u) && c->nreads <= (1u << 30)) {
         if (!ensure_bytes(c, c->w_aent2, 8 * T + 64) && !ensure_bytes(c, c->w_aov, 2 * T + 64)) {
             k_layout_rowlists<<<nw < 4096u ? nw : 4096u, kRowListBlock, 0, c->stream>>>(sa.Bptr, sa.Bent, sa.Aent, ptr<uint64_t>(c->w_off), sa.roff, d_cols, nw,
-                                                                                        ptr<uint2>(c->w_aent2), ptr<uint16_t>(c->w_aov));
+                                                                                        ptr<uint2>(c->w_aent2), ptr<uint16_t>(c->w_aov), sa.inl);
             KCHK(c);
             a.Aent2 = ptr<uint2>(c->w_aent2); a.Aov = ptr<uint16_t>(c->w_aov); a.Arow = nullptr;
             lists = true;
@@ -2053,6 +2063,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     SpgemmArgs a;
     a.Bptr = layout_bptr(c);
     a.Bent = ptr<uint2>(c->Bent);
+    a.inl = c->layout_inline;
     a.Aent = ptr<uint2>(c->Aent);
     a.Aent2 = c->have_rowlists ? ptr<uint2>(c->Aent2) : nullptr;
     a.Aov = c->have_rowlists ? ptr<uint16_t>(c->Aov) : nullptr;
@@ -2434,7 +2445,7 @@ int bella_hip_count_pairs(bella_ctx* c, const bella_params* p, uint64_t* colptrC
     }
     if (nown) {
         CountArgs a;
-        a.Bptr = layout_bptr(c); a.Bent = ptr<uint2>(c->Bent); a.Aent = ptr<uint2>(c->Aent);
+        a.Bptr = layout_bptr(c); a.Bent = ptr<uint2>(c->Bent); a.Aent = ptr<uint2>(c->Aent); a.inl = c->layout_inline;
         a.Aent2 = c->have_rowlists ? ptr<uint2>(c->Aent2) : nullptr;
         a.Arow = c->have_rowlists ? ptr<uint64_t>(c->Arow) : nullptr;
         a.i0 = i0; a.stride = c->part_stride; a.nown = nown;

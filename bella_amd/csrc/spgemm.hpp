@@ -82,6 +82,7 @@ struct SpgemmArgs {
     uint32_t nreads;
     const uint32_t* Bptr;
     const uint2* Bent;
+    uint32_t inl;                // the layout has B' entries in the INLINE form (util.hpp)
     const uint2* Aent;
     const uint2* Aent2;          // ready-made products (assemble.hpp: k_layout_rowlists), nullptr: expand B' x A' in the pass
     const uint16_t* Aov;         // the partner read's length of every product
@@ -226,13 +227,13 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         for (uint32_t u = 0; u < RMAX; ++u) {
             be[u] = be0[u];
             if (jb) { be[u] = make_uint2(0u, 0u); if (u < R && j0 + u < nn) be[u] = a.Bent[b0 + jb + j0 + u]; }
-            csum += (be[u].y >> 16) & 0x3FFFu;
+            csum += bent_count(be[u], a.inl);
         }
         uint32_t tot;
         uint32_t p = running + block_excl_scan<kRowWaves>(csum, m.scr, &tot);
 #pragma unroll
         for (uint32_t u = 0; u < RMAX; ++u) {
-            const uint32_t cnt = (be[u].y >> 16) & 0x3FFFu;
+            const uint32_t cnt = bent_count(be[u], a.inl);            // (an INLINE entry leaves itself: bit 31 of A_hv marks it)
             for (uint32_t t = 0; t < cnt; ++t) { m.A_hv[p] = be[u].x + t; m.A_gov[p] = be[u].y; ++p; }
         }
         running += tot;
@@ -249,14 +250,22 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     for (uint32_t base = 0; base < F; base += XB * kRowBlock) {
         uint2 ae[XB];
         uint32_t bw[XB];
+        bool inl[XB];
 #pragma unroll
         for (uint32_t u = 0; u < XB; ++u) {
             const uint32_t p = base + u * kRowBlock + tid;
             ae[u] = make_uint2(0u, 0u);
             bw[u] = 0;
+            inl[u] = false;
             if (p < F) {
                 if (RL) { ae[u] = a.Aent2[arow + p]; bw[u] = a.Aov[arow + p]; }
-                else { ae[u] = a.Aent[m.A_hv[p]]; bw[u] = m.A_gov[p]; }
+                else {
+                    const uint32_t at = m.A_hv[p];
+                    bw[u] = m.A_gov[p];
+                    inl[u] = a.inl && (at >> 31);
+                    if (inl[u]) { const uint32_t pr = at & 0x3FFFFFFFu; ae[u] = make_uint2(at, (uint32_t)(a.roff[pr + 1] - a.roff[pr])); }   // no gather: the partner's length only
+                    else ae[u] = a.Aent[at];
+                }
             }
         }
 #pragma unroll
@@ -268,6 +277,13 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             if (RL) {                                          // {partner | pal << 30 | oriented << 31, posH | posV << 16}, partner's length
                 key = ae[u].x & 0x3FFFFFFFu; pal = (ae[u].x >> 30) & 1u; oriented = (ae[u].x >> 31) != 0; hv = ae[u].y;
                 ov = (uint32_t)overlap_estimate(hv & 0xFFFFu, hv >> 16, bw[u], lenV, oriented, k) & 0xFFFFu;
+            } else if (inl[u]) {                               // {partner | oriented << 30 | 1 << 31, its length}, posV | posH << 16
+                key = ae[u].x & 0x3FFFFFFFu;
+                const uint32_t posH = bw[u] >> 16, posV = bw[u] & 0xFFFFu;
+                pal = 0;
+                oriented = ((ae[u].x >> 30) & 1u) != 0;
+                ov = (uint32_t)overlap_estimate(posH, posV, ae[u].y, lenV, oriented, k) & 0xFFFFu;
+                hv = posH | (posV << 16);
             } else {
                 key = ae[u].x & 0x7FFFFFFFu;
                 const uint32_t posH = ae[u].y & 0xFFFFu, lenH = ae[u].y >> 16;
@@ -790,7 +806,7 @@ __global__ __launch_bounds__(64) void k_fold_overflow(FoldArgs a) {
 // the LDS tiers (cap/4 when at most ~1/5 of a column's products open a new pair, else cap/2).  One workgroup per sampled
 // column, the distinct row ids counted with a bitmap in LDS.  out[0] = max over the sample of 1024*d/F.
 __global__ __launch_bounds__(kBlock) void k_sample_pair_ratio(const uint32_t* Bptr, const uint2* Bent, const uint2* Aent, uint32_t nreads,
-                                                              uint32_t first, uint32_t stride, uint32_t* out) {
+                                                              uint32_t first, uint32_t stride, uint32_t* out, uint32_t inl) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* bits = (uint32_t*)smem;
     __shared__ uint32_t s_d, s_f;
@@ -803,10 +819,10 @@ __global__ __launch_bounds__(kBlock) void k_sample_pair_ratio(const uint32_t* Bp
     uint32_t d = 0, f = 0;
     for (uint32_t e = Bptr[i] + threadIdx.x; e < Bptr[i + 1]; e += kBlock) {
         const uint2 be = Bent[e];
-        const uint32_t cnt = (be.y >> 16) & 0x3FFFu;
+        const uint32_t cnt = bent_count(be, inl);
         f += cnt;
         for (uint32_t t = 0; t < cnt; ++t) {
-            const uint32_t key = Aent[(uint64_t)be.x + t].x & 0x7FFFFFFFu;
+            const uint32_t key = bent_partner(be, t, Aent, inl);
             const uint32_t bit = 1u << (key & 31);
             if (!(atomicOr(&bits[key >> 5], bit) & bit)) d++;
         }
@@ -833,6 +849,7 @@ struct CountArgs {
     const uint2* Aent;
     const uint2* Aent2;          // row lists (nullptr: expand B' x A')
     const uint64_t* Arow;
+    uint32_t inl;                // B' entries in the INLINE form (util.hpp)
     uint32_t i0, stride, nown;
     uint32_t words;              // bitmap words = ceil(nreads / 32)
     uint32_t* gmap;              // global bitmaps, `words` per workgroup (nullptr: LDS)
@@ -865,9 +882,9 @@ __global__ __launch_bounds__(kCountBlock) void k_count_pairs(CountArgs a) {
             } else {
                 for (uint32_t e = a.Bptr[i] + tid; e < a.Bptr[i + 1]; e += kCountBlock) {
                     const uint2 be = a.Bent[e];
-                    const uint32_t cnt = (be.y >> 16) & 0x3FFFu;
+                    const uint32_t cnt = bent_count(be, a.inl);
                     for (uint32_t t = 0; t < cnt; ++t) {
-                        const uint32_t key = a.Aent[(uint64_t)be.x + t].x & 0x7FFFFFFFu;
+                        const uint32_t key = bent_partner(be, t, a.Aent, a.inl);
                         if (mode == 0) { const uint32_t bit = 1u << (key & 31u); if (!(atomicOr(&bits[key >> 5], bit) & bit)) d++; }
                         else bits[key >> 5] = 0;
                     }

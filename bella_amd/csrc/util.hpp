@@ -54,6 +54,34 @@ __device__ __forceinline__ uint32_t pow2_at_least(uint32_t minsz, uint32_t n) {
     return s;
 }
 
+// ---- B' entries (assemble.hpp: k_layout_emit) -----------------------------------------------------------------------------------------
+// Plain form: {index of the first LATER read in the k-mer's list of A', posV | later reads << 16 | palindrome << 30 | orientation << 31}.
+// INLINE form (layouts built with it: read ids < 2^30, nnz(A) < 2^31, so that bit 31 of the index is free): an entry whose k-mer
+// has exactly ONE later read -- 58 % of the entries with products at 30x -- carries that read instead of pointing at it:
+// {partner | same orientation << 30 | 1 << 31, posV | partner's posH << 16} (never a palindrome: those keep the plain form).  The
+// pass then reads nothing from A' for it: every avoided gather is a 128-byte line from HBM for eight useful bytes.  The partner's
+// read length, the one thing its A' entry also held, comes from the read offsets (cache-resident).
+__device__ __forceinline__ bool bent_is_inline(uint2 be, uint32_t inl) { return inl && (be.x >> 31); }
+__device__ __forceinline__ uint32_t bent_count(uint2 be, uint32_t inl) { return bent_is_inline(be, inl) ? 1u : (be.y >> 16) & 0x3FFFu; }
+struct BProduct { uint32_t key, posH, posV, lenH, pal; bool oriented; };
+// product t of entry be (t < bent_count)
+__device__ __forceinline__ BProduct bent_product(uint2 be, uint32_t t, const uint2* Aent, const uint64_t* roff, uint32_t inl) {
+    BProduct r;
+    if (bent_is_inline(be, inl)) {
+        r.key = be.x & 0x3FFFFFFFu; r.oriented = ((be.x >> 30) & 1u) != 0; r.pal = 0; r.posV = be.y & 0xFFFFu; r.posH = be.y >> 16;
+        r.lenH = (uint32_t)(roff[r.key + 1] - roff[r.key]);
+    } else {
+        const uint2 ae = Aent[(uint64_t)be.x + t];
+        r.key = ae.x & 0x7FFFFFFFu; r.posH = ae.y & 0xFFFFu; r.lenH = ae.y >> 16; r.posV = be.y & 0xFFFFu; r.pal = (be.y >> 30) & 1u;
+        r.oriented = (ae.x >> 31) == (be.y >> 31);
+    }
+    return r;
+}
+// the partner read of product t alone (symbolic phase: no positions)
+__device__ __forceinline__ uint32_t bent_partner(uint2 be, uint32_t t, const uint2* Aent, uint32_t inl) {
+    return bent_is_inline(be, inl) ? be.x & 0x3FFFFFFFu : Aent[(uint64_t)be.x + t].x & 0x7FFFFFFFu;
+}
+
 // any-size table index for our own (non-reference) hash tables: multiplicative hash + range reduction
 __device__ __forceinline__ uint32_t hash_range(uint32_t key, uint32_t size) {
     const uint32_t h = key * 2654435761u;

@@ -24,6 +24,7 @@ struct WideArgs {
     const uint64_t* woff;        // [nw+1] start of each column's products in the W arrays
     const uint32_t* Bptr;
     const uint2* Bent;
+    uint32_t inl;                // B' entries in the INLINE form (util.hpp)
     const uint2* Aent;
     const uint2* Aent2;          // ready-made products (assemble.hpp: k_layout_rowlists; nullptr: expand from B' x A')
     const uint16_t* Aov;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
             const uint32_t j = jb + threadIdx.x;
             uint2 be = make_uint2(0u, 0u);
             if (j < n) be = a.Bent[b0 + j];
-            const uint32_t cnt = (be.y >> 16) & 0x3FFFu;
+            const uint32_t cnt = bent_count(be, a.inl);
             uint32_t tot;
             const uint32_t ex = block_excl_scan<kWideExpandBlock / 64>(cnt, scr, &tot);
             s_off[threadIdx.x] = ex; s_be[threadIdx.x] = be;
@@ -122,11 +123,9 @@ __global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
                 }
                 const uint2 eb = s_be[lo];
                 const uint32_t t = q - s_off[lo];
-                const uint2 ae = a.Aent[(uint64_t)eb.x + t];
-                const uint32_t posV = eb.y & 0xFFFFu, pal = (eb.y >> 30) & 1u;
-                const uint32_t key = ae.x & 0x7FFFFFFFu;
-                const uint32_t posH = ae.y & 0xFFFFu, lenH = ae.y >> 16;
-                const bool oriented = (ae.x >> 31) == (eb.y >> 31);
+                const BProduct pr = bent_product(eb, t, a.Aent, a.roff, a.inl);
+                const uint32_t posV = pr.posV, pal = pr.pal, key = pr.key, posH = pr.posH, lenH = pr.lenH;
+                const bool oriented = pr.oriented;
                 const uint32_t ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, (uint32_t)a.k) & 0xFFFFu;
                 const uint32_t fl = (oriented ? 1u : 0u) | (pal << 1);
                 const uint32_t hvw = posH | (posV << 16);

@@ -343,7 +343,10 @@ int bella_hip_get_memory(bella_ctx* ctx, bella_memory* m);
  * bit12 = tests: the columns above the LDS tiers are grouped by the radix sort also when the row lists would allow grouping in LDS;
  * bit13 = tests: the symbolic phase (bella_hip_count_pairs) keeps its bitmaps in global memory also when they fit in LDS;
  * bit14 = tests: k-mer counting looks every position up in a hash table over the dictionary (the path of syncmer mode, of k-mers too
- * long to share a 64-bit sort key with their position, and of the distributed count) also where the sorted words carry their positions */
+ * long to share a 64-bit sort key with their position, and of the distributed count) also where the sorted words carry their positions;
+ * bit15 (read when the operands are assembled) = tests: every entry of B' in the plain form (default, when A' is larger than the last-level
+ * cache: an entry whose k-mer has exactly one later read carries that read instead of an index into A'; the plain form is also that of
+ * inputs with 2^30 reads or 2^31 nonzeros and more); bit16 (same moment) = tests: that inline form on inputs of any size */
 int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
 /* Per-context tuning parameters (tests and A/B measurements; nothing here changes results).  what:
  *   BELLA_TUNE_LDS_TIERS      values = ascending product capacities of the row kernels' LDS tiers, each in [64, 11008] (n = 0: defaults)

@@ -48,11 +48,13 @@ def test_assembly_matches_reference_layout(eng, golden):
         assert np.array_equal(a, b)           # colptr, k-mer ids in MergeDuplicates slot order, positions
 
 
-@pytest.mark.parametrize("debug,rowlists", [(0, 0), (1, 0), (1024, 0), (1025, 0), (0, 1), (1, 1), (2048, 1)])
+@pytest.mark.parametrize("debug,rowlists", [(0, 0), (1, 0), (1024, 0), (1025, 0), (0, 1), (1, 1), (2048, 1), (65536, 0), (65537, 0), (65536, 1)])
 def test_spgemm_pairs_bit_exact(eng, golden, debug, rowlists):
     g = golden
     eng.set_debug(debug)                       # 1 = force the global-workspace row path; 1024 = the lists of A' in order of first appearance
-                                               # (default: k-mer order); 2048 = as if the row lists asked for did not fit in memory
+                                               # (default: k-mer order); 2048 = as if the row lists asked for did not fit in memory;
+                                               # 65536 = B' entries with one later read carry it instead of pointing at it (default from
+                                               # A' > 192 MB on: the 100k-read tests)
     eng.set_tuning("row_lists", rowlists)      # 1 = the products ready-made at assembly time (callers with repeated passes); default: every
                                                # pass expands B' x A' itself
     try:
@@ -73,7 +75,7 @@ def test_spgemm_pairs_bit_exact(eng, golden, debug, rowlists):
         eng.set_tuning("row_lists")
 
 
-@pytest.mark.parametrize("debug,rowlists", [(0, 0), (8192, 0), (0, 1)])
+@pytest.mark.parametrize("debug,rowlists", [(0, 0), (8192, 0), (0, 1), (65536, 0)])
 def test_symbolic_phase_alone_matches_oracle(eng, golden, debug, rowlists):
     """bella_hip_count_pairs = estimateFLOP + estimateNNZ_Hash + prefixsum (overlap.hpp:157-276,110-146): colptrC, nnz(C) and the products
     without a numeric pass -- whole, per stage (column range) and per partition; then the numeric phase on the same context"""
@@ -1208,7 +1210,8 @@ def test_baseline_config4_hifi_100k_reads(eng, upper, stages):
           % (upper, nk, nt, flops, n, stages, len(exp), t1 - t0, t2 - t1, t3 - t2, time.time() - t0))
 
 
-@pytest.mark.parametrize("name,dbg", [("toy120", 32), ("toyrep90", 32), ("toyhifi50", 32), ("toysync60", 32), ("toyrep90", 32 | 64)])
+@pytest.mark.parametrize("name,dbg", [("toy120", 32), ("toyrep90", 32), ("toyhifi50", 32), ("toysync60", 32), ("toyrep90", 32 | 64),
+                                      ("toy120", 32 | 65536), ("toyrep90", 32 | 65536), ("toy120", 32 | 4096 | 65536)])
 def test_columns_above_the_lds_tiers_on_the_sort_based_path(name, dbg):
     """the path of the columns with more products than the largest LDS tier when a pass has many of them (wide.hpp: expand, radix
     sort, slot order, one workgroup per pair with the closed-form fold): with a 64-product LDS tier and debug bit 5 most
@@ -1218,7 +1221,8 @@ def test_columns_above_the_lds_tiers_on_the_sort_based_path(name, dbg):
     e = Engine(0)
     try:
         e.set_tuning("lds_tiers", 64)                                # (per context: no process-wide state)
-        e.set_debug(dbg)                                             # bit 6: 64-bit sort keys (the default here is 32-bit)
+        e.set_debug(dbg)                                             # bit 6: 64-bit sort keys (the default here is 32-bit); bit 16: one-partner B' entries carry
+                                                                     # the partner (k_wide_expand / the batch's own product lists read them); bit 12: radix-sort grouping
         e.set_reads(g.rs)
         e.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
         n, flops = e.overlap(BellaPars(skipAlignment=True, kmerSize=g.k))
