@@ -378,8 +378,8 @@ __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64
         mine = own_stride == 1u || r % own_stride == own_first;               // B' entries only for the columns this context owns
         dstkey = Bloc[r] + ((uint32_t)v >> 16);
         dstval = (uint64_t)(cs + rk + 1) | ((uint64_t)(pos | ((dg - 1 - rk) << 16) | (pal << 30) | (ori << 31)) << 32);
-        if (inl && dg == 2u && rk == 0u && !pal) {                            // exactly one later read: the entry carries it (util.hpp: INLINE form)
-            const uint64_t v1 = sval[lo + 1];
+        if (inl && rk + 2u == dg && !pal) {                                   // exactly one later read (the last but one of any list): the entry carries it (util.hpp)
+            const uint64_t v1 = sval[x + 1];
             const uint32_t hi1 = (uint32_t)(v1 >> 32);
             dstval = (uint64_t)((hi1 & rmask) | ((hi1 >> 31) == ori ? 1u << 30 : 0u) | (1u << 31)) | ((uint64_t)(pos | (((uint32_t)v1 & 0xFFFFu) << 16)) << 32);
         }

@@ -57,7 +57,8 @@ __device__ __forceinline__ uint32_t pow2_at_least(uint32_t minsz, uint32_t n) {
 // ---- B' entries (assemble.hpp: k_layout_emit) -----------------------------------------------------------------------------------------
 // Plain form: {index of the first LATER read in the k-mer's list of A', posV | later reads << 16 | palindrome << 30 | orientation << 31}.
 // INLINE form (layouts built with it: read ids < 2^30, nnz(A) < 2^31, so that bit 31 of the index is free): an entry whose k-mer
-// has exactly ONE later read -- 58 % of the entries with products at 30x -- carries that read instead of pointing at it:
+// has exactly ONE later read -- the last but one entry of every list: 58 % of the entries with products at 30x are the first of a list
+// of two -- carries that read instead of pointing at it:
 // {partner | same orientation << 30 | 1 << 31, posV | partner's posH << 16} (never a palindrome: those keep the plain form).  The
 // pass then reads nothing from A' for it: every avoided gather is a 128-byte line from HBM for eight useful bytes.  The partner's
 // read length, the one thing its A' entry also held, comes from the read offsets (cache-resident).
