@@ -249,13 +249,13 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     constexpr uint32_t XB = BELLA_GATHER_BATCH(kRowBlock);    // A' loads in flight per lane
     for (uint32_t base = 0; base < F; base += XB * kRowBlock) {
         uint2 ae[XB];
-        uint32_t bw[XB];
+        uint32_t bw[XB], ax[XB];
         bool inl[XB];
 #pragma unroll
         for (uint32_t u = 0; u < XB; ++u) {
             const uint32_t p = base + u * kRowBlock + tid;
             ae[u] = make_uint2(0u, 0u);
-            bw[u] = 0;
+            bw[u] = 0; ax[u] = 0;
             inl[u] = false;
             if (p < F) {
                 if (RL) { ae[u] = a.Aent2[arow + p]; bw[u] = a.Aov[arow + p]; }
@@ -263,8 +263,11 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
                     const uint32_t at = m.A_hv[p];
                     bw[u] = m.A_gov[p];
                     inl[u] = a.inl && (at >> 31);
-                    if (inl[u]) { const uint32_t pr = at & 0x3FFFFFFFu; ae[u] = make_uint2(at, (uint32_t)(a.roff[pr + 1] - a.roff[pr])); }   // no gather: the partner's length only
-                    else ae[u] = a.Aent[at];
+                    ax[u] = at;
+                    if (inl[u]) {                              // no gather: the partner's length only -- the two offsets travel like a gathered entry
+                        const uint32_t* ro = (const uint32_t*)a.roff + 2u * (at & 0x3FFFFFFFu);    // (and are subtracted where it would be used)
+                        ae[u] = make_uint2(ro[0], ro[2]);
+                    } else ae[u] = a.Aent[at];
                 }
             }
         }
@@ -277,12 +280,12 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             if (RL) {                                          // {partner | pal << 30 | oriented << 31, posH | posV << 16}, partner's length
                 key = ae[u].x & 0x3FFFFFFFu; pal = (ae[u].x >> 30) & 1u; oriented = (ae[u].x >> 31) != 0; hv = ae[u].y;
                 ov = (uint32_t)overlap_estimate(hv & 0xFFFFu, hv >> 16, bw[u], lenV, oriented, k) & 0xFFFFu;
-            } else if (inl[u]) {                               // {partner | oriented << 30 | 1 << 31, its length}, posV | posH << 16
-                key = ae[u].x & 0x3FFFFFFFu;
+            } else if (inl[u]) {                               // the entry itself: partner | oriented << 30 | 1 << 31, posV | posH << 16
+                key = ax[u] & 0x3FFFFFFFu;
                 const uint32_t posH = bw[u] >> 16, posV = bw[u] & 0xFFFFu;
                 pal = 0;
-                oriented = ((ae[u].x >> 30) & 1u) != 0;
-                ov = (uint32_t)overlap_estimate(posH, posV, ae[u].y, lenV, oriented, k) & 0xFFFFu;
+                oriented = ((ax[u] >> 30) & 1u) != 0;
+                ov = (uint32_t)overlap_estimate(posH, posV, ae[u].y - ae[u].x, lenV, oriented, k) & 0xFFFFu;
                 hv = posH | (posV << 16);
             } else {
                 key = ae[u].x & 0x7FFFFFFFu;
