@@ -1,4 +1,5 @@
-// development microbenchmark: rocPRIM onesweep radix sort, bits per pass (8 = library default) -- see DESIGN 8
+// development microbenchmark: rocPRIM onesweep radix sort, bits per pass (8 = library default); profiles/r04_sort_radix_bits.txt
+// build: hipcc --offload-arch=gfx950 -O3 -DTRY10 -o tools/_old/sort_radix_bits tools/ubench/sort_radix_bits.hip ; run on the GPU box
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
