@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void k_layout_prep(const uint32_t* Bptr, co
         key[e] = km;
         // read ids below 2^30 leave bit 30 of the high word to the palindrome flag: the emit pass then reads no sequence at all
         val[e] = ((uint64_t)(r | (ori << 31) | (nreads <= (1u << 30) ? pal << 30 : 0u)) << 32) | (pos | ((e - b0) << 16));
-        w[e] = 0;
+        if (w) w[e] = 0;                                                     // (only the first-appearance layout scans w)
     }
 }
 
@@ -347,19 +347,44 @@ __device__ __forceinline__ void run_bounds(const uint32_t* skey, uint64_t nnz, u
 // radix pass on the top bits of e and k_layout_place then write B' region by region (the writes of a region meet in the caches).
 // by_kmer (the row-list layout, k_layout_rowlists below): the lists of A' stay in k-mer order = the sorted order itself -- no list
 // starts to scatter, scan and look up (k_layout_heads is not run), A' is written in place.
-constexpr int kLayoutEmitPartBlock = 1024;      // workgroup of the partitioned launch (own_stride > 1); any size otherwise
+// per read: its first B' entry and its length side by side -- the two things k_layout_emit looks up per ENTRY by read id (one 8-byte
+// load instead of three from two arrays: that kernel runs at the L2's request rate, not at HBM's)
+__global__ void k_layout_rinfo(const uint32_t* Bloc, const uint64_t* roff, uint32_t nreads, uint2* rinfo) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nreads) rinfo[r] = make_uint2(Bloc[r], (uint32_t)(roff[r + 1] - roff[r]));
+}
+constexpr int kLayoutEmitPartBlock = 1024;      // workgroup of the partitioned launch (own_stride > 1); at most this otherwise
+constexpr uint32_t kEmitHalo = 32;              // keys on either side of the workgroup's entries in its LDS window
 __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64_t nnz, const uint32_t* Bptr, const uint32_t* Bloc, const uint32_t* wscan,
                               const uint32_t* packed, const uint64_t* roff, uint32_t k, uint32_t rmask, uint2* Aent, uint32_t* ekey, uint64_t* eval,
-                              uint32_t by_kmer, uint32_t own_first, uint32_t own_stride, uint32_t* counter, uint32_t* status, uint32_t inl) {
+                              uint32_t by_kmer, uint32_t own_first, uint32_t own_stride, uint32_t* counter, uint32_t* status, uint32_t inl,
+                              const uint2* rinfo) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool mine = false;
     uint32_t dstkey = 0;
     uint64_t dstval = 0;
+    // the workgroup's keys and 32 on either side in LDS: a run's bounds are a few LDS reads (they were a chain of dependent global
+    // loads per entry: 4.05 ms of this kernel's time at 100k reads was that chain); runs that leave the window take the global search
+    __shared__ uint32_t s_key[kLayoutEmitPartBlock + 2 * kEmitHalo];
+    const uint64_t x0 = (uint64_t)blockIdx.x * blockDim.x;
+    for (uint32_t i = threadIdx.x; i < blockDim.x + 2u * kEmitHalo; i += blockDim.x) {
+        const uint64_t g = x0 + i;                                           // (window position i = entry x0 - halo + i)
+        s_key[i] = g >= kEmitHalo && g - kEmitHalo < nnz ? skey[g - kEmitHalo] : 0xFFFFFFFFu;   // (no k-mer id: ids are < nkmers < 2^32 - 16)
+    }
+    __syncthreads();
     if (x < nnz) {
         uint64_t lo, hi;
-        run_bounds(skey, nnz, x, lo, hi);
+        {
+            const uint32_t me = threadIdx.x + kEmitHalo, km = s_key[me], wend = blockDim.x + 2u * kEmitHalo;
+            uint32_t a = me, b = me + 1;
+            while (a > 0 && s_key[a - 1] == km) --a;
+            while (b < wend && s_key[b] == km) ++b;
+            if ((a == 0 && x0 > kEmitHalo) || (b == wend && x0 + blockDim.x + kEmitHalo < nnz)) run_bounds(skey, nnz, x, lo, hi);   // the run may go on outside
+            else { lo = x0 + a - kEmitHalo; hi = x0 + b - kEmitHalo; }
+        }
         const uint32_t dg = (uint32_t)(hi - lo), rk = (uint32_t)(x - lo);
-        const uint64_t vf = sval[lo], v = sval[x];
+        const bool need_first = !by_kmer || rmask != 0x3FFFFFFFu;            // (the default layout never looks at the run's first entry)
+        const uint64_t vf = need_first ? sval[lo] : 0ull, v = sval[x];
         const uint32_t rf = (uint32_t)(vf >> 32) & rmask;
         if (dg > 16383u && rk == 0) atomicOr(status, 64u);                   // Bent's product count field holds 14 bits
         // by_kmer: the list starts where its run starts; else at the scanned degree of the run's first entry (k_layout_heads: indexed
@@ -373,10 +398,11 @@ __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64
             pal = kmer_fw_from_le(le, k) == kmer_rc_from_le(le, k) ? 1u : 0u;
         }
         const uint32_t ori = pal ? 0u : hiw >> 31;                            // (palindromes count as canonical)
-        const uint32_t len = (uint32_t)(roff[r + 1] - roff[r]);
+        const uint2 ri = rinfo[r];                                            // {first B' entry of read r, its length}
+        const uint32_t len = ri.y;
         Aent[cs + rk] = make_uint2(r | (ori << 31), pos | (len << 16));
         mine = own_stride == 1u || r % own_stride == own_first;               // B' entries only for the columns this context owns
-        dstkey = Bloc[r] + ((uint32_t)v >> 16);
+        dstkey = ri.x + ((uint32_t)v >> 16);
         dstval = (uint64_t)(cs + rk + 1) | ((uint64_t)(pos | ((dg - 1 - rk) << 16) | (pal << 30) | (ori << 31)) << 32);
         if (inl && rk + 2u == dg && !pal) {                                   // exactly one later read (the last but one of any list): the entry carries it (util.hpp)
             const uint64_t v1 = sval[x + 1];

@@ -115,7 +115,7 @@ struct bella_ctx {
     uint64_t panel_nnz = 0;
     // assembly temporaries
     Buf t_kmer, t_read, t_pos, tstart, Bk_tmp, Bpos_tmp, rowcnt, asm_ws, asm_cls;
-    Buf lk_key, lk_key2, lk_val, lk_val2, w, wscan;
+    Buf lk_key, lk_key2, lk_val, lk_val2, w, wscan, lk_rinfo;
     // overlap
     uint64_t flops = 0, npairs = 0;
     uint32_t pair_ratio1024 = 1024;   // max over sampled columns of 1024 * pairs/products
@@ -288,6 +288,7 @@ int build_layout(bella_ctx* c) {
     ENSURE(c, c->lk_key2, 4 * nnz);
     ENSURE(c, c->lk_val, 8 * nnz);
     ENSURE(c, c->lk_val2, 8 * nnz);
+    ENSURE(c, c->lk_rinfo, 8 * ((size_t)c->nreads + 1));
     ENSURE(c, c->w, 4 * (nnz + 1));
     ENSURE(c, c->wscan, 4 * (nnz + 1));
     ENSURE(c, c->Aent, 8 * nnz + 64);
@@ -320,8 +321,8 @@ int build_layout(bella_ctx* c) {
     if (nnz) {
         k_layout_prep<<<nblk(c->nreads, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos), c->nreads,
                                                                         ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), c->kmer_size, nk,
-                                                                        ptr<uint32_t>(c->lk_key), ptr<uint64_t>(c->lk_val), ptr<uint32_t>(c->w),
-                                                                        ptr<uint32_t>(c->status));
+                                                                        ptr<uint32_t>(c->lk_key), ptr<uint64_t>(c->lk_val),
+                                                                        (c->debug & 1024u) ? ptr<uint32_t>(c->w) : nullptr, ptr<uint32_t>(c->status));
         KCHK(c);
         // bad input (k-mer id out of range, k-mer past the end of its read) stops here: the passes below trust the keys
         uint32_t st0 = 0;
@@ -362,9 +363,12 @@ int build_layout(bella_ctx* c) {
         uint64_t* eval = dv.Alternate();
         uint32_t* counter = ptr<uint32_t>(c->status) + 7;
         HIPCHK(c, hipMemsetAsync(counter, 0, 4, c->stream));
+        uint2* rinfo = ptr<uint2>(c->lk_rinfo);
+        k_layout_rinfo<<<nblk(c->nreads), 256, 0, c->stream>>>(Bloc, ptr<uint64_t>(c->roff), c->nreads, rinfo);
+        KCHK(c);
         k_layout_emit<<<nblk(nnz, ps > 1 ? kLayoutEmitPartBlock : 256), ps > 1 ? kLayoutEmitPartBlock : 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), Bloc, ptr<uint32_t>(c->wscan), ptr<uint32_t>(c->packed),
                                                         ptr<uint64_t>(c->roff), c->kmer_size, rmask, ptr<uint2>(c->Aent), ekey, eval, by_kmer, pf, ps, counter,
-                                                        ptr<uint32_t>(c->status), inl);
+                                                        ptr<uint32_t>(c->status), inl, rinfo);
         KCHK(c);
         {   // a k-mer in more than 16,383 reads overflows the count field of the B' entries: stop before anything trusts them
             uint32_t st1 = 0;
@@ -462,7 +466,7 @@ int build_layout(bella_ctx* c) {
     if (rc) return rc;
     c->pair_ratio1024 = ratio1024;
     // assembly temporaries are large (tens of bytes per nonzero): give them back
-    release(c->lk_key); release(c->lk_key2); release(c->lk_val); release(c->lk_val2); release(c->w); release(c->wscan);
+    release(c->lk_key); release(c->lk_key2); release(c->lk_val); release(c->lk_val2); release(c->w); release(c->wscan); release(c->lk_rinfo);
     c->tm.layout_ms = ev_ms(c->ev[4], c->ev[5]);
     c->have_matrix = true;
     c->layout_gen++;
@@ -563,7 +567,7 @@ void bella_hip_destroy(bella_ctx* c) {
     if (c->comm && c->api) { (void)c->api->CommDestroy(c->comm); c->comm = nullptr; }
     release(c->comm_meta);
     Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Bcnt, &c->Aent, &c->Aent2, &c->Aov, &c->Arow, &c->Bloc, &c->t_kmer, &c->t_read, &c->t_pos,
-                  &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->asm_cls, &c->lk_key, &c->lk_key2, &c->lk_val, &c->lk_val2,
+                  &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->asm_cls, &c->lk_key, &c->lk_key2, &c->lk_val, &c->lk_val2, &c->lk_rinfo,
                   &c->w, &c->wscan, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC,
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
                   &c->status, &c->cubtmp, &c->alns, &c->seeds, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->orderlist, &c->order_ws, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx, &c->w_idx2, &c->w_hv, &c->w_ovfl,
@@ -2502,7 +2506,7 @@ int bella_hip_get_memory(bella_ctx* c, bella_memory* m) {
                          &c->w_idx2, &c->w_hv, &c->w_ovfl, &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_redo, &c->w_segfirst, &c->w_toff, &c->w_table,
                          &c->w_nruns, &c->w_desc, &c->w_gtab, &c->w_gcount, &c->w_gbase, &c->w_rfirst, &c->w_aent2, &c->w_aov});
     m->other_bytes = sum({&c->t_kmer, &c->t_read, &c->t_pos, &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->asm_cls, &c->lk_key, &c->lk_key2, &c->lk_val,
-                          &c->lk_val2, &c->w, &c->wscan, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen, &c->kc_flag, &c->kc_slot, &c->kc_nruns,
+                          &c->lk_val2, &c->lk_rinfo, &c->w, &c->wscan, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen, &c->kc_flag, &c->kc_slot, &c->kc_nruns,
                           &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->kc_opos, &c->kc_oid, &c->kc_opos2, &c->kc_oid2, &c->alns,
                           &c->seeds, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch, &c->status, &c->comm_meta});
     m->owned_nnz = c->have_matrix ? c->owned_nnz : 0;
