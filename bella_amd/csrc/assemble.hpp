@@ -426,8 +426,13 @@ __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64
     if (mine) { const uint32_t o = s_base + ex; ekey[o] = dstkey; eval[o] = dstval; }
 }
 
+// XCD-aware: consecutive workgroups go to the eight XCDs in turn, each with an L2 of its own.  Walking the sorted entries in launch
+// order, all eight would write into the SAME region of B' at any time and each L2 would hold, and evict, its own partial copy of every
+// line; here XCD j takes the j-th eighth of the entries (32 regions of its own), so that the writes to a line meet in one L2.
 __global__ void k_layout_place(const uint32_t* ekey, const uint64_t* eval, uint64_t n, uint2* Bent) {
-    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t per = gridDim.x >> 3;                                      // (the grid is a multiple of eight workgroups)
+    const uint64_t chunk = (uint64_t)(blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const uint64_t x = chunk * blockDim.x + threadIdx.x;
     if (x >= n) return;
     const uint64_t v = eval[x];
     Bent[ekey[x]] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));

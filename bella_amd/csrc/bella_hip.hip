@@ -388,7 +388,7 @@ int build_layout(bella_ctx* c) {
                 ENSURE(c, c->cubtmp, tb2);
                 HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb2, ek, ev, (uint64_t)nown_nnz, ebits - 8, ebits, c->stream));
             }
-            k_layout_place<<<nblk(nown_nnz), 256, 0, c->stream>>>(ek.Current(), ev.Current(), nown_nnz, ptr<uint2>(c->Bent));
+            k_layout_place<<<((nblk(nown_nnz) + 7u) / 8u) * 8u, 256, 0, c->stream>>>(ek.Current(), ev.Current(), nown_nnz, ptr<uint2>(c->Bent));
             KCHK(c);
         }
         if (nown_nnz) {
