@@ -33,9 +33,20 @@ using namespace bella;
 
 namespace {
 
+// Large device buffers a context gives up are kept on a free list and handed to the next request they fit, instead of going back to the
+// driver: hipMalloc hands out freshly freed VRAM only after the driver has wiped it, and a phase that frees tens of GB right before
+// the next one asks for as much waits about a second for that (200k reads: assembly 1.05 s instead of 60 ms, first pass 0.75 s
+// instead of 15 ms).  Same synchronisation as hipFree (the device is idle when a buffer changes hands); what is pooled counts as free
+// memory wherever the library sizes something by it, and goes back to the driver when an allocation fails or the context is destroyed.
+struct BufPool {
+    std::vector<std::pair<void*, size_t>> free;
+    size_t bytes = 0;
+};
+constexpr size_t kPoolMinBytes = 128ull << 20, kPoolMaxBytes = 160ull << 30;
 struct Buf {
     void* p = nullptr;
     size_t cap = 0;
+    BufPool* pool = nullptr;     // where the buffer goes when it is released (set by ensure_bytes)
 };
 
 // Column tiers by product count.  A column runs in one 512-thread workgroup with 14.5 B of LDS per product (19 B with the
@@ -154,6 +165,7 @@ struct bella_ctx {
     uint64_t kcount_budget = 1ull << 30, wide_budget = 1ull << 30;   // items per pass of the counting sort / of the wide-column path
     bool lane_order_ok = true;           // k_lane_order_selftest at init
     uint64_t xdrop_class_min = 4ull * 4096 * 64;   // extensions of a batch from which on the slices run it as four classes (BELLA_TUNE_XDROP_CLASS_MIN)
+    BufPool pool;                        // released device buffers waiting for the next request they fit
     uint32_t layout_inline = 0;          // the device layout holds B' entries in the INLINE form (util.hpp); 0 / 1
     uint32_t xdrop_variant = 1;          // 0: one launch in length-sorted order; 1 (default): slices with compaction; 2: packed kernel in pair order; 3: scalar statement
     size_t lds_attr[18] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
@@ -187,14 +199,34 @@ int fail(bella_ctx* c, int code, const char* fmt, ...) {
             return fail(c, BELLA_ERR_HIP, "%s failed: %s", #call, c->api && c->api->GetErrorString ? c->api->GetErrorString(r_) : "RCCL error"); \
     } while (0)
 
+void release(Buf& b);
+void trim_pool(BufPool& pl) {
+    for (auto& q : pl.free) (void)hipFree(q.first);
+    pl.free.clear();
+    pl.bytes = 0;
+}
 int ensure_bytes(bella_ctx* c, Buf& b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return 0;
-    if (b.p) HIPCHK(c, hipFree(b.p));
-    b.p = nullptr;
-    b.cap = 0;
+    release(b);
+    BufPool& pl = c->pool;
+    b.pool = &pl;
     const size_t want = bytes + bytes / 16 + 256;
+    int best = -1;                                              // best fit on the free list: at least `want`, at most about twice that
+    for (int i = 0; i < (int)pl.free.size(); ++i)
+        if (pl.free[i].second >= want && pl.free[i].second <= 2 * want + (64ull << 20) && (best < 0 || pl.free[i].second < pl.free[best].second)) best = i;
+    if (best >= 0) {
+        b.p = pl.free[best].first; b.cap = pl.free[best].second;
+        pl.bytes -= b.cap;
+        pl.free.erase(pl.free.begin() + best);
+        return 0;
+    }
     hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess && !pl.free.empty()) {                  // what the free list holds back may be what is missing
+        (void)hipGetLastError();
+        trim_pool(pl);
+        e = hipMalloc(&b.p, want);
+    }
     if (e != hipSuccess) {
         b.p = nullptr;
         return fail(c, BELLA_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
@@ -209,7 +241,16 @@ int ensure_bytes(bella_ctx* c, Buf& b, size_t bytes) {
     } while (0)
 
 void release(Buf& b) {
-    if (b.p) (void)hipFree(b.p);
+    if (b.p) {
+        BufPool* pl = b.pool;
+        if (pl && b.cap >= kPoolMinBytes && pl->free.size() < 32 && pl->bytes + b.cap <= kPoolMaxBytes) {
+            (void)hipDeviceSynchronize();                       // (what hipFree does: nothing in flight touches the buffer when it changes hands)
+            pl->free.emplace_back(b.p, b.cap);
+            pl->bytes += b.cap;
+        } else {
+            (void)hipFree(b.p);
+        }
+    }
     b.p = nullptr;
     b.cap = 0;
 }
@@ -435,6 +476,7 @@ int build_layout(bella_ctx* c) {
             }
             size_t mfree = 0, mtotal = 0;
             HIPCHK(c, hipMemGetInfo(&mfree, &mtotal));
+            mfree += c->pool.bytes;                                 // (released buffers the context still holds are free for this purpose)
             // 10 bytes per product for the lists; a pass over all owned columns then needs about 60 more per product (records twice,
             // product lists, scratch, diagnostics) -- the lists are only built when both fit (debug bit 11: tests, "no room")
             const bool fits = (double)F * 70.0 + 1e8 <= (double)mfree && !(c->debug & 2048u);
@@ -574,6 +616,7 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->w_plist, &c->w_scr, &c->w_rlen, &c->w_rstart, &c->w_rrank, &c->w_redo, &c->w_segfirst, &c->w_toff, &c->w_table, &c->w_nruns, &c->w_desc, &c->w_gtab, &c->w_gcount, &c->w_gbase, &c->w_rfirst, &c->w_aent2, &c->w_aov, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen,
                   &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->kc_opos, &c->kc_oid, &c->kc_opos2, &c->kc_oid2, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch};
     for (Buf* b : all) release(*b);
+    trim_pool(c->pool);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& st : c->side) (void)hipStreamDestroy(st);
     (void)hipEventDestroy(c->fork);
@@ -2509,6 +2552,7 @@ int bella_hip_get_memory(bella_ctx* c, bella_memory* m) {
                           &c->lk_val2, &c->lk_rinfo, &c->w, &c->wscan, &c->kc_nk, &c->kc_koff, &c->kc_hist, &c->kc_keys, &c->kc_alt, &c->kc_runlen, &c->kc_flag, &c->kc_slot, &c->kc_nruns,
                           &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->kc_opos, &c->kc_oid, &c->kc_opos2, &c->kc_oid2, &c->alns,
                           &c->seeds, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch, &c->status, &c->comm_meta});
+    m->other_bytes += c->pool.bytes;                               // (released buffers waiting for the next request they fit)
     m->owned_nnz = c->have_matrix ? c->owned_nnz : 0;
     return 0;
 }
@@ -2651,7 +2695,7 @@ static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_se
                 {
                     size_t mfree = 0, mtotal = 0;
                     if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
-                        const uint64_t held = c->xstate.cap + c->xlive.cap;
+                        const uint64_t held = c->xstate.cap + c->xlive.cap + c->pool.bytes;
                         const uint64_t fit = ((uint64_t)mfree + held) / 4 / (4 * (uint64_t)kXStateWords + 8);
                         if (capB > fit) capB = fit;
                     }

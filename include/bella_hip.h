@@ -327,7 +327,7 @@ typedef struct {
     uint64_t layout_B_bytes;   /* B' entries + their count stream: owned columns only                                      */
     uint64_t rowlist_bytes;    /* row lists (BELLA_TUNE_ROW_LISTS) + row pointers: owned columns only                      */
     uint64_t pass_bytes;       /* buffers of the passes (records, product lists, workspaces): follow the pass's products   */
-    uint64_t other_bytes;      /* counting / assembly / alignment buffers still held                                        */
+    uint64_t other_bytes;      /* counting / assembly / alignment buffers still held, and released ones kept for reuse      */
     uint64_t owned_nnz;        /* B' entries laid out (= nnz of the owned columns)                                         */
 } bella_memory;
 int bella_hip_get_memory(bella_ctx* ctx, bella_memory* m);
