@@ -1,6 +1,6 @@
 #!/bin/bash
 # development aid: compile the X-drop kernels alone and print the slice kernel's registers, spills and loop mix.  usage: xs_probe.sh [-D...]
-cd /tmp/isa && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off "$@" -I/root/repo/include -I/root/repo/bella_amd/csrc --cuda-device-only -S -o xs.s xs.hip 2>&1 | grep -E "error" -A4
+mkdir -p /tmp/isa && cd /tmp/isa && printf '#include <hip/hip_runtime.h>\n#include <cstdint>\n#include "bella_hip.h"\n#include "core.hpp"\n#include "util.hpp"\n#include "xdrop_packed.hpp"\n' > xs.hip && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off "$@" -I/root/repo/include -I/root/repo/bella_amd/csrc --cuda-device-only -S -o xs.s xs.hip 2>&1 | grep -E "error" -A4
 grep -E "k_xdrop_slice\w*\.(num_vgpr|private_seg_size)" xs.s
 python3 /root/repo/tools/dev/isa_loop.py xs.s k_xdrop_slice | sed -n 1,3p
 python3 - <<'PY'
