@@ -159,6 +159,7 @@ struct bella_ctx {
     uint32_t pass_tcnt[20] = {};
     uint64_t pass_products = 0;
     bool pass_rare_free = false;         // the last pass on pass_sig needed no rerun, no overflow fold, no wide column
+    bool pass_big_free = false;          // ... and had no column with more than 1,024 pairs (k_order_block)
     uint32_t tier_caps[kNumTiers] = {};  // ascending LDS caps, last = 65535 (global-workspace tier); per context
     uint32_t ntiers = 0;
     bool tiers_from_env = false;         // custom tier table (bella_hip_set_tuning)
@@ -2034,6 +2035,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     // is again a function of the operands: a warm pass whose predecessor needed neither leaves them out and checks the counters
     // in the final control block (should they be non-zero after all, the pass is run again with them).
     const bool skip_rare = warm && c->pass_rare_free && !(c->debug & 4u);
+    const bool skip_big = warm && c->pass_big_free && !(c->debug & 4u);
     uint32_t launches = 0;
     int rc = 0;
     uint32_t* const ctl_host = c->pinned + 32;
@@ -2320,12 +2322,24 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
             oa.pairs = ptr<bella_pair>(c->pairs); oa.ext = want_ext ? ptr<bella_pair_ext>(c->ext) : nullptr;
             oa.totals = (uint64_t*)(d_ctl + kCtlTotals);
             oa.nbig = d_ctl + kCtlOrderBig; oa.biglist = ptr<uint32_t>(c->orderlist); oa.ws = ptr<uint8_t>(c->order_ws);
-            k_order_wave<512, 0><<<nblk(nown ? nown : 1, kOrderBlock / 64), kOrderBlock, 0, c->stream>>>(oa);
-            KCHK(c);
-            k_order_wave<kOrderWaveHt, 512><<<nblk(nown ? nown : 1, kOrderBlock / 64), kOrderBlock, 0, c->stream>>>(oa);
-            KCHK(c);
-            k_order_block<<<kOrderBigGrid, kOrderBlock, (size_t)6 * kOrderLdsHt, c->stream>>>(oa);
-            KCHK(c);
+            // two instances share the columns by table size (the small one keeps more columns in flight per CU: tuned at 100k reads);
+            // on a small pass the second launch costs more than it buys (10k reads: two launches and the gap between them for 0.3 M
+            // records), so one instance takes all tables up to 1,024 slots there
+            if (nown <= kOrderOneLaunchMax) {
+                k_order_wave<kOrderWaveHt, 0><<<nblk(nown ? nown : 1, kOrderBlock / 64), kOrderBlock, 0, c->stream>>>(oa);
+                KCHK(c);
+            } else {
+                k_order_wave<512, 0><<<nblk(nown ? nown : 1, kOrderBlock / 64), kOrderBlock, 0, c->stream>>>(oa);
+                KCHK(c);
+                k_order_wave<kOrderWaveHt, 512><<<nblk(nown ? nown : 1, kOrderBlock / 64), kOrderBlock, 0, c->stream>>>(oa);
+                KCHK(c);
+            }
+            // columns with more than 1,024 pairs: a warm pass whose predecessor had none leaves the kernel out and checks the count in the
+            // final control block (like the rerun and overflow kernels above)
+            if (!skip_big) {
+                k_order_block<<<kOrderBigGrid, kOrderBlock, (size_t)6 * kOrderLdsHt, c->stream>>>(oa);
+                KCHK(c);
+            }
         }
         EVREC(7);
         HIPCHK(c, hipMemcpyAsync(ctl_host, d_ctl, 4 * kCtlWords, hipMemcpyDeviceToHost, c->stream));
@@ -2353,8 +2367,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     rc = enqueue();
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (skip_rare && (ctl_host[kCtlRetry] || ctl_host[kCtlOverflow])) {   // the pass needed the kernels it left out: once more, with them
+    if ((skip_rare && (ctl_host[kCtlRetry] || ctl_host[kCtlOverflow])) || (skip_big && ctl_host[kCtlOrderBig])) {   // the pass needed the kernels it left out: once more, with them
         c->pass_rare_free = false;
+        c->pass_big_free = false;
         if (depth > 0) return fail(c, BELLA_ERR_STATE, "internal: rare kernels still skipped");
         return run_spgemm(c, p, status_out, depth + 1);
     }
@@ -2377,6 +2392,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     }
     c->pass_known = true;
     c->pass_rare_free = c->n_retry == 0 && c->n_overflow == 0 && c->n_wide == 0;
+    c->pass_big_free = ctl_host[kCtlOrderBig] == 0;
     c->tm.symbolic_ms = ev_ms(c->ev[2], c->ev[3]);
     c->tm.spgemm_ms = ev_ms(c->ev[3], c->ev[5]);
     c->tm.fold_ms = skip_rare ? 0.f : ev_ms(c->ev[5], c->ev[8]);

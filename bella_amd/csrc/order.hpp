@@ -26,6 +26,7 @@ constexpr uint32_t kOrderWaveHt = 1024;                    // largest table a si
 constexpr uint32_t kOrderLdsHt = 16384;                    // largest table a workgroup holds in LDS (64 KB + 32 KB)
 constexpr uint32_t kOrderBlock = 256;
 constexpr uint32_t kOrderBigGrid = 512;                    // persistent workgroups of k_order_block
+constexpr uint32_t kOrderOneLaunchMax = 32768;             // columns of a pass up to which ONE wavefront-per-column launch takes all table sizes
 constexpr uint64_t kOrderWsBytes = (uint64_t)6 * 65536;    // global tables of one workgroup for columns with more than 16,384 pairs
 
 struct OrderArgs {
