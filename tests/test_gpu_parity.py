@@ -321,8 +321,12 @@ def test_exact_xdrop_mode_matches_logan_oracle_and_seqan_answers(eng):
             eng.set_debug(0)
 
 
-def test_partition_union_equals_whole(eng):
+@pytest.mark.parametrize("layout", [0, 65536])
+def test_partition_union_equals_whole(eng, layout):
     g = load_golden("toy120")
+    eng.set_debug(layout)                                  # 65536: one-partner B' entries in the inline form (the default of sets whose A' is
+                                                           # larger than the cache -- what every rank of a multi-GPU run of 100k reads has),
+                                                           # here together with the partitioned layout (B' entries of the owned columns only)
     eng.set_reads(g.rs)
     eng.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
     eng.set_partition(0, 1)
@@ -338,6 +342,7 @@ def test_partition_union_equals_whole(eng):
             parts.append(p)
     finally:
         eng.set_partition(0, 1)
+        eng.set_debug(0)
     merged = np.concatenate(parts)
     order = np.argsort(merged["cid"], kind="stable")      # columns ascending, slot order kept inside a column
     assert np.array_equal(merged[order], whole)
