@@ -59,6 +59,7 @@ SIGNATURES = [
     ("bella_hip_last_error", C.c_char_p, [vp]),
     ("bella_hip_set_reads", C.c_int, [vp, vp, vp, C.c_uint32]),
     ("bella_hip_load_fastq", C.c_int, [vp, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    ("bella_hip_load_fastq_list", C.c_int, [vp, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     ("bella_hip_get_ingest_stats", C.c_int, [vp, C.c_void_p]),
     ("bella_hip_get_read_names", C.c_int, [vp, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]),
     ("bella_hip_get_read_lengths", C.c_int, [vp, vp]),

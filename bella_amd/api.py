@@ -77,10 +77,15 @@ class Engine:
         self.lengths = rs.lengths
         self.names = rs.names
 
-    def load_fastq(self, path: str):
-        """ParallelFASTQ + get_fq_name (kmercode/fq_reader.c) + 2-bit packing: the file goes straight into the library"""
+    def load_fastq(self, path):
+        """ParallelFASTQ + get_fq_name (kmercode/fq_reader.c) + 2-bit packing: the file goes straight into the library.
+        `path` may be a list of files (the reference's -f list, kmercount.hpp:82-105): read ids continue from file to file."""
         n, nb = C.c_uint32(0), C.c_uint64(0)
-        self._chk(self.lib.bella_hip_load_fastq(self.h, os.fsencode(path), C.byref(n), C.byref(nb)))
+        if isinstance(path, (list, tuple)):
+            arr = (C.c_char_p * max(len(path), 1))(*[os.fsencode(x) for x in path])
+            self._chk(self.lib.bella_hip_load_fastq_list(self.h, arr, len(path), C.byref(n), C.byref(nb)))
+        else:
+            self._chk(self.lib.bella_hip_load_fastq(self.h, os.fsencode(path), C.byref(n), C.byref(nb)))
         self.nreads = n.value
         need = C.c_uint64(0)
         self._chk(self.lib.bella_hip_get_read_names(self.h, None, 0, None, C.byref(need)))

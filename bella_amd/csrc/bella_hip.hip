@@ -331,7 +331,9 @@ int build_layout(bella_ctx* c) {
     ENSURE(c, c->lk_val, 8 * nnz);
     ENSURE(c, c->lk_val2, 8 * nnz);
     ENSURE(c, c->lk_rinfo, 8 * ((size_t)c->nreads + 1));
-    ENSURE(c, c->w, 4 * (nnz + 1));
+    // (w also holds one word per READ: the owned rows' lengths of a partitioned layout, the rows' product counts of the row lists --
+    // a matrix with fewer nonzeros than reads must not shrink it below that)
+    ENSURE(c, c->w, 4 * std::max<uint64_t>(nnz + 1, (uint64_t)c->nreads + 2));
     ENSURE(c, c->wscan, 4 * (nnz + 1));
     ENSURE(c, c->Aent, 8 * nnz + 64);
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
@@ -745,24 +747,55 @@ int bella_hip_set_reads(bella_ctx* c, const uint8_t* bases, const uint64_t* offs
 // ---- FASTQ ingest (fastq.hpp) ---------------------------------------------------------------------------------------------
 // The file is mapped and indexed on all cores; the bases go mapping -> pinned buffer -> device one 64 MB chunk at a time, the
 // gather of chunk i+1 overlapping the transfer of chunk i.  The concatenated bases never exist on the host.
-int bella_hip_load_fastq(bella_ctx* c, const char* path, uint32_t* nreads, uint64_t* nbases) {
-    if (!c || !path) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
-    FastqIndex ix;
+// One file or several: the reference's -f names a LIST of FASTQ files whose reads are numbered through in list order
+// (kmercount.hpp:82-105 GetFiles, main.cpp:339-423).  Every file is mapped and indexed for itself; the base stream of the set is the
+// files' streams back to back, and a chunk that spans a file boundary is gathered from both sides.
+int bella_hip_load_fastq_list(bella_ctx* c, const char* const* paths, uint32_t nfiles, uint32_t* nreads, uint64_t* nbases) {
+    if (!c || (nfiles && !paths)) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+    std::vector<FastqIndex> ix(nfiles);
+    std::vector<uint64_t> first(nfiles + 1, 0);                 // first[f]: where file f's bases start in the set's base stream
+    std::vector<uint64_t> offsets(1, 0);
     std::string err;
     const auto t0 = std::chrono::steady_clock::now();
-    if (ix.build(path, err)) return fail(c, BELLA_ERR_BAD_ARG, "%s", err.c_str());
-    if (ix.names.size() >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "more than 2^32 reads");
+    uint64_t file_bytes = 0, total_reads = 0;
+    unsigned threads = 1;
+    for (uint32_t f = 0; f < nfiles; ++f) {
+        if (!paths[f]) return fail(c, BELLA_ERR_BAD_ARG, "null path");
+        if (ix[f].build(paths[f], err)) return fail(c, BELLA_ERR_BAD_ARG, "%s", err.c_str());
+        total_reads += ix[f].names.size();
+        if (total_reads >= 0xFFFFFFF0ull) return fail(c, BELLA_ERR_BAD_ARG, "more than 2^32 reads");
+        first[f + 1] = first[f] + ix[f].nbases();
+        for (uint32_t r = 0; r < ix[f].nreads(); ++r) offsets.push_back(first[f] + ix[f].offsets[r + 1]);
+        file_bytes += (uint64_t)ix[f].file.n;
+        threads = std::max(threads, ix[f].threads);
+    }
     const auto t1 = std::chrono::steady_clock::now();
-    int rc = set_reads_impl(c, ix.offsets.data(), ix.nreads(),
-                            [&ix](void* pinned, size_t o, size_t n) { ix.gather_parallel((uint8_t*)pinned, o, n); });
+    int rc = set_reads_impl(c, offsets.data(), (uint32_t)total_reads, [&](void* pinned, size_t o, size_t n) {
+        uint32_t f = (uint32_t)(std::upper_bound(first.begin(), first.end(), (uint64_t)o) - first.begin()) - 1;
+        uint8_t* dst = (uint8_t*)pinned;
+        while (n) {
+            while (f + 1 < nfiles && first[f + 1] <= o) ++f;    // (files without bases)
+            const size_t take = (size_t)std::min<uint64_t>(n, first[f + 1] - o);
+            ix[f].gather_parallel(dst, o - first[f], take);
+            dst += take; o += take; n -= take;
+        }
+    });
     if (rc) return rc;
     const auto t2 = std::chrono::steady_clock::now();
-    c->ingest = {(uint64_t)ix.file.n, ix.nbases(), ix.nreads(), ix.threads, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+    c->ingest = {file_bytes, c->total_bases, c->nreads, threads, std::chrono::duration<double, std::milli>(t1 - t0).count(),
                  std::chrono::duration<double, std::milli>(t2 - t1).count()};
-    c->names = std::move(ix.names);
+    c->names.clear();
+    c->names.reserve(total_reads);
+    for (uint32_t f = 0; f < nfiles; ++f)
+        for (auto& nm : ix[f].names) c->names.push_back(std::move(nm));
     if (nreads) *nreads = c->nreads;
     if (nbases) *nbases = c->total_bases;
     return 0;
+}
+
+int bella_hip_load_fastq(bella_ctx* c, const char* path, uint32_t* nreads, uint64_t* nbases) {
+    if (!c || !path) return fail(c, BELLA_ERR_BAD_ARG, "null argument");
+    return bella_hip_load_fastq_list(c, &path, 1, nreads, nbases);
 }
 
 int bella_hip_get_ingest_stats(bella_ctx* c, bella_ingest_stats* out) {

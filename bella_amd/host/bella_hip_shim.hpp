@@ -70,7 +70,7 @@ struct CallStats {
     uint64_t layout_B_bytes_max = 0, layout_B_bytes_sum = 0;   // B' per context: follows the partition
     uint64_t host_upload_bytes = 0;  // matrix bytes that went host -> device, all contexts together
 };
-inline CallStats& last_call_stats() { static CallStats s; return s; }
+inline CallStats& last_call_stats() { static CallStats s; return s; }   // single caller, like HashSpGEMM itself (not re-entrant: overlap.hpp:92)
 // the reference's printLog (include/common/common.h:40-44): "INFO:\tfile(line)\tname = value" on stderr
 #define BELLA_HIP_LOG(var) do { std::cerr << "INFO:\t" << "bella_hip_shim.hpp" << "(" << __LINE__ << ")\t" << #var << " = " << (var) << std::endl; } while (0)
 }  // namespace bella_hip_detail
@@ -167,7 +167,8 @@ void HashSpGEMM(const CSC<uint32_t, unsigned short>& A, const CSC<uint32_t, unsi
     uint64_t flops_all = 0;
     for (uint64_t f : wflops) flops_all += f;
     bool computed = false;                                                    // the numeric phase already ran over all columns
-    if (safety_net * (double)flops_all * per_nnz <= free_memory) {
+    const bool no_budget = !(free_memory > 0.0);                              // -m 0 or unset: one stage (the formula would divide by it)
+    if (no_budget || safety_net * (double)flops_all * per_nnz <= free_memory) {
         do_overlap(0, nreads);
         computed = true;
     } else {
@@ -182,9 +183,9 @@ void HashSpGEMM(const CSC<uint32_t, unsigned short>& A, const CSC<uint32_t, unsi
     nnzc = colptrC[nreads];
     std::cout << nnzc << std::endl;                                           // overlap.hpp:686
     const uint64_t required_memory = (uint64_t)(safety_net * nnzc * per_nnz);
-    int stages = (int)std::ceil((double)required_memory / free_memory);       // overlap.hpp:683
+    int stages = no_budget ? 1 : (int)std::ceil((double)required_memory / free_memory);       // overlap.hpp:683
     if (stages < 1) stages = 1;
-    const uint64_t nnzcperstage = (uint64_t)(free_memory / (safety_net * per_nnz));
+    const uint64_t nnzcperstage = no_budget ? nnzc + 1 : (uint64_t)(free_memory / (safety_net * per_nnz));
     std::vector<uint32_t> colStart((size_t)stages + 1, 0);
     for (int i = 1; i < stages; ++i) {                                        // overlap.hpp:704-710
         auto upper = std::upper_bound(colptrC.begin(), colptrC.end(), (uint64_t)i * nnzcperstage);

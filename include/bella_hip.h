@@ -138,7 +138,10 @@ int bella_hip_set_reads(bella_ctx* ctx, const uint8_t* bases, const uint64_t* of
  * the transfer of chunk i) and are packed to 2 bit/base on the device.  Same effect as bella_hip_set_reads; the names (without
  * '@', cut at the comment as the reference does) stay in the context. */
 int bella_hip_load_fastq(bella_ctx* ctx, const char* path, uint32_t* nreads, uint64_t* nbases);
-/* what the last bella_hip_load_fastq did */
+/* the same for the reference's LIST of FASTQ files (-f: include/kmercount.hpp:82-105 GetFiles reads one path per line; src/main.cpp:339-423
+ * numbers the reads through the files in list order): read ids continue from file to file, every file is mapped and indexed for itself. */
+int bella_hip_load_fastq_list(bella_ctx* ctx, const char* const* paths, uint32_t nfiles, uint32_t* nreads, uint64_t* nbases);
+/* what the last bella_hip_load_fastq / _list did (file_bytes, threads: over all files) */
 typedef struct bella_ingest_stats {
     uint64_t file_bytes;
     uint64_t bases;

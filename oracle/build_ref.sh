@@ -12,6 +12,9 @@
 #   oracle/_ref/bella_ref        the reference CLI (src/main.cpp)            -> golden .out files
 #   oracle/_ref/bella_ref_dump   same with -DWRITEDATAMATRIX (bellaio.h:2-47)  -> readbykmers.mtx
 #   oracle/_ref/libbella_dropin.so  oracle/dropin_shim.cpp: reference headers + bella_amd/host/bella_hip_shim.hpp (drop-in proof)
+#   oracle/_ref/bella_dropin     the reference CLI itself, GPU-backed: src/main.cpp UNCHANGED but for the one #include line of
+#                                INTEGRATION.md section 1 (inserted on the fly by sed into the compiler's stdin: the patched text is
+#                                never written anywhere), linked against libbella_hip.so as makefile-nersc:60-61 would be
 #   oracle/_ref/libbella_ref.so  oracle/ref_shim.cpp (ours) #including the reference headers:
 #                                C entry points around HashSpGEMM / xavierAlign for tests + cpu_baseline
 set -euo pipefail
@@ -29,6 +32,8 @@ ROOTDIR="$(cd "$HERE/.." && pwd)"
 if [ -f "$stamp" ] && [ "$OUT/libbella_ref.so" -nt "$HERE/ref_shim.cpp" ] && [ -x "$OUT/bella_ref" ] \
    && [ -x "$OUT/bella_ref_dump" ] && [ "$OUT/libbella_dropin.so" -nt "$HERE/dropin_shim.cpp" ] \
    && [ "$OUT/libbella_dropin.so" -nt "$ROOTDIR/bella_amd/host/bella_hip_shim.hpp" ] && [ -x "$OUT/bella_eval" ] \
+   && [ -x "$OUT/bella_dropin" ] && [ "$OUT/bella_dropin" -nt "$ROOTDIR/bella_amd/host/bella_hip_shim.hpp" ] \
+   && [ "$OUT/bella_dropin" -nt "$ROOTDIR/include/bella_hip.h" ] \
    && [ "${1:-}" != "--force" ]; then
   echo "build_ref: up to date"; exit 0
 fi
@@ -54,6 +59,13 @@ if [ -f "$ROOTDIR/bella_amd/libbella_hip.so" ]; then
 g++ -std=c++14 -w -O2 $INC -I"$REF" -I"$ROOTDIR/include" -I"$ROOTDIR/bella_amd/host" -mavx2 -fopenmp -fpermissive -fPIC -shared \
     -o "$OUT/libbella_dropin.so" "$HERE/dropin_shim.cpp" $OBJS -L"$ROOTDIR/bella_amd" -lbella_hip \
     -Wl,-rpath,'$ORIGIN/../../bella_amd' -lpthread &
+# The real CLI proof: the reference's own main.cpp with `#include "bella_hip_shim.hpp"` after its `#include "../include/align.hpp"`
+# (main.cpp:55) -- the only change INTEGRATION.md asks a maintainer for -- so that the unchanged call at main.cpp:498-525 resolves
+# to the shim's overload.  The compiler reads the patched text from stdin with src/ as its working directory (main.cpp's includes
+# are relative to it); nothing of the reference is copied.
+( cd "$REF/src" && sed 's|^#include "../include/align.hpp"|&\n#include "bella_hip_shim.hpp"|' main.cpp | \
+  g++ -x c++ -std=c++14 -w -O3 $INC -I"$REF/src" -I"$ROOTDIR/include" -I"$ROOTDIR/bella_amd/host" -mavx2 -fopenmp -fpermissive \
+      -o "$OUT/bella_dropin" - -x none $OBJS -L"$ROOTDIR/bella_amd" -lbella_hip -Wl,-rpath,'$ORIGIN/../../bella_amd' -lpthread ) &
 fi
 wait
 set +x

@@ -348,6 +348,34 @@ def test_partition_union_equals_whole(eng, layout):
     assert np.array_equal(merged[order], whole)
 
 
+def test_partitioned_layout_of_a_matrix_with_fewer_nonzeros_than_reads(eng):
+    """the partitioned layout keeps one word per READ in a scratch array that used to be sized by nnz(A) alone:
+    nnz == 0 and nnz << nreads, several partitions, with and without the row lists"""
+    nr = 3000
+    rs = synth.readset_from_seqs([b"ACGTTGCA" * 6] * nr)
+    eng.set_reads(rs)
+    tk = np.array([3, 3, 4, 4, 4], np.uint32); tr = np.array([5, 2900, 17, 1200, 2999], np.uint32); tp = np.array([0, 4, 8, 4, 12], np.uint16)
+    order = np.argsort(tr, kind="stable")
+    tk, tr, tp = tk[order], tr[order], tp[order]
+    try:
+        for rl in (0, 1):
+            eng.set_tuning("row_lists", rl)
+            for ntup in (0, len(tk)):
+                got = []
+                for r in range(3):
+                    eng.set_partition(r, 3)                 # BEFORE the operands: the layout is built for the partition
+                    eng.assemble_tuples(17, 9, tk[:ntup], tr[:ntup], tp[:ntup])
+                    n, _ = eng.overlap(BellaPars(skipAlignment=True))
+                    p, _, _ = eng.get_pairs(ext=False)
+                    assert n == len(p) and (p["cid"] % 3 == r).all()
+                    got += [(int(x["cid"]), int(x["rid"]), int(x["count"])) for x in p]
+                exp = [] if ntup == 0 else [(5, 2900, 1), (17, 1200, 1), (17, 2999, 1), (1200, 2999, 1)]
+                assert sorted(got) == exp
+    finally:
+        eng.set_partition(0, 1)
+        eng.set_tuning("row_lists")
+
+
 def test_medium_synthetic_vs_oracle(eng):
     """2,000 reads x 6 kb (SpGEMM) -- bigger hash tables, LDS tiers and the ordering emulation under load"""
     rs = synth.make_reads(2000, read_len=6000, err=0.15, seed=21)
@@ -474,6 +502,74 @@ def test_dropin_shim_from_reference_call_site(eng, tmp_path):
             nums = so.value.decode().split()
             assert nums[:3] == g.stdout[key][:3]            # nkmer, nnz(A) after merge, nnz(C): the stdout protocol
             assert open(f, "rb").read() == g.out[key]       # the reference's file, byte for byte (no tolerance)
+
+
+def _run_cli(binary, fastqs, flags, cwd, env_extra=None):
+    """the reference's CLI contract (main.cpp:65-175): -f names a newline-terminated list of FASTQ files, -o the output stem"""
+    import subprocess
+    import re
+    os.makedirs(cwd, exist_ok=True)
+    with open(os.path.join(cwd, "in.txt"), "w") as f:
+        f.write("".join(p + "\n" for p in fastqs))            # (kmercount.hpp:96: every line must end in '\n')
+    env = dict(os.environ, OMP_NUM_THREADS="1")                # 1-thread libcuckoo ids are the golden ids (SURVEY A.6)
+    env.update(env_extra or {})
+    p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", binary), "-f", "in.txt", "-o", "out"] + list(flags), cwd=cwd, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    so = p.stdout.decode(errors="replace")
+    nums = [ln.strip() for ln in so.splitlines() if re.fullmatch(r"[0-9.eE+-]+", ln.strip())]
+    out = os.path.join(cwd, "out.out")
+    assert os.path.exists(out), (p.returncode, so[-2000:], p.stderr.decode(errors="replace")[-2000:])
+    return nums, open(out, "rb").read(), p.stderr.decode(errors="replace")
+
+
+def test_reference_cli_built_from_its_unchanged_main_runs_on_the_gpu(golden, tmp_path):
+    """oracle/_ref/bella_dropin = the reference's src/main.cpp with the ONE include line of INTEGRATION.md section 1, linked
+    against libbella_hip.so (oracle/build_ref.sh): flags (main.cpp:65-175), the FASTQ list, the reference's own k-mer counting and
+    CSC constructor on the host, then the unchanged call at main.cpp:498-525 -> the shim -> the C ABI.  Output file and the stdout
+    protocol (nkmer, nnz(A), nnz(C), outputted: main.cpp:472-473, overlap.hpp:686,771) against the reference binary's goldens."""
+    import gzip
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "bella_dropin")):
+        pytest.skip("oracle/_ref/bella_dropin not built (needs /root/reference at build time)")
+    g = golden
+    fq = str(tmp_path / "reads.fastq")
+    with gzip.open(os.path.join(GOLD, g.name, "reads.fastq.gz"), "rb") as src, open(fq, "wb") as dst:
+        dst.write(src.read())
+    for extra, key in ((["--skip-alignment"], "skip"), ([], "align"), (["--paf"], "paf")):
+        nums, data, err = _run_cli("bella_dropin", [fq], g.meta["flags"] + extra, str(tmp_path / key))
+        assert data == g.out[key], (g.name, key)                # byte for byte, no tolerance
+        if key in g.stdout:
+            assert nums[:-1] == g.stdout[key][:-1], (nums, g.stdout[key])   # every protocol line but the last (the run time)
+        assert "bella_hip_shim.hpp" in err                      # the shim's log lines: the call really went through it
+
+
+def test_reference_cli_on_the_gpu_with_a_fastq_list_several_gpus_and_stages(tmp_path):
+    """the same executable with what the small goldens cannot exercise: a -f list of TWO files (kmercount.hpp:82-105 GetFiles), -g 2
+    (two contexts sharing the one GPU) and a -m that forces the reference's stage loop (overlap.hpp:682-710) -- against the reference
+    binary itself (oracle/_ref/bella_ref, single stage: its multi-stage run overwrites the file from offset 0, overlap.hpp:613-636)"""
+    for b in ("bella_dropin", "bella_ref"):
+        if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", b)):
+            pytest.skip("oracle/_ref/%s not built" % b)
+    rs = synth.make_reads(2200, read_len=4000, err=0.15, seed=77)
+    fa, fb = str(tmp_path / "a.fastq"), str(tmp_path / "b.fastq")
+    synth.write_fastq(fa, rs.subset(900))
+    tail = synth.ReadSet(rs.codes[rs.offsets[900]:], rs.offsets[900:] - rs.offsets[900], rs.names[900:])
+    synth.write_fastq(fb, tail)
+    over = {"BELLA_HIP_SHIM_OVERSUBSCRIBE": "1"}
+    for extra, key, variants in ((["--skip-alignment"], "skip", (([], None), (["-g", "2"], over), (["-m", "1"], None), (["-m", "1", "-g", "2"], over))),
+                                 ([], "align", ((["-m", "1", "-g", "2"], over),))):
+        rnums, ref, _ = _run_cli("bella_ref", [fa, fb], extra, str(tmp_path / ("ref_" + key)))
+        nnzc = int(rnums[2])
+        assert nnzc > 53000                                     # 1.5 * nnzc * 20 B > 1 MB: -m 1 means at least two stages
+        stages = int(np.ceil(1.5 * nnzc * 20 / (1024.0 * 1024.0)))
+        assert stages >= 2
+        for flags, env in variants:
+            nums, data, err = _run_cli("bella_dropin", [fa, fb], extra + flags, str(tmp_path / ("d_%s_%s" % (key, "_".join(flags)))), env)
+            assert data == ref, (key, flags)
+            assert nums[:3] == rnums[:3]
+            if "-m" in flags:
+                assert err.count("ColumnsRange") == stages, err[-1500:]
+            if key == "align":                                  # "outputted" is printed per stage (overlap.hpp:771)
+                assert sum(int(x) for x in nums[3:-1]) == int(rnums[3])
 
 
 def test_dropin_shim_stages_and_gpus_from_bellapars(eng, tmp_path, monkeypatch):
@@ -961,6 +1057,33 @@ def test_load_fastq_equals_set_reads(eng, golden, tmp_path):
     b = eng.get_tuples()
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+def test_load_fastq_list_numbers_the_reads_through_the_files(eng, tmp_path):
+    """the reference's -f list (kmercount.hpp:82-105): several files, read ids in list order; an empty file in the middle; chunks of
+    the base stream that span file boundaries"""
+    rs = synth.make_reads(260, read_len=3000, coverage=20.0, err=0.15, seed=9)
+    cuts = [0, 1, 1, 120, 259, 260]                        # one read, an EMPTY file, 119 reads, 139 reads, one read
+    paths = []
+    for f in range(len(cuts) - 1):
+        lo, hi = cuts[f], cuts[f + 1]
+        part = synth.ReadSet(rs.codes[rs.offsets[lo]:rs.offsets[hi]], rs.offsets[lo:hi + 1] - rs.offsets[lo], rs.names[lo:hi])
+        p = str(tmp_path / ("part%d.fastq" % f))
+        synth.write_fastq(p, part)
+        paths.append(p)
+    n, nb = eng.load_fastq(paths)
+    assert n == rs.nreads and nb == int(rs.offsets[-1])
+    assert eng.names == rs.names and np.array_equal(eng.lengths, rs.lengths)
+    st = eng.ingest_stats()
+    assert int(st["file_bytes"]) == sum(os.path.getsize(p) for p in paths)
+    eng.count_kmers(17, 2, 8)
+    a = eng.get_tuples()
+    eng.set_reads(rs)
+    eng.count_kmers(17, 2, 8)
+    for x, y in zip(a, eng.get_tuples()):
+        assert np.array_equal(x, y)
+    n0, _ = eng.load_fastq([])                             # an empty list is an empty read set, not an error
+    assert n0 == 0
 
 
 def test_load_fastq_streams_a_file_larger_than_the_pinned_chunk(eng, tmp_path):
