@@ -244,6 +244,12 @@ class Engine:
     # ---- HashSpGEMM ----
     TUNE = {"lds_tiers": 0, "kcount_budget": 1, "wide_budget": 2, "xdrop_variant": 3, "row_lists": 4, "xdrop_class_min": 5}
 
+    def reserve(self, nbytes: int) -> float:
+        """bella_hip_reserve: one slab of device memory up front (the stages then allocate nothing from the driver); returns the ms it took"""
+        ms = C.c_double(0.0)
+        self._chk(self.lib.bella_hip_reserve(self.h, int(nbytes), C.byref(ms)))
+        return ms.value
+
     def set_tuning(self, what: str, *values):
         """bella_hip_set_tuning: per-context tuning parameters (tests, A/B measurements); no values = the default"""
         v = np.asarray(values, dtype=np.uint64)

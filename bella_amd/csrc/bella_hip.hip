@@ -6,12 +6,15 @@
 #include <algorithm>
 #include <cmath>
 #include <initializer_list>
+#include <iterator>
+#include <map>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bella_hip.h"
@@ -38,9 +41,44 @@ namespace {
 // the next one asks for as much waits about a second for that (200k reads: assembly 1.05 s instead of 60 ms, first pass 0.75 s
 // instead of 15 ms).  Same synchronisation as hipFree (the device is idle when a buffer changes hands); what is pooled counts as free
 // memory wherever the library sizes something by it, and goes back to the driver when an allocation fails or the context is destroyed.
+// An ARENA (bella_hip_reserve): one slab taken from the driver up front, from which the buffers below are cut.  The first hipMalloc
+// of a multi-GB buffer costs ~30 ms per GB on this stack (the driver maps and wipes the pages): at 100k reads the first k-mer count paid
+// 850 ms for its 30 GB of sort buffers and the first assembly 210 ms, against 47 and 21 ms of kernels.  A process that will run the
+// pipeline reserves once; every stage then finds its memory in place.  First fit over an offset-ordered free list with coalescing.
+struct Arena {
+    char* base = nullptr;
+    size_t size = 0, in_use = 0, peak = 0;
+    std::map<size_t, size_t> holes;                             // offset -> length of the free ranges
+    static size_t round(size_t n) { return (n + 4095) & ~(size_t)4095; }
+    bool owns(const void* p) const { return base && (const char*)p >= base && (const char*)p < base + size; }
+    size_t free_bytes() const { return size - in_use; }
+    void* take(size_t n) {
+        n = round(n);
+        for (auto it = holes.begin(); it != holes.end(); ++it)
+            if (it->second >= n) {
+                const size_t off = it->first, len = it->second;
+                holes.erase(it);
+                if (len > n) holes.emplace(off + n, len - n);
+                in_use += n;
+                peak = std::max(peak, in_use);
+                return base + off;
+            }
+        return nullptr;
+    }
+    void give(void* p, size_t n) {
+        n = round(n);
+        in_use -= n;
+        size_t off = (size_t)((char*)p - base);
+        auto nx = holes.lower_bound(off);
+        if (nx != holes.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == off) { off = pv->first; n += pv->second; holes.erase(pv); } }
+        if (nx != holes.end() && off + n == nx->first) { n += nx->second; holes.erase(nx); }
+        holes.emplace(off, n);
+    }
+};
 struct BufPool {
     std::vector<std::pair<void*, size_t>> free;
     size_t bytes = 0;
+    Arena arena;
 };
 constexpr size_t kPoolMinBytes = 128ull << 20, kPoolMaxBytes = 160ull << 30;
 struct Buf {
@@ -222,6 +260,10 @@ int ensure_bytes(bella_ctx* c, Buf& b, size_t bytes) {
         pl.free.erase(pl.free.begin() + best);
         return 0;
     }
+    if (pl.arena.base) {                                        // the reserved slab first (bella_hip_reserve): no trip to the driver
+        void* q = pl.arena.take(want);
+        if (q) { b.p = q; b.cap = Arena::round(want); return 0; }
+    }
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess && !pl.free.empty()) {                  // what the free list holds back may be what is missing
         (void)hipGetLastError();
@@ -244,7 +286,10 @@ int ensure_bytes(bella_ctx* c, Buf& b, size_t bytes) {
 void release(Buf& b) {
     if (b.p) {
         BufPool* pl = b.pool;
-        if (pl && b.cap >= kPoolMinBytes && pl->free.size() < 32 && pl->bytes + b.cap <= kPoolMaxBytes) {
+        if (pl && pl->arena.owns(b.p)) {
+            (void)hipDeviceSynchronize();                       // (as below: nothing in flight touches the range when it changes hands)
+            pl->arena.give(b.p, b.cap);
+        } else if (pl && b.cap >= kPoolMinBytes && pl->free.size() < 32 && pl->bytes + b.cap <= kPoolMaxBytes) {
             (void)hipDeviceSynchronize();                       // (what hipFree does: nothing in flight touches the buffer when it changes hands)
             pl->free.emplace_back(b.p, b.cap);
             pl->bytes += b.cap;
@@ -395,7 +440,7 @@ int build_layout(bella_ctx* c) {
         // branch (10k reads, A' = 92 MB: 0.360 -> 0.367 ms per step).  debug bit 15 (tests): the plain form everywhere, as for inputs
         // beyond those bounds; bit 16: the inline form on any size
         const bool inl_pays = 8ull * nnz > (192ull << 20) || (c->debug & 65536u);
-        const uint32_t inl = by_kmer && rmask == 0x3FFFFFFFu && nnz < 0x80000000ull && inl_pays && !(c->debug & 32768u) ? 1u : 0u;
+        const uint32_t inl = rmask == 0x3FFFFFFFu && nnz < 0x80000000ull && inl_pays && !(c->debug & 32768u) ? 1u : 0u;
         c->layout_inline = inl;
         if (!by_kmer) {
             k_layout_heads<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), rmask, ptr<uint32_t>(c->w), ptr<uint32_t>(c->status));
@@ -479,7 +524,7 @@ int build_layout(bella_ctx* c) {
             }
             size_t mfree = 0, mtotal = 0;
             HIPCHK(c, hipMemGetInfo(&mfree, &mtotal));
-            mfree += c->pool.bytes;                                 // (released buffers the context still holds are free for this purpose)
+            mfree += c->pool.bytes + c->pool.arena.free_bytes();    // (released buffers and the unused part of the reserved slab are free for this purpose)
             // 10 bytes per product for the lists; a pass over all owned columns then needs about 60 more per product (records twice,
             // product lists, scratch, diagnostics) -- the lists are only built when both fit (debug bit 11: tests, "no room")
             const bool fits = (double)F * 70.0 + 1e8 <= (double)mfree && !(c->debug & 2048u);
@@ -620,6 +665,7 @@ void bella_hip_destroy(bella_ctx* c) {
                   &c->kc_flag, &c->kc_slot, &c->kc_nruns, &c->kc_dcode, &c->kc_dcount, &c->kc_hkey, &c->kc_hval, &c->kc_found, &c->kc_tstart, &c->kc_cursor, &c->kc_sel, &c->kc_ringo, &c->kc_ringp, &c->kc_opos, &c->kc_oid, &c->kc_opos2, &c->kc_oid2, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch};
     for (Buf* b : all) release(*b);
     trim_pool(c->pool);
+    if (c->pool.arena.base) { (void)hipFree(c->pool.arena.base); c->pool.arena = Arena(); }
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& st : c->side) (void)hipStreamDestroy(st);
     (void)hipEventDestroy(c->fork);
@@ -668,6 +714,34 @@ int bella_hip_set_tuning(bella_ctx* c, uint32_t what, const uint64_t* values, ui
             return 0;
     }
     return fail(c, BELLA_ERR_BAD_ARG, "unknown tuning parameter %u", what);
+}
+
+// One slab from the driver, up front (see Arena): bytes == 0 gives an existing, unused slab back.  A larger request replaces an unused
+// slab; while buffers live in the slab it stays as it is (BELLA_ERR_STATE).  What does not fit the slab later goes to hipMalloc as before.
+int bella_hip_reserve(bella_ctx* c, uint64_t bytes, double* ms) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    Arena& a = c->pool.arena;
+    if (ms) *ms = 0.0;
+    if (a.base && a.in_use) return bytes <= a.size ? 0 : fail(c, BELLA_ERR_STATE, "the reserved slab is in use (%zu of %zu bytes)", a.in_use, a.size);
+    if (a.base && bytes && bytes <= a.size) return 0;
+    if (a.base) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(a.base); a = Arena(); }
+    if (!bytes) return 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    void* q = nullptr;
+    trim_pool(c->pool);
+    const size_t sz = Arena::round((size_t)bytes);
+    hipError_t e = hipMalloc(&q, sz);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(c, BELLA_ERR_NOMEM, "hipMalloc(%zu) for the reserved slab failed: %s", sz, hipGetErrorString(e)); }
+    // touch it now: the driver maps (and wipes) pages on first use, which is the cost this call exists to take out of the stages
+    e = hipMemsetAsync(q, 0, sz, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(q); return fail(c, BELLA_ERR_HIP, "reserve: %s", hipGetErrorString(e)); }
+    a.base = (char*)q; a.size = sz; a.in_use = 0; a.peak = 0;
+    a.holes.clear();
+    a.holes.emplace(0, sz);
+    if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
 }
 
 int bella_hip_set_debug(bella_ctx* c, uint32_t flags) {
@@ -1028,6 +1102,7 @@ static int grow_keep(bella_ctx* c, Buf& b, size_t need, size_t used) {
 // reads (1/N of the sort), the partial dictionaries (ascending, so their concatenation in rank order is the whole ascending
 // dictionary) are exchanged with one grouped send/recv, and tuples are generated for the reads bfirst .. bfirst + brows - 1 only
 static int comm_agree(bella_ctx* c, int local_rc);
+static int comm_sync(bella_ctx* c, const char* what);
 
 static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, uint32_t upper, uint32_t mode, uint32_t window,
                             uint32_t* nkmers_out, uint64_t* ntuples_out, uint64_t* ndistinct_out, bool dist = false, uint32_t bfirst = 0,
@@ -1278,7 +1353,7 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
         NCCLCHK(c, c->api->AllGather(d_meta + 4 * (size_t)NR, d_meta, 4, ncclUint64, c->comm, c->stream));
         std::vector<uint64_t> meta(4 * (size_t)NR);
         HIPCHK(c, hipMemcpyAsync(meta.data(), d_meta, 8 * 4 * (size_t)NR, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        { const int sr = comm_sync(c, "dictionary sizes"); if (sr) return sr; }
         std::vector<uint64_t> off((size_t)NR + 1, 0);
         uint64_t nd_all = 0;
         for (int r = 0; r < NR; ++r) { off[r + 1] = off[r] + meta[4 * r]; nd_all += meta[4 * r + 1]; }
@@ -1310,7 +1385,7 @@ static int count_kmers_impl(bella_ctx* c, uint16_t kmer_size, uint32_t lower, ui
             const ncclResult_t ge = c->api->GroupEnd();
             if (nr2 == ncclSuccess) nr2 = ge;
         }
-        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he == hipSuccess && nr2 == ncclSuccess) { const int sr = comm_sync(c, "dictionary exchange"); if (sr) { release(ncode); release(ncount); return sr; } }
         if (nr2 != ncclSuccess || he != hipSuccess) {
             release(ncode); release(ncount);
             return fail(c, BELLA_ERR_HIP, "dictionary exchange failed: %s", nr2 != ncclSuccess ? (c->api->GetErrorString ? c->api->GetErrorString(nr2) : "RCCL error") : hipGetErrorString(he));
@@ -1654,6 +1729,54 @@ static int comm_id_impl(const Rccl& api, uint8_t id[BELLA_HIP_COMM_ID_BYTES]) {
 int bella_hip_comm_id(uint8_t id[BELLA_HIP_COMM_ID_BYTES]) { return comm_id_impl(rccl(), id); }
 int bella_hip_comm_id_local(uint8_t id[BELLA_HIP_COMM_ID_BYTES]) { return comm_id_impl(loopback(), id); }
 
+// Wait for what the collective calls put on the stream -- with a deadline (BELLA_HIP_COMM_TIMEOUT_S, default 120 s): a peer that never
+// arrives must not hang the process.  On expiry the communicator is aborted (ncclCommAbort, where the transport has it) and the call
+// fails like any other error: the caller falls back (bench.py, bella_amd/dist.py: the torch.distributed exchange).
+static int comm_sync(bella_ctx* c, const char* what) {
+    static const double limit = [] { const char* e = getenv("BELLA_HIP_COMM_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 120.0; }();
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); return fail(c, BELLA_ERR_HIP, "%s: %s", what, hipGetErrorString(q)); }
+        (void)hipGetLastError();
+        if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            if (c->comm && c->api && c->api->CommAbort) { (void)c->api->CommAbort(c->comm); c->comm = nullptr; c->comm_ranks = 0; }
+            return fail(c, BELLA_ERR_STATE, "%s: no completion within %.0f s (a peer did not arrive); the communicator was aborted", what, limit);
+        }
+    }
+}
+
+// Every entry point of the transport once, right after the communicator exists (all ranks are inside bella_hip_comm_init together): an
+// all-gather of the ranks' numbers and a grouped send/recv to the rank ITSELF -- a missing symbol, an ABI mismatch or a communicator
+// that does not move data fails HERE, at init, not inside the first exchange of a run.
+static int comm_selftest(bella_ctx* c) {
+    const int N = c->comm_ranks, me = c->comm_rank;
+    ENSURE(c, c->comm_meta, 8 * 4 * ((size_t)N + 1) + 64);
+    uint64_t* d = ptr<uint64_t>(c->comm_meta);
+    const uint64_t mine[4] = {0xBE11A000ull + (uint64_t)me, ~(uint64_t)me, 0, 0};
+    HIPCHK(c, hipMemsetAsync(d, 0, 8 * 4 * ((size_t)N + 1) + 64, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d + 4 * (size_t)N, mine, 16, hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, c->api->AllGather(d + 4 * (size_t)N, d, 1, ncclUint64, c->comm, c->stream));
+    ncclResult_t r = c->api->GroupStart();
+    if (r == ncclSuccess) r = c->api->Send(d + 4 * (size_t)N + 1, 1, ncclUint64, me, c->comm, c->stream);
+    if (r == ncclSuccess) r = c->api->Recv(d + 4 * (size_t)N + 2, 1, ncclUint64, me, c->comm, c->stream);
+    const ncclResult_t ge = c->api->GroupEnd();
+    if (r == ncclSuccess) r = ge;
+    if (r != ncclSuccess) return fail(c, BELLA_ERR_HIP, "communicator self-test: %s", c->api->GetErrorString ? c->api->GetErrorString(r) : "RCCL error");
+    std::vector<uint64_t> got((size_t)N + 4, 0);
+    HIPCHK(c, hipMemcpyAsync(got.data(), d, 8 * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(got.data() + N, d + 4 * (size_t)N, 24, hipMemcpyDeviceToHost, c->stream));
+    int rc = comm_sync(c, "communicator self-test");
+    if (rc) return rc;
+    for (int q = 0; q < N; ++q)
+        if (got[(size_t)q] != 0xBE11A000ull + (uint64_t)q) return fail(c, BELLA_ERR_STATE, "communicator self-test: the all-gather delivered %llx for rank %d", (unsigned long long)got[(size_t)q], q);
+    if (got[(size_t)N + 2] != ~(uint64_t)me) return fail(c, BELLA_ERR_STATE, "communicator self-test: send/recv to self delivered %llx", (unsigned long long)got[(size_t)N + 2]);
+    return 0;
+}
+
 static int comm_init_impl(bella_ctx* c, const Rccl& api, int nranks, int rank, const uint8_t id[BELLA_HIP_COMM_ID_BYTES]) {
     if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, BELLA_ERR_BAD_ARG, "bad communicator arguments");
     if (!api.ok()) return fail(c, BELLA_ERR_STATE, "librccl could not be loaded");
@@ -1665,7 +1788,12 @@ static int comm_init_impl(bella_ctx* c, const Rccl& api, int nranks, int rank, c
     NCCLCHK(c, api.CommInitRank(&c->comm, nranks, u, rank));
     c->comm_ranks = nranks;
     c->comm_rank = rank;
-    return 0;
+    const int rc = comm_selftest(c);
+    if (rc) {                                                    // a communicator that fails its self-test is not kept
+        if (c->comm) { (void)(api.CommAbort ? api.CommAbort(c->comm) : api.CommDestroy(c->comm)); c->comm = nullptr; }
+        c->comm_ranks = 0;
+    }
+    return rc;
 }
 int bella_hip_comm_init(bella_ctx* c, int nranks, int rank, const uint8_t id[BELLA_HIP_COMM_ID_BYTES]) {
     return comm_init_impl(c, rccl(), nranks, rank, id);
@@ -1695,8 +1823,8 @@ static int comm_agree(bella_ctx* c, int local_rc) {
     ncclResult_t r = c->api->AllGather(d_meta + 4 * (size_t)N, d_meta, 1, ncclUint64, c->comm, c->stream);
     if (r != ncclSuccess) return local_rc ? local_rc : fail(c, BELLA_ERR_HIP, "status exchange failed");
     if (e == hipSuccess) e = hipMemcpyAsync(all.data(), d_meta, 8 * (size_t)N, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return local_rc ? local_rc : fail(c, BELLA_ERR_HIP, "status exchange: %s", hipGetErrorString(e));
+    { const int sr = comm_sync(c, "status exchange"); if (sr) return local_rc ? local_rc : sr; }
     if (local_rc) return local_rc;
     for (int q = 0; q < N; ++q)
         if (all[(size_t)q]) return fail(c, BELLA_ERR_STATE, "rank %d failed inside the collective call; all ranks leave it", q);
@@ -1720,7 +1848,8 @@ int bella_hip_allgather_panels(bella_ctx* c) {
     NCCLCHK(c, c->api->AllGather(d_meta + 4 * (size_t)N, d_meta, 4, ncclUint64, c->comm, c->stream));
     std::vector<uint64_t> meta(4 * (size_t)N);
     HIPCHK(c, hipMemcpyAsync(meta.data(), d_meta, 8 * 4 * (size_t)N, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = comm_sync(c, "panel sizes");
+    if (rc) return rc;
     // (the checks below see the same numbers on every rank: all ranks fail them together)
     std::vector<uint64_t> roff((size_t)N + 1, 0), eoff((size_t)N + 1, 0);
     for (int r = 0; r < N; ++r) {
@@ -1774,7 +1903,7 @@ int bella_hip_allgather_panels(bella_ctx* c) {
         return fail(c, BELLA_ERR_HIP, "panel exchange failed: %s", nr2 != ncclSuccess ? (c->api->GetErrorString ? c->api->GetErrorString(nr2) : "RCCL error") : hipGetErrorString(he));
     }
     rc = scan_u32(c, cnt, ptr<uint32_t>(nBptr), (uint64_t)c->nreads + 1);
-    if (!rc) { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) rc = fail(c, BELLA_ERR_HIP, "allgather_panels: %s", hipGetErrorString(e)); }
+    if (!rc) rc = comm_sync(c, "panel exchange");
     release(nCnt);
     if (rc) { release(nBk); release(nBpos); release(nBptr); return rc; }
     release(c->Bptr); release(c->Bk); release(c->Bpos);
@@ -2744,7 +2873,7 @@ static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_se
                 {
                     size_t mfree = 0, mtotal = 0;
                     if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
-                        const uint64_t held = c->xstate.cap + c->xlive.cap + c->pool.bytes;
+                        const uint64_t held = c->xstate.cap + c->xlive.cap + c->pool.bytes + c->pool.arena.free_bytes();
                         const uint64_t fit = ((uint64_t)mfree + held) / 4 / (4 * (uint64_t)kXStateWords + 8);
                         if (capB > fit) capB = fit;
                     }

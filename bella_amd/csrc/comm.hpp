@@ -23,6 +23,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;          // optional: tears a stalled communicator down (comm_sync's deadline)
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -45,6 +46,7 @@ inline const Rccl& rccl() {
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+        r.CommAbort = (decltype(r.CommAbort))dlsym(r.h, "ncclCommAbort");
         r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
         r.Send = (decltype(r.Send))dlsym(r.h, "ncclSend");
         r.Recv = (decltype(r.Recv))dlsym(r.h, "ncclRecv");

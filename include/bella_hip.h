@@ -351,6 +351,12 @@ int bella_hip_get_memory(bella_ctx* ctx, bella_memory* m);
  * cache: an entry whose k-mer has exactly one later read carries that read instead of an index into A'; the plain form is also that of
  * inputs with 2^30 reads or 2^31 nonzeros and more); bit16 (same moment) = tests: that inline form on inputs of any size */
 int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
+/* Reserve device memory up front: ONE slab of `bytes` taken from the driver (and touched) now, from which the stages' buffers are cut
+ * afterwards.  The reference has no counterpart (its vectors grow on the host); here the first hipMalloc of a multi-GB buffer costs
+ * tens of ms per GB (the driver maps and wipes the pages), which a process that runs the pipeline should pay once, not inside its first
+ * k-mer count, assembly and pass.  *ms (optional) = what the reservation took.  bytes == 0 gives an unused slab back.  What does not fit
+ * the slab later is allocated as before; the slab goes with the context. */
+int bella_hip_reserve(bella_ctx* ctx, uint64_t bytes, double* ms);
 /* Per-context tuning parameters (tests and A/B measurements; nothing here changes results).  what:
  *   BELLA_TUNE_LDS_TIERS      values = ascending product capacities of the row kernels' LDS tiers, each in [64, 11008] (n = 0: defaults)
  *   BELLA_TUNE_KCOUNT_BUDGET  values[0] = k-mers per pass of the counting sort (default 2^30)

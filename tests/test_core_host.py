@@ -336,3 +336,21 @@ def test_fastq_index_equals_the_serial_parse_for_any_slicing(H, tmp_path):
     assert _parse2(H, str(p), 0)[0] == 0 and _parse2(H, str(p), 1, 2, 1)[0] == 0
     p.write_bytes(b"@a\nAC\n+\n!!\nbad")                                          # header of a short last record is still checked
     assert _parse2(H, str(p), 0) == _parse2(H, str(p), 1, 2, 3) and _parse2(H, str(p), 0)[0] == -1
+
+
+def test_torch_read_generator_follows_the_numpy_generator_statistically():
+    """bella_testkit.synth.make_reads_torch (the GPU box's fast generator of the SURVEY 8(d) sets) against make_reads: same read
+    length distribution, same yield of reliable k-mers and tuples (the parameters are the contract, the PRNG is not); truth in
+    the names; reproducible per seed"""
+    from bella_testkit import synth
+    a = synth.make_reads_torch(240, read_len=3000, err=0.15, seed=4, device="cpu", chunk_bases=100000)   # several chunks
+    b = synth.make_reads(240, read_len=3000, err=0.15, seed=4)
+    assert a.nreads == b.nreads == 240 and int(a.codes.max()) <= 3
+    assert abs(float(a.lengths.mean()) - float(b.lengths.mean())) < 10          # 3000 * (1 - 0.045 + 0.09) = 3135
+    ta, tb = synth.count_and_tuples(a, 17, 2, 8), synth.count_and_tuples(b, 17, 2, 8)
+    assert abs(ta.nkmers - tb.nkmers) < 0.08 * tb.nkmers and abs(len(ta.kmer) - len(tb.kmer)) < 0.08 * len(tb.kmer)
+    for nm, ln in zip(a.names[:5], a.lengths[:5]):
+        idx, start, L, strand = (int(x) for x in nm[1:].split("_"))
+        assert L == 3000 and strand in (0, 1) and 0 <= start
+    again = synth.make_reads_torch(240, read_len=3000, err=0.15, seed=4, device="cpu", chunk_bases=100000)
+    assert np.array_equal(again.codes, a.codes) and again.names == a.names

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/sq
 mkdir -p "$OUT"
 CTRS="${CTRS:-SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS}"
-rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d "$OUT/p" -o t -- python "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-100k --no-xdrop --no-dropin --no-hifi --no-layout-ab ${BENCH_ARGS:-} > "$OUT/bench.json" 2> "$OUT/bench.err" || true
+rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d "$OUT/p" -o t -- python "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-10k --no-xdrop --no-dropin --no-hifi --no-layout-ab ${BENCH_ARGS:---reads 10000} > "$OUT/bench.json" 2> "$OUT/bench.err" || true
 python - <<PY
 import csv, collections, glob
 f = glob.glob("$OUT/p/*counter_collection.csv")

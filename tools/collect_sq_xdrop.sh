@@ -4,7 +4,7 @@ set -uo pipefail
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/sqx; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/p -o t -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-100k --no-dropin --no-hifi --no-layout-ab > $OUT/bench.json 2> $OUT/bench.err || true
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/p -o t -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-10k ${BENCH_ARGS:---reads 10000} --no-dropin --no-hifi --no-layout-ab > $OUT/bench.json 2> $OUT/bench.err || true
 python - <<PY
 import csv, collections, glob
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()

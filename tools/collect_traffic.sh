@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/traffic
 mkdir -p "$OUT"; rm -rf "$OUT/$KEY"_*
 STEPS=4
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/${KEY}_$C" -o t -- python "$R/bench.py" --steps $STEPS --warmup 1 --no-cpu-baseline --no-100k --no-xdrop --no-dropin --no-hifi --no-layout-ab "$@" > "$OUT/${KEY}_bench_$C.json" 2> "$OUT/${KEY}_bench_$C.err" || true
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/${KEY}_$C" -o t -- python "$R/bench.py" --steps $STEPS --warmup 1 --no-cpu-baseline --no-10k --no-xdrop --no-dropin --no-hifi --no-layout-ab ${@:---reads 10000} > "$OUT/${KEY}_bench_$C.json" 2> "$OUT/${KEY}_bench_$C.err" || true
 done
 python - <<PY
 import csv, collections, json, glob

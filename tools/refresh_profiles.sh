@@ -7,10 +7,10 @@ TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/refresh; rm -rf $OUT; mkdir -p $OUT
 cd $R
-python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 for KEY in 10k 100k; do
-  if [ $KEY = 10k ]; then ARGS="--steps 20 --warmup 3"; else ARGS="--reads 100000 --steps 5 --warmup 2"; fi
-  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$KEY -o s -- python $R/bench.py $ARGS --no-cpu-baseline --no-100k --no-xdrop --no-dropin --no-hifi --no-layout-ab > $OUT/${TAG}_bench_under_rocprof_$KEY.json 2>/dev/null )
+  if [ $KEY = 10k ]; then ARGS="--reads 10000 --steps 20 --warmup 3"; else ARGS="--reads 100000 --steps 5 --warmup 2"; fi
+  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$KEY -o s -- python $R/bench.py $ARGS --no-cpu-baseline --no-10k --no-xdrop --no-dropin --no-hifi --no-layout-ab > $OUT/${TAG}_bench_under_rocprof_$KEY.json 2>/dev/null )
   python tools/summarize_rocprof.py $OUT/prof_$KEY/s_kernel_stats.csv 30 > $OUT/${TAG}_kernel_stats_$KEY.txt
   cp $OUT/prof_$KEY/s_kernel_stats.csv $OUT/${TAG}_kernel_stats_$KEY.csv
   python tools/timeline.py $OUT/prof_$KEY/s_kernel_trace.csv > $OUT/${TAG}_step_timeline_$KEY.txt

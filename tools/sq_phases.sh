@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cp $R/bella_amd/libbella_hip.so /tmp/prod.so; cp $R/tools/_old/libbella_prof.so $R/bella_amd/libbella_hip.so
 for S in ${STOPS:-0 1 2 3 4 5 6 -1}; do
   OUT=$R/gpurun_out/sqp/s$S; rm -rf $OUT; mkdir -p $OUT
-  BELLA_DEV_STOP=$S rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT -o t -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-xdrop --no-100k --no-dropin --no-hifi ${BENCH_ARGS:-} > /dev/null 2>&1
+  BELLA_DEV_STOP=$S rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT -o t -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-xdrop --no-10k --no-dropin --no-hifi ${BENCH_ARGS:---reads 10000} > /dev/null 2>&1
   python - <<PY
 import csv, collections, glob
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
