@@ -206,8 +206,13 @@ struct bella_ctx {
     uint64_t xdrop_class_min = 4ull * 4096 * 64;   // extensions of a batch from which on the slices run it as four classes (BELLA_TUNE_XDROP_CLASS_MIN)
     BufPool pool;                        // released device buffers waiting for the next request they fit
     uint32_t layout_inline = 0;          // the device layout holds B' entries in the INLINE form (util.hpp); 0 / 1
+    // layout and path choices (bella_hip_set_tuning; the matching bella_hip_set_debug bits of earlier rounds are still read as aliases)
+    uint32_t tune_layout_order = 0;      // BELLA_TUNE_LAYOUT_ORDER: 0 lists of A' in k-mer order, 1 in order of first appearance in B'
+    uint32_t tune_inline = 0;            // BELLA_TUNE_INLINE_ENTRIES: 0 by the size of A' against the last-level cache, 1 never, 2 always
+    uint32_t tune_row_path = 0;          // BELLA_TUNE_ROW_PATH: 0 LDS tiers, 1 every column on the global-workspace (repairing) path
+    uint64_t tune_cache_bytes = 192ull << 20;   // BELLA_TUNE_CACHE_BYTES: A' above this size counts as "larger than the last-level cache"
     uint32_t xdrop_variant = 1;          // 0: one launch in length-sorted order; 1 (default): slices with compaction; 2: packed kernel in pair order; 3: scalar statement
-    size_t lds_attr[18] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
+    size_t lds_attr[24] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
     hipStream_t side[kNumTiers + 1]{};   // independent tier launches / fold instances run concurrently
     hipEvent_t fork = nullptr, join[kNumTiers + 1]{};
 };
@@ -407,11 +412,12 @@ int build_layout(bella_ctx* c) {
     if (c->Bent.cap > 16 * nown_nnz + (1u << 20)) release(c->Bent);
     if (c->Bcnt.cap > 4 * nown_nnz + (1u << 20)) release(c->Bcnt);
     ENSURE(c, c->Bent, 8 * nown_nnz);
+    const bool first_app = c->tune_layout_order == 1 || (c->debug & 1024u);
     if (nnz) {
         k_layout_prep<<<nblk(c->nreads, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos), c->nreads,
                                                                         ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), c->kmer_size, nk,
                                                                         ptr<uint32_t>(c->lk_key), ptr<uint64_t>(c->lk_val),
-                                                                        (c->debug & 1024u) ? ptr<uint32_t>(c->w) : nullptr, ptr<uint32_t>(c->status));
+                                                                        first_app ? ptr<uint32_t>(c->w) : nullptr, ptr<uint32_t>(c->status));
         KCHK(c);
         // bad input (k-mer id out of range, k-mer past the end of its read) stops here: the passes below trust the keys
         uint32_t st0 = 0;
@@ -433,14 +439,14 @@ int build_layout(bella_ctx* c) {
         // Default: the lists of A' stay in k-mer order (= the sorted order itself; nothing to scatter, scan or look up) and every pass
         // expands B' x A' itself: the fastest ONE-SHOT call (layout + first pass).  debug bit 10 (tests): the lists in
         // order of first appearance in B' (the owner row of a list streams it; three more random-access passes here).
-        const uint32_t by_kmer = (c->debug & 1024u) == 0 ? 1u : 0u;
+        const uint32_t by_kmer = first_app ? 0u : 1u;
         // entries whose k-mer has exactly one later read carry that read (util.hpp: INLINE form) when bit 31 of the list index and bit 30
         // of a read id are free -- and when A' is larger than the last-level cache (256 MB): the form saves a line from HBM per such
         // entry and pass (row kernels 4.03 -> 3.69 ms at 100k reads, A' = 1.6 GB), but where the gather is a cache hit it only adds a
         // branch (10k reads, A' = 92 MB: 0.360 -> 0.367 ms per step).  debug bit 15 (tests): the plain form everywhere, as for inputs
         // beyond those bounds; bit 16: the inline form on any size
-        const bool inl_pays = 8ull * nnz > (192ull << 20) || (c->debug & 65536u);
-        const uint32_t inl = rmask == 0x3FFFFFFFu && nnz < 0x80000000ull && inl_pays && !(c->debug & 32768u) ? 1u : 0u;
+        const bool inl_pays = 8ull * nnz > c->tune_cache_bytes || c->tune_inline == 2 || (c->debug & 65536u);
+        const uint32_t inl = rmask == 0x3FFFFFFFu && nnz < 0x80000000ull && inl_pays && c->tune_inline != 1 && !(c->debug & 32768u) ? 1u : 0u;
         c->layout_inline = inl;
         if (!by_kmer) {
             k_layout_heads<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), rmask, ptr<uint32_t>(c->w), ptr<uint32_t>(c->status));
@@ -507,7 +513,7 @@ int build_layout(bella_ctx* c) {
         // Long-list inputs send most of their columns to the path above the LDS tiers, which groups a column's products in LDS from a
         // product list -- expanded per batch and per pass when the layout has none.  The same expansion once, here, costs a one-shot
         // call nothing and every further pass less: such inputs get the row lists whenever they fit.
-        const bool auto_lists = samp[1] > 0 && samp[0] <= samp[1] && !(c->debug & 1u) && c->lane_order_ok;   // >= 64 products per pair on the sample
+        const bool auto_lists = samp[1] > 0 && samp[0] <= samp[1] && !(c->debug & 1u) && c->tune_row_path != 1 && c->lane_order_ok;   // >= 64 products per pair on the sample
         if (by_kmer && (c->want_rowlists || auto_lists) && c->nreads <= (1u << 30)) {
             // row lists (BELLA_TUNE_ROW_LISTS): products per owned row -> row starts -> the tails of the lists copied in product order.
             // Optional in every respect: if they do not fit next to what a pass needs, or an allocation fails, the layout stands without them.
@@ -711,6 +717,22 @@ int bella_hip_set_tuning(bella_ctx* c, uint32_t what, const uint64_t* values, ui
         case BELLA_TUNE_ROW_LISTS:
             if (n && values[0] > 1) return fail(c, BELLA_ERR_BAD_ARG, "row lists: 0 or 1");
             c->want_rowlists = n && values[0] == 1;
+            return 0;
+        case BELLA_TUNE_LAYOUT_ORDER:
+            if (n && values[0] > 1) return fail(c, BELLA_ERR_BAD_ARG, "layout order: 0 (k-mer order) or 1 (first appearance)");
+            c->tune_layout_order = n ? (uint32_t)values[0] : 0u;
+            return 0;
+        case BELLA_TUNE_INLINE_ENTRIES:
+            if (n && values[0] > 2) return fail(c, BELLA_ERR_BAD_ARG, "inline entries: 0 (by size), 1 (never) or 2 (always)");
+            c->tune_inline = n ? (uint32_t)values[0] : 0u;
+            return 0;
+        case BELLA_TUNE_ROW_PATH:
+            if (n && values[0] > 1) return fail(c, BELLA_ERR_BAD_ARG, "row path: 0 (LDS tiers) or 1 (global workspace)");
+            c->tune_row_path = n ? (uint32_t)values[0] : 0u;
+            c->pass_known = false;
+            return 0;
+        case BELLA_TUNE_CACHE_BYTES:
+            c->tune_cache_bytes = n && values[0] ? values[0] : (192ull << 20);
             return 0;
     }
     return fail(c, BELLA_ERR_BAD_ARG, "unknown tuning parameter %u", what);
@@ -2151,7 +2173,7 @@ static int layout_for_partition(bella_ctx* c) {
 
 static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out, int depth = 0) {
     const uint32_t nr = c->nreads;
-    const bool force_global = (c->debug & 1u) != 0 || !c->lane_order_ok;   // (self-test failed: every column on the repairing path)
+    const bool force_global = (c->debug & 1u) != 0 || c->tune_row_path == 1 || !c->lane_order_ok;   // (self-test failed: every column on the repairing path)
     const bool want_ext = (c->debug & 2u) == 0;
     const uint64_t ws_stride = (row_mem_bytes(65535, 65535, false) + 255) & ~(size_t)255;
     ENSURE(c, c->flopsr, 4 * ((size_t)nr + 2));
@@ -2385,18 +2407,28 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         } else if (blk == 256) {                                  // cap <= 2752 <= 11 * 256
             ki = 7;
             kern = BELLA_ROWS_KERN(11, 256);
-        } else {                                                  // cap <= 689 <= 6 * 128
+        } else if (blk == 128) {                                  // cap <= 689 <= 6 * 128
             ki = 8;
             kern = BELLA_ROWS_KERN(6, 128);
+        } else if (a.cap <= 11 * 64) {                            // ONE wavefront per column (no workgroup barriers): cap <= 689 <= 11 * 64
+            ki = 18;
+            kern = BELLA_ROWS_KERN(11, 64);
+        } else {                                                  // cap <= 1394 <= 22 * 64
+            ki = 19;
+            kern = BELLA_ROWS_KERN(22, 64);
         }
 #undef BELLA_ROWS_KERN
-        if (rl) ki += 9;
+        if (rl) ki += ki >= 18 ? 2 : 9;
         if (lds > c->lds_attr[ki]) {                             // once per kernel and size, not per launch
             HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             c->lds_attr[ki] = lds;
         }
 #ifdef BELLA_DEV_PROF
         a.prof = (unsigned long long*)c->prof.p + 10 * l;
+        {   // development builds only: leave classes out (timing experiments; the results are then incomplete)
+            static const int skip = getenv("BELLA_DEV_SKIP_CLASSES") ? atoi(getenv("BELLA_DEV_SKIP_CLASSES")) : 0;
+            if (skip & (1 << l)) { a.prof = nullptr; return 0; }
+        }
 #endif
         kern<<<ln[l].rows, blk, lds, sst>>>(a);
 #ifdef BELLA_DEV_PROF

@@ -131,7 +131,8 @@ struct RowMem {
     uint32_t* T1first;  // [dcap]  X: products in ranges 2 | 3 << 16 ; C..S: their scatter cursors ; then END of the pair's list | output index << 16
     uint32_t* Gaux;     // [dcap]  C..S: products | output index << 16 ; then plain chain: surviving positions (diagnostics), else (bins - 1) << 16
     uint16_t* S_p;      // [cap]   per-pair lists of product indices ; from phase P on: Par (u16 [cap]; global path u32 [cap])
-    uint16_t* G;        // [dcap]  first product of a multi-product pair (its slot-order priority, k_order_*)
+    uint32_t* M;        // [dcap / 2] the multi-product pairs, dense: T1 slot | first product << 16 (its slot-order priority, k_order_*): the
+                        //        per-pair passes after phase S (final words, emit) run over this list, not over the table's slots
     uint8_t* A_fl;      // [cap]  flags: bit0 oriented (checkstrand), bit1 palindromic k-mer   (global path only)
     uint8_t* L_fl;      // [cap]  the same in rank order                                        (global path only)
     uint32_t* L_hv;     // [cap]  rank-order lists: posH | posV << 16           (== A_hv when overlaid)
@@ -150,7 +151,7 @@ __device__ __forceinline__ RowMem carve(uint8_t* base, uint32_t cap, uint32_t dc
     m.T1first = w;         w += dcap;
     m.Gaux = w;            w += dcap;
     m.S_p = (uint16_t*)w;  w += (overlay ? 1 : 2) * (((cap + 3) & ~3u) / 2);
-    m.G = (uint16_t*)w;    w += (dcap + 1) / 2;
+    m.M = w;               w += (dcap + 1) / 2;
     if (overlay) { m.L_hv = m.A_hv; m.L_gov = m.A_gov; m.A_fl = nullptr; m.L_fl = nullptr; }
     else { m.L_hv = w; w += cap; m.L_gov = w; w += cap; m.A_fl = (uint8_t*)w; w += (cap + 3) / 4; m.L_fl = (uint8_t*)w; }
     m.cap = cap;
@@ -181,6 +182,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     uint32_t* s_chunk = m.scr + 48;
     uint32_t* s_fail = m.scr + 49;
     uint32_t* s_np = m.scr + 50;                              // LDS tiers: some pair of the column is not a plain chain
+    uint32_t* s_nm = m.scr + 51;                              // multi-product pairs of the column (length of the dense list M)
+    const uint32_t Mcap = (m.dcap + 1) / 2;
     const uint32_t k = (uint32_t)a.k;
     constexpr uint32_t GMASK = OVERLAY ? 0x1FFFu : 0xFFFFu;   // LDS tiers (<= 2752 slots): flags and the LAST mark ride on top of the T1 slot
     constexpr uint32_t kLastBit = 1u << 29;                   // L_gov (LDS tiers) / bit 2 of L_fl (global path): last product of its pair's list
@@ -206,7 +209,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
         }
     }
     for (uint32_t s = tid; s < H1; s += kRowBlock) { m.T1key[s] = kEmpty; m.T1first[s] = 0; m.T1cnt[s] = 0; }
-    if (tid == 0) { *s_chunk = 0; *s_fail = 0; *s_np = 0; }
+    if (tid == 0) { *s_chunk = 0; *s_fail = 0; *s_np = 0; *s_nm = 0; }
     __syncthreads();
 #ifdef BELLA_DEV_PROF                                          // the head of the column: descriptor + first B' entries arrived, tables initialised
     { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long t2_ = clock64(); if (tid == 0 && a.prof) atomicAdd(a.prof + 8, (unsigned long long)(t2_ - tc_)); tc_ = t2_; }
@@ -271,6 +274,9 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
                 }
             }
         }
+        // (Measured and not kept, round 5: every product of the batch decoded first and ONE probe loop for all of them -- the
+        // compare-and-swaps of a lane's products in flight together -- with one decode for both forms of a B' entry: bit-exact, row
+        // kernels 3.58 -> 4.82 ms at 100k reads, 0.28 -> 0.33 ms at 10k.)
 #pragma unroll
         for (uint32_t u = 0; u < XB; ++u) {
             const uint32_t p = base + u * kRowBlock + tid;
@@ -346,6 +352,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
                 m.T1cnt[s] = st | ((st + c0) << 16);
                 m.T1first[s] = (st + c0 + c1) | ((st + c0 + c1 + c2) << 16);
                 st += mm;
+                const uint32_t j = atomicAdd(s_nm, 1u);       // (a few per wavefront instruction: one pair in twenty-five has more than one product)
+                if (j < Mcap) m.M[j] = s;
             }
             rank++;
         }
@@ -430,24 +438,23 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // ---- C2 + R: the per-pair words take their final meaning (END of list | output index, products | count, first product); every
     // product's exact rank inside its pair's list (global path: list position corrected by the chunk-mates on the wrong side; LDS
     // tiers: checked) and the lists in rank order: L_hv / L_gov. -------------------------------------------------------------
-    for (uint32_t s = tid; s < H1; s += kRowBlock) {
-        if (m.T1key[s] == kEmpty) continue;
+    const uint32_t nm = *s_nm;
+    if (nm > Mcap) return false;                              // more multi-product pairs than the dense list holds: the global path has room for any column
+    for (uint32_t j = tid; j < nm; j += kRowBlock) {
+        const uint32_t s = m.M[j];
         const uint32_t ga = m.Gaux[s];
         const uint32_t mm = ga & 0xFFFFu;
-        uint32_t end = 0;
-        if (mm > 1) {
-            end = m.T1first[s] >> 16;                         // range 3's cursor ran to the end of the list
-            uint32_t fp = S_p[end - mm];
-            if (!OVERLAY) {                                   // chunk-mates may be swapped here (phase R repairs): the smallest of the first chunk
-                const uint32_t ch = fp / kScatterChunk;
-                for (uint32_t y = end - mm + 1; y < end; ++y) {
-                    const uint32_t o = S_p[y];
-                    if (o / kScatterChunk != ch) break;
-                    fp = o < fp ? o : fp;
-                }
+        const uint32_t end = m.T1first[s] >> 16;              // range 3's cursor ran to the end of the list
+        uint32_t fp = S_p[end - mm];
+        if (!OVERLAY) {                                       // chunk-mates may be swapped here (phase R repairs): the smallest of the first chunk
+            const uint32_t ch = fp / kScatterChunk;
+            for (uint32_t y = end - mm + 1; y < end; ++y) {
+                const uint32_t o = S_p[y];
+                if (o / kScatterChunk != ch) break;
+                fp = o < fp ? o : fp;
             }
-            m.G[s] = (uint16_t)fp;
         }
+        m.M[j] = s | (fp << 16);
         m.T1first[s] = end | (ga & 0xFFFF0000u);
         m.T1cnt[s] = mm | (mm << 16);
         m.Gaux[s] = 0;
@@ -645,16 +652,17 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     BELLA_BPROF(6)
 
     // ---- E: one record per multi-product pair, at the pair's output index (the single-product pairs left in phase S) -------------
-    for (uint32_t g = tid; g < H1; g += kRowBlock) {
+    for (uint32_t j = tid; j < nm; j += kRowBlock) {
+        const uint32_t mj = m.M[j];
+        const uint32_t g = mj & 0xFFFFu;
         const uint32_t cw = m.T1cnt[g];
         const uint32_t mm = cw & 0xFFFFu;
-        if (mm < 2) continue;
         const uint32_t aux = m.Gaux[g];
         const uint32_t tf = m.T1first[g];
         const uint32_t r = tf >> 16;                          // output index
         const uint32_t st = (tf & 0xFFFFu) - mm;
         const uint32_t keyw = m.T1key[g];
-        const uint32_t firstp = m.G[g];
+        const uint32_t firstp = mj >> 16;
         // plain chain: one bin, headed by the last product (which phase P skips: it always survives)
         uint32_t win = mm - 1, sup = (aux & 0xFFFFu) + 1, nroots = 1;
         if (keyw >> 31) {
@@ -701,7 +709,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 // LDS tiers: one column per workgroup, dynamic LDS = row_mem_bytes(cap, dcap); NX * 512 >= cap (8: the tiers up to 4096 products,
 // 16: the two big tiers that keep HiFi-like columns with long lists off the global path)
 template <uint32_t NX, int BLK = BELLA_ROW_BLOCK, bool RL = false>
-__global__ __launch_bounds__(BLK, (BLK == 1024 ? (NX <= 4 ? 8 : 4) : BLK <= 256 ? 8 : (NX <= 8 ? 6 : 2))) void k_spgemm_rows_lds(SpgemmArgs a) {
+__global__ __launch_bounds__(BLK, (BLK == 64 ? (NX <= 11 ? 4 : 2) : BLK == 1024 ? (NX <= 4 ? 8 : 4) : BLK <= 256 ? 8 : (NX <= 8 ? 6 : 2))) void k_spgemm_rows_lds(SpgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // the launch covers the tiers of one LDS class, largest columns first: workgroup x -> (tier, place in the tier's list)
     uint32_t x = blockIdx.x, t = a.tier_hi;

@@ -300,6 +300,7 @@ def main():
     ap.add_argument("--no-dropin", action="store_true", help="N=1: skip the dropin_call records (the shim's call sequence, cold, wall clock)")
     ap.add_argument("--no-layout-ab", action="store_true", help="N=1: skip the layout A/B records (default layout vs row lists: layout + cold pass + warm step)")
     ap.add_argument("--debug-flags", type=int, default=0, help="extra bella_hip_set_debug bits (development A/B)")
+    ap.add_argument("--layout-debug", type=int, default=0, help="bella_hip_set_debug bits in force while the operands are laid out (development A/B)")
     ap.add_argument("--cpu-baseline-child", default=None)
     ap.add_argument("--threads", type=int, default=0)
     a = ap.parse_args()
@@ -354,6 +355,8 @@ def main():
                 reserve_ms = eng.reserve(want)
             except Exception as e:
                 log("[bench] rank %d: bella_hip_reserve(%d) failed (%r): the stages allocate for themselves" % (rank, want, e))
+        if a.layout_debug:
+            eng.set_debug(a.layout_debug)
         eng.set_reads(rs)                                   # reads are replicated (2 bit/base)
         t_setup = time.time()
         have_comm = False

@@ -372,9 +372,18 @@ int bella_hip_reserve(bella_ctx* ctx, uint64_t bytes, double* ms);
  *                             (layout + first pass); bella_timings.expand_ms reports the expansion when they are built.
  *   BELLA_TUNE_XDROP_CLASS_MIN values[0] = extensions of a batch from which on the slices of variant 1 run the batch as four classes by step
  *                             estimate, the three classes of long extensions on streams of their own at a higher priority (default 2^20:
- *                             four times the wavefronts the device holds at once; tests set it low, UINT64_MAX = never) */
+ *                             four times the wavefronts the device holds at once; tests set it low, UINT64_MAX = never)
+ *   BELLA_TUNE_LAYOUT_ORDER   values[0] = 0 (default): the lists of A' in k-mer order; 1: in order of first appearance in B' (the owner row of a
+ *                             list streams it; three more random-access passes at layout time).  Read when operands are installed.
+ *   BELLA_TUNE_INLINE_ENTRIES values[0] = 0 (default): an entry of B' whose k-mer has exactly one later read carries that read (util.hpp)
+ *                             when A' is larger than BELLA_TUNE_CACHE_BYTES; 1: never (plain entries); 2: always.  Read at layout time.
+ *   BELLA_TUNE_ROW_PATH       values[0] = 0 (default): columns in the LDS tiers; 1: every column on the global-workspace path (the
+ *                             repairing path a device that fails the lane-order self-test gets)
+ *   BELLA_TUNE_CACHE_BYTES    values[0] = size of A' from which on it counts as larger than the last-level cache (default 192 MB: three
+ *                             quarters of the 256 MB Infinity Cache of an MI355X; the HIP runtime does not report that cache)
+ * (bella_hip_set_debug bits 0, 10, 15 and 16 of earlier rounds still select the same things: aliases, no longer needed) */
 enum { BELLA_TUNE_LDS_TIERS = 0, BELLA_TUNE_KCOUNT_BUDGET = 1, BELLA_TUNE_WIDE_BUDGET = 2, BELLA_TUNE_XDROP_VARIANT = 3, BELLA_TUNE_ROW_LISTS = 4,
-       BELLA_TUNE_XDROP_CLASS_MIN = 5 };
+       BELLA_TUNE_XDROP_CLASS_MIN = 5, BELLA_TUNE_LAYOUT_ORDER = 6, BELLA_TUNE_INLINE_ENTRIES = 7, BELLA_TUNE_ROW_PATH = 8, BELLA_TUNE_CACHE_BYTES = 9 };
 int bella_hip_set_tuning(bella_ctx* ctx, uint32_t what, const uint64_t* values, uint32_t n);
 
 #ifdef __cplusplus

@@ -165,11 +165,21 @@ def _num_job(cols):
     return out[:int(nz.sum())]
 
 
+def seq_pointers(asc: np.ndarray, offsets: np.ndarray):
+    """char** into ONE ASCII buffer (reads back to back, no terminators: the restatement takes lengths): what a million-read set
+    hands the restatement instead of a million bytes objects.  Returns (pointer array, lengths); `asc` must stay alive."""
+    offs = np.asarray(offsets, np.int64)
+    addr = (np.uint64(asc.ctypes.data) + offs[:-1].astype(np.uint64)).astype(np.uint64)
+    arr = (C.c_char_p * max(len(addr), 1)).from_buffer_copy(addr.tobytes() if len(addr) else b"\0" * 8)
+    return arr, np.diff(offs).astype(np.uint32)
+
+
 def spgemm_parallel(seqs, nkmers, Bc, Br, Bv, sample_cols, k=17, bin_size=500, procs=None):
     """symbolic phase on ALL columns and numeric phase on `sample_cols` only, over a fork pool.
-    returns (colflop, colnnz, {col: pairs[PAIR_DT] in slot order})"""
+    returns (colflop, colnnz, {col: pairs[PAIR_DT] in slot order}).  `seqs`: a list of bytes, or (ascii buffer, offsets)."""
     import multiprocessing as mp
-    nreads = len(seqs)
+    packed = isinstance(seqs, tuple)
+    nreads = len(seqs[1]) - 1 if packed else len(seqs)
     Ac, Ar, Av = transpose(nreads, nkmers, Bc, Br, Bv)
     procs = procs or min(64, os.cpu_count() or 1)
     _PAR.update(nreads=nreads, Bc=Bc, Br=_pad(Br, np.uint32), Bv=_pad(Bv, np.uint16), Ac=Ac, Ar=_pad(Ar, np.uint32), Av=_pad(Av, np.uint16), k=k,
@@ -183,7 +193,11 @@ def spgemm_parallel(seqs, nkmers, Bc, Br, Bv, sample_cols, k=17, bin_size=500, p
             flop[lo:hi] = f
             nnzc[lo:hi] = z
     sample_cols = np.asarray(sample_cols, np.uint32)
-    _PAR.update(nnzc=nnzc, arr=(C.c_char_p * nreads)(*[bytes(s) for s in seqs]), lens=np.asarray([len(s) for s in seqs], np.uint32))
+    if packed:
+        arr, lens = seq_pointers(seqs[0], seqs[1])
+        _PAR.update(nnzc=nnzc, arr=arr, lens=lens, keep=seqs[0])
+    else:
+        _PAR.update(nnzc=nnzc, arr=(C.c_char_p * nreads)(*[bytes(s) for s in seqs]), lens=np.asarray([len(s) for s in seqs], np.uint32))
     chunks = [sample_cols[x:x + 16] for x in range(0, len(sample_cols), 16)]
     per_col = {}
     with mp.get_context("fork").Pool(procs) as pool:

@@ -68,3 +68,14 @@ def load_golden(name):
 @pytest.fixture(params=GOLDEN_SETS)
 def golden(request):
     return load_golden(request.param)
+
+
+def set_mode(eng, bits: int):
+    """The parameter tables of the GPU tests name a layout / path combination by the bits earlier rounds passed to
+    bella_hip_set_debug.  The layout and path CHOICES among them now go through their named tuning parameters
+    (BELLA_TUNE_LAYOUT_ORDER, BELLA_TUNE_INLINE_ENTRIES, BELLA_TUNE_ROW_PATH); what is left in the debug word is fault injection
+    and test switches.  set_mode(eng, 0) restores the defaults."""
+    eng.set_tuning("row_path", 1 if bits & 1 else 0)
+    eng.set_tuning("layout_order", 1 if bits & 1024 else 0)
+    eng.set_tuning("inline_entries", 1 if bits & 32768 else 2 if bits & 65536 else 0)
+    eng.set_debug(bits & ~(1 | 1024 | 32768 | 65536))

@@ -10,7 +10,7 @@ import _oracle as O
 from bella_amd import BellaPars, Engine, api
 from bella_testkit import synth
 from bella_amd.api import BellaHipError
-from conftest import GOLD, ROOT, load_golden
+from conftest import GOLD, ROOT, load_golden, set_mode
 
 pytestmark = pytest.mark.gpu
 
@@ -51,7 +51,7 @@ def test_assembly_matches_reference_layout(eng, golden):
 @pytest.mark.parametrize("debug,rowlists", [(0, 0), (1, 0), (1024, 0), (1025, 0), (0, 1), (1, 1), (2048, 1), (65536, 0), (65537, 0), (65536, 1)])
 def test_spgemm_pairs_bit_exact(eng, golden, debug, rowlists):
     g = golden
-    eng.set_debug(debug)                       # 1 = force the global-workspace row path; 1024 = the lists of A' in order of first appearance
+    set_mode(eng, debug)                       # 1 = force the global-workspace row path; 1024 = the lists of A' in order of first appearance
                                                # (default: k-mer order); 2048 = as if the row lists asked for did not fit in memory;
                                                # 65536 = B' entries with one later read carry it instead of pointing at it (default from
                                                # A' > 192 MB on: the 100k-read tests)
@@ -71,7 +71,7 @@ def test_spgemm_pairs_bit_exact(eng, golden, debug, rowlists):
         assert np.array_equal(colptrC, ecol.astype(np.uint64))
         check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
     finally:
-        eng.set_debug(0)
+        set_mode(eng, 0)
         eng.set_tuning("row_lists")
 
 
@@ -80,7 +80,7 @@ def test_symbolic_phase_alone_matches_oracle(eng, golden, debug, rowlists):
     """bella_hip_count_pairs = estimateFLOP + estimateNNZ_Hash + prefixsum (overlap.hpp:157-276,110-146): colptrC, nnz(C) and the products
     without a numeric pass -- whole, per stage (column range) and per partition; then the numeric phase on the same context"""
     g = golden
-    eng.set_debug(debug)                       # 8192: the bitmaps of the symbolic phase in global memory
+    set_mode(eng, debug)                       # 8192: the bitmaps of the symbolic phase in global memory
     eng.set_tuning("row_lists", rowlists)
     try:
         eng.set_reads(g.rs)
@@ -109,7 +109,7 @@ def test_symbolic_phase_alone_matches_oracle(eng, golden, debug, rowlists):
         check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
         assert eng.timings().numeric_columns == t1.numeric_columns + nr
     finally:
-        eng.set_debug(0)
+        set_mode(eng, 0)
         eng.set_tuning("row_lists")
         eng.set_column_range(0, 0xFFFFFFFF)
         eng.set_partition(0, 1)
@@ -313,18 +313,18 @@ def test_exact_xdrop_mode_matches_logan_oracle_and_seqan_answers(eng):
         assert npass == int(alns["passed"].sum()) and (step > 1 or ok_cnt == npass)
         assert not alns["flagged"].any()
         # the launch goes in chunks of extensions (grid x block stays below 2^32 threads at 100k-read scale): tiny chunks, same records
-        eng.set_debug(256)
+        set_mode(eng, 256)
         try:
             assert eng.align_pairs(pars, exact=True) == npass
             assert np.array_equal(eng.get_alignments(), alns)
         finally:
-            eng.set_debug(0)
+            set_mode(eng, 0)
 
 
 @pytest.mark.parametrize("layout", [0, 65536])
 def test_partition_union_equals_whole(eng, layout):
     g = load_golden("toy120")
-    eng.set_debug(layout)                                  # 65536: one-partner B' entries in the inline form (the default of sets whose A' is
+    set_mode(eng, layout)                                  # 65536: one-partner B' entries in the inline form (the default of sets whose A' is
                                                            # larger than the cache -- what every rank of a multi-GPU run of 100k reads has),
                                                            # here together with the partitioned layout (B' entries of the owned columns only)
     eng.set_reads(g.rs)
@@ -342,7 +342,7 @@ def test_partition_union_equals_whole(eng, layout):
             parts.append(p)
     finally:
         eng.set_partition(0, 1)
-        eng.set_debug(0)
+        set_mode(eng, 0)
     merged = np.concatenate(parts)
     order = np.argsort(merged["cid"], kind="stable")      # columns ascending, slot order kept inside a column
     assert np.array_equal(merged[order], whole)
@@ -831,13 +831,13 @@ def test_baseline_config3_100k_read_set_parity(eng):
     """BASELINE configs[3]'s read set (100k reads x 10 kb) on one GPU, the size the roofline target is quoted on and a different
     regime from 10k reads (~500 pairs per column, 92 % of them single-product, half-size key tables, four LDS classes):
       * every column's product count and pair count (colptrC) against the oracle's symbolic phase (all 100k columns, host cores),
-      * every record of a quarter of the columns (every fourth column and the 200 pair-richest) against the oracle's numeric phase,
+      * every record of EVERY column (~50 M records) against the oracle's numeric phase on the host cores,
       * size-independent properties of all ~50 M records,
       * X-drop on ALL pairs, 200,000 of them (mostly chance pairs) against the oracle's scalar Xavier;
       * the engine's tuples against the test kit's independent counter."""
     import time
     t0 = time.time()
-    rs = synth.make_reads(100000, read_len=10000, coverage=30.0, err=0.15, seed=1)
+    rs = synth.make_reads_fast(100000, read_len=10000, coverage=30.0, err=0.15, seed=1)
     seqs = rs.seqs()
     eng.set_reads(rs)
     nk, nt, _ = eng.count_kmers(17, 2, 8)
@@ -863,15 +863,14 @@ def test_baseline_config3_100k_read_set_parity(eng):
     for a_, b_ in zip(eng.get_B(), (Bc, Br, Bv)):
         assert np.array_equal(a_, b_)
     per_row = np.diff(colptrC.astype(np.int64))
-    big = np.argsort(per_row)[-200:]                                                 # the columns with the most pairs
-    sample = np.unique(np.concatenate([np.arange(0, rs.nreads, 4), big])).astype(np.uint32)   # 25 % of the columns
-    flop, nnzc, per_col = O.spgemm_parallel(seqs, nk, Bc, Br, Bv, sample, 17)
+    sample = np.arange(rs.nreads, dtype=np.uint32)                                   # ALL columns (round 4 compared a quarter of them)
+    flop, nnzc, per_col = O.spgemm_parallel(seqs, nk, Bc, Br, Bv, sample, 17, procs=min(192, os.cpu_count() or 1))
     t2 = time.time()
     assert flops == int(flop.astype(np.int64).sum())
     assert np.array_equal(per_row, nnzc.astype(np.int64))
-    got_idx = np.concatenate([np.arange(int(colptrC[c]), int(colptrC[c + 1])) for c in sample])
-    exp = np.concatenate([per_col[int(c)] for c in sample])
-    check_pairs(pairs[got_idx], ext[got_idx], exp, rs.lengths, 17)
+    exp = np.concatenate([per_col[int(c)] for c in sample])                          # column-major, slot order inside: the engine's order
+    del per_col
+    check_pairs(pairs, ext, exp, rs.lengths, 17)
     # configs[3] aligns: X-drop on all pairs
     npass = eng.align_pairs(pars)
     alns = eng.get_alignments()
@@ -938,12 +937,12 @@ def test_count_kmers_parameter_sweep(eng, k, lower, upper):
     # the sorted words carry their positions where word + position index fit 64 bits (all of these but k = 32); debug bit 14 takes the
     # hash-table look-up path that the other cases use; one pass over all words, then several passes over the bins
     for dbg, budget in ((0, 0), (16384, 0), (0, 9000), (16384, 9000)):
-        eng.set_debug(dbg)
+        set_mode(eng, dbg)
         eng.set_tuning("kcount_budget", budget)
         try:
             nk, nt, nd = eng.count_kmers(k, lower, upper)
         finally:
-            eng.set_debug(0)
+            set_mode(eng, 0)
             eng.set_tuning("kcount_budget")
         assert (nk, nt, nd) == (len(codes), len(tk), ndist)
         dc, dn = eng.get_dictionary()
@@ -981,11 +980,11 @@ def test_count_minimizers_parameter_sweep(eng, k, window, lower, upper):
     codes, counts, tk, tr, tp, ndist = O.count_kmers(rs.seqs(), k, lower, upper, False, window)
     for budget, dbg in ((0, 0), (2000, 0), (0, 16384)):                # (debug bit 14: the look-up path instead of positions in the sort keys)
         eng.set_tuning("kcount_budget", budget)
-        eng.set_debug(dbg)
+        set_mode(eng, dbg)
         try:
             nk, nt, nd = eng.count_kmers(k, lower, upper, False, window)
         finally:
-            eng.set_debug(0)
+            set_mode(eng, 0)
         assert (nk, nt, nd) == (len(codes), len(tk), ndist)
         dc, dn = eng.get_dictionary()
         gk, gr, gp = eng.get_tuples()
@@ -1141,7 +1140,7 @@ def test_wide_columns_bit_exact(eng, budget, layout, passdbg, rowlists):
     """70 near-identical reads with -u 80: every k-mer is shared by all of them, column 0 has ~200k products (the row kernels
     index products with 16 bits); strands mixed, two reads carry a 700-base deletion plus a random tail (a second overlap bin)"""
     eng.set_tuning("wide_budget", budget)                            # 300000: several batches of wide columns
-    eng.set_debug(layout)                                            # 1024: A' in order of first appearance; 2048: the row lists asked for "do not fit"
+    set_mode(eng, layout)                                            # 1024: A' in order of first appearance; 2048: the row lists asked for "do not fit"
     eng.set_tuning("row_lists", rowlists)                            # 1: grouping of the wide columns in LDS from the row lists; 0 (default): a long-list input like this one
                                                                      # gets them anyway when they fit (2048: "no room", 1024: other layout -> a list expanded per batch)
     rng = np.random.default_rng(17)
@@ -1158,9 +1157,9 @@ def test_wide_columns_bit_exact(eng, budget, layout, passdbg, rowlists):
     nk, nt, _ = eng.count_kmers(17, 2, 80)
     tk, tr, tp = eng.get_tuples()
     eng.assemble_counted()
-    eng.set_debug(passdbg)                                           # 4096: the sort-based grouping of the wide columns also with row lists
+    set_mode(eng, passdbg)                                           # 4096: the sort-based grouping of the wide columns also with row lists
     n, flops = eng.overlap(BellaPars(skipAlignment=True))
-    eng.set_debug(0)
+    set_mode(eng, 0)
     eng.set_tuning("row_lists")
     pairs, ext, colptrC = eng.get_pairs()
     _, flop, ecol, exp = oracle_pairs(rs, rs.seqs(), nk, tk, tr, tp, 17)
@@ -1338,6 +1337,82 @@ def test_baseline_config4_hifi_100k_reads(eng, upper, stages):
           % (upper, nk, nt, flops, n, stages, len(exp), t1 - t0, t2 - t1, t3 - t2, time.time() - t0))
 
 
+class _PackedSeqs:
+    """read r's bases out of one ASCII buffer (what a million-read set keeps instead of a million bytes objects)"""
+    def __init__(self, asc, offsets):
+        self.asc, self.offsets = asc, offsets
+
+    def __getitem__(self, r):
+        return self.asc[int(self.offsets[r]):int(self.offsets[r + 1])].tobytes()
+
+
+def test_baseline_config4_hifi_1M_reads(eng):
+    """BASELINE configs[4] at ITS OWN size on one GPU: 1,000,000 synthetic HiFi reads (15 kb, 0.5 % error, 30x: 15 G bases), syncmer
+    selection, the reference's default bound -u 8 (-u 40 stays at 100k reads: ~3e10 products are a many-stage run).
+    Reads from the device generator (bella_testkit.synth.make_reads_torch), then the whole device pipeline -- count, assemble, the
+    symbolic phase alone, the numeric phase, X-drop on every candidate pair -- and: size-independent properties of ALL records; the
+    pair and product count of EVERY column against the engine's own symbolic phase and against the oracle's; every record of > 1 % of
+    the columns against the oracle's numeric phase; > 5,000 alignments against the oracle.  BELLA_TEST_HIFI_READS overrides the size."""
+    import time
+    import multiprocessing as mp
+    nreads = int(os.environ.get("BELLA_TEST_HIFI_READS", "1000000"))
+    t0 = time.time()
+    _BIG_SETS.clear()
+    rs = synth.make_reads_fast(nreads, read_len=15000, coverage=30.0, err=0.005, seed=4, mix=(1 / 3, 1 / 3, 1 / 3))
+    asc = np.ascontiguousarray(api._ACGT[rs.codes])
+    rs.codes = None                                             # (15 GB: the ASCII buffer is what everything below reads)
+    offs = np.ascontiguousarray(rs.offsets, dtype=np.uint64)
+    t1 = time.time()
+    eng.set_reads_raw(asc, offs, names=rs.names)
+    nk, nt, _ = eng.count_kmers(17, 2, 8, syncmer=True)
+    eng.assemble_counted()
+    pars = BellaPars(errorRate=0.005)
+    colS, nS, fS = eng.count_pairs(pars)                        # estimateFLOP + estimateNNZ_Hash + prefixsum on all columns
+    n, flops = eng.overlap(pars)
+    pairs, ext, colptrC = eng.get_pairs()
+    npass = eng.align_pairs(pars)
+    alns = eng.get_alignments()
+    t2 = time.time()
+    assert n == nS == len(pairs) and flops == fS and n > nreads // 20 and 0 < npass <= n
+    assert np.array_equal(colptrC, colS)
+    assert (pairs["rid"] > pairs["cid"]).all() and (np.diff(pairs["cid"].astype(np.int64)) >= 0).all()
+    key = pairs["cid"].astype(np.uint64) << np.uint64(32) | pairs["rid"].astype(np.uint64)
+    assert len(np.unique(key)) == len(key)
+    del key
+    per_row = np.diff(colS.astype(np.int64))
+    assert np.array_equal(np.bincount(pairs["cid"], minlength=nreads), per_row)
+    assert ((ext["nbins"] >= 1) & (ext["support"] >= 1)).all()
+    lens = np.diff(rs.offsets)
+    assert (pairs["seedH"].astype(np.int64) + 17 <= lens[pairs["rid"]]).all() and (pairs["seedV"].astype(np.int64) + 17 <= lens[pairs["cid"]]).all()
+    passed = alns["passed"] != 0
+    assert int(passed.sum()) == npass
+    # the oracle: B from the engine's tuples (host, one thread), the symbolic phase of all columns and the numeric phase of a sample
+    tk, tr, tp = eng.get_tuples()
+    Bc, Br, Bv = O.build_B(nreads, tk, tr, tp)
+    del tk, tr, tp
+    for a_, b_ in zip(eng.get_B(), (Bc, Br, Bv)):
+        assert np.array_equal(a_, b_)
+    sample = np.unique(np.concatenate([np.arange(0, nreads, 90), np.argsort(per_row)[-200:]])).astype(np.uint32)
+    assert len(sample) >= nreads // 100
+    flop, nnzc, per_col = O.spgemm_parallel((asc, rs.offsets), nk, Bc, Br, Bv, sample, 17, procs=min(128, os.cpu_count() or 1))
+    t3 = time.time()
+    assert flops == int(flop.astype(np.int64).sum()) and np.array_equal(per_row, nnzc.astype(np.int64))
+    got_idx = np.concatenate([np.arange(int(colS[c]), int(colS[c + 1])) for c in sample])
+    exp = np.concatenate([per_col[int(c)] for c in sample])
+    check_pairs(pairs[got_idx], ext[got_idx], exp, rs.lengths, 17)
+    pick = np.sort(np.random.default_rng(5).choice(len(pairs), size=min(6000, len(pairs)), replace=False))
+    global _XSEQS
+    _XSEQS = _PackedSeqs(asc, rs.offsets)
+    jobs = list(zip(pairs["rid"][pick].tolist(), pairs["cid"][pick].tolist(), pairs["seedH"][pick].tolist(), pairs["seedV"][pick].tolist()))
+    with mp.get_context("fork").Pool(min(128, os.cpu_count() or 1)) as pool:
+        res = pool.map(_xavier_job, jobs, chunksize=16)
+    bad = sum((int(alns[i]["score"]), int(alns[i]["begH"]), int(alns[i]["endH"]), int(alns[i]["begV"]), int(alns[i]["endV"])) != e for i, e in zip(pick, res))
+    assert bad == 0, bad
+    _XSEQS = None
+    print("HiFi %d reads -u 8: %d reliable syncmers, %d tuples, %d products, %d pairs, %d passed; %d columns / %d records / %d alignments against the oracle; reads %.0f s, engine %.0f s, oracle %.0f s, total %.0f s"
+          % (nreads, nk, nt, flops, n, npass, len(sample), len(exp), len(pick), t1 - t0, t2 - t1, t3 - t2, time.time() - t0))
+
+
 @pytest.mark.parametrize("name,dbg", [("toy120", 32), ("toyrep90", 32), ("toyhifi50", 32), ("toysync60", 32), ("toyrep90", 32 | 64),
                                       ("toy120", 32 | 65536), ("toyrep90", 32 | 65536), ("toy120", 32 | 4096 | 65536)])
 def test_columns_above_the_lds_tiers_on_the_sort_based_path(name, dbg):
@@ -1349,7 +1424,7 @@ def test_columns_above_the_lds_tiers_on_the_sort_based_path(name, dbg):
     e = Engine(0)
     try:
         e.set_tuning("lds_tiers", 64)                                # (per context: no process-wide state)
-        e.set_debug(dbg)                                             # bit 6: 64-bit sort keys (the default here is 32-bit); bit 16: one-partner B' entries carry
+        set_mode(e, dbg)                                             # bit 6: 64-bit sort keys (the default here is 32-bit); bit 16: one-partner B' entries carry
                                                                      # the partner (k_wide_expand / the batch's own product lists read them); bit 12: radix-sort grouping
         e.set_reads(g.rs)
         e.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
@@ -1466,7 +1541,7 @@ def test_library_communicator_allgather_single_rank(eng):
 
 def test_half_size_key_tables_layout_bit_exact(eng, monkeypatch):
     """the LDS layout of pair-rich inputs (key tables of cap/2 slots, Gaux inside T2's upper half) on the multi-bin golden set"""
-    eng.set_debug(16)
+    set_mode(eng, 16)
     for name in ("toyrep90", "toy120"):
         g = load_golden(name)
         eng.set_reads(g.rs)
@@ -1482,7 +1557,7 @@ def test_out_of_order_lists_fall_back_to_the_repairing_path(eng):
     """the LDS tiers only CHECK that the ordered scatter produced product order (it always does on gfx950) and hand a column
     to the global path, which repairs, otherwise: inject the failure for every fifth column -> same results"""
     g = load_golden("toyrep90")
-    eng.set_debug(4)
+    set_mode(eng, 4)
     try:
         eng.set_reads(g.rs)
         eng.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
@@ -1492,11 +1567,11 @@ def test_out_of_order_lists_fall_back_to_the_repairing_path(eng):
         assert n == len(exp)
         check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
         assert eng.timings().retry_columns >= 5                          # the redone columns are counted and reported
-        eng.set_debug(0)
+        set_mode(eng, 0)
         eng.overlap(BellaPars(skipAlignment=True))
         assert eng.timings().retry_columns == 0                         # gfx950 keeps product order: nothing is redone
     finally:
-        eng.set_debug(0)
+        set_mode(eng, 0)
 
 
 def test_staged_output_equals_single_stage(eng, golden, tmp_path):
