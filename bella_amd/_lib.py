@@ -106,6 +106,7 @@ SIGNATURES = [
     ("bella_hip_get_memory", C.c_int, [vp, C.POINTER(Memory)]),
     ("bella_hip_set_debug", C.c_int, [vp, C.c_uint32]),
     ("bella_hip_reserve", C.c_int, [vp, C.c_uint64, C.POINTER(C.c_double)]),
+    ("bella_hip_trim", C.c_int, [vp]),
     ("bella_hip_set_tuning", C.c_int, [vp, C.c_uint32, vp, C.c_uint32]),
 ]
 

@@ -251,6 +251,10 @@ class Engine:
         self._chk(self.lib.bella_hip_reserve(self.h, int(nbytes), C.byref(ms)))
         return ms.value
 
+    def trim(self):
+        """bella_hip_trim: released buffers the context keeps for reuse go back to the driver"""
+        self._chk(self.lib.bella_hip_trim(self.h))
+
     def set_tuning(self, what: str, *values):
         """bella_hip_set_tuning: per-context tuning parameters (tests, A/B measurements); no values = the default"""
         v = np.asarray(values, dtype=np.uint64)

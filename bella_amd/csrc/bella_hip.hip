@@ -738,6 +738,16 @@ int bella_hip_set_tuning(bella_ctx* c, uint32_t what, const uint64_t* values, ui
     return fail(c, BELLA_ERR_BAD_ARG, "unknown tuning parameter %u", what);
 }
 
+// Released buffers the context keeps for reuse (BufPool) go back to the driver: for hosts that share the device with other allocators
+// (another context, RCCL, PyTorch) and would rather have the memory than the faster next stage.  The reserved slab is not touched.
+int bella_hip_trim(bella_ctx* c) {
+    if (!c) return BELLA_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    trim_pool(c->pool);
+    return 0;
+}
+
 // One slab from the driver, up front (see Arena): bytes == 0 gives an existing, unused slab back.  A larger request replaces an unused
 // slab; while buffers live in the slab it stays as it is (BELLA_ERR_STATE).  What does not fit the slab later goes to hipMalloc as before.
 int bella_hip_reserve(bella_ctx* c, uint64_t bytes, double* ms) {
@@ -3000,6 +3010,36 @@ static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_se
                     }
                     for (int k2 = 0; k2 < nside; ++k2)              // (the next batch reuses the state slots and the lists; k_xdrop_finish reads every result)
                         HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[k2], 0));
+                    if (nside) {
+                        // the long classes ran a FIXED number of slices (the bound lenH + lenV of an extension's steps): their final survivor
+                        // counts are checked, and a class that the bound did not finish -- it never happened; a change of the slice size or of
+                        // Phase 4's length could make it happen -- goes on slicing here, like the bulk, until nobody is left
+                        const int fin = (nsl_bound - 1) & 1;
+                        HIPCHK(c, hipMemcpyAsync(c->pinned + 101, counters + 2, 4 * 6, hipMemcpyDeviceToHost, c->stream));
+                        HIPCHK(c, hipStreamSynchronize(c->stream));
+                        for (int k2 = 0; k2 < nside; ++k2) {
+                            uint64_t live = c->pinned[101 + 2 * k2 + fin];
+                            if (!live) continue;
+                            const uint64_t c0 = cb[k2], cn = cb[k2 + 1] - cb[k2];
+                            XdropSliceArgs ya = xa;
+                            ya.state = ptr<uint32_t>(c->xstate) + c0;
+                            ya.count = cn;
+                            uint32_t* const lists[2] = {L + 2 * c0, L + 2 * c0 + cn};
+                            uint32_t* const cnts = counters + 2 * (k2 + 1);
+                            ya.live_in = lists[fin]; ya.nlive_in = cnts + fin;
+                            for (int it = 0, o = fin ^ 1; live; ++it, o ^= 1) {
+                                ya.live_out = lists[o]; ya.nlive_out = cnts + o;
+                                HIPCHK(c, hipMemsetAsync(ya.nlive_out, 0, 4, c->stream));
+                                k_xdrop_slice<<<nblk(live, kXdropBlock), kXdropBlock, 0, c->stream>>>(ya);
+                                KCHK(c);
+                                HIPCHK(c, hipMemcpyAsync(c->pinned + 100, ya.nlive_out, 4, hipMemcpyDeviceToHost, c->stream));
+                                HIPCHK(c, hipStreamSynchronize(c->stream));
+                                live = c->pinned[100];
+                                ya.live_in = ya.live_out; ya.nlive_in = ya.nlive_out;
+                                if (it > 4096) return fail(c, BELLA_ERR_STATE, "internal: X-drop slices do not terminate");
+                            }
+                        }
+                    }
                 }
                 }   // have_state
             }
@@ -3026,7 +3066,7 @@ static int align_pairs_impl(bella_ctx* c, const bella_params* p, uint64_t* npass
     ENSURE(c, c->alns, sizeof(bella_aln) * c->npairs);
     rc = exact ? run_logan(c, p, nullptr, ptr<bella_pair>(c->pairs), c->npairs, ptr<bella_aln>(c->alns))
                : run_xdrop(c, p, nullptr, ptr<bella_pair>(c->pairs), c->npairs, ptr<bella_aln>(c->alns));
-    if (rc) return rc;
+    if (rc) { (void)hipDeviceSynchronize(); return rc; }      // (an error may leave class slices in flight on the side streams)
     c->nalns = c->npairs;
     c->have_alns = true;
     if (npassed) {

@@ -357,6 +357,11 @@ int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
  * k-mer count, assembly and pass.  *ms (optional) = what the reservation took.  bytes == 0 gives an unused slab back.  What does not fit
  * the slab later is allocated as before; the slab goes with the context. */
 int bella_hip_reserve(bella_ctx* ctx, uint64_t bytes, double* ms);
+/* Device buffers of >= 128 MB that a stage released stay with the context for the next stage that fits them (a hipMalloc right after a
+ * hipFree of tens of GB waits for the driver to wipe the pages); they are counted as free wherever the library sizes something by free
+ * memory and are given up when one of its own allocations fails.  bella_hip_trim gives them back to the driver NOW: for hosts whose
+ * other allocators (another context, RCCL, a framework) need the memory. */
+int bella_hip_trim(bella_ctx* ctx);
 /* Per-context tuning parameters (tests and A/B measurements; nothing here changes results).  what:
  *   BELLA_TUNE_LDS_TIERS      values = ascending product capacities of the row kernels' LDS tiers, each in [64, 11008] (n = 0: defaults)
  *   BELLA_TUNE_KCOUNT_BUDGET  values[0] = k-mers per pass of the counting sort (default 2^30)
