@@ -52,6 +52,47 @@ __device__ __forceinline__ void order_copy_record(const OrderArgs& a, uint64_t f
     if (a.ext) a.ext[to] = a.tmp_ext[from];
 }
 
+// The two table scans of a wavefront-ordered column, lane-INTERLEAVED (lane l takes slots 64 b + l): a block of 64 slots is one
+// conflict-free LDS access and one ballot, where the chunked form of slotorder.hpp (lane l takes ht / 64 consecutive slots) puts all
+// lanes of a 32-lane group on two of the 32 banks (stride 16 words at ht = 1,024).  (Round 5: the kernel's time did not change -- 0.597 ms
+// for the 50 M records of the 100k set either way: it moves 2.4 GB at 4 TB/s, the copy ceiling of these boxes being 5 TB/s.  Measured and
+// not kept: the records read ONCE, whole, into registers and scattered to their ranks with 16-byte stores -- 1.6 GB instead of 2.4 GB,
+// but 0.67 ms: scattered 16-byte stores cost more than scattered 16-byte loads.)
+// nf[s] = first empty slot at or after s, cyclically; false: the table is full
+__device__ __forceinline__ bool wave_next_free(const uint32_t* T2, uint16_t* nf, uint32_t ht) {
+    const uint32_t lane = lane_id();
+    const uint32_t nb = (ht + 63u) >> 6;
+    uint32_t carry = 0xFFFFFFFFu;                             // first empty slot above the current block; after the first sweep: of the whole table
+#pragma unroll 1
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        for (uint32_t b = nb; b-- > 0;) {
+            const uint32_t s = (b << 6) + lane;
+            const bool empty = s < ht && T2[s] == kEmpty;
+            const unsigned long long m = __ballot(empty);
+            if (sweep == 1 && s < ht) {
+                const unsigned long long up = m >> lane;      // empty slots of this block at or after mine
+                nf[s] = (uint16_t)(up ? s + (uint32_t)__ffsll((long long)up) - 1u : carry);
+            }
+            if (m) carry = (b << 6) + (uint32_t)__ffsll((long long)m) - 1u;
+        }
+        if (carry == 0xFFFFFFFFu) return false;
+    }
+    return true;
+}
+// ord[rank] = record index of the rank-th occupied slot (the slot order itself)
+__device__ __forceinline__ void wave_rank_slots(const uint32_t* T2, uint16_t* ord, uint32_t ht) {
+    const uint32_t lane = lane_id();
+    const uint32_t nb = (ht + 63u) >> 6;
+    uint32_t base = 0;
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint32_t s = (b << 6) + lane;
+        const uint32_t it = s < ht ? T2[s] : kEmpty;
+        const unsigned long long m = __ballot(it != kEmpty);
+        if (it != kEmpty) ord[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(it & 0xFFFFu);
+        base += (uint32_t)__popcll(m);
+    }
+}
+
 // one wavefront per column: tables of HTLO < ht <= HT slots (HT <= kOrderWaveHt; two instances share the columns: the small one keeps
 // fewer records per lane in registers and half the LDS, so more of its columns are in flight per CU).  The instance with HTLO == 0
 // also copies the columns that are in order already and lists the ones above kOrderWaveHt for k_order_block.
@@ -97,7 +138,7 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_wave(OrderArgs a) {
     uint32_t prev = 0;
     for (uint32_t rd = 0;; ++rd) {                            // rounds by insertion time (slotorder.hpp)
         const uint32_t bound = round_bound(rd, ht, d, tmax);
-        if (rd) { (void)build_next_free<64>(T2, ord, ht, nullptr); group_sync<64>(); }
+        if (rd) { (void)wave_next_free(T2, ord, ht); group_sync<64>(); }
 #pragma unroll
         for (uint32_t u = 0; u < NI; ++u) {
             if (fp[u] < prev || fp[u] >= bound) continue;
@@ -109,17 +150,7 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_wave(OrderArgs a) {
         if (bound >= tmax) break;
         prev = bound;
     }
-    {
-        const uint32_t c = ht >= 64 ? ht / 64 : 1u;
-        const uint32_t lo = lane * c < ht ? lane * c : ht, hi = lo + c < ht ? lo + c : ht;
-        uint32_t occ = 0;
-        for (uint32_t s = lo; s < hi; ++s) occ += T2[s] != kEmpty ? 1u : 0u;
-        uint32_t rank = wave_incl_scan(occ) - occ;
-        for (uint32_t s = lo; s < hi; ++s) {
-            const uint32_t it = T2[s];
-            if (it != kEmpty) ord[rank++] = (uint16_t)(it & 0xFFFFu);
-        }
-    }
+    wave_rank_slots(T2, ord, ht);
     group_sync<64>();
     {   // four records in flight per lane
         uint32_t r = lane;
