@@ -133,7 +133,7 @@ def roofline_of(acc, nnz_share, copy_gbps, traffic_key, expand_ms=0.0, layout="d
     # HBM traffic of the same kernels from the PMC counters (tools/collect_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes,
     # gfx950 FETCH_SIZE x2 correction calibrated on our own stream): a separate profiling run, read from the committed summary and
     # accepted only if it was taken on the same workload AND layout
-    for tag in ("r04",):
+    for tag in ("r05", "r04"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag)))[traffic_key]
             if abs(tr["algorithmic_bytes"] - alg_bytes) < 1e-3 * alg_bytes and tr.get("layout", "default") == layout:

@@ -5,7 +5,7 @@ import numpy as np
 from bella_amd import Engine, BellaPars
 from bella_testkit import synth
 n = int(sys.argv[1])
-rs = synth.make_reads(n, read_len=10000, coverage=30.0, err=0.15, seed=1)
+rs = synth.make_reads_fast(n, read_len=10000, coverage=30.0, err=0.15, seed=1)
 eng = Engine(0); eng.set_reads(rs)
 nk, nt, nd = eng.count_kmers(17, 2, 8)
 for _ in range(2):

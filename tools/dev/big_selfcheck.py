@@ -7,7 +7,7 @@ from bella_amd import Engine, BellaPars
 from bella_testkit import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 t0 = time.time()
-rs = synth.make_reads(n, read_len=10000, coverage=30.0, err=0.15, seed=5)
+rs = synth.make_reads_fast(n, read_len=10000, coverage=30.0, err=0.15, seed=5)
 print("reads %d made in %.0f s" % (n, time.time() - t0), flush=True)
 out = {}
 for name, dbg in (("new", 0), ("old", 16384 | 32768)):

@@ -4,7 +4,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.getcwd()))
 from bella_amd import Engine
 from bella_testkit import synth
 n = int(sys.argv[1]); reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-rs = synth.make_reads(n, read_len=10000, coverage=30.0, err=0.15, seed=1)
+rs = synth.make_reads_fast(n, read_len=10000, coverage=30.0, err=0.15, seed=1)
 e = Engine(0); e.set_reads(rs)
 for it in range(reps):
     t0 = time.perf_counter(); nk, nt, nd = e.count_kmers(17, 2, 8); w = (time.perf_counter() - t0) * 1e3

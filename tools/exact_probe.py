@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 import numpy as np
 from bella_amd import BellaPars, Engine
 from bella_testkit import synth
-rs = synth.make_reads(10000, read_len=10000, coverage=30.0, err=0.15, seed=1)
+rs = synth.make_reads_fast(10000, read_len=10000, coverage=30.0, err=0.15, seed=1)
 eng = Engine(0); eng.set_reads(rs); eng.count_kmers(17, 2, 8); eng.assemble_counted()
 pars = BellaPars()
 n, _ = eng.overlap(pars)

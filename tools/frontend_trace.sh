@@ -10,7 +10,7 @@ import sys, time
 sys.path.insert(0, "$R")
 from bella_amd import Engine, BellaPars
 from bella_testkit import synth
-rs = synth.make_reads($N, read_len=10000, coverage=30.0, err=0.15, seed=1)
+rs = synth.make_reads_fast($N, read_len=10000, coverage=30.0, err=0.15, seed=1)
 e = Engine(0)
 e.set_reads(rs)
 for it in range(2):

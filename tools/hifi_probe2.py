@@ -4,7 +4,7 @@ import numpy as np
 from bella_amd import BellaPars, Engine
 from bella_testkit import synth
 n = int(sys.argv[1]); upper = int(sys.argv[2]); sync = int(sys.argv[3])
-rs = synth.make_reads(n, read_len=15000, coverage=30.0, err=0.005, seed=2, mix=(1 / 3, 1 / 3, 1 / 3))
+rs = synth.make_reads_fast(n, read_len=15000, coverage=30.0, err=0.005, seed=2, mix=(1 / 3, 1 / 3, 1 / 3))
 eng = Engine(0)
 eng.set_reads(rs)
 nk, nt, nd = eng.count_kmers(17, 2, upper, syncmer=bool(sync))

@@ -5,7 +5,7 @@ import numpy as np
 from bella_amd import BellaPars, Engine
 from bella_testkit import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-rs = synth.make_reads(n, read_len=10000, coverage=30.0, err=0.15, seed=1)
+rs = synth.make_reads_fast(n, read_len=10000, coverage=30.0, err=0.15, seed=1)
 eng = Engine(0); eng.set_reads(rs)
 eng.count_kmers(17, 2, 8)
 ref = None

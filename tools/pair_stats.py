@@ -6,7 +6,7 @@ from bella_testkit import synth
 from bella_amd.api import Engine, BellaPars
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-rs = synth.make_reads(n, read_len=10000, coverage=30.0, err=0.15, seed=1)
+rs = synth.make_reads_fast(n, read_len=10000, coverage=30.0, err=0.15, seed=1)
 tup = synth.count_and_tuples(rs, 17, 2, 8, device="cuda:0")
 eng = Engine(0)
 eng.set_reads(rs)

@@ -11,7 +11,7 @@ from bella_amd import BellaPars, Engine, evaluate as ev, hash_spgemm
 
 from bella_testkit import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-rs = synth.make_reads(n, read_len=10000, coverage=30.0, err=0.15, seed=1)
+rs = synth.make_reads_fast(n, read_len=10000, coverage=30.0, err=0.15, seed=1)
 eng = Engine(0)
 t0 = time.perf_counter()
 eng.set_reads(rs)

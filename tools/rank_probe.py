@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bella_amd import BellaPars, Engine
 from bella_testkit import synth
 Ns = [int(x) for x in sys.argv[1:]] or [2, 4, 8]
-rs = synth.make_reads(100000, read_len=10000, coverage=30.0, err=0.15, seed=1)
+rs = synth.make_reads_fast(100000, read_len=10000, coverage=30.0, err=0.15, seed=1)
 eng = Engine(0)
 eng.set_reads(rs)
 eng.count_kmers(17, 2, 8)

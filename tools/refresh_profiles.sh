@@ -1,9 +1,9 @@
 #!/usr/bin/env bash
 # Regenerates the judged artefacts of a round on the GPU box: the bench line, rocprofv3 kernel stats + the step timeline of the
-# same commands (10k and 100k reads), HBM traffic (PMC) and SQ counters.  usage: bash tools/refresh_profiles.sh r04
+# same commands (10k and 100k reads), HBM traffic (PMC) and SQ counters.  usage: bash tools/refresh_profiles.sh r05
 # (outputs under gpurun_out/refresh/; copy into profiles/)
 set -uo pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/refresh; rm -rf $OUT; mkdir -p $OUT
 cd $R
