@@ -376,6 +376,36 @@ def test_partitioned_layout_of_a_matrix_with_fewer_nonzeros_than_reads(eng):
         eng.set_tuning("row_lists")
 
 
+def test_reserved_slab_serves_the_stages_and_changes_nothing(golden):
+    """bella_hip_reserve: the stages cut their buffers from one slab taken up front; same results as without; a slab in use is neither
+    replaced nor given back; what does not fit the slab is allocated as before; bella_hip_trim is harmless at any time"""
+    g = golden
+    e = Engine(0)
+    try:
+        ms = e.reserve(192 << 20)
+        assert ms > 0.0
+        assert e.reserve(64 << 20) == 0.0                  # a smaller request is served by the slab that exists
+        e.set_reads(g.rs)
+        e.assemble_tuples(g.k, g.nkmers, g.tk, g.tr, g.tp)
+        n, flops = e.overlap(BellaPars(skipAlignment=True, kmerSize=g.k))
+        pairs, ext, _ = e.get_pairs()
+        _, flop, _, exp = oracle_pairs(g.rs, g.seqs, g.nkmers, g.tk, g.tr, g.tp, g.k)
+        assert flops == int(flop.sum()) and n == len(exp)
+        check_pairs(pairs, ext, exp, g.rs.lengths, g.k)
+        with pytest.raises(BellaHipError) as err:          # buffers live in the slab: it stays
+            e.reserve(1 << 30)
+        assert err.value.code == -7                        # BELLA_ERR_STATE
+        e.trim()
+        e.set_tuning("kcount_budget", 1 << 30)
+        if g.nkmers and not g.syncmer and not g.window:    # a stage that outgrows the 192 MB slab falls back to the driver
+            e.count_kmers(g.k, g.lower, g.upper)
+            e.assemble_counted()
+            n2, _ = e.overlap(BellaPars(skipAlignment=True, kmerSize=g.k))
+            assert n2 == n
+    finally:
+        e.close()
+
+
 def test_medium_synthetic_vs_oracle(eng):
     """2,000 reads x 6 kb (SpGEMM) -- bigger hash tables, LDS tiers and the ordering emulation under load"""
     rs = synth.make_reads(2000, read_len=6000, err=0.15, seed=21)
