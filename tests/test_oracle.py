@@ -235,3 +235,17 @@ def test_logan_restatement_matches_seqan_in_process():
         assert [int(o["score"]), int(o["begH"]), int(o["endH"]), int(o["begV"]), int(o["endV"])] == ref and ("c" if o["strand"] else "n") == st, trial
         n += 1
     assert n > 100
+
+
+def test_parallel_restatement_takes_the_reads_as_one_buffer():
+    """_oracle.spgemm_parallel with (ASCII buffer, offsets) -- what the million-read GPU test hands it -- equals the list-of-bytes form"""
+    from bella_testkit import synth
+    rs = synth.make_reads(200, read_len=2000, coverage=20.0, err=0.15, seed=21)
+    t = synth.count_and_tuples(rs, 17, 2, 8)
+    Bc, Br, Bv = O.build_B(rs.nreads, t.kmer, t.read, t.pos)
+    cols = np.arange(0, rs.nreads, 5)
+    a = O.spgemm_parallel(rs.seqs(), t.nkmers, Bc, Br, Bv, cols, procs=2)
+    asc = np.ascontiguousarray(synth.BASES[rs.codes])
+    b = O.spgemm_parallel((asc, rs.offsets), t.nkmers, Bc, Br, Bv, cols, procs=2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert all(a[2][c].tobytes() == b[2][c].tobytes() for c in a[2]) and sum(len(v) for v in a[2].values()) > 50
