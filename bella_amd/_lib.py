@@ -45,7 +45,8 @@ class Timings(C.Structure):
 
 class Memory(C.Structure):
     _fields_ = [("reads_bytes", C.c_uint64), ("matrix_bytes", C.c_uint64), ("layout_A_bytes", C.c_uint64), ("layout_B_bytes", C.c_uint64),
-                ("rowlist_bytes", C.c_uint64), ("pass_bytes", C.c_uint64), ("other_bytes", C.c_uint64), ("owned_nnz", C.c_uint64)]
+                ("rowlist_bytes", C.c_uint64), ("pass_bytes", C.c_uint64), ("other_bytes", C.c_uint64), ("owned_nnz", C.c_uint64),
+                ("layout_shared", C.c_uint64)]
 
 
 # every symbol include/bella_hip.h declares: (name, restype, argtypes)

@@ -355,13 +355,14 @@ __global__ void k_layout_rinfo(const uint32_t* Bloc, const uint64_t* roff, uint3
 }
 constexpr int kLayoutEmitPartBlock = 1024;      // workgroup of the partitioned launch (own_stride > 1); at most this otherwise
 constexpr uint32_t kEmitHalo = 32;              // keys on either side of the workgroup's entries in its LDS window
+constexpr uint32_t kOwnerMax = 64;              // ranks of a communicator the shared formation of A' serves (build_layout, dist)
 __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64_t nnz, const uint32_t* Bptr, const uint32_t* Bloc, const uint32_t* wscan,
                               const uint32_t* packed, const uint64_t* roff, uint32_t k, uint32_t rmask, uint2* Aent, uint32_t* ekey, uint64_t* eval,
                               uint32_t by_kmer, uint32_t own_first, uint32_t own_stride, uint32_t* counter, uint32_t* status, uint32_t inl,
-                              const uint2* rinfo) {
+                              const uint2* rinfo, uint32_t abase = 0, unsigned long long* cursor = nullptr) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool mine = false;
-    uint32_t dstkey = 0;
+    uint32_t dstkey = 0, owner = 0;
     uint64_t dstval = 0;
     // the workgroup's keys and 32 on either side in LDS: a run's bounds are a few LDS reads (they were a chain of dependent global
     // loads per entry: 4.05 ms of this kernel's time at 100k reads was that chain); runs that leave the window take the global search
@@ -400,15 +401,31 @@ __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64
         const uint32_t ori = pal ? 0u : hiw >> 31;                            // (palindromes count as canonical)
         const uint2 ri = rinfo[r];                                            // {first B' entry of read r, its length}
         const uint32_t len = ri.y;
-        Aent[cs + rk] = make_uint2(r | (ori << 31), pos | (len << 16));
-        mine = own_stride == 1u || r % own_stride == own_first;               // B' entries only for the columns this context owns
+        // (abase: the sorted entries are one rank's SLICE of the k-mer id space -- build_layout's shared formation of A' --: the list
+        // positions of the slice start at abase in the whole A')
+        Aent[abase + cs + rk] = make_uint2(r | (ori << 31), pos | (len << 16));
+        owner = r % own_stride;
+        mine = own_stride == 1u || owner == own_first;                        // B' entries only for the columns this context owns
         dstkey = ri.x + ((uint32_t)v >> 16);
-        dstval = (uint64_t)(cs + rk + 1) | ((uint64_t)(pos | ((dg - 1 - rk) << 16) | (pal << 30) | (ori << 31)) << 32);
+        dstval = (uint64_t)(abase + cs + rk + 1) | ((uint64_t)(pos | ((dg - 1 - rk) << 16) | (pal << 30) | (ori << 31)) << 32);
         if (inl && rk + 2u == dg && !pal) {                                   // exactly one later read (the last but one of any list): the entry carries it (util.hpp)
             const uint64_t v1 = sval[x + 1];
             const uint32_t hi1 = (uint32_t)(v1 >> 32);
             dstval = (uint64_t)((hi1 & rmask) | ((hi1 >> 31) == ori ? 1u << 30 : 0u) | (1u << 31)) | ((uint64_t)(pos | (((uint32_t)v1 & 0xFFFFu) << 16)) << 32);
         }
+    }
+    if (cursor) {                                                             // shared formation: every entry leaves, into the range of the rank that owns its row
+        __shared__ uint32_t s_oc[kOwnerMax];                                   // (one atomic per owner and workgroup on the ranges' cursors)
+        __shared__ unsigned long long s_ob[kOwnerMax];
+        if (threadIdx.x < kOwnerMax) s_oc[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t at = 0;
+        if (x < nnz) at = atomicAdd(&s_oc[owner], 1u);
+        __syncthreads();
+        if (threadIdx.x < own_stride && s_oc[threadIdx.x]) s_ob[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)s_oc[threadIdx.x]);
+        __syncthreads();
+        if (x < nnz) { const unsigned long long d = s_ob[owner] + at; ekey[d] = dstkey; eval[d] = dstval; }
+        return;
     }
     if (own_stride == 1u) {                                                   // every entry has a B' entry: it leaves at its sorted place
         if (x < nnz) { ekey[x] = dstkey; eval[x] = dstval; }
@@ -424,6 +441,87 @@ __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64
     if (threadIdx.x == 0) s_base = tot ? atomicAdd(counter, tot) : 0u;
     __syncthreads();
     if (mine) { const uint32_t o = s_base + ex; ekey[o] = dstkey; eval[o] = dstval; }
+}
+
+// ---- the formation of A' shared over the ranks of a communicator (bella_hip.hip: build_layout, dist) --------------------------------
+// Rank g of N keeps the entries of B whose k-mer id lies in [klo, khi) -- the g-th N-th of the id space --, sorts THEM (1/N of the sort),
+// emits its slice of A' and the B' entries of ALL rows for those k-mers; the slices and the entries then travel (one grouped all-gather,
+// one grouped all-to-all).  The compaction of a row's in-range entries is stable (the sort is, too: a list of A' stays in ascending read
+// order).
+__global__ __launch_bounds__(kBlock) void k_range_rowcount(const uint32_t* Bptr, const uint32_t* Bk, uint32_t nreads, uint32_t klo, uint32_t khi,
+                                                           uint32_t* cnt) {
+    const uint32_t r = blockIdx.x * kWaves + wave_id();
+    if (r > nreads) return;
+    uint32_t n = 0;
+    if (r < nreads)
+        for (uint32_t e = Bptr[r] + lane_id(); e < Bptr[r + 1]; e += 64) { const uint32_t km = Bk[e]; n += km >= klo && km < khi ? 1u : 0u; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n += __shfl_xor(n, d, 64);
+    if (lane_id() == 0) cnt[r] = n;
+}
+// k_layout_prep for the in-range entries only, written compacted at rowbase[r] + (rank inside the row)
+__global__ __launch_bounds__(kBlock) void k_layout_prep_range(const uint32_t* Bptr, const uint32_t* Bk, const uint16_t* Bpos, uint32_t nreads,
+                                                              const uint32_t* packed, const uint64_t* roff, uint32_t k, uint32_t nkmers,
+                                                              uint32_t klo, uint32_t khi, const uint32_t* rowbase, uint32_t* key, uint64_t* val,
+                                                              uint32_t* status) {
+    const uint32_t r = blockIdx.x * kWaves + wave_id();
+    if (r >= nreads) return;
+    const uint64_t base = roff[r];
+    const uint32_t len = (uint32_t)(roff[r + 1] - base);
+    const uint32_t b0 = Bptr[r], b1 = Bptr[r + 1];
+    uint32_t out = rowbase[r];
+    for (uint32_t e0 = b0; e0 < b1; e0 += 64) {
+        const uint32_t e = e0 + lane_id();
+        uint32_t km = 0, pos = 0;
+        bool in = false;
+        if (e < b1) {
+            km = Bk[e]; pos = Bpos[e];
+            if (km >= nkmers) atomicOr(status, 32u);
+            if (pos + k > len) atomicOr(status, 128u);
+            in = km >= klo && km < khi;
+        }
+        const unsigned long long m = __ballot(in);
+        if (in) {
+            uint32_t ori = 0, pal = 0;
+            if (pos + k <= len) {
+                const uint64_t le = kmer_le(packed, base + pos, k);
+                const uint64_t fw = kmer_fw_from_le(le, k), rc = kmer_rc_from_le(le, k);
+                ori = fw > rc ? 1u : 0u;
+                pal = fw == rc ? 1u : 0u;
+            }
+            const uint32_t o = out + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+            key[o] = km;
+            val[o] = ((uint64_t)(r | (ori << 31) | (nreads <= (1u << 30) ? pal << 30 : 0u)) << 32) | (pos | ((e - b0) << 16));
+        }
+        out += (uint32_t)__popcll(m);
+    }
+}
+// the rows' lengths in OWNER-major order: P[(r % N) * M + r / N] = length of row r (M = ceil(nreads / N)); the exclusive scan of P,
+// minus the scan at the owner's first place, is where row r starts in ITS owner's compacted B'
+__global__ void k_owner_lengths(const uint32_t* Bptr, uint32_t nreads, uint32_t N, uint32_t M, uint32_t* P) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x > N * M) return;
+    const uint32_t o = x / M, j = x % M;
+    const uint64_t r = (uint64_t)j * N + o;
+    P[x] = x < N * M && r < nreads ? Bptr[r + 1] - Bptr[r] : 0u;
+}
+__global__ void k_layout_rinfo_owner(const uint32_t* scanP, const uint64_t* roff, uint32_t nreads, uint32_t N, uint32_t M, uint2* rinfo) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nreads) return;
+    const uint32_t o = r % N, j = r / N;
+    rinfo[r] = make_uint2(scanP[o * M + j] - scanP[o * M], (uint32_t)(roff[r + 1] - roff[r]));
+}
+// B' entries by owner: how many entries of this rank's slice belong to the rows of each rank (from the per-row counts: the owner of row r
+// is r % N); k_layout_emit then hands every entry a place in its owner's range (order inside a range: any -- k_layout_place puts
+// every entry at its own index)
+__global__ __launch_bounds__(256) void k_owner_hist_rows(const uint32_t* cnt, uint32_t nreads, uint32_t N, unsigned long long* hist) {
+    __shared__ uint32_t s_h[kOwnerMax];
+    if (threadIdx.x < kOwnerMax) s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nreads) { const uint32_t n = cnt[r]; if (n) atomicAdd(&s_h[r % N], n); }    // (256 rows of < 2^16 entries: no overflow)
+    __syncthreads();
+    if (threadIdx.x < N && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
 }
 
 // XCD-aware: consecutive workgroups go to the eight XCDs in turn, each with an L2 of its own.  Walking the sorted entries in launch

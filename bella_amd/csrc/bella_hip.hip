@@ -210,6 +210,9 @@ struct bella_ctx {
     uint32_t tune_layout_order = 0;      // BELLA_TUNE_LAYOUT_ORDER: 0 lists of A' in k-mer order, 1 in order of first appearance in B'
     uint32_t tune_inline = 0;            // BELLA_TUNE_INLINE_ENTRIES: 0 by the size of A' against the last-level cache, 1 never, 2 always
     uint32_t tune_row_path = 0;          // BELLA_TUNE_ROW_PATH: 0 LDS tiers, 1 every column on the global-workspace (repairing) path
+    uint32_t tune_dist_layout = 1;       // BELLA_TUNE_DIST_LAYOUT: bella_hip_allgather_panels forms A' by k-mer id ranges over the communicator's ranks
+    bool dist_agreed = false;            // ... and every rank of the communicator said it can (bella_hip_allgather_panels asks)
+    bool layout_dist = false;            // ... and the current layout was built that way
     uint64_t tune_cache_bytes = 192ull << 20;   // BELLA_TUNE_CACHE_BYTES: A' above this size counts as "larger than the last-level cache"
     uint32_t xdrop_variant = 1;          // 0: one launch in length-sorted order; 1 (default): slices with compaction; 2: packed kernel in pair order; 3: scalar statement
     size_t lds_attr[24] = {};             // largest dynamic-LDS size already granted to each row-kernel instantiation
@@ -366,7 +369,15 @@ void release_count_scratch(bella_ctx* c) {
     release(c->kc_keys); release(c->kc_alt); release(c->kc_runlen); release(c->kc_flag); release(c->kc_slot);
 }
 
-int build_layout(bella_ctx* c) {
+// (bella_hip_allgather_panels with BELLA_TUNE_DIST_LAYOUT: the formation of A' shared over the ranks; defined behind the collectives)
+int layout_dist(bella_ctx* c, uint64_t nown_nnz, uint32_t rmask, uint32_t inl, int kbits, uint32_t** ekey_out, uint64_t** eval_out,
+                uint32_t** fkey_out, uint64_t** fval_out);
+void layout_dist_fail(bella_ctx* c);
+bool layout_dist_eligible(const bella_ctx* c);
+
+// collective: every rank of the context's communicator is inside this call (bella_hip_allgather_panels) -- the only caller that may
+// take the shared formation of A'
+int build_layout(bella_ctx* c, bool collective = false) {
     release_count_scratch(c);
     const uint64_t nnz = c->nnz;
     const uint32_t nk = c->nkmers;
@@ -376,15 +387,21 @@ int build_layout(bella_ctx* c) {
     c->have_rowlists = false;
     c->layout_inline = 0;
     c->tm.expand_ms = 0.f;
-    ENSURE(c, c->lk_key, 4 * nnz);
-    ENSURE(c, c->lk_key2, 4 * nnz);
-    ENSURE(c, c->lk_val, 8 * nnz);
-    ENSURE(c, c->lk_val2, 8 * nnz);
+    // shared formation of A' (layout_dist): every rank agreed to it in bella_hip_allgather_panels, so a rank that fails BEFORE it gets
+    // there still says so in the formation's metadata exchange -- the others leave instead of waiting for it
+    const bool dist = collective && c->dist_agreed;
+    struct Bail { bella_ctx* c; bool armed; ~Bail() { if (armed) layout_dist_fail(c); } } bail{c, dist};
+    if (!dist) {                                                   // (shared: the sort buffers are sized by the rank's share)
+        ENSURE(c, c->lk_key, 4 * nnz);
+        ENSURE(c, c->lk_key2, 4 * nnz);
+        ENSURE(c, c->lk_val, 8 * nnz);
+        ENSURE(c, c->lk_val2, 8 * nnz);
+    }
     ENSURE(c, c->lk_rinfo, 8 * ((size_t)c->nreads + 1));
     // (w also holds one word per READ: the owned rows' lengths of a partitioned layout, the rows' product counts of the row lists --
     // a matrix with fewer nonzeros than reads must not shrink it below that)
     ENSURE(c, c->w, 4 * std::max<uint64_t>(nnz + 1, (uint64_t)c->nreads + 2));
-    ENSURE(c, c->wscan, 4 * (nnz + 1));
+    ENSURE(c, c->wscan, 4 * std::max<uint64_t>(nnz + 1, (uint64_t)c->nreads + 2));
     ENSURE(c, c->Aent, 8 * nnz + 64);
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, 4, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
@@ -413,7 +430,34 @@ int build_layout(bella_ctx* c) {
     if (c->Bcnt.cap > 4 * nown_nnz + (1u << 20)) release(c->Bcnt);
     ENSURE(c, c->Bent, 8 * nown_nnz);
     const bool first_app = c->tune_layout_order == 1 || (c->debug & 1024u);
-    if (nnz) {
+    c->layout_dist = dist;
+    if (nnz || dist) {
+        int kbits = 1;
+        while (kbits < 32 && (1ull << kbits) < (uint64_t)nk) ++kbits;
+        const uint32_t rmask = c->nreads <= (1u << 30) ? 0x3FFFFFFFu : 0x7FFFFFFFu;   // read id field of the sort value
+        // Default: the lists of A' stay in k-mer order (= the sorted order itself; nothing to scatter, scan or look up) and every pass
+        // expands B' x A' itself: the fastest ONE-SHOT call (layout + first pass).  BELLA_TUNE_LAYOUT_ORDER 1 (tests): the lists in
+        // order of first appearance in B' (the owner row of a list streams it; three more random-access passes here).
+        const uint32_t by_kmer = first_app ? 0u : 1u;
+        // entries whose k-mer has exactly one later read carry that read (util.hpp: INLINE form) when bit 31 of the list index and bit 30
+        // of a read id are free -- and when A' is larger than the last-level cache (256 MB): the form saves a line from HBM per such
+        // entry and pass (row kernels 4.03 -> 3.69 ms at 100k reads, A' = 1.6 GB), but where the gather is a cache hit it only adds a
+        // branch (10k reads, A' = 92 MB: 0.360 -> 0.367 ms per step).  BELLA_TUNE_INLINE_ENTRIES 1: the plain form everywhere, as for inputs
+        // beyond those bounds; 2: the inline form on any size
+        const bool inl_pays = 8ull * nnz > c->tune_cache_bytes || c->tune_inline == 2 || (c->debug & 65536u);
+        const uint32_t inl = rmask == 0x3FFFFFFFu && nnz < 0x80000000ull && inl_pays && c->tune_inline != 1 && !(c->debug & 32768u) ? 1u : 0u;
+        c->layout_inline = inl;
+        uint32_t* ekey = nullptr;                                  // the nown_nnz B' entries of this context's rows {own index, entry}, any order ...
+        uint64_t* eval = nullptr;
+        const uint32_t* skey = nullptr;                            // ... and two free buffers of that size for the partition pass below
+        const uint64_t* sval = nullptr;
+        if (dist) {
+            uint32_t *fk = nullptr; uint64_t* fv = nullptr;
+            bail.armed = false;                                    // (from here on layout_dist speaks for this rank)
+            int rcd = layout_dist(c, nown_nnz, rmask, inl, kbits, &ekey, &eval, &fk, &fv);
+            if (rcd) return rcd;
+            skey = fk; sval = fv;
+        } else {
         k_layout_prep<<<nblk(c->nreads, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos), c->nreads,
                                                                         ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), c->kmer_size, nk,
                                                                         ptr<uint32_t>(c->lk_key), ptr<uint64_t>(c->lk_val),
@@ -425,37 +469,22 @@ int build_layout(bella_ctx* c) {
         if (rc0) return rc0;
         rc0 = status_to_error(c, st0);
         if (rc0) return rc0;
-        int kbits = 1;
-        while (kbits < 32 && (1ull << kbits) < (uint64_t)nk) ++kbits;
         hipcub::DoubleBuffer<uint32_t> dk(ptr<uint32_t>(c->lk_key), ptr<uint32_t>(c->lk_key2));
         hipcub::DoubleBuffer<uint64_t> dv(ptr<uint64_t>(c->lk_val), ptr<uint64_t>(c->lk_val2));
         size_t tb = 0;
         HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (uint64_t)nnz, 0, kbits, c->stream));
         ENSURE(c, c->cubtmp, tb);
         HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb, dk, dv, (uint64_t)nnz, 0, kbits, c->stream));
-        const uint32_t* skey = dk.Current();
-        const uint64_t* sval = dv.Current();
-        const uint32_t rmask = c->nreads <= (1u << 30) ? 0x3FFFFFFFu : 0x7FFFFFFFu;   // read id field of the sort value
-        // Default: the lists of A' stay in k-mer order (= the sorted order itself; nothing to scatter, scan or look up) and every pass
-        // expands B' x A' itself: the fastest ONE-SHOT call (layout + first pass).  debug bit 10 (tests): the lists in
-        // order of first appearance in B' (the owner row of a list streams it; three more random-access passes here).
-        const uint32_t by_kmer = first_app ? 0u : 1u;
-        // entries whose k-mer has exactly one later read carry that read (util.hpp: INLINE form) when bit 31 of the list index and bit 30
-        // of a read id are free -- and when A' is larger than the last-level cache (256 MB): the form saves a line from HBM per such
-        // entry and pass (row kernels 4.03 -> 3.69 ms at 100k reads, A' = 1.6 GB), but where the gather is a cache hit it only adds a
-        // branch (10k reads, A' = 92 MB: 0.360 -> 0.367 ms per step).  debug bit 15 (tests): the plain form everywhere, as for inputs
-        // beyond those bounds; bit 16: the inline form on any size
-        const bool inl_pays = 8ull * nnz > c->tune_cache_bytes || c->tune_inline == 2 || (c->debug & 65536u);
-        const uint32_t inl = rmask == 0x3FFFFFFFu && nnz < 0x80000000ull && inl_pays && c->tune_inline != 1 && !(c->debug & 32768u) ? 1u : 0u;
-        c->layout_inline = inl;
+        skey = dk.Current();
+        sval = dv.Current();
         if (!by_kmer) {
             k_layout_heads<<<nblk(nnz), 256, 0, c->stream>>>(skey, sval, nnz, ptr<uint32_t>(c->Bptr), rmask, ptr<uint32_t>(c->w), ptr<uint32_t>(c->status));
             KCHK(c);
             int rc = scan_u32(c, ptr<uint32_t>(c->w), ptr<uint32_t>(c->wscan), nnz);
             if (rc) return rc;
         }
-        uint32_t* ekey = dk.Alternate();                           // (the sort's other buffers are free now)
-        uint64_t* eval = dv.Alternate();
+        ekey = dk.Alternate();                                     // (the sort's other buffers are free now)
+        eval = dv.Alternate();
         uint32_t* counter = ptr<uint32_t>(c->status) + 7;
         HIPCHK(c, hipMemsetAsync(counter, 0, 4, c->stream));
         uint2* rinfo = ptr<uint2>(c->lk_rinfo);
@@ -472,6 +501,7 @@ int build_layout(bella_ctx* c) {
             rc1 = status_to_error(c, st1);
             if (rc1) return rc1;
         }
+        }   // !dist
         if (nown_nnz) {   // one radix pass on the top 8 bits of the entry index: B' is then written region by region
             int ebits = 1;
             while (ebits < 32 && (1ull << ebits) < nown_nnz) ++ebits;
@@ -730,6 +760,10 @@ int bella_hip_set_tuning(bella_ctx* c, uint32_t what, const uint64_t* values, ui
             if (n && values[0] > 1) return fail(c, BELLA_ERR_BAD_ARG, "row path: 0 (LDS tiers) or 1 (global workspace)");
             c->tune_row_path = n ? (uint32_t)values[0] : 0u;
             c->pass_known = false;
+            return 0;
+        case BELLA_TUNE_DIST_LAYOUT:
+            if (n && values[0] > 1) return fail(c, BELLA_ERR_BAD_ARG, "distributed layout: 0 or 1");
+            c->tune_dist_layout = n ? (uint32_t)values[0] : 0u;
             return 0;
         case BELLA_TUNE_CACHE_BYTES:
             c->tune_cache_bytes = n && values[0] ? values[0] : (192ull << 20);
@@ -1863,18 +1897,206 @@ static int comm_agree(bella_ctx* c, int local_rc) {
     return 0;
 }
 
+// ---- the formation of A' shared over the ranks (BELLA_TUNE_DIST_LAYOUT; kernels: assemble.hpp) ---------------------------------------
+// Every rank holds the whole exchanged matrix B (6 B per nonzero) and computes the columns i % N == rank.  Replicated, the device layout
+// sorts ALL entries by k-mer on every rank to form A' (prep + sort: 7.7 of a rank's 11.4 ms at N = 8, 100k reads).  Here rank g keeps the
+// entries whose k-mer id lies in the g-th N-th of the id space, sorts those, emits ITS slice of A' (in place in the whole array) and
+// the B' entries of ALL rows for those k-mers; then two grouped exchanges: the slices of A' (all-gather: 8 B per nonzero) and the B'
+// entries to the owners of their rows (all-to-all: 12 B per nonzero).  Same layout as the replicated one, entry for entry.
+extern "C++" {
+namespace {
+// what a rank needs for the shared formation (asked of every rank in bella_hip_allgather_panels; taken only if all can)
+bool layout_dist_eligible(const bella_ctx* c) {
+    const bool first_app = c->tune_layout_order == 1 || (c->debug & 1024u);
+    return c->tune_dist_layout && c->comm && c->api && c->comm_ranks > 1 && (uint32_t)c->comm_ranks <= kOwnerMax &&
+           c->part_stride == (uint32_t)c->comm_ranks && c->part_first == (uint32_t)c->comm_rank && !first_app && c->nreads <= (1u << 30);
+}
+// a rank that failed before its formation began: its line of the metadata exchange says so (the ranks inside layout_dist read it and leave)
+void layout_dist_fail(bella_ctx* c) {
+    const size_t N = (size_t)c->comm_ranks, W = N + 3;
+    if (ensure_bytes(c, c->comm_meta, 8 * (W * (N + 1) + 4 * (N + 1))) || !c->comm_meta.p) return;
+    uint64_t* d_meta = ptr<uint64_t>(c->comm_meta);
+    std::vector<uint64_t> line(W, 0);
+    line[0] = 1;
+    if (hipMemcpyAsync(d_meta + W * N, line.data(), 8 * W, hipMemcpyHostToDevice, c->stream) != hipSuccess) return;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return;
+    if (c->api->AllGather(d_meta + W * N, d_meta, W, ncclUint64, c->comm, c->stream) != ncclSuccess) return;
+    (void)comm_sync(c, "layout metadata");
+}
+int layout_dist(bella_ctx* c, uint64_t nown_nnz, uint32_t rmask, uint32_t inl, int kbits, uint32_t** ekey_out, uint64_t** eval_out,
+                uint32_t** fkey_out, uint64_t** fval_out) {
+    const int N = c->comm_ranks, me = c->comm_rank;
+    const uint32_t nr = c->nreads, nk = c->nkmers;
+    const uint64_t nnz = c->nnz;
+    const uint32_t klo = (uint32_t)((uint64_t)nk * (uint64_t)me / (uint64_t)N), khi = (uint32_t)((uint64_t)nk * (uint64_t)(me + 1) / (uint64_t)N);
+    const uint32_t M = (nr + (uint32_t)N - 1) / (uint32_t)N;      // rows per owner, at most
+    const size_t W = (size_t)N + 3;                               // words of a rank's line of the metadata exchange
+    Buf pbuf, sbuf, hbuf;                                         // owner-major row lengths + their scan; per-owner counters and cursors
+    auto done = [&](int rc) { release(pbuf); release(sbuf); release(hbuf); return rc; };
+    // (1) this rank's entries: per row how many, where they go, how many for the rows of each rank.  Host synchronisations of the
+    // whole formation: this read-back, the metadata exchange, the end of the data exchange, the closing agreement.
+    int rc = ensure_bytes(c, pbuf, 4 * ((size_t)N * M + 2));
+    if (!rc) rc = ensure_bytes(c, sbuf, 4 * ((size_t)N * M + 2));
+    if (!rc) rc = ensure_bytes(c, hbuf, 8 * 2 * (size_t)kOwnerMax);
+    if (!rc) rc = ensure_bytes(c, c->comm_meta, 8 * (W * ((size_t)N + 1) + 4 * ((size_t)N + 1)));
+    uint32_t* cnt = ptr<uint32_t>(c->w);
+    uint32_t* rowbase = ptr<uint32_t>(c->wscan);
+    unsigned long long* hist = ptr<unsigned long long>(hbuf);
+    std::vector<uint64_t> line(W, 0);                             // {failed, entries of my slice, entries of my rows, entries for the rows of rank 0 .. N-1}
+    uint32_t nsel32 = 0;
+    if (!rc) rc = [&]() -> int {
+        HIPCHK(c, hipMemsetAsync(hist, 0, 8 * 2 * (size_t)kOwnerMax, c->stream));
+        k_range_rowcount<<<nblk((uint64_t)nr + 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bk), nr, klo, khi, cnt);
+        KCHK(c);
+        k_owner_hist_rows<<<nblk(nr ? nr : 1), 256, 0, c->stream>>>(cnt, nr, (uint32_t)N, hist);
+        KCHK(c);
+        const int sr = scan_u32(c, cnt, rowbase, (uint64_t)nr + 1);
+        if (sr) return sr;
+        HIPCHK(c, hipMemcpyAsync(&nsel32, rowbase + nr, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(line.data() + 3, hist, 8 * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }();
+    const uint64_t nsel = nsel32;
+    // (2) buffers for the rank's share: what it sorts (nsel) and what it receives (nown_nnz)
+    const uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(nsel, nown_nnz), 1);
+    if (!rc) rc = ensure_bytes(c, c->lk_key, 4 * cap);
+    if (!rc) rc = ensure_bytes(c, c->lk_key2, 4 * cap);
+    if (!rc) rc = ensure_bytes(c, c->lk_val, 8 * cap);
+    if (!rc) rc = ensure_bytes(c, c->lk_val2, 8 * cap);
+    // (3) every rank's line to every rank: all take the same decision from the same table
+    if (!c->comm_meta.p) return done(rc ? rc : BELLA_ERR_NOMEM);  // (nothing to exchange through: cannot happen after the first collective call)
+    uint64_t* d_meta = ptr<uint64_t>(c->comm_meta);
+    line[0] = rc ? 1 : 0; line[1] = nsel; line[2] = nown_nnz;
+    std::vector<uint64_t> T(W * (size_t)N, 0);
+    {
+        hipError_t e = hipMemcpyAsync(d_meta + W * (size_t)N, line.data(), 8 * W, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        const ncclResult_t r = c->api->AllGather(d_meta + W * (size_t)N, d_meta, W, ncclUint64, c->comm, c->stream);
+        if (r != ncclSuccess) return done(rc ? rc : fail(c, BELLA_ERR_HIP, "layout metadata exchange failed"));
+        if (e == hipSuccess) e = hipMemcpyAsync(T.data(), d_meta, 8 * W * (size_t)N, hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) return done(rc ? rc : fail(c, BELLA_ERR_HIP, "layout metadata exchange: %s", hipGetErrorString(e)));
+        const int sr = comm_sync(c, "layout metadata");
+        if (sr) return done(rc ? rc : sr);
+    }
+    if (rc) return done(rc);
+    std::vector<uint64_t> abase((size_t)N + 1, 0), roffs((size_t)N + 1, 0), ooff((size_t)N + 1, 0);
+    for (int p = 0; p < N; ++p) {
+        if (T[W * (size_t)p]) return done(fail(c, BELLA_ERR_STATE, "rank %d failed inside the collective call; all ranks leave it", p));
+        abase[(size_t)p + 1] = abase[(size_t)p] + T[W * (size_t)p + 1];
+    }
+    if (abase[(size_t)N] != nnz)
+        return done(fail(c, BELLA_ERR_STATE, "the ranks' slices hold %llu of %llu entries (different matrices or dictionaries?)",
+                         (unsigned long long)abase[(size_t)N], (unsigned long long)nnz));
+    for (int q = 0; q < N; ++q) {                                 // (every rank checks every rank's rows: the same verdict everywhere)
+        uint64_t got = 0;
+        for (int p = 0; p < N; ++p) got += T[W * (size_t)p + 3 + (size_t)q];
+        if (got != T[W * (size_t)q + 2])
+            return done(fail(c, BELLA_ERR_STATE, "the ranks hold %llu entries for the rows of rank %d, its rows have %llu", (unsigned long long)got, q,
+                             (unsigned long long)T[W * (size_t)q + 2]));
+    }
+    auto S = [&](int p, int q) { return T[W * (size_t)p + 3 + (size_t)q]; };    // entries rank p holds for the rows of rank q
+    for (int p = 0; p < N; ++p) { roffs[(size_t)p + 1] = roffs[(size_t)p] + S(p, me); ooff[(size_t)p + 1] = ooff[(size_t)p] + S(me, p); }
+    // (4) my entries in k-mer order
+    hipcub::DoubleBuffer<uint32_t> dk(ptr<uint32_t>(c->lk_key), ptr<uint32_t>(c->lk_key2));
+    hipcub::DoubleBuffer<uint64_t> dv(ptr<uint64_t>(c->lk_val), ptr<uint64_t>(c->lk_val2));
+    uint32_t *okey = nullptr, *rkey = nullptr;
+    uint64_t *oval = nullptr, *rval = nullptr;
+    rc = [&]() -> int {
+        if (nsel) {
+            k_layout_prep_range<<<nblk(nr, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos), nr,
+                                                                           ptr<uint32_t>(c->packed), ptr<uint64_t>(c->roff), c->kmer_size, nk, klo, khi,
+                                                                           rowbase, dk.Current(), dv.Current(), ptr<uint32_t>(c->status));
+            KCHK(c);
+            size_t tb = 0;
+            HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (uint64_t)nsel, 0, kbits, c->stream));
+            ENSURE(c, c->cubtmp, tb);
+            HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cubtmp.p, tb, dk, dv, (uint64_t)nsel, 0, kbits, c->stream));
+        }
+        // (5) where a row starts in ITS owner's B': owner-major lengths, one scan
+        uint2* rinfo = ptr<uint2>(c->lk_rinfo);
+        k_owner_lengths<<<nblk((uint64_t)N * M + 1), 256, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), nr, (uint32_t)N, M, ptr<uint32_t>(pbuf));
+        KCHK(c);
+        const int sr = scan_u32(c, ptr<uint32_t>(pbuf), ptr<uint32_t>(sbuf), (uint64_t)N * M + 1);
+        if (sr) return sr;
+        k_layout_rinfo_owner<<<nblk(nr ? nr : 1), 256, 0, c->stream>>>(ptr<uint32_t>(sbuf), ptr<uint64_t>(c->roff), nr, (uint32_t)N, M, rinfo);
+        KCHK(c);
+        // (6) my slice of A' (in place in the whole array) and the B' entries of all rows for my k-mers, each into its owner's range
+        okey = dk.Alternate(); oval = dv.Alternate();
+        rkey = dk.Current(); rval = dv.Current();                 // (the sorted arrays are free after this pass: what the rank receives goes there)
+        if (nsel) {
+            HIPCHK(c, hipMemcpyAsync(hist + kOwnerMax, ooff.data(), 8 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+            k_layout_emit<<<nblk(nsel, kLayoutEmitPartBlock), kLayoutEmitPartBlock, 0, c->stream>>>(
+                dk.Current(), dv.Current(), nsel, ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bloc), ptr<uint32_t>(c->wscan), ptr<uint32_t>(c->packed),
+                ptr<uint64_t>(c->roff), c->kmer_size, rmask, ptr<uint2>(c->Aent), okey, oval, 1u, (uint32_t)me, (uint32_t)N, nullptr, ptr<uint32_t>(c->status),
+                inl, rinfo, (uint32_t)abase[(size_t)me], hist + kOwnerMax);
+            KCHK(c);
+        }
+        return 0;
+    }();
+    // A rank that could not launch its passes still takes part in the exchange (the sizes are agreed: nobody waits); its error leaves
+    // with the closing agreement.
+    // (7) the two exchanges, one group: B' entries to their owners, slices of A' into place
+    hipError_t he = hipSuccess;
+    ncclResult_t nr2 = ncclSuccess;
+    if (okey) {
+        if (S(me, me)) {
+            he = hipMemcpyAsync(rkey + roffs[(size_t)me], okey + ooff[(size_t)me], 4 * (size_t)S(me, me), hipMemcpyDeviceToDevice, c->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(rval + roffs[(size_t)me], oval + ooff[(size_t)me], 8 * (size_t)S(me, me), hipMemcpyDeviceToDevice, c->stream);
+        }
+        uint64_t* A64 = ptr<uint64_t>(c->Aent);
+        nr2 = c->api->GroupStart();
+        for (int p = 0; p < N && nr2 == ncclSuccess; ++p) {
+            if (p == me) continue;
+            const uint64_t to = S(me, p), from = S(p, me), theirs = T[W * (size_t)p + 1];
+            if (to) {
+                nr2 = c->api->Send(okey + ooff[(size_t)p], to, ncclUint32, p, c->comm, c->stream);
+                if (nr2 == ncclSuccess) nr2 = c->api->Send(oval + ooff[(size_t)p], to, ncclUint64, p, c->comm, c->stream);
+            }
+            if (from && nr2 == ncclSuccess) {
+                nr2 = c->api->Recv(rkey + roffs[(size_t)p], from, ncclUint32, p, c->comm, c->stream);
+                if (nr2 == ncclSuccess) nr2 = c->api->Recv(rval + roffs[(size_t)p], from, ncclUint64, p, c->comm, c->stream);
+            }
+            if (nsel && nr2 == ncclSuccess) nr2 = c->api->Send(A64 + abase[(size_t)me], nsel, ncclUint64, p, c->comm, c->stream);
+            if (theirs && nr2 == ncclSuccess) nr2 = c->api->Recv(A64 + abase[(size_t)p], theirs, ncclUint64, p, c->comm, c->stream);
+        }
+        {
+            const ncclResult_t ge = c->api->GroupEnd();           // the group is closed on every path
+            if (nr2 == ncclSuccess) nr2 = ge;
+        }
+    }
+    uint32_t st = 0;
+    if (he == hipSuccess && nr2 == ncclSuccess) he = hipMemcpyAsync(&st, ptr<uint32_t>(c->status), 4, hipMemcpyDeviceToHost, c->stream);
+    if (nr2 != ncclSuccess || he != hipSuccess) {
+        (void)hipStreamSynchronize(c->stream);
+        if (!rc) rc = fail(c, BELLA_ERR_HIP, "layout exchange failed: %s", nr2 != ncclSuccess ? (c->api->GetErrorString ? c->api->GetErrorString(nr2) : "RCCL error") : hipGetErrorString(he));
+    } else {
+        const int sr = comm_sync(c, "layout exchange");
+        if (!rc) rc = sr;
+        if (!rc) rc = status_to_error(c, st);
+    }
+    rc = comm_agree(c, rc);                                       // all ranks hold the layout's inputs, or all leave
+    if (rc) return done(rc);
+    *ekey_out = rkey; *eval_out = rval; *fkey_out = okey; *fval_out = oval;
+    return done(0);
+}
+}  // namespace
+}  // extern "C++"
+
 int bella_hip_allgather_panels(bella_ctx* c) {
     if (!c) return BELLA_ERR_BAD_ARG;
     if (!c->comm) return fail(c, BELLA_ERR_STATE, "bella_hip_comm_init first");
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->comm_ranks, me = c->comm_rank;
+    c->dist_agreed = false;
     // a rank without a panel still takes part in the status exchange: all ranks leave the call together
     int rc = comm_agree(c, c->have_panel ? 0 : fail(c, BELLA_ERR_STATE, "assemble_panel first"));
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     // who holds what: {first read, rows, nnz} of every rank
     ENSURE(c, c->comm_meta, 8 * 4 * ((size_t)N + 1));
-    uint64_t mine[4] = {c->panel_first, c->panel_rows, c->panel_nnz, c->nkmers};
+    // (the fourth word also says whether this rank can take the shared formation of A': all must, or none does)
+    uint64_t mine[4] = {c->panel_first, c->panel_rows, c->panel_nnz, (uint64_t)c->nkmers | (layout_dist_eligible(c) ? 1ull << 32 : 0ull)};
     uint64_t* d_meta = ptr<uint64_t>(c->comm_meta);
     HIPCHK(c, hipMemcpyAsync(d_meta + 4 * (size_t)N, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
     NCCLCHK(c, c->api->AllGather(d_meta + 4 * (size_t)N, d_meta, 4, ncclUint64, c->comm, c->stream));
@@ -1884,7 +2106,10 @@ int bella_hip_allgather_panels(bella_ctx* c) {
     if (rc) return rc;
     // (the checks below see the same numbers on every rank: all ranks fail them together)
     std::vector<uint64_t> roff((size_t)N + 1, 0), eoff((size_t)N + 1, 0);
+    c->dist_agreed = true;
     for (int r = 0; r < N; ++r) {
+        if (!(meta[4 * r + 3] >> 32)) c->dist_agreed = false;
+        meta[4 * r + 3] &= 0xFFFFFFFFull;
         if (meta[4 * r] != roff[r]) return fail(c, BELLA_ERR_BAD_ARG, "panels must be consecutive read blocks in rank order (rank %d starts at %llu, expected %llu)",
                                                 r, (unsigned long long)meta[4 * r], (unsigned long long)roff[r]);
         if (meta[4 * r + 3] != meta[3]) return fail(c, BELLA_ERR_BAD_ARG, "rank %d counted a different k-mer dictionary", r);
@@ -1943,7 +2168,7 @@ int bella_hip_allgather_panels(bella_ctx* c) {
     c->have_panel = false;
     c->have_matrix = c->have_pairs = c->have_alns = false;
     c->nnz = nnz;
-    rc = build_layout(c);
+    rc = build_layout(c, true);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev[1]));
@@ -2774,6 +2999,7 @@ int bella_hip_get_memory(bella_ctx* c, bella_memory* m) {
                           &c->seeds, &c->xest, &c->xest2, &c->xids, &c->xorder, &c->xres, &c->xstate, &c->xlive, &c->lg_res, &c->lg_redo, &c->lg_scratch, &c->status, &c->comm_meta});
     m->other_bytes += c->pool.bytes;                               // (released buffers waiting for the next request they fit)
     m->owned_nnz = c->have_matrix ? c->owned_nnz : 0;
+    m->layout_shared = c->have_matrix && c->layout_dist ? 1 : 0;
     return 0;
 }
 

@@ -434,7 +434,7 @@ def main():
             info["asm_ms"] += eng.timings().assemble_ms
             mem = eng.memory()
             info["mem"] = {"layout_B_bytes": int(mem.layout_B_bytes), "layout_A_bytes": int(mem.layout_A_bytes), "matrix_bytes": int(mem.matrix_bytes),
-                           "owned_nnz": int(mem.owned_nnz)}
+                           "owned_nnz": int(mem.owned_nnz), "layout_shared": int(mem.layout_shared)}
         info["lib_failures"] = info_fail
         info["setup_wall_ms"] = (time.time() - t_setup) * 1e3                     # reads on the device -> operands laid out (count + assemble + exchange + layout)
         return eng, info
@@ -645,6 +645,8 @@ def main():
             "setup_ms_max_over_ranks": m["setup_ms_max"], "layout_ms_max_over_ranks": m["layout_ms_max"],
             "per_rank_layout": {"B_bytes_max": m["layout_B_bytes_max"], "B_bytes_sum": m["layout_B_bytes_sum"], "owned_nnz_max": m["owned_nnz_max"],
                                 "owned_nnz_sum": m["owned_nnz_sum"], "nnz": nnz,
+                                "formation": ("shared: every rank sorts its N-th of the k-mer id space, slices of A' and B' entries exchanged (BELLA_TUNE_DIST_LAYOUT)"
+                                              if (info.get("mem") or {}).get("layout_shared") else "replicated: every rank sorts all entries"),
                                 "note": "B' (10 B per entry) exists for the rank's own columns only; A' (8 B per entry) and the exchanged matrix (6 B) are whole on every rank"},
             "xdrop": xd,
             "single_gpu_same_workload": single,

@@ -1642,11 +1642,14 @@ def _run_ranks(nranks, body, timeout=300):
     return out, err
 
 
+@pytest.mark.parametrize("shared", [False, True])
 @pytest.mark.parametrize("bounds", [[0, 70, 150], [0, 90, 90, 150], [0, 1, 60, 150]])
-def test_collectives_with_several_ranks_on_the_in_process_transport(bounds):
+def test_collectives_with_several_ranks_on_the_in_process_transport(bounds, shared):
     """The N > 1 logic of bella_hip_count_kmers_dist and bella_hip_allgather_panels -- code-space split, dictionary concatenation,
     grouped send/recv offsets, uneven panels, an empty panel -- on the one GPU there is: N contexts, one host thread each, the
-    library's in-process transport (bella_hip_comm_init_local) in RCCL's place.  Bit-exact against the one-shot assembly."""
+    library's in-process transport (bella_hip_comm_init_local) in RCCL's place.  Bit-exact against the one-shot assembly.
+    shared: A' formed over the ranks by k-mer range (BELLA_TUNE_DIST_LAYOUT, the default); else on every rank: the same layout entry
+    for entry, hence the same pairs in the same order."""
     from bella_amd import dist as bd
     nranks = len(bounds) - 1
     rs = synth.make_reads(150, read_len=2000, coverage=15.0, err=0.15, seed=43)
@@ -1670,9 +1673,12 @@ def test_collectives_with_several_ranks_on_the_in_process_transport(bounds):
         dic = e.get_dictionary()
         e.assemble_counted_panel(lo, n)
         e.set_partition(r, nranks)             # BEFORE the exchange: the layout it ends with holds B' for the owned columns only
+        if not shared and r != 1:              # (one rank that cannot is enough: the call asks every rank, all form A' whole)
+            e.set_tuning("dist_layout", 0)
         e.allgather_panels()
         B = e.get_B()
         mem = e.memory()
+        assert mem.layout_shared == (1 if shared else 0)
         e.overlap(BellaPars(skipAlignment=True))
         own = e.get_pairs()
         # another partition on a context laid out for (r, nranks): the layout is rebuilt from the resident B
