@@ -664,7 +664,9 @@ int bella_hip_init(int device, bella_ctx** out) {
         if (he == hipSuccess) he = hipDeviceGetStreamPriorityRange(&least, &greatest);
         int si = 0;
         for (auto& st : c->side) {
-            if (he == hipSuccess) he = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, si < 2 ? greatest : least);
+            // (the last one carries the host-driven sort-based path of wide.hpp next to the class launches: its small kernels and
+            // copies must not queue behind the classes' workgroups)
+            if (he == hipSuccess) he = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, si < 2 || si == kNumTiers ? greatest : least);
             ++si;
         }
     }
@@ -2340,10 +2342,10 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     KCHK(c);
     if (np) {
         // one workgroup per pair (closed-form fold); what it leaves over (lists of >= 32768 products, > 16 bins) to the serial fold
-        ENSURE(c, c->w_redo, 4 * ((size_t)np + 1));
+        ENSURE(c, c->w_redo, 4 * ((size_t)np + 4));
         a.redo = ptr<uint32_t>(c->w_redo);
-        HIPCHK(c, hipMemsetAsync(a.redo + np, 0, 4, c->stream));
-        ENSURE(c, c->w_desc, sizeof(WidePairAddr) * (size_t)np);
+        HIPCHK(c, hipMemsetAsync(a.redo + np, 0, 16, c->stream));   // (the redo count and the three class counts of k_wide_desc)
+        ENSURE(c, c->w_desc, 3 * sizeof(WidePairAddr) * (size_t)np);
         a.desc = (WidePairAddr*)c->w_desc.p;
         k_wide_desc<<<nblk(np), 256, 0, c->stream>>>(a);
         KCHK(c);
@@ -2353,8 +2355,20 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
         (void)hipMemsetAsync(d_clk, 0, 64, c->stream);
         a.clk = d_clk;
 #endif
-        k_wide_fold_wg<<<np < 16384u ? np : 16384u, kWideFoldBlock, 0, c->stream>>>(a);
+        // (three instances by list length, wide.hpp: the class counts are on the device, workgroups beyond a class's pairs leave at once)
+        // The instances run side by side (other pairs, other lists; the redo list and its counter take atomics): the short lists on a
+        // stream of their own, so that one instance's last pairs do not hold up the next one's first.
+        hipStream_t const s2 = c->side[kNumTiers - 1];
+        HIPCHK(c, hipEventRecord(c->fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(s2, c->fork, 0));
+        k_wide_fold_wg<kWideFoldBlockLarge, kWideFoldMid, kGridBucketsLarge, 1, 6><<<np < 16384u ? np : 16384u, kWideFoldBlockLarge, 0, c->stream>>>(a);
         KCHK(c);
+        k_wide_fold_wg<kWideFoldBlockSmall, kWideFoldSmall, 2048, 0, 6><<<np < 16384u ? np : 16384u, kWideFoldBlockSmall, 0, s2>>>(a);
+        KCHK(c);
+        k_wide_fold_wg<kWideFoldBlockLarge, kWideFoldLdsLarge, kGridBucketsLarge, 2, 4><<<np < 4096u ? np : 4096u, kWideFoldBlockLarge, 0, c->stream>>>(a);
+        KCHK(c);
+        HIPCHK(c, hipEventRecord(c->join[kNumTiers - 1], s2));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[kNumTiers - 1], 0));
 #ifdef BELLA_WF_CLOCK
         {
             unsigned long long h[8];
@@ -2706,6 +2720,26 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
             if (rc) return rc;
         }
     }
+    // The columns of the sort-based path (wide.hpp) are other columns than the LDS classes': the path -- host-driven, several
+    // synchronisations -- runs on a stream of its own NEXT to the class launches above instead of after them (HiFi-like input with a
+    // raised -u, 10k reads: the classes take 1.35 ms of a pass whose wide path takes 8.7)
+    c->n_wide = tcnt[g_ntiers] + (mid_to_wide ? n_mid : 0);
+    if (c->n_wide) {
+        uint32_t* const widelist = (uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr);
+        hipStream_t const main_stream = c->stream, wst = c->side[kNumTiers];
+        HIPCHK(c, hipStreamWaitEvent(wst, c->ev[3], 0));
+        c->stream = wst;                                           // (everything run_wide enqueues, allocates for and waits on)
+        int rw = 0;
+        if (mid_to_wide) {
+            k_desc_cols<<<nblk(n_mid), 256, 0, c->stream>>>(ptr<uint4>(c->rowlists) + (size_t)(g_ntiers - 1) * nr, n_mid, widelist + tcnt[g_ntiers]);
+            if (hipGetLastError() != hipSuccess) rw = fail(c, BELLA_ERR_HIP, "k_desc_cols launch failed");
+        }
+        if (!rw) rw = run_wide(c, a, c->n_wide, widelist);
+        c->stream = main_stream;
+        if (rw) { (void)hipStreamSynchronize(wst); return rw; }
+        HIPCHK(c, hipEventRecord(c->join[kNumTiers], wst));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[kNumTiers], 0));
+    }
     for (int w = 0; w < 3; ++w)
         if (used[w]) {
             HIPCHK(c, hipEventRecord(c->join[w], c->side[w]));
@@ -2775,16 +2809,6 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         return 0;
     };
     if (!skip_rare) { rc = rerun_columns(); if (rc) return rc; }
-    c->n_wide = tcnt[g_ntiers] + (mid_to_wide ? n_mid : 0);
-    if (c->n_wide) {                                              // columns with >= 65536 products, and the mid-size ones (wide.hpp); host-driven
-        uint32_t* const widelist = (uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr);
-        if (mid_to_wide) {
-            k_desc_cols<<<nblk(n_mid), 256, 0, c->stream>>>(ptr<uint4>(c->rowlists) + (size_t)(g_ntiers - 1) * nr, n_mid, widelist + tcnt[g_ntiers]);
-            KCHK(c);
-        }
-        rc = run_wide(c, a, c->n_wide, widelist);
-        if (rc) return rc;
-    }
     EVREC(5);
     // the row kernels fold every pair themselves; only pairs that end with > 16 bins are left (their count stays on the device)
     if (!skip_rare) { k_fold_overflow<<<256, 64, 0, c->stream>>>(fa); KCHK(c); EVREC(8); }

@@ -392,9 +392,40 @@ __device__ __forceinline__ WidePairAddr desc_decode(uint32_t raw) {
     q.roffH = w[6] | ((uint64_t)w[7] << 32); q.roffV = w[8] | ((uint64_t)w[9] << 32); q.out = w[10] | ((uint64_t)w[11] << 32);
     return q;
 }
+// The descriptors leave in three classes by list length (k_wide_fold_wg has an instance per class): class c fills
+// desc[c * npairs ..) in the order its wavefronts arrive (one atomic per wavefront and class; neighbouring pairs stay neighbours),
+// the counts stand behind the redo list (redo[npairs + 1 + c]); the pair's own index travels in the descriptor (pad).
+constexpr uint32_t kWideFoldSmall = 1024, kWideFoldMid = 2048, kWideFoldTiny = 16;
+__device__ __forceinline__ uint32_t wide_fold_class(uint32_t mm) { return mm <= kWideFoldSmall ? 0u : mm <= kWideFoldMid ? 1u : 2u; }
 __global__ void k_wide_desc(WideArgs a) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < a.npairs) a.desc[r] = wide_pair_addr(a, r);
+    const bool ok = r < a.npairs;
+    WidePairAddr q{};
+    uint32_t cls = 3;
+    if (ok) { q = wide_pair_addr(a, r); q.pad = r; cls = wide_fold_class(q.mm); }
+    const uint32_t lane = lane_id();
+    {   // the shortest lists (a third of the pairs of a HiFi-like set have ONE product) are not worth a workgroup and its barriers:
+        // straight to the list of the serial fold (k_wide_fold: one lane per pair)
+        const bool tiny = ok && q.mm <= kWideFoldTiny;
+        const unsigned long long mask = __ballot(tiny);
+        if (mask) {
+            const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&a.redo[a.npairs], (uint32_t)__popcll(mask));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+            if (tiny) { a.redo[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = r; cls = 3; }
+        }
+    }
+#pragma unroll
+    for (uint32_t cc = 0; cc < 3; ++cc) {
+        const unsigned long long mask = __ballot(cls == cc);
+        if (!mask) continue;
+        const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&a.redo[a.npairs + 1 + cc], (uint32_t)__popcll(mask));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+        if (cls == cc) a.desc[(size_t)cc * a.npairs + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = q;
+    }
 }
 __device__ __forceinline__ void wide_write_pair(const WideArgs& a, const WidePairAddr& q, const FoldResult& fr) {
     const uint32_t key = q.key, cid = q.cid;
@@ -428,7 +459,6 @@ __device__ __forceinline__ void wide_write_pair(const WideArgs& a, const WidePai
 #ifndef BELLA_WIDE_FOLD_W
 #define BELLA_WIDE_FOLD_W 16
 #endif
-constexpr int kWideFoldBlock = BELLA_WIDE_FOLD_BLOCK;
 #ifndef BELLA_WIDE_FOLD_LDS
 #define BELLA_WIDE_FOLD_LDS 4096
 #endif
@@ -438,9 +468,20 @@ constexpr int kWideFoldBlock = BELLA_WIDE_FOLD_BLOCK;
 #ifndef BELLA_WIDE_GRID_BUCKETS
 #define BELLA_WIDE_GRID_BUCKETS 4096
 #endif
-constexpr uint32_t kGridBuckets = BELLA_WIDE_GRID_BUCKETS, kGridMax = BELLA_WIDE_FOLD_LDS < 4096 ? BELLA_WIDE_FOLD_LDS : 4096, kGridMin = 96;   // lists of kGridMin < m <= kGridMax products use the grid
-constexpr uint32_t kWideFoldLds = BELLA_WIDE_FOLD_LDS;                    // products of a list staged in LDS (positions + overlap estimates, 24 KB; with the grid 72 KB: two workgroups per CU)
-__global__ __launch_bounds__(kWideFoldBlock, 4) void k_wide_fold_wg(WideArgs a) {
+constexpr int kWideFoldBlockLarge = BELLA_WIDE_FOLD_BLOCK;
+constexpr uint32_t kWideFoldLdsLarge = BELLA_WIDE_FOLD_LDS, kGridBucketsLarge = BELLA_WIDE_GRID_BUCKETS;
+constexpr uint32_t kGridMin = 96;                                         // lists of kGridMin < m <= (staged products, at most 4,096) use the grid
+// Three instances share the pairs by list length (k_wide_desc sorts the descriptors into the classes): lists of up to kWideFoldSmall
+// products are staged with 2,048 buckets in 22 KB of LDS -- six 256-thread workgroups per CU --, lists of up to kWideFoldMid in 44 KB
+// (4,096 buckets, 512 threads, three per CU), the rest in 72 KB (two per CU, as all pairs until round 5).  A pair's ~8 phases are a
+// chain of barriers and LDS round trips: the pairs in flight are what fills a CU (HiFi-like reads with -u 40: 72 % of the products
+// stand in lists of 1,025 ... 2,048; that instance 4.33 -> 3.26 ms with three pairs per CU instead of two).
+constexpr int kWideFoldBlockSmall = 256;
+template <int kWideFoldBlock, uint32_t kWideFoldLds, uint32_t kGridBuckets, uint32_t kClass, int kMinWaves>
+__global__ __launch_bounds__(kWideFoldBlock, kMinWaves) void k_wide_fold_wg(WideArgs a) {
+    const uint32_t npairs = a.redo[a.npairs + 1 + kClass];          // this class's pairs, their descriptors
+    const WidePairAddr* const desc = a.desc + (size_t)kClass * a.npairs;
+    constexpr uint32_t kGridMax = kWideFoldLds < 4096 ? kWideFoldLds : 4096;
     __shared__ uint32_t s_flag, s_contrib, s_surv, s_roots;
     __shared__ unsigned long long s_best;
     __shared__ uint32_t s_hv[kWideFoldLds + 16];
@@ -476,14 +517,14 @@ __global__ __launch_bounds__(kWideFoldBlock, 4) void k_wide_fold_wg(WideArgs a) 
     uint2 pre[kPre];
     WidePairAddr d1{};                                             // of the pair r
     uint32_t d2raw = 0;                                            // of the pair r + gridDim.x (mm = 0 beyond the last pair)
-    if (blockIdx.x < a.npairs) d1 = a.desc[blockIdx.x];
-    if (blockIdx.x + gridDim.x < a.npairs) d2raw = desc_load_raw(a.desc + blockIdx.x + gridDim.x);
+    if (blockIdx.x < npairs) d1 = desc[blockIdx.x];
+    if (blockIdx.x + gridDim.x < npairs) d2raw = desc_load_raw(desc + blockIdx.x + gridDim.x);
     if (d1.mm <= kWideFoldLds) {
 #pragma unroll
         for (uint32_t u = 0; u < kPre; ++u) { const uint32_t y = tid + u * kWideFoldBlock; if (y < d1.mm) pre[u] = a.plist[d1.lo + y]; }
     }
-    for (uint32_t r = blockIdx.x; r < a.npairs; r += gridDim.x) {
-        const uint32_t mm = d1.mm;
+    for (uint32_t r = blockIdx.x; r < npairs; r += gridDim.x) {
+        const uint32_t mm = d1.mm, rg = d1.pad;                    // (rg: the pair's index among all pairs)
         const uint64_t lo = d1.lo;
         uint2* w = a.plist + lo;
         const bool staged = mm <= kWideFoldLds;
@@ -498,7 +539,7 @@ __global__ __launch_bounds__(kWideFoldBlock, 4) void k_wide_fold_wg(WideArgs a) 
             }
         }
         d1 = desc_decode(d2raw);                                   // the next pair: its list now, the descriptor of the one after it
-        if (d1.mm <= kWideFoldLds && r + gridDim.x < a.npairs) {
+        if (d1.mm <= kWideFoldLds && r + gridDim.x < npairs) {
 #pragma unroll
             for (uint32_t u = 0; u < kPre; ++u) {
                 const uint32_t y = tid + u * kWideFoldBlock;
@@ -506,9 +547,9 @@ __global__ __launch_bounds__(kWideFoldBlock, 4) void k_wide_fold_wg(WideArgs a) 
             }
         }
         d2raw = 0;
-        if ((uint64_t)r + 2ull * gridDim.x < a.npairs) d2raw = desc_load_raw(a.desc + r + 2 * gridDim.x);
+        if ((uint64_t)r + 2ull * gridDim.x < npairs) d2raw = desc_load_raw(desc + r + 2 * gridDim.x);
         if (mm >= kRoot) {                                         // parent links are u16
-            if (tid == 0) a.redo[atomicAdd(&a.redo[a.npairs], 1u)] = r;
+            if (tid == 0) a.redo[atomicAdd(&a.redo[a.npairs], 1u)] = rg;
             continue;
         }
         uint16_t* Par = a.sort_scratch + lo;
@@ -705,7 +746,7 @@ __global__ __launch_bounds__(kWideFoldBlock, 4) void k_wide_fold_wg(WideArgs a) 
         } else {
             const uint32_t nroots = s_roots;
             if (nroots > 16) {                                     // std::sort leaves the insertion-sort regime (common.h:145)
-                if (tid == 0) a.redo[atomicAdd(&a.redo[a.npairs], 1u)] = r;
+                if (tid == 0) a.redo[atomicAdd(&a.redo[a.npairs], 1u)] = rg;
                 __syncthreads();
                 continue;
             }
@@ -732,14 +773,14 @@ __global__ __launch_bounds__(kWideFoldBlock, 4) void k_wide_fold_wg(WideArgs a) 
         }
         ++npend;
         if (npend == kPend) {
-            if (tid < kPend) wide_write_pair(a, a.desc[s_pr[tid]], s_pfr[tid]);
+            if (tid < kPend) wide_write_pair(a, desc[s_pr[tid]], s_pfr[tid]);
             npend = 0;
         }
         WFCLK(6);
         __syncthreads();
         WFCLK(7);
     }
-    if (tid < npend) wide_write_pair(a, a.desc[s_pr[tid]], s_pfr[tid]);
+    if (tid < npend) wide_write_pair(a, desc[s_pr[tid]], s_pfr[tid]);
 #ifdef BELLA_WF_CLOCK
     if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&a.clk[i], c_acc[i]);
 #endif
