@@ -31,6 +31,7 @@ hipcc --offload-arch=gfx950 -O3 -w -o /tmp/valu_rates tools/ubench/valu_rates.hi
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/lds_ops tools/ubench/lds_ops.hip && /tmp/lds_ops > $OUT/${TAG}_lds_ops.txt 2>&1
 # the HiFi-like probe (columns above the LDS tiers on the sort-based path) and one rank's share of the strong-scaling run
 ( python tools/hifi_probe2.py 3000 40 1 2>&1 | tail -1; bash tools/hifi_trace.sh 3000 40 1 2>&1 | tail -18 ) > $OUT/${TAG}_hifi_probe.txt
+( python tools/hifi_probe2.py 10000 40 1 2>&1 | tail -1; bash tools/hifi_trace.sh 10000 40 1 2>&1 | tail -18 ) > $OUT/${TAG}_hifi_probe_10k.txt
 python tools/rank_probe.py 2 4 8 2>&1 | tail -8 > $OUT/${TAG}_rank_probe_100k.txt
 # the front end kernel by kernel, and the N > 1 branch of bench.py end to end on this one GPU (two ranks, gloo rendezvous)
 bash tools/frontend_trace.sh 100000 > $OUT/${TAG}_frontend_100k.txt 2>&1
