@@ -391,6 +391,7 @@ int build_layout(bella_ctx* c, bool collective = false) {
     // there still says so in the formation's metadata exchange -- the others leave instead of waiting for it
     const bool dist = collective && c->dist_agreed;
     struct Bail { bella_ctx* c; bool armed; ~Bail() { if (armed) layout_dist_fail(c); } } bail{c, dist};
+    if (dist && (c->debug & 262144u)) return fail(c, BELLA_ERR_STATE, "debug bit 18: this rank fails before its share of the formation");
     if (!dist) {                                                   // (shared: the sort buffers are sized by the rank's share)
         ENSURE(c, c->lk_key, 4 * nnz);
         ENSURE(c, c->lk_key2, 4 * nnz);

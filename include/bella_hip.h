@@ -350,7 +350,9 @@ int bella_hip_get_memory(bella_ctx* ctx, bella_memory* m);
  * long to share a 64-bit sort key with their position, and of the distributed count) also where the sorted words carry their positions;
  * bit15 (read when the operands are assembled) = tests: every entry of B' in the plain form (default, when A' is larger than the last-level
  * cache: an entry whose k-mer has exactly one later read carries that read instead of an index into A'; the plain form is also that of
- * inputs with 2^30 reads or 2^31 nonzeros and more); bit16 (same moment) = tests: that inline form on inputs of any size */
+ * inputs with 2^30 reads or 2^31 nonzeros and more); bit16 (same moment) = tests: that inline form on inputs of any size;
+ * bit18 = tests: inside bella_hip_allgather_panels this rank fails after the ranks agreed on the shared formation of A' and before its own
+ * share begins (every rank must leave the call with an error, none may wait) */
 int bella_hip_set_debug(bella_ctx* ctx, uint32_t flags);
 /* Reserve device memory up front: ONE slab of `bytes` taken from the driver (and touched) now, from which the stages' buffers are cut
  * afterwards.  The reference has no counterpart (its vectors grow on the host); here the first hipMalloc of a multi-GB buffer costs

@@ -1736,6 +1736,20 @@ def test_a_failing_rank_takes_all_ranks_out_of_the_collective():
     out, err = _run_ranks(3, body, timeout=120)
     assert sorted(r for r, _ in err) == [0, 1, 2] and all(isinstance(e, BellaHipError) for _, e in err)
 
+    def body3(r):                              # a rank that fails AFTER the ranks agreed on the shared formation of A', before its share begins
+        e = engines[r]
+        e.count_kmers_dist(bounds[r], bounds[r + 1] - bounds[r], 17, 2, 8)
+        e.assemble_counted_panel(bounds[r], bounds[r + 1] - bounds[r])
+        e.set_partition(r, 3)
+        e.set_debug(262144 if r == 1 else 0)
+        try:
+            e.allgather_panels()
+        finally:
+            e.set_debug(0)
+        return True
+    out, err = _run_ranks(3, body3, timeout=120)
+    assert sorted(r for r, _ in err) == [0, 1, 2] and all(isinstance(e, BellaHipError) for _, e in err)
+
     def body2(r):                              # a rank with a bad ARGUMENT (k = 40) takes part in the agreement too: nobody waits for its dictionary
         engines[r].count_kmers_dist(bounds[r], bounds[r + 1] - bounds[r], 40 if r == 2 else 17, 2, 8)
         return True
