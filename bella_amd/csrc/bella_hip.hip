@@ -2198,7 +2198,8 @@ __global__ void k_wide_sizes(const uint32_t* cols, const uint32_t* flops, uint32
 }
 
 // columns with >= 65536 products: expand -> sort by (column, partner) -> pairs -> slot order -> serial fold (wide.hpp)
-static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint32_t* d_cols) {
+// T: the batch's products (run_wide has the columns' sizes on the host: no second trip for their sum)
+static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint32_t* d_cols, uint64_t T) {
     ENSURE(c, c->w_f, 4 * ((size_t)nw + 2));
     ENSURE(c, c->w_off, 8 * ((size_t)nw + 2));
     ENSURE(c, c->w_nruns, 16);
@@ -2206,9 +2207,6 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     KCHK(c);
     int rc = scan_u32_to_u64(c, ptr<uint32_t>(c->w_f), ptr<uint64_t>(c->w_off), (uint64_t)nw + 1);
     if (rc) return rc;
-    uint64_t T = 0;
-    HIPCHK(c, hipMemcpyAsync(&T, ptr<uint64_t>(c->w_off) + nw, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (T >= 0x7FFF0000ull) return fail(c, BELLA_ERR_ROW_TOO_LARGE, "the columns with >= 65536 products hold %llu products together (limit 2^31)",
                                         (unsigned long long)T);
     ENSURE(c, c->w_plist, 8 * (T + 64)); ENSURE(c, c->w_scr, 2 * T);
@@ -2402,7 +2400,7 @@ static int run_wide(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint3
         uint64_t t = wf[b];
         uint32_t e = b + 1;
         while (e < nw && t + wf[e] <= budget) t += wf[e++];
-        int rc = run_wide_batch(c, sa, e - b, d_cols + b);
+        int rc = run_wide_batch(c, sa, e - b, d_cols + b, t);
         if (rc) return rc;
         b = e;
     }

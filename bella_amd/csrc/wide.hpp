@@ -393,39 +393,39 @@ __device__ __forceinline__ WidePairAddr desc_decode(uint32_t raw) {
     return q;
 }
 // The descriptors leave in three classes by list length (k_wide_fold_wg has an instance per class): class c fills
-// desc[c * npairs ..) in the order its wavefronts arrive (one atomic per wavefront and class; neighbouring pairs stay neighbours),
+// desc[c * npairs ..) in the order its workgroups arrive (neighbouring pairs stay neighbours),
 // the counts stand behind the redo list (redo[npairs + 1 + c]); the pair's own index travels in the descriptor (pad).
 constexpr uint32_t kWideFoldSmall = 1024, kWideFoldMid = 2048, kWideFoldTiny = 16;
 __device__ __forceinline__ uint32_t wide_fold_class(uint32_t mm) { return mm <= kWideFoldSmall ? 0u : mm <= kWideFoldMid ? 1u : 2u; }
-__global__ void k_wide_desc(WideArgs a) {
+__global__ __launch_bounds__(256) void k_wide_desc(WideArgs a) {
+    // class 3: the shortest lists (a third of the pairs of a HiFi-like set have ONE product) are not worth a workgroup and its barriers:
+    // straight to the list of the serial fold (k_wide_fold: one lane per pair).  One global atomic per WORKGROUP and class (the four
+    // counters share a cache line: one per wavefront was 30,000 atomics queueing on it, 0.17 ms at 479 k pairs).
+    __shared__ uint32_t s_cnt[4], s_base[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = r < a.npairs;
     WidePairAddr q{};
-    uint32_t cls = 3;
-    if (ok) { q = wide_pair_addr(a, r); q.pad = r; cls = wide_fold_class(q.mm); }
+    uint32_t cls = 4;
+    if (ok) { q = wide_pair_addr(a, r); q.pad = r; cls = q.mm <= kWideFoldTiny ? 3u : wide_fold_class(q.mm); }
     const uint32_t lane = lane_id();
-    {   // the shortest lists (a third of the pairs of a HiFi-like set have ONE product) are not worth a workgroup and its barriers:
-        // straight to the list of the serial fold (k_wide_fold: one lane per pair)
-        const bool tiny = ok && q.mm <= kWideFoldTiny;
-        const unsigned long long mask = __ballot(tiny);
-        if (mask) {
-            const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&a.redo[a.npairs], (uint32_t)__popcll(mask));
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
-            if (tiny) { a.redo[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = r; cls = 3; }
-        }
-    }
+    uint32_t at = 0;                                               // my place among the workgroup's pairs of my class
 #pragma unroll
-    for (uint32_t cc = 0; cc < 3; ++cc) {
+    for (uint32_t cc = 0; cc < 4; ++cc) {
         const unsigned long long mask = __ballot(cls == cc);
         if (!mask) continue;
         const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
         uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&a.redo[a.npairs + 1 + cc], (uint32_t)__popcll(mask));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
-        if (cls == cc) a.desc[(size_t)cc * a.npairs + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = q;
+        if (lane == leader) base = atomicAdd(&s_cnt[cc], (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, (int)leader, 64);
+        if (cls == cc) at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     }
+    __syncthreads();
+    if (threadIdx.x < 4 && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&a.redo[a.npairs + (threadIdx.x == 3 ? 0u : 1u + threadIdx.x)], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (cls == 3) a.redo[s_base[3] + at] = r;
+    else if (cls < 3) a.desc[(size_t)cls * a.npairs + s_base[cls] + at] = q;
 }
 __device__ __forceinline__ void wide_write_pair(const WideArgs& a, const WidePairAddr& q, const FoldResult& fr) {
     const uint32_t key = q.key, cid = q.cid;
