@@ -196,6 +196,7 @@ struct bella_ctx {
     uint64_t pass_sig[6] = {};
     uint32_t pass_tcnt[20] = {};
     uint64_t pass_products = 0;
+    uint64_t pass_wide_products[2] = {};  // ... of the last tier's columns and of the wide columns (what wide.hpp's path will hold)
     bool pass_rare_free = false;         // the last pass on pass_sig needed no rerun, no overflow fold, no wide column
     bool pass_big_free = false;          // ... and had no column with more than 1,024 pairs (k_order_block)
     uint32_t tier_caps[kNumTiers] = {};  // ascending LDS caps, last = 65535 (global-workspace tier); per context
@@ -2388,7 +2389,10 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
 }
 
 // batches of wide columns holding at most `budget` products each (38 bytes of HBM per product in flight)
-static int run_wide(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint32_t* d_cols) {
+// Tall: the products of all nw columns (known from the symbolic kernels' control block): when they fit one batch -- the usual case -- the
+// columns' sizes need not come to the host at all
+static int run_wide(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint32_t* d_cols, uint64_t Tall) {
+    if (Tall && Tall <= c->wide_budget) return run_wide_batch(c, sa, nw, d_cols, Tall);
     ENSURE(c, c->w_f, 4 * ((size_t)nw + 2));
     k_wide_sizes<<<nblk((uint64_t)nw + 1), 256, 0, c->stream>>>(d_cols, ptr<uint32_t>(c->flopsr), nw, ptr<uint32_t>(c->w_f));
     KCHK(c);
@@ -2523,10 +2527,11 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     uint32_t* const tcnt = c->pass_tcnt;
     if (!warm) {
         c->pass_known = false;
-        HIPCHK(c, hipMemcpyAsync(c->pinned, d_ctl + kCtlTierCnt, 4 * (kCtlTotals + 4 - kCtlTierCnt), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->pinned, d_ctl + kCtlTierCnt, 4 * (kCtlTotals + 8 - kCtlTierCnt), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         std::memcpy(c->pass_tcnt, c->pinned, sizeof(c->pass_tcnt));
         std::memcpy(&c->pass_products, c->pinned + (kCtlTotals - kCtlTierCnt) + 2, 8);
+        std::memcpy(c->pass_wide_products, c->pinned + (kCtlTotals - kCtlTierCnt) + 4, 16);
         std::memcpy(c->pass_sig, psig, sizeof(psig));
     }
     // the product-sized buffers follow THIS pass's product count (a column partition or a stage only pays for its share; the
@@ -2733,7 +2738,7 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
             k_desc_cols<<<nblk(n_mid), 256, 0, c->stream>>>(ptr<uint4>(c->rowlists) + (size_t)(g_ntiers - 1) * nr, n_mid, widelist + tcnt[g_ntiers]);
             if (hipGetLastError() != hipSuccess) rw = fail(c, BELLA_ERR_HIP, "k_desc_cols launch failed");
         }
-        if (!rw) rw = run_wide(c, a, c->n_wide, widelist);
+        if (!rw) rw = run_wide(c, a, c->n_wide, widelist, c->pass_wide_products[1] + (mid_to_wide ? c->pass_wide_products[0] : 0));
         c->stream = main_stream;
         if (rw) { (void)hipStreamSynchronize(wst); return rw; }
         HIPCHK(c, hipEventRecord(c->join[kNumTiers], wst));

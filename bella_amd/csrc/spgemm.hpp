@@ -68,7 +68,7 @@ constexpr uint32_t kCtlStatus = 19;       // bit0: a pair ended with > 16 bins a
 constexpr uint32_t kCtlRetry = 21;        // columns whose key table overflowed in an LDS tier (rerun on the global path)
 constexpr uint32_t kCtlOrderBig = 22;     // columns with more than 1,024 pairs, left to k_order_block (order.hpp)
 constexpr uint32_t kCtlTierCnt = 32;      // [16] columns per tier, last used entry = wide columns
-constexpr uint32_t kCtlTotals = 48;       // u64[2]: nnz(C), products (8-byte aligned)
+constexpr uint32_t kCtlTotals = 48;       // u64[4]: nnz(C), products, products of the last tier's columns, of the wide columns (8-byte aligned)
 constexpr uint32_t kCtlWords = 64;
 
 struct SpgemmArgs {
@@ -1003,6 +1003,14 @@ __global__ __launch_bounds__(kBlock) void k_tier_lists(const uint32_t* flops, ui
         if (lane_id() == 0 && tot) base = atomicAdd(total, tot);
         base = __shfl(base, 0, 64);
         if (j < nown) obase[i] = base + inc - f;
+        // the products of the columns above the LDS tiers (total[1]: <= 65,535 products each, the last tier) and of the wide ones
+        // (total[2]): what the sort-based path of wide.hpp will hold -- the host sizes its batch from it without asking again
+        if (__ballot(tier + 1 >= ntiers && tier != 0xFFFFFFFFu)) {
+            unsigned long long m2 = tier + 1 == ntiers ? f : 0u, w2 = tier == ntiers ? f : 0u;
+#pragma unroll
+            for (int dlt = 32; dlt > 0; dlt >>= 1) { m2 += __shfl_xor(m2, dlt, 64); w2 += __shfl_xor(w2, dlt, 64); }
+            if (lane_id() == 0) { if (m2) atomicAdd(total + 1, m2); if (w2) atomicAdd(total + 2, w2); }
+        }
     }
     uint32_t my = 0;                                       // place inside the workgroup's share of my tier's list
     for (uint32_t t = 0; t <= ntiers; ++t) {
