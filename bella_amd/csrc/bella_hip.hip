@@ -2004,8 +2004,9 @@ int layout_dist(bella_ctx* c, uint64_t nown_nnz, uint32_t rmask, uint32_t inl, i
     // (4) my entries in k-mer order
     hipcub::DoubleBuffer<uint32_t> dk(ptr<uint32_t>(c->lk_key), ptr<uint32_t>(c->lk_key2));
     hipcub::DoubleBuffer<uint64_t> dv(ptr<uint64_t>(c->lk_val), ptr<uint64_t>(c->lk_val2));
-    uint32_t *okey = nullptr, *rkey = nullptr;
-    uint64_t *oval = nullptr, *rval = nullptr;
+    // (valid buffers of the agreed sizes whatever happens below: a rank whose passes fail still moves its -- then meaningless -- share)
+    uint32_t *okey = ptr<uint32_t>(c->lk_key2), *rkey = ptr<uint32_t>(c->lk_key);
+    uint64_t *oval = ptr<uint64_t>(c->lk_val2), *rval = ptr<uint64_t>(c->lk_val);
     rc = [&]() -> int {
         if (nsel) {
             k_layout_prep_range<<<nblk(nr, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bk), ptr<uint16_t>(c->Bpos), nr,
@@ -2043,7 +2044,7 @@ int layout_dist(bella_ctx* c, uint64_t nown_nnz, uint32_t rmask, uint32_t inl, i
     // (7) the two exchanges, one group: B' entries to their owners, slices of A' into place
     hipError_t he = hipSuccess;
     ncclResult_t nr2 = ncclSuccess;
-    if (okey) {
+    {
         if (S(me, me)) {
             he = hipMemcpyAsync(rkey + roffs[(size_t)me], okey + ooff[(size_t)me], 4 * (size_t)S(me, me), hipMemcpyDeviceToDevice, c->stream);
             if (he == hipSuccess) he = hipMemcpyAsync(rval + roffs[(size_t)me], oval + ooff[(size_t)me], 8 * (size_t)S(me, me), hipMemcpyDeviceToDevice, c->stream);
