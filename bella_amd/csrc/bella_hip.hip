@@ -2229,6 +2229,7 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     a.R_first = nullptr;
     uint32_t np = 0;
     bool grouped = false;
+    std::vector<uint32_t> segf;                                    // first pair of every column (host: sizes of the slot-order tables)
     // wide columns with few partners (HiFi-like input): group in LDS, two streaming passes over the columns' products (wide.hpp) --
     // unless a column's partners do not fit the table, the lane-order self-test failed, or debug bit 12 asks for the sort-based path
     // (tests).  The products are read from the row lists; a layout without them (the default) expands the BATCH's columns into a
@@ -2257,9 +2258,12 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
         rc = scan_u32(c, ptr<uint32_t>(c->w_gcount), ptr<uint32_t>(c->w_gbase), (uint64_t)nw + 1);
         if (rc) return rc;
         uint32_t fin[2] = {0, 0};
-        HIPCHK(c, hipMemcpyAsync(&fin[0], ptr<uint32_t>(c->w_gbase) + nw, 4, hipMemcpyDeviceToHost, c->stream));
+        // (the columns' first pairs come along: the slot-order tables below are sized from them -- no trip of their own after the append pass)
+        segf.resize((size_t)nw + 1);
+        HIPCHK(c, hipMemcpyAsync(segf.data(), ptr<uint32_t>(c->w_gbase), 4 * ((size_t)nw + 1), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(&fin[1], ptr<uint32_t>(c->w_gcount) + nw + 1, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        fin[0] = segf[nw];
         if (fin[1] == 0) {
             np = fin[0];
             ENSURE(c, c->w_rlen, 4 * ((size_t)np + 1)); ENSURE(c, c->w_rstart, 4 * ((size_t)np + 2)); ENSURE(c, c->w_rrank, 4 * ((size_t)np + 1));
@@ -2320,9 +2324,11 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
         k_wide_segments<<<nblk((uint64_t)np + 1), 256, 0, c->stream>>>(a);
         KCHK(c);
     }
-    std::vector<uint32_t> segf((size_t)nw + 1);
-    HIPCHK(c, hipMemcpyAsync(segf.data(), a.seg_first, 4 * ((size_t)nw + 1), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!grouped) {
+        segf.resize((size_t)nw + 1);
+        HIPCHK(c, hipMemcpyAsync(segf.data(), a.seg_first, 4 * ((size_t)nw + 1), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     std::vector<uint64_t> toff((size_t)nw + 1, 0);
     for (uint32_t s = 0; s < nw; ++s) {
         const uint64_t d = segf[s + 1] - segf[s];
