@@ -1643,7 +1643,7 @@ def _run_ranks(nranks, body, timeout=300):
 
 
 @pytest.mark.parametrize("shared", [False, True])
-@pytest.mark.parametrize("bounds", [[0, 70, 150], [0, 90, 90, 150], [0, 1, 60, 150]])
+@pytest.mark.parametrize("bounds", [[0, 70, 150], [0, 90, 90, 150], [0, 1, 60, 150], [0, 40, 40, 100, 149, 150]])
 def test_collectives_with_several_ranks_on_the_in_process_transport(bounds, shared):
     """The N > 1 logic of bella_hip_count_kmers_dist and bella_hip_allgather_panels -- code-space split, dictionary concatenation,
     grouped send/recv offsets, uneven panels, an empty panel -- on the one GPU there is: N contexts, one host thread each, the
