@@ -243,7 +243,7 @@ class Engine:
 
     # ---- HashSpGEMM ----
     TUNE = {"lds_tiers": 0, "kcount_budget": 1, "wide_budget": 2, "xdrop_variant": 3, "row_lists": 4, "xdrop_class_min": 5,
-            "layout_order": 6, "inline_entries": 7, "row_path": 8, "cache_bytes": 9, "dist_layout": 10}
+            "layout_order": 6, "inline_entries": 7, "row_path": 8, "cache_bytes": 9, "dist_layout": 10, "compact_b": 11}
 
     def reserve(self, nbytes: int) -> float:
         """bella_hip_reserve: one slab of device memory up front (the stages then allocate nothing from the driver); returns the ms it took"""

@@ -544,10 +544,41 @@ __global__ void k_layout_own_lengths(const uint32_t* Bptr, uint32_t nreads, uint
     len[i] = i < nreads && i % own_stride == own_first ? Bptr[i + 1] - Bptr[i] : 0u;
 }
 
+// ---- B' without the entries that have no later read (round 6) ---------------------------------------------------------------------
+// An entry of row i whose k-mer occurs in no read > i has no product in the strict lower triangle (overlap.hpp:157-202 counts none for
+// it, LocalSpGEMM :281-363 skips its whole list): 38 % of the entries at 30x coverage, nearly all entries of the last columns.  Every
+// pass streamed them, decoded them and scanned their zero counts.  They are dropped here, once: one wavefront per row counts its live
+// entries, a scan gives the new row pointers, a second pass moves the live entries -- in their order, so the product order of a column
+// (entry by entry, then down the list) is what it was.  BELLA_TUNE_COMPACT_B 1 keeps every entry (tests, A/B).
+__global__ __launch_bounds__(kBlock) void k_layout_live(const uint32_t* Bloc, const uint2* Bent, uint32_t nreads, uint32_t inl, uint32_t* len) {
+    const uint32_t i = blockIdx.x * kWaves + wave_id();
+    if (i > nreads) return;
+    uint32_t n = 0;
+    if (i < nreads)
+        for (uint32_t e = Bloc[i] + lane_id(); e < Bloc[i + 1]; e += 64) n += bent_count(Bent[e], inl) ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n += __shfl_xor(n, d, 64);
+    if (lane_id() == 0) len[i] = n;                                   // (len[nreads] = 0: the scan's last element)
+}
+__global__ __launch_bounds__(kBlock) void k_layout_compact(const uint32_t* Bloc, const uint32_t* Bnew, const uint2* Bent, uint32_t nreads, uint32_t inl,
+                                                           uint2* out) {
+    const uint32_t i = blockIdx.x * kWaves + wave_id();
+    if (i >= nreads) return;
+    const uint32_t b0 = Bloc[i], b1 = Bloc[i + 1];
+    uint32_t o = Bnew[i];
+    for (uint32_t e0 = b0; e0 < b1; e0 += 64) {
+        const uint32_t e = e0 + lane_id();
+        uint2 be = make_uint2(0u, 0u);
+        if (e < b1) be = Bent[e];
+        const bool live = e < b1 && bent_count(be, inl) != 0;
+        const unsigned long long m = __ballot(live);
+        if (live) out[o + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull))] = be;
+        o += (uint32_t)__popcll(m);
+    }
+}
+
 // the products of every entry once more, compact: estimateFLOP streams 2 B per nonzero.  (Its own pass, 0.43 ms at 100k reads: written
 // from k_layout_place next to the entry -- a scattered 2-byte store per entry -- that kernel goes from 2.8 to 7.5 ms.)
-// (Measured and not kept, round 4: B' without the entries that have no later read -- 38 % of the entries at 30x, nearly all entries of
-// the last columns: two more streaming passes at layout time, +0.9 ms at 100k reads, for 0.13 ms per pass.)
 __global__ void k_layout_bcnt(const uint2* Bent, uint64_t nnz, uint16_t* Bcnt, uint32_t inl) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < nnz) Bcnt[e] = (uint16_t)bent_count(Bent[e], inl);

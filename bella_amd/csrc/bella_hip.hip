@@ -155,7 +155,8 @@ struct bella_ctx {
     bool want_rowlists = false;          // BELLA_TUNE_ROW_LISTS: build them with the next layouts (when they fit)
     uint32_t part_first = 0, part_stride = 1;
     uint32_t layout_first = 0, layout_stride = 1;   // the partition the current layout was built for (B' / row lists: owned columns only)
-    uint64_t owned_nnz = 0;              // B' entries of the current layout
+    uint64_t owned_nnz = 0;              // nonzeros of the owned columns (what the current layout was built from)
+    uint64_t live_nnz = 0;               // B' entries of the current layout: those with a later read (all of them with BELLA_TUNE_COMPACT_B 1)
     uint64_t sym_sig[6] = {};            // what flops / nnzC were last cleared for
     uint64_t layout_gen = 0;             // bumped by every build of the device layout
     uint32_t range_lo = 0, range_hi = 0xFFFFFFFFu;   // stage: the contiguous column range computed by the next passes
@@ -211,6 +212,7 @@ struct bella_ctx {
     uint32_t tune_layout_order = 0;      // BELLA_TUNE_LAYOUT_ORDER: 0 lists of A' in k-mer order, 1 in order of first appearance in B'
     uint32_t tune_inline = 0;            // BELLA_TUNE_INLINE_ENTRIES: 0 by the size of A' against the last-level cache, 1 never, 2 always
     uint32_t tune_row_path = 0;          // BELLA_TUNE_ROW_PATH: 0 LDS tiers, 1 every column on the global-workspace (repairing) path
+    uint32_t tune_compact_b = 0;         // BELLA_TUNE_COMPACT_B: 0 the layout drops the B' entries that have no later read, 1 keeps them
     uint32_t tune_dist_layout = 1;       // BELLA_TUNE_DIST_LAYOUT: bella_hip_allgather_panels forms A' by k-mer id ranges over the communicator's ranks
     bool dist_agreed = false;            // ... and every rank of the communicator said it can (bella_hip_allgather_panels asks)
     bool layout_dist = false;            // ... and the current layout was built that way
@@ -518,13 +520,37 @@ int build_layout(bella_ctx* c, bool collective = false) {
             k_layout_place<<<((nblk(nown_nnz) + 7u) / 8u) * 8u, 256, 0, c->stream>>>(ek.Current(), ev.Current(), nown_nnz, ptr<uint2>(c->Bent));
             KCHK(c);
         }
-        if (nown_nnz) {
-            int rc = ensure_bytes(c, c->Bcnt, 2 * nown_nnz);
+        c->owned_nnz = nown_nnz;
+        c->live_nnz = nown_nnz;
+        if (nown_nnz && !c->tune_compact_b) {
+            // B' without the entries that have no later read (assemble.hpp: k_layout_live / k_layout_compact): new row pointers by a scan
+            // of the rows' live counts, the live entries moved in their order; from here on Bloc indexes the compacted B'
+            uint32_t* len = ptr<uint32_t>(c->w);
+            uint32_t* bnew = ptr<uint32_t>(c->wscan);
+            k_layout_live<<<nblk((uint64_t)c->nreads + 1, kWaves), kBlock, 0, c->stream>>>(Bloc, ptr<uint2>(c->Bent), c->nreads, inl, len);
+            KCHK(c);
+            int rc = scan_u32(c, len, bnew, (uint64_t)c->nreads + 1);
             if (rc) return rc;
-            k_layout_bcnt<<<nblk(nown_nnz), 256, 0, c->stream>>>(ptr<uint2>(c->Bent), nown_nnz, ptr<uint16_t>(c->Bcnt), inl);
+            uint32_t live = 0;
+            HIPCHK(c, hipMemcpyAsync(&live, bnew + c->nreads, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            Buf out;
+            rc = ensure_bytes(c, out, 8 * (size_t)live);
+            if (rc) return rc;
+            k_layout_compact<<<nblk(c->nreads, kWaves), kBlock, 0, c->stream>>>(Bloc, bnew, ptr<uint2>(c->Bent), c->nreads, inl, ptr<uint2>(out));
+            if (hipGetLastError() != hipSuccess) { release(out); return fail(c, BELLA_ERR_HIP, "k_layout_compact failed to launch"); }
+            HIPCHK(c, hipMemcpyAsync(c->Bloc.p, bnew, 4 * ((size_t)c->nreads + 1), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            std::swap(c->Bent, out);
+            release(out);
+            c->live_nnz = live;
+        }
+        if (c->live_nnz) {
+            int rc = ensure_bytes(c, c->Bcnt, 2 * c->live_nnz);
+            if (rc) return rc;
+            k_layout_bcnt<<<nblk(c->live_nnz), 256, 0, c->stream>>>(ptr<uint2>(c->Bent), c->live_nnz, ptr<uint16_t>(c->Bcnt), inl);
             KCHK(c);
         }
-        c->owned_nnz = nown_nnz;
         // pairs/products on a sample of (owned) columns -> key-table budget of the LDS tiers (see k_sample_pair_ratio), and: is this a
         // long-list input (HiFi-like: at most one pair in 64 products)?
         const size_t bitmap_bytes = 4 * (((size_t)c->nreads + 31) / 32);
@@ -771,6 +797,10 @@ int bella_hip_set_tuning(bella_ctx* c, uint32_t what, const uint64_t* values, ui
             return 0;
         case BELLA_TUNE_CACHE_BYTES:
             c->tune_cache_bytes = n && values[0] ? values[0] : (192ull << 20);
+            return 0;
+        case BELLA_TUNE_COMPACT_B:
+            if (n && values[0] > 1) return fail(c, BELLA_ERR_BAD_ARG, "compact B': 0 (drop the entries without a later read) or 1 (keep them)");
+            c->tune_compact_b = n ? (uint32_t)values[0] : 0u;
             return 0;
     }
     return fail(c, BELLA_ERR_BAD_ARG, "unknown tuning parameter %u", what);

@@ -301,6 +301,7 @@ def main():
     ap.add_argument("--no-layout-ab", action="store_true", help="N=1: skip the layout A/B records (default layout vs row lists: layout + cold pass + warm step)")
     ap.add_argument("--debug-flags", type=int, default=0, help="extra bella_hip_set_debug bits (development A/B)")
     ap.add_argument("--layout-debug", type=int, default=0, help="bella_hip_set_debug bits in force while the operands are laid out (development A/B)")
+    ap.add_argument("--tune", action="append", default=[], help="name=value for bella_hip_set_tuning on every context (development A/B), e.g. compact_b=1")
     ap.add_argument("--cpu-baseline-child", default=None)
     ap.add_argument("--threads", type=int, default=0)
     a = ap.parse_args()
@@ -357,6 +358,9 @@ def main():
                 log("[bench] rank %d: bella_hip_reserve(%d) failed (%r): the stages allocate for themselves" % (rank, want, e))
         if a.layout_debug:
             eng.set_debug(a.layout_debug)
+        for tv in a.tune:
+            tn, _, tval = tv.partition("=")
+            eng.set_tuning(tn, int(tval))
         eng.set_reads(rs)                                   # reads are replicated (2 bit/base)
         t_setup = time.time()
         have_comm = False

@@ -331,7 +331,7 @@ typedef struct {
     uint64_t rowlist_bytes;    /* row lists (BELLA_TUNE_ROW_LISTS) + row pointers: owned columns only                      */
     uint64_t pass_bytes;       /* buffers of the passes (records, product lists, workspaces): follow the pass's products   */
     uint64_t other_bytes;      /* counting / assembly / alignment buffers still held, and released ones kept for reuse      */
-    uint64_t owned_nnz;        /* B' entries laid out (= nnz of the owned columns)                                         */
+    uint64_t owned_nnz;        /* nnz of the owned columns (B' keeps those of them that have a later read: BELLA_TUNE_COMPACT_B) */
     uint64_t layout_shared;    /* 1: the current layout was formed shared over the ranks (BELLA_TUNE_DIST_LAYOUT), else 0  */
 } bella_memory;
 int bella_hip_get_memory(bella_ctx* ctx, bella_memory* m);
@@ -395,9 +395,12 @@ int bella_hip_trim(bella_ctx* ctx);
  *                             entries travel in one more grouped exchange.  The same layout entry for entry.  Taken when EVERY rank can: the
  *                             partition (first, stride) = (rank, ranks) set by bella_hip_set_partition before the call, at most 64 ranks,
  *                             BELLA_TUNE_LAYOUT_ORDER 0 (the call asks all ranks and falls back to the replicated formation on all of them).
- * (bella_hip_set_debug bits 0, 10, 15 and 16 of earlier rounds still select the same things: aliases, no longer needed) */
+ *   BELLA_TUNE_COMPACT_B      values[0] = 0 (default): the device layout drops the entries of B' whose k-mer has no later read (they have
+ *                             no product in the strict lower triangle, overlap.hpp:157-202); 1: every entry stays.  Read at layout time.
+ * (bella_hip_set_debug bits 0, 10, 15 and 16 of earlier rounds still select the same things: aliases, no longer needed)
+ */
 enum { BELLA_TUNE_LDS_TIERS = 0, BELLA_TUNE_KCOUNT_BUDGET = 1, BELLA_TUNE_WIDE_BUDGET = 2, BELLA_TUNE_XDROP_VARIANT = 3, BELLA_TUNE_ROW_LISTS = 4,
-       BELLA_TUNE_XDROP_CLASS_MIN = 5, BELLA_TUNE_LAYOUT_ORDER = 6, BELLA_TUNE_INLINE_ENTRIES = 7, BELLA_TUNE_ROW_PATH = 8, BELLA_TUNE_CACHE_BYTES = 9, BELLA_TUNE_DIST_LAYOUT = 10 };
+       BELLA_TUNE_XDROP_CLASS_MIN = 5, BELLA_TUNE_LAYOUT_ORDER = 6, BELLA_TUNE_INLINE_ENTRIES = 7, BELLA_TUNE_ROW_PATH = 8, BELLA_TUNE_CACHE_BYTES = 9, BELLA_TUNE_DIST_LAYOUT = 10, BELLA_TUNE_COMPACT_B = 11 };
 int bella_hip_set_tuning(bella_ctx* ctx, uint32_t what, const uint64_t* values, uint32_t n);
 
 #ifdef __cplusplus
