@@ -620,9 +620,20 @@ __global__ __launch_bounds__(kXdropBlock, BELLA_XSLICE_WAVES) void k_xdrop_slice
     // Phase 4 (:185-251) share the body: the per-lane choices are masks, not branches.  A finished lane has stored its result and idles
     // for the rest of the slice.
     bool done = false;
+#ifndef BELLA_X_FLAT_LOOP
+    // sixteen steps between two checkpoints are one inner loop: the wave-uniform exit test and the checkpoint test are made once per
+    // sixteen steps instead of every step (a wavefront whose last lane ends idles at most fifteen steps more)
+    for (int step16 = 0; step16 < xa.steps; step16 += 16) {
+        if (!__ballot(active && !done)) break;                    // (wave-uniform)
+        H.checkpoint((uint32_t)hoff); V.checkpoint((uint32_t)voff);
+#pragma unroll 1
+      for (int step = 0; step < 16; ++step) {
+#else
     for (int step = 0; step < xa.steps; ++step) {
         if (!__ballot(active && !done)) break;                    // (wave-uniform)
         if ((step & 15) == 0) { H.checkpoint((uint32_t)hoff); V.checkpoint((uint32_t)voff); }
+      {
+#endif
         BELLA_PSTEP()
         int mx, lo;
         BELLA_PKEY(mx, lo)
@@ -675,6 +686,7 @@ __global__ __launch_bounds__(kXdropBlock, BELLA_XSLICE_WAVES) void k_xdrop_slice
                 }
             }
         }
+      }
     }
     if (active && done) st[kXsFlags * cap] = 1u << 15;
     const bool keep = active && !done;

@@ -42,38 +42,7 @@
 #include <vector>
 
 #include "bella_hip.h"
-
-namespace bella_hip_detail {
-inline void check(bella_ctx* c, int rc, const char* what) {
-    if (rc == 0) return;
-    std::cerr << "bella_hip: " << what << " failed: " << (c ? bella_hip_last_error(c) : bella_hip_strerror(rc)) << " (" << rc << ")"
-              << std::endl;
-    std::abort();
-}
-}  // namespace bella_hip_detail
-
-namespace bella_hip_detail {
-// one context = one GPU: B in, then per stage [lo, hi): overlap (+ alignment) and the records of ITS columns
-struct Worker {
-    bella_ctx* ctx = nullptr;
-    std::vector<uint64_t> colptr;            // colptrC of the last pass (nreads + 1)
-    std::vector<bella_pair> pairs;
-    std::vector<bella_aln> alns;
-    uint64_t nnzc = 0;
-};
-// what the last HashSpGEMM call of this process did (tests, logs): every column must be computed by the numeric phase exactly once
-struct CallStats {
-    uint64_t numeric_columns = 0;    // sum over the contexts of the columns their numeric passes computed
-    uint64_t numeric_passes = 0, symbolic_passes = 0;
-    uint64_t nreads = 0;
-    int stages = 0, contexts = 0;
-    uint64_t layout_B_bytes_max = 0, layout_B_bytes_sum = 0;   // B' per context: follows the partition
-    uint64_t host_upload_bytes = 0;  // matrix bytes that went host -> device, all contexts together
-};
-inline CallStats& last_call_stats() { static CallStats s; return s; }   // single caller, like HashSpGEMM itself (not re-entrant: overlap.hpp:92)
-// the reference's printLog (include/common/common.h:40-44): "INFO:\tfile(line)\tname = value" on stderr
-#define BELLA_HIP_LOG(var) do { std::cerr << "INFO:\t" << "bella_hip_shim.hpp" << "(" << __LINE__ << ")\t" << #var << " = " << (var) << std::endl; } while (0)
-}  // namespace bella_hip_detail
+#include "bella_hip_driver.hpp"      // stage plan, passes, alignment, output file and stdout protocol (shared with the native command line)
 
 template <typename MultiplyOperation, typename AddOperation>
 void HashSpGEMM(const CSC<uint32_t, unsigned short>& A, const CSC<uint32_t, unsigned short>& B, MultiplyOperation, AddOperation,
@@ -91,26 +60,30 @@ void HashSpGEMM(const CSC<uint32_t, unsigned short>& A, const CSC<uint32_t, unsi
     std::string flat;
     flat.reserve(offs[nreads]);
     for (uint32_t r = 0; r < nreads; ++r) flat += reads[r].seq;
-    bella_params p;
-    p.kmer_size = bpars.kmerSize;
-    p.bin_size = bpars.binSize;
-    p.xdrop = bpars.xDrop;
-    p.skip_alignment = bpars.skipAlignment;
-    p.error_rate = bpars.errorRate;
-    p.delta_chernoff = bpars.deltaChernoff;
+    StageOpts o;
+    o.N = N;
+    o.nreads = nreads;
+    o.p.kmer_size = bpars.kmerSize;
+    o.p.bin_size = bpars.binSize;
+    o.p.xdrop = bpars.xDrop;
+    o.p.skip_alignment = bpars.skipAlignment;
+    o.p.error_rate = bpars.errorRate;
+    o.p.delta_chernoff = bpars.deltaChernoff;
+    o.paf = bpars.outputPaf ? 1 : 0;
+    o.total_memory_mb = bpars.totalMemory;
+    o.per_nnz = (double)(sizeof(spmatPtr_) + sizeof(uint32_t));
+    o.filename = filename;
+    o.tag = "bella_hip_shim.hpp";
 
     std::vector<Worker> W((size_t)N);
-    auto on_all = [&](const std::function<void(int)>& fn) {                  // one host thread per context
-        if (N == 1) { fn(0); return; }
-        std::vector<std::thread> th;
-        for (int g = 0; g < N; ++g) th.emplace_back(fn, g);
-        for (auto& t : th) t.join();
-    };
     uint8_t comm_id[BELLA_HIP_COMM_ID_BYTES];
     if (N > 1) check(nullptr, bella_hip_comm_id_local(comm_id), "bella_hip_comm_id_local");
-    on_all([&](int g) {
+    on_all(N, [&](int g) {
         Worker& w = W[(size_t)g];
         check(nullptr, bella_hip_init(g % ndev, &w.ctx), "bella_hip_init");
+        // one slab up front: the matrix, its layout and a pass cut their buffers from it (6 + 26 bytes per nonzero and about 70 per
+        // product: about as much as the reads' 44 bytes per base on PacBio-like input)
+        reserve_for(w.ctx, offs[nreads], (N + ndev - 1) / ndev);
         check(w.ctx, bella_hip_set_reads(w.ctx, (const uint8_t*)flat.data(), offs.data(), nreads), "bella_hip_set_reads");
         if (N == 1) {
             check(w.ctx, bella_hip_set_B(w.ctx, bpars.kmerSize, (uint32_t)B.rows, B.colptr, B.rowids, B.values), "bella_hip_set_B");
@@ -124,141 +97,12 @@ void HashSpGEMM(const CSC<uint32_t, unsigned short>& A, const CSC<uint32_t, unsi
         check(w.ctx, bella_hip_allgather_panels(w.ctx), "bella_hip_allgather_panels");
     });
     std::string().swap(flat);
-    auto do_overlap = [&](uint32_t lo, uint32_t hi) {                        // the numeric phase on the columns [lo, hi) of every context
-        on_all([&](int g) {
-            Worker& w = W[(size_t)g];
-            check(w.ctx, bella_hip_set_column_range(w.ctx, lo, hi - lo), "bella_hip_set_column_range");
-            uint64_t flops = 0;
-            check(w.ctx, bella_hip_overlap(w.ctx, &p, &w.nnzc, &flops), "bella_hip_overlap");
-            w.colptr.assign((size_t)nreads + 1, 0);
-            check(w.ctx, bella_hip_get_pairs(w.ctx, nullptr, nullptr, w.colptr.data()), "bella_hip_get_pairs");
-        });
-    };
-    auto fetch = [&]() {                                                     // the records of the last pass (+ their alignments)
-        on_all([&](int g) {
-            Worker& w = W[(size_t)g];
-            w.pairs.resize(w.nnzc);
-            check(w.ctx, bella_hip_get_pairs(w.ctx, w.pairs.data(), nullptr, nullptr), "bella_hip_get_pairs");
-            if (!bpars.skipAlignment) {
-                uint64_t npass = 0;
-                check(w.ctx, bella_hip_align_pairs(w.ctx, &p, &npass), "bella_hip_align_pairs");
-                w.alns.resize(w.nnzc);
-                if (w.nnzc) check(w.ctx, bella_hip_get_alignments(w.ctx, w.alns.data()), "bella_hip_get_alignments");
-            }
-        });
-    };
-    auto merged_colptr = [&](std::vector<uint64_t>& colptrC) {               // column i lives on context i % N
-        colptrC.assign((size_t)nreads + 1, 0);
-        for (uint32_t i = 0; i < nreads; ++i) {
-            const Worker& w = W[(size_t)(i % (uint32_t)N)];
-            colptrC[i + 1] = colptrC[i] + (w.colptr[i + 1] - w.colptr[i]);
-        }
-    };
-    // Stage plan (overlap.hpp:365-404,682-710).  The products (estimateFLOP, a sum over a count stream) bound nnz(C) from above: if
-    // even they fit one stage the numeric phase runs at once over all columns; otherwise the symbolic phase (bella_hip_count_pairs =
-    // the reference's estimateNNZ_Hash + prefixsum, :674-679) gives the exact colptrC the boundaries are taken from.
-    const double free_memory = bpars.totalMemory * 1024 * 1024;               // estimateMemory, overlap.hpp:365-404 (no LINUX/OSX define)
-    const double safety_net = 1.5;                                            // overlap.hpp:92
-    const double per_nnz = (double)(sizeof(spmatPtr_) + sizeof(uint32_t));
-    std::vector<uint64_t> colptrC;
-    uint64_t nnzc = 0;
-    std::vector<uint64_t> wflops((size_t)N, 0);
-    on_all([&](int g) { check(W[(size_t)g].ctx, bella_hip_count_pairs(W[(size_t)g].ctx, &p, nullptr, nullptr, &wflops[(size_t)g]), "bella_hip_count_pairs (flops)"); });
-    uint64_t flops_all = 0;
-    for (uint64_t f : wflops) flops_all += f;
-    bool computed = false;                                                    // the numeric phase already ran over all columns
-    const bool no_budget = !(free_memory > 0.0);                              // -m 0 or unset: one stage (the formula would divide by it)
-    if (no_budget || safety_net * (double)flops_all * per_nnz <= free_memory) {
-        do_overlap(0, nreads);
-        computed = true;
-    } else {
-        on_all([&](int g) {
-            Worker& w = W[(size_t)g];
-            w.colptr.assign((size_t)nreads + 1, 0);
-            uint64_t fl = 0;
-            check(w.ctx, bella_hip_count_pairs(w.ctx, &p, w.colptr.data(), &w.nnzc, &fl), "bella_hip_count_pairs");
-        });
-    }
-    merged_colptr(colptrC);
-    nnzc = colptrC[nreads];
-    std::cout << nnzc << std::endl;                                           // overlap.hpp:686
-    const uint64_t required_memory = (uint64_t)(safety_net * nnzc * per_nnz);
-    int stages = no_budget ? 1 : (int)std::ceil((double)required_memory / free_memory);       // overlap.hpp:683
-    if (stages < 1) stages = 1;
-    const uint64_t nnzcperstage = no_budget ? nnzc + 1 : (uint64_t)(free_memory / (safety_net * per_nnz));
-    std::vector<uint32_t> colStart((size_t)stages + 1, 0);
-    for (int i = 1; i < stages; ++i) {                                        // overlap.hpp:704-710
-        auto upper = std::upper_bound(colptrC.begin(), colptrC.end(), (uint64_t)i * nnzcperstage);
-        colStart[(size_t)i] = (uint32_t)(upper - colptrC.begin() - 1);
-    }
-    colStart[(size_t)stages] = nreads;
-
     // names and lengths once; the writer (bella_hip_write_output: per-thread buffers, offset writes, overlap.hpp:603-642) appends
     std::vector<const char*> names(nreads);
     std::vector<uint32_t> lens(nreads);
     for (uint32_t r = 0; r < nreads; ++r) { names[r] = reads[r].nametag.c_str(); lens[r] = (uint32_t)reads[r].seq.length(); }
-    for (int b = 0; b < stages; ++b) {
-        const uint32_t lo = colStart[(size_t)b], hi = colStart[(size_t)b + 1];
-        const auto t_stage = std::chrono::steady_clock::now();
-        if (!computed) do_overlap(lo, hi);                                    // (computed: one stage was certain, the pass over all columns ran above)
-        fetch();
-        const double aligntime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage).count();
-        // the stage's records in the reference's column order (N contexts: column i lives on context i % N)
-        const bella_pair* pp = W[0].pairs.data();
-        const bella_aln* aa = W[0].alns.data();
-        uint64_t np = W[0].nnzc;
-        std::vector<bella_pair> mp;
-        std::vector<bella_aln> ma;
-        if (N > 1) {
-            for (uint32_t i = lo; i < hi; ++i) {
-                const Worker& w = W[(size_t)(i % (uint32_t)N)];
-                mp.insert(mp.end(), w.pairs.begin() + (std::ptrdiff_t)w.colptr[i], w.pairs.begin() + (std::ptrdiff_t)w.colptr[i + 1]);
-                if (!bpars.skipAlignment) ma.insert(ma.end(), w.alns.begin() + (std::ptrdiff_t)w.colptr[i], w.alns.begin() + (std::ptrdiff_t)w.colptr[i + 1]);
-            }
-            pp = mp.data(); aa = ma.data(); np = mp.size();
-        }
-        bella_write_stats ws;
-        const int wrc = bella_hip_write_output(filename, &p, bpars.outputPaf ? 1 : 0, nreads, names.data(), lens.data(), pp, bpars.skipAlignment ? nullptr : aa, np, 0, &ws);
-        if (wrc) check(nullptr, wrc, "bella_hip_write_output");
-        const std::string ColumnsRange = "[" + std::to_string(lo) + " - " + std::to_string(hi) + "]";
-        BELLA_HIP_LOG(ColumnsRange);
-        if (!bpars.skipAlignment) {                                           // the per-stage statistics of overlap.hpp:750-777
-            const std::string AlignmentTime = std::to_string(aligntime) + " seconds";
-            BELLA_HIP_LOG(AlignmentTime);
-            const std::string AlignmentRate = std::to_string((long long)((double)ws.aligned_bases / aligntime)) + " bases/second";
-            BELLA_HIP_LOG(AlignmentRate);
-            const std::string AverageReadLength = std::to_string(ws.aligned_pairs ? (long long)((double)ws.total_read_len / (2.0 * (double)ws.aligned_pairs)) : 0LL);
-            BELLA_HIP_LOG(AverageReadLength);
-            const std::string PairsAligned = std::to_string(ws.aligned_pairs);
-            BELLA_HIP_LOG(PairsAligned);
-            std::cout << ws.lines << std::endl;                               // overlap.hpp:771 (per stage)
-            const std::string AverageLengthSuccessfulAlignment = std::to_string(ws.lines ? (long long)((double)ws.bases_passed / (double)ws.lines) : 0LL) + " bps";
-            BELLA_HIP_LOG(AverageLengthSuccessfulAlignment);
-            const uint64_t nfail = ws.aligned_pairs - ws.lines;
-            const std::string AverageLengthFailedAlignment = std::to_string(nfail ? (long long)((double)ws.bases_failed / (double)nfail) : 0LL) + " bps";
-            BELLA_HIP_LOG(AverageLengthFailedAlignment);
-        }
-        const uint64_t LinesOutputted = ws.lines;
-        BELLA_HIP_LOG(LinesOutputted);
-        const std::string OutputtingTime = std::to_string(ws.seconds) + " seconds";
-        BELLA_HIP_LOG(OutputtingTime);
-    }
-    {
-        CallStats& cs = last_call_stats();
-        cs = CallStats();
-        cs.nreads = nreads; cs.stages = stages; cs.contexts = N;
-        for (auto& w : W) {
-            bella_timings tm;
-            bella_memory mm;
-            if (bella_hip_get_timings(w.ctx, &tm) == 0) { cs.numeric_columns += tm.numeric_columns; cs.numeric_passes += tm.numeric_passes; cs.symbolic_passes += tm.symbolic_passes; }
-            if (bella_hip_get_memory(w.ctx, &mm) == 0) { cs.layout_B_bytes_sum += mm.layout_B_bytes; cs.layout_B_bytes_max = std::max<uint64_t>(cs.layout_B_bytes_max, mm.layout_B_bytes); }
-        }
-        cs.host_upload_bytes = (uint64_t)6 * (uint64_t)B.colptr[nreads] + (uint64_t)4 * ((uint64_t)nreads + 1) * (uint64_t)(N == 1 ? 1 : 0);
-        const uint64_t NumericColumns = cs.numeric_columns, NumericPasses = cs.numeric_passes, SymbolicPasses = cs.symbolic_passes;
-        BELLA_HIP_LOG(NumericColumns);
-        BELLA_HIP_LOG(NumericPasses);
-        BELLA_HIP_LOG(SymbolicPasses);
-    }
+    run_stages(W, o, names.data(), lens.data());
+    last_call_stats().host_upload_bytes = (uint64_t)6 * (uint64_t)B.colptr[nreads] + (uint64_t)4 * ((uint64_t)nreads + 1) * (uint64_t)(N == 1 ? 1 : 0);
     for (auto& w : W) bella_hip_destroy(w.ctx);
 }
 

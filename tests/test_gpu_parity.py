@@ -602,6 +602,111 @@ def test_reference_cli_on_the_gpu_with_a_fastq_list_several_gpus_and_stages(tmp_
                 assert sum(int(x) for x in nums[3:-1]) == int(rnums[3])
 
 
+def _run_native(fastqs, flags, cwd, env_extra=None):
+    """bella_amd/bin/bella-hip (bella_amd/host/bella_hip_main.cpp): the reference's CLI contract, the whole pipeline on the device"""
+    import subprocess
+    import re
+    exe = os.path.join(ROOT, "bella_amd", "bin", "bella-hip")
+    assert os.path.exists(exe), "bella_amd/bin/bella-hip is not built (bella_amd/build.py builds it)"
+    os.makedirs(cwd, exist_ok=True)
+    with open(os.path.join(cwd, "in.txt"), "w") as f:
+        f.write("".join(p + "\n" for p in fastqs))
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    p = subprocess.run([exe, "-f", "in.txt", "-o", "out"] + list(flags), cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    so, se = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+    assert p.returncode == 0, (p.returncode, so[-2000:], se[-2000:])
+    nums = [ln.strip() for ln in so.splitlines() if re.fullmatch(r"[0-9.eE+-]+", ln.strip())]
+    out = os.path.join(cwd, "out.out")
+    assert os.path.exists(out), (so[-2000:], se[-2000:])
+    return nums, open(out, "rb").read(), se
+
+
+def _write_mtx(path, g):
+    """the reference's readbykmers.mtx dump (include/common/bellaio.h:2-47) from a golden set's tuples: pins the k-mer ids"""
+    with open(path, "w") as f:
+        f.write("%d\t%d\t%d\n" % (g.rs.nreads, g.nkmers, len(g.tk)))
+        f.write("".join("%d\t%d\t%d\n" % (r + 1, k + 1, q) for k, r, q in zip(g.tk.tolist(), g.tr.tolist(), g.tp.tolist())))
+
+
+def test_native_cli_with_the_reference_ids_is_byte_identical(golden, tmp_path):
+    """bella-hip with --tuples <readbykmers.mtx of the reference run>: FASTQ ingest, assembly, SpGEMM, X-drop and the writer on the
+    device behind the reference's flags -- the three output files and the stdout protocol (nkmer, nnz(A), nnz(C), outputted:
+    main.cpp:472-473, CSC.cpp:405, overlap.hpp:686,771) byte for byte against the reference binary's goldens"""
+    import gzip
+    g = golden
+    fq = str(tmp_path / "reads.fastq")
+    with gzip.open(os.path.join(GOLD, g.name, "reads.fastq.gz"), "rb") as src, open(fq, "wb") as dst:
+        dst.write(src.read())
+    mtx = str(tmp_path / "readbykmers.mtx")
+    _write_mtx(mtx, g)
+    for extra, key in ((["--skip-alignment"], "skip"), ([], "align"), (["--paf"], "paf")):
+        nums, data, err = _run_native([fq], g.meta["flags"] + extra + ["--tuples", mtx], str(tmp_path / key))
+        assert data == g.out[key], (g.name, key)                # byte for byte, no tolerance
+        if key in g.stdout:
+            assert nums[:-1] == g.stdout[key][:-1], (nums, g.stdout[key])
+        assert "bella_hip_main.cpp" in err and "ColumnsRange" in err
+
+
+def test_native_cli_counts_on_the_device(golden, tmp_path):
+    """the same executable without --tuples: k-mer counting / syncmer / minimizer selection, the dictionary and the tuples on the device
+    (ids = ascending canonical words: labels).  Same dictionary size, same nnz(A), same nnz(C), the same candidate pair set as the
+    reference; with alignment the few pairs whose seed follows the fold order may pass or fail differently (as in the reference between
+    thread counts) and the quality evaluation agrees."""
+    import gzip
+    from bella_amd import evaluate as ev
+    g = golden
+    fq = str(tmp_path / "reads.fastq")
+    with gzip.open(os.path.join(GOLD, g.name, "reads.fastq.gz"), "rb") as src, open(fq, "wb") as dst:
+        dst.write(src.read())
+    key = lambda data: {tuple(ln.split(b"\t")[:2]) for ln in data.split(b"\n") if ln}
+    nums, data, _ = _run_native([fq], g.meta["flags"] + ["--skip-alignment"], str(tmp_path / "skip"))
+    assert nums[:3] == g.stdout["skip"][:3], (nums, g.stdout["skip"])
+    assert key(data) == key(g.out["skip"]) and len(data.splitlines()) == len(g.out["skip"].splitlines())
+    nums, data, _ = _run_native([fq], g.meta["flags"], str(tmp_path / "align"))
+    assert nums[:3] == g.stdout["align"][:3]
+    mine, ref = key(data), key(g.out["align"])
+    assert len(mine ^ ref) <= max(2, 0.03 * len(ref)), (len(mine), len(ref), len(mine ^ ref))
+    if g.name.startswith("toy") and g.name != "toyjunk220":
+        try:
+            G = ev.truth_pairs(ev.truth_from_names(g.names), 500)
+        except Exception:
+            G = None
+        if G:
+            r1, r2 = ev.evaluate(ev.read_bella_output(data, 500), G), ev.evaluate(ev.read_bella_output(g.out["align"], 500), G)
+            assert abs(r1["recall"] - r2["recall"]) < 1.0 and abs(r1["precision"] - r2["precision"]) < 1.0
+
+
+def test_native_cli_list_of_files_several_contexts_and_stages(tmp_path):
+    """bella-hip on a -f list of TWO files, with -g 2 (two contexts sharing the one GPU: BELLA_HIP_OVERSUBSCRIBE) and a -m that forces
+    the reference's stage loop (overlap.hpp:682-710): the same output file as its own single-context single-stage run, and the same
+    protocol numbers; flags the reference has and this program does not build are refused"""
+    import subprocess
+    rs = synth.make_reads(2200, read_len=4000, err=0.15, seed=77)
+    fa, fb = str(tmp_path / "a.fastq"), str(tmp_path / "b.fastq")
+    synth.write_fastq(fa, rs.subset(900))
+    tail = synth.ReadSet(rs.codes[rs.offsets[900]:], rs.offsets[900:] - rs.offsets[900], rs.names[900:])
+    synth.write_fastq(fb, tail)
+    over = {"BELLA_HIP_OVERSUBSCRIBE": "1"}
+    for extra, key in ((["--skip-alignment"], "skip"), ([], "align")):
+        bnums, base, _ = _run_native([fa, fb], extra, str(tmp_path / ("b_" + key)))
+        nnzc = int(bnums[2])
+        stages = int(np.ceil(1.5 * nnzc * 20 / (1024.0 * 1024.0)))
+        assert stages >= 2
+        for flags, env in (([("-g"), "2"], over), (["-m", "1"], None), (["-m", "1", "-g", "2"], over)):
+            nums, data, err = _run_native([fa, fb], extra + flags, str(tmp_path / ("v_%s_%s" % (key, "_".join(flags)))), env)
+            assert data == base, (key, flags)
+            assert nums[:3] == bnums[:3]
+            if "-m" in flags:
+                assert err.count("ColumnsRange") == stages
+            if key == "align":
+                assert sum(int(x) for x in nums[3:-1]) == int(bnums[3])
+    exe = os.path.join(ROOT, "bella_amd", "bin", "bella-hip")
+    for bad in (["--hopc"], ["--estimate"], ["--split-count", "2"], ["--no-such-flag"]):
+        p = subprocess.run([exe, "-f", "in.txt", "-o", "x"] + bad, cwd=str(tmp_path / "b_skip"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        assert p.returncode != 0 and b"bella-hip:" in p.stderr, bad
+
+
 def test_dropin_shim_stages_and_gpus_from_bellapars(eng, tmp_path, monkeypatch):
     """BELLApars::totalMemory (-m) -> the reference's stage count and boundaries (overlap.hpp:365-404,682-710); BELLApars::numGPU
     (-g) -> that many contexts (here sharing the one GPU): the file stays the reference's single-stage file, byte for byte"""
