@@ -128,3 +128,26 @@ def test_synth_dictionary_matches_reference_counts():
     # same partition of tuples into k-mer classes
     a = np.unique(np.stack([t.kmer, g.tk]), axis=1)
     assert a.shape[1] == g.nkmers
+
+
+def test_native_cli_flags_without_a_device(tmp_path):
+    """bella_amd/bin/bella-hip (built by bella_amd/build.py): the reference's option surface (main.cpp:65-175).  What needs no device:
+    --help and a missing -f / -o print the usage and exit 0 as the reference does (:97-145); flags the reference has and this program
+    does not build (--hopc, --estimate, --split-count > 1), unknown options and malformed values are refused with a message; a list
+    file whose last line has no newline names no file (kmercount.hpp:96)."""
+    import subprocess
+    from bella_amd import build as b
+    exe = b.build_cli()
+    run = lambda args: subprocess.run([exe] + args, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    for args in (["--help"], ["-h"], [], ["-f", "in.txt"], ["-o", "x"], ["-f", "in.txt", "-o", "x", "--score-deviation", "1.5"]):
+        p = run(args)
+        assert p.returncode == 0 and b"--skip-alignment" in p.stdout and b"-u, --upper-freq" in p.stdout, args
+    for bad, msg in ((["--hopc"], b"--hopc"), (["--estimate"], b"--estimate"), (["--split-count", "2"], b"--split-count"), (["--bogus"], b"does not exist"),
+                     (["-k", "seventeen"], b"not an integer"), (["-k"], b"missing an argument"), (["--paf=1"], b"takes no value"), (["-k", "40"], b"[1,32]")):
+        p = run(["-f", "in.txt", "-o", "x"] + bad)
+        assert p.returncode == 1 and b"bella-hip:" in p.stderr and msg in p.stderr, (bad, p.stderr)
+    open(tmp_path / "in.txt", "w").write("/nonexistent/a.fastq")           # no trailing newline
+    p = run(["-f", "in.txt", "-o", "x", "-k17", "--kmer=17", "--xdrop", "7"])
+    assert p.returncode == 1 and b"no FASTQ file" in p.stderr
+    p = run(["-f", "missing.txt", "-o", "x"])
+    assert p.returncode == 1 and b"Could not open missing.txt" in p.stderr
