@@ -202,6 +202,18 @@ def kcount_record(info, eng):
                          "kernel": "k_emit_codes + radix sort of the canonical words + run/dictionary/tuple passes (one call)"}}
 
 
+# k_xdrop_slice, per anti-diagonal step of one wavefront (64 extensions), from the device assembly (tools/xdrop_isa.py ->
+# profiles/r06_xdrop_isa.txt; tests/test_abi_cpu.py checks these constants against that listing): the instructions EVERY step
+# executes, split by issue rate (profiles/r05_valu_rates.txt: ~4.15 cycles per SIMD for packed-16 / perm / min-max / shifts-left /
+# compares, ~2.4 for add / logic / shift-right / mov), plus the sequence windows' checkpoint once per sixteen steps.  Rebase, clamp, the
+# Phase-4 bookkeeping and the result stores are rare events and not counted: the figure is a LOWER bound of the issue time.
+XDROP_VALU_HALF_RATE = 190
+XDROP_VALU_FULL_RATE = 40
+XDROP_VALU_CHECKPOINT = 5
+XDROP_CYC_HALF, XDROP_CYC_FULL = 4.15, 2.4
+GPU_SIMDS, GPU_CLOCK_HZ = 256 * 4, 2.4e9
+
+
 def xdrop_record(eng, workload):
     """RunPairWiseAlignments on the candidate pairs the engine holds (one pass, outside the SpGEMM timing)"""
     from bella_amd import BellaPars
@@ -214,8 +226,18 @@ def xdrop_record(eng, workload):
     rec = {"workload": workload % len(al), "pairs": int(len(al)), "passed": int(npass), "ms": xms,
            "pairs_per_s": len(al) / (xms * 1e-3) if xms else None, "antidiagonal_steps": steps_tot,
            "gcups": 31 * steps_tot / (xms * 1e-3) / 1e9 if xms else None, "flagged": int(al["flagged"].sum()),
-           "bound": "VALU issue: packed-i16 / v_perm band updates issue one wavefront-instruction per SIMD every ~4 cycles "
-                    "(profiles/r04_valu_rates.txt; 264 VALU instructions per anti-diagonal of 64 extensions: profiles/r04_xdrop_sq.txt, a separate profiled run)"}
+           "bound": "VALU issue on a serial chain (one lane per extension, the band in VGPRs as packed i16)"}
+    # in-run utilisation: the SIMD cycles the stage's anti-diagonal steps need at the measured issue rates if every wavefront ran 64 live
+    # lanes, over the SIMD cycles the stage had.  1 - frac = idle lanes (an extension that ends idles its lane for the rest of its
+    # 512-step slice), the rare regions, slice prologues / epilogues, launch gaps.
+    if xms:
+        insts = XDROP_VALU_HALF_RATE + XDROP_VALU_FULL_RATE + XDROP_VALU_CHECKPOINT
+        cyc = (XDROP_VALU_HALF_RATE + XDROP_VALU_CHECKPOINT) * XDROP_CYC_HALF + XDROP_VALU_FULL_RATE * XDROP_CYC_FULL
+        rec["valu_insts_per_wave_step"] = insts
+        rec["valu_issue_cycles_per_wave_step"] = cyc
+        rec["valu_issue_frac"] = (steps_tot / 64.0) * cyc / (GPU_SIMDS * GPU_CLOCK_HZ * xms * 1e-3)
+        rec["valu_issue_source"] = ("profiles/r06_xdrop_isa.txt (instructions every step executes, from the ISA) x profiles/r05_valu_rates.txt (issue rates); "
+                                    "steps and time measured in this run; SQ_INSTS_VALU of a profiled run: profiles/r06_xdrop_sq.txt")
     del al
     return rec
 
@@ -262,8 +284,9 @@ def dropin_call_record(rs, Bhost, nk, device):
     return rec
 
 
-def ingest_record(rs, device):
-    """FASTQ file -> packed reads on the device (bella_hip_load_fastq) on a fresh context, the file in the page cache"""
+def ingest_record(rs, device, with_e2e=False, with_alignment=False):
+    """FASTQ file -> packed reads on the device (bella_hip_load_fastq) on a fresh context, the file in the page cache; and, on the same
+    file, the native command line end to end (e2e_record)"""
     import tempfile
     from bella_amd import Engine
     from bella_testkit import synth
@@ -281,9 +304,43 @@ def ingest_record(rs, device):
                         "file_bytes": int(st["file_bytes"]), "reads": int(n), "bases": int(nb),
                         "file_gb_per_s": st["file_bytes"] / (wall * 1e-3) / 1e9}
         eng.close()
-    best["what"] = ("bella_hip_load_fastq, warm: mmap + threaded line index, bases gathered into pinned 64 MB chunks under the previous "
-                    "chunk's transfer, 2-bit pack on the device, names and lengths kept; wall clock on the host")
-    return best
+        best["what"] = ("bella_hip_load_fastq, warm: mmap + threaded line index, bases gathered into pinned 64 MB chunks under the previous "
+                        "chunk's transfer, 2-bit pack on the device, names and lengths kept; wall clock on the host")
+        e2e = e2e_record(f, tmp, with_alignment) if with_e2e else None
+    return best, e2e
+
+
+def e2e_record(fastq, tmp, with_alignment):
+    """bella_amd/bin/bella-hip (bella_amd/host/bella_hip_main.cpp) as a user runs it: FASTQ file in, output file out, a fresh process
+    per run -- process start, context, reservation, ingest, k-mer counting, assembly, overlap, (alignment,) records to the host, the
+    writer.  Wall clock of the process; the FASTQ is in the page cache (it was just written), the output goes to the same tmpfs / disk."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "bella_amd", "bin", "bella-hip")
+    if not os.path.exists(exe):
+        return {"error": "bella_amd/bin/bella-hip is not built"}
+    with open(os.path.join(tmp, "in.txt"), "w") as fl:
+        fl.write(fastq + "\n")
+    rec = {"what": "wall clock of one `bella-hip -f in.txt -o out [--skip-alignment]` process on the FASTQ of this read set (k=17, defaults); "
+                   "stages = the program's own log lines"}
+    for key, flags in (("skip_alignment", ["--skip-alignment"]),) + ((("aligned", []),) if with_alignment else ()):
+        t0 = time.perf_counter()
+        p = subprocess.run([exe, "-f", "in.txt", "-o", "e2e_" + key] + flags, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        wall = time.perf_counter() - t0
+        err = p.stderr.decode(errors="replace")
+        nums = [ln.strip() for ln in p.stdout.decode(errors="replace").splitlines() if re.fullmatch(r"[0-9.eE+-]+", ln.strip())]
+        if p.returncode != 0 or len(nums) < 4:
+            rec[key] = {"error": "rc %d: %s" % (p.returncode, err[-300:])}
+            continue
+        grab = lambda name: (lambda m: float(m.group(1)) if m else None)(re.search(r"%s = ([0-9.]+) seconds" % name, err))
+        out = os.path.join(tmp, "e2e_" + key + ".out")
+        rec[key] = {"wall_s": wall, "nkmers": int(nums[0]), "nnzA": int(nums[1]), "pairs": int(nums[2]), "lines": int(nums[3]) if key == "aligned" else int(nums[2]),
+                    "output_bytes": os.path.getsize(out) if os.path.exists(out) else 0,
+                    "ingest_s": grab("fastqParsingTime"), "kcount_s": grab("KmerCountingTime"), "assemble_s": grab("SparseMatrixCreationTime"),
+                    "output_s": grab("OutputtingTime"), "program_total_s": grab("TotalRuntime")}
+        if os.path.exists(out):
+            os.remove(out)
+    return rec
 
 
 def main():
@@ -298,6 +355,7 @@ def main():
     ap.add_argument("--no-xdrop", action="store_true", help="N=1: skip the X-drop records (configs[2]; configs[3]'s alignment stage)")
     ap.add_argument("--no-hifi", action="store_true", help="N=1: skip the config_hifi sub-record (configs[4]'s regime, 10k HiFi reads)")
     ap.add_argument("--no-dropin", action="store_true", help="N=1: skip the dropin_call records (the shim's call sequence, cold, wall clock)")
+    ap.add_argument("--no-e2e", action="store_true", help="N=1: skip the e2e records (bella_amd/bin/bella-hip on the read set's FASTQ, wall clock)")
     ap.add_argument("--no-layout-ab", action="store_true", help="N=1: skip the layout A/B records (default layout vs row lists: layout + cold pass + warm step)")
     ap.add_argument("--debug-flags", type=int, default=0, help="extra bella_hip_set_debug bits (development A/B)")
     ap.add_argument("--layout-debug", type=int, default=0, help="bella_hip_set_debug bits in force while the operands are laid out (development A/B)")
@@ -505,7 +563,9 @@ def main():
             if not a.no_dropin:
                 rec["dropin_call"] = dropin_call_record(info["rs"], Bhost, info["nk"], local)
                 rec["dropin_call"]["pairs_match_step"] = rec["dropin_call"]["pairs"] == int(acc["npairs"])
-                rec["ingest"] = ingest_record(info["rs"], local)
+                rec["ingest"], e2e = ingest_record(info["rs"], local, with_e2e=not a.no_e2e, with_alignment=not a.no_xdrop)
+                if e2e is not None:
+                    rec["e2e"] = e2e
             if want_cpu:
                 if cpu_thread is not None:
                     cpu_thread.join()
@@ -530,7 +590,7 @@ def main():
             "roofline": big["roofline"], "phases_ms_per_step": big["phases_ms_per_step"],
             "kcount_ms": big["kcount_ms"], "assemble_ms": big["assemble_ms"], "panel_allgather_ms": None,
         }
-        for k2 in ("assemble", "kcount", "reserve_ms", "reserve_bytes", "layout_ab", "xdrop", "dropin_call", "ingest", "cpu_baseline"):
+        for k2 in ("assemble", "kcount", "reserve_ms", "reserve_bytes", "layout_ab", "xdrop", "dropin_call", "ingest", "e2e", "cpu_baseline"):
             if k2 in big:
                 out[k2] = big[k2]
         if not a.no_10k and not a.reads:

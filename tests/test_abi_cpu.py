@@ -151,3 +151,20 @@ def test_native_cli_flags_without_a_device(tmp_path):
     assert p.returncode == 1 and b"no FASTQ file" in p.stderr
     p = run(["-f", "missing.txt", "-o", "x"])
     assert p.returncode == 1 and b"Could not open missing.txt" in p.stderr
+
+
+def test_bench_xdrop_instruction_constants_match_the_isa_listing():
+    """bench.py's in-run X-drop utilisation figure (xdrop.valu_issue_frac) multiplies the measured anti-diagonal steps by per-step
+    instruction counts: those constants are the "every step" line of the committed ISA listing (tools/xdrop_isa.py)"""
+    import re
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    txt = open(os.path.join(ROOT, "profiles", "r06_xdrop_isa.txt")).read()
+    m = re.search(r"every step: (\d+) VALU = (\d+) at ~4\.15 cycles \+ (\d+) at ~2\.4 cycles", txt)
+    o = re.search(r"outer loop \(once per 16 steps\): \d+ instructions, (\d+) VALU", txt)
+    assert m and o
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    get = lambda name: int(re.search(r"^%s = (\d+)" % name, src, re.M).group(1))
+    assert get("XDROP_VALU_HALF_RATE") == int(m.group(2)) and get("XDROP_VALU_FULL_RATE") == int(m.group(3))
+    assert int(m.group(1)) == int(m.group(2)) + int(m.group(3))
+    assert get("XDROP_VALU_CHECKPOINT") == round(int(o.group(1)) / 16.0)
