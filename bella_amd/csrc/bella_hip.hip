@@ -213,7 +213,9 @@ struct bella_ctx {
     uint32_t tune_inline = 0;            // BELLA_TUNE_INLINE_ENTRIES: 0 by the size of A' against the last-level cache, 1 never, 2 always
     uint32_t tune_row_path = 0;          // BELLA_TUNE_ROW_PATH: 0 LDS tiers, 1 every column on the global-workspace (repairing) path
     uint32_t tune_compact_b = 0;         // BELLA_TUNE_COMPACT_B: 0 the layout drops the B' entries that have no later read, 1 keeps them
-    uint32_t tune_dist_layout = 1;       // BELLA_TUNE_DIST_LAYOUT: bella_hip_allgather_panels forms A' by k-mer id ranges over the communicator's ranks
+    uint32_t tune_dist_layout = 2;       // BELLA_TUNE_DIST_LAYOUT: bella_hip_allgather_panels forms A' by k-mer id ranges over the communicator's ranks
+                                         // (1: always, 0: never, 2 = default: on the in-process transport only -- over RCCL the path has not run on
+                                         // more than one device yet, and its extra 20 B per nonzero of traffic want a measurement first)
     bool dist_agreed = false;            // ... and every rank of the communicator said it can (bella_hip_allgather_panels asks)
     bool layout_dist = false;            // ... and the current layout was built that way
     uint64_t tune_cache_bytes = 192ull << 20;   // BELLA_TUNE_CACHE_BYTES: A' above this size counts as "larger than the last-level cache"
@@ -792,8 +794,8 @@ int bella_hip_set_tuning(bella_ctx* c, uint32_t what, const uint64_t* values, ui
             c->pass_known = false;
             return 0;
         case BELLA_TUNE_DIST_LAYOUT:
-            if (n && values[0] > 1) return fail(c, BELLA_ERR_BAD_ARG, "distributed layout: 0 or 1");
-            c->tune_dist_layout = n ? (uint32_t)values[0] : 0u;
+            if (n && values[0] > 2) return fail(c, BELLA_ERR_BAD_ARG, "distributed layout: 0 (never), 1 (always) or 2 (on the in-process transport only)");
+            c->tune_dist_layout = n ? (uint32_t)values[0] : 2u;
             return 0;
         case BELLA_TUNE_CACHE_BYTES:
             c->tune_cache_bytes = n && values[0] ? values[0] : (192ull << 20);
@@ -1833,7 +1835,7 @@ int bella_hip_comm_id_local(uint8_t id[BELLA_HIP_COMM_ID_BYTES]) { return comm_i
 // arrives must not hang the process.  On expiry the communicator is aborted (ncclCommAbort, where the transport has it) and the call
 // fails like any other error: the caller falls back (bench.py, bella_amd/dist.py: the torch.distributed exchange).
 static int comm_sync(bella_ctx* c, const char* what) {
-    static const double limit = [] { const char* e = getenv("BELLA_HIP_COMM_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 120.0; }();
+    const double limit = loop_timeout_s();                      // BELLA_HIP_COMM_TIMEOUT_S, default 120 (comm.hpp)
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     for (;;) {
@@ -1942,7 +1944,8 @@ namespace {
 // what a rank needs for the shared formation (asked of every rank in bella_hip_allgather_panels; taken only if all can)
 bool layout_dist_eligible(const bella_ctx* c) {
     const bool first_app = c->tune_layout_order == 1 || (c->debug & 1024u);
-    return c->tune_dist_layout && c->comm && c->api && c->comm_ranks > 1 && (uint32_t)c->comm_ranks <= kOwnerMax &&
+    const bool wanted = c->tune_dist_layout == 1 || (c->tune_dist_layout == 2 && c->api == &loopback());
+    return wanted && c->comm && c->api && c->comm_ranks > 1 && (uint32_t)c->comm_ranks <= kOwnerMax &&
            c->part_stride == (uint32_t)c->comm_ranks && c->part_first == (uint32_t)c->comm_rank && !first_app && c->nreads <= (1u << 30);
 }
 // a rank that failed before its formation began: its line of the metadata exchange says so (the ranks inside layout_dist read it and leave)

@@ -7,6 +7,9 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -59,19 +62,27 @@ inline const Rccl& rccl() {
 }
 
 // ---- in-process transport with RCCL's call shapes -----------------------------------------------------------------------------
-// The "ranks" are contexts of ONE process, each driven by its own host thread (the shim's numGPU contexts; tests that exercise the
-// N > 1 send/recv offset logic of the collective entry points on a single GPU).  A communicator is a seat in a group keyed by the
+// The "ranks" are contexts of ONE process, each driven by its own host thread (the host programs' -g N contexts; tests that exercise
+// the N > 1 send/recv offset logic of the collective entry points on a single GPU).  A communicator is a seat in a group keyed by the
 // 128-byte id; all-gather and grouped send/recv rendezvous on the host and move the bytes with device-to-device copies on the
 // caller's stream.  Same semantics as the RCCL calls the library makes: grouped point-to-point operations between a pair of ranks
 // match in program order; every call returns when the caller's buffers may be reused.
+// Seats on DIFFERENT devices (a real -g N run): every seat records its device at init; once all have joined, a seat enables peer
+// access to every other device it can reach (hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess: xGMI between the GPUs of a node) and
+// the copies between two devices are hipMemcpyPeerAsync -- which the runtime stages through the host where there is no peer path, so
+// a pair without one is slow, not wrong (said once on stderr).
+// Every rendezvous wait has a deadline (BELLA_HIP_COMM_TIMEOUT_S, default 120 s, as the stream waits of bella_hip.hip: comm_sync): a
+// seat that waits longer marks the group broken and leaves with an error; every other seat's waits end at once with the same error.
 struct LoopGroup {
     std::mutex mu;
     std::condition_variable cv;
     int nranks = 0;
     int seated = 0;
+    bool broken = false;                                        // a seat gave up waiting (or failed): every wait of the group ends
     uint64_t bar_gen = 0;
     int bar_count = 0;
     std::vector<const void*> pub;                               // all-gather: every rank's send buffer
+    std::vector<int> dev;                                       // every rank's device
     struct Msg { const void* p; size_t bytes; };
     std::vector<std::deque<Msg>> mail;                          // [src * nranks + dst]
     std::vector<uint64_t> taken;                                // [src * nranks + dst] messages the receiver has copied out
@@ -87,6 +98,18 @@ inline std::mutex& loop_registry_mu() { static std::mutex m; return m; }
 inline std::map<std::string, std::shared_ptr<LoopGroup>>& loop_registry() { static std::map<std::string, std::shared_ptr<LoopGroup>> r; return r; }
 inline int& loop_group_depth() { static thread_local int d = 0; return d; }
 inline std::vector<LoopOp>& loop_pending() { static thread_local std::vector<LoopOp> v; return v; }
+inline double loop_timeout_s() {
+    const char* e = getenv("BELLA_HIP_COMM_TIMEOUT_S");          // (read at every wait: a host program may set it per phase)
+    const double v = e ? atof(e) : 0.0;
+    return v > 0.0 ? v : 120.0;
+}
+// cv.wait with the group's deadline: false = the deadline passed or the group is broken (the group is marked broken either way)
+template <class Pred>
+inline bool loop_wait(LoopGroup& g, std::unique_lock<std::mutex>& lk, Pred pred) {
+    const bool ok = g.cv.wait_for(lk, std::chrono::duration<double>(loop_timeout_s()), [&] { return g.broken || pred(); });
+    if (!ok || (g.broken && !pred())) { g.broken = true; g.cv.notify_all(); return false; }
+    return true;
+}
 
 inline size_t loop_type_bytes(ncclDataType_t t) {
     switch (t) {
@@ -96,10 +119,15 @@ inline size_t loop_type_bytes(ncclDataType_t t) {
         default: return 2;
     }
 }
-inline void loop_barrier(LoopGroup& g, std::unique_lock<std::mutex>& lk) {
+inline bool loop_barrier(LoopGroup& g, std::unique_lock<std::mutex>& lk) {
     const uint64_t gen = g.bar_gen;
-    if (++g.bar_count == g.nranks) { g.bar_count = 0; ++g.bar_gen; g.cv.notify_all(); }
-    else g.cv.wait(lk, [&] { return g.bar_gen != gen; });
+    if (++g.bar_count == g.nranks) { g.bar_count = 0; ++g.bar_gen; g.cv.notify_all(); return !g.broken; }
+    return loop_wait(g, lk, [&] { return g.bar_gen != gen; });
+}
+// bytes from a buffer on device sdev to one on device ddev, on the receiver's stream
+inline hipError_t loop_copy(void* dst, int ddev, const void* src, int sdev, size_t bytes, hipStream_t st) {
+    if (ddev == sdev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+    return hipMemcpyPeerAsync(dst, ddev, src, sdev, bytes, st);
 }
 inline ncclResult_t loop_GetUniqueId(ncclUniqueId* id) {
     static std::atomic<uint64_t> next{1};
@@ -120,6 +148,7 @@ inline ncclResult_t loop_CommInitRank(ncclComm_t* out, int nranks, ncclUniqueId 
             slot = std::make_shared<LoopGroup>();
             slot->nranks = nranks;
             slot->pub.assign((size_t)nranks, nullptr);
+            slot->dev.assign((size_t)nranks, -1);
             slot->mail.resize((size_t)nranks * nranks);
             slot->taken.assign((size_t)nranks * nranks, 0);
             slot->sent.assign((size_t)nranks * nranks, 0);
@@ -127,14 +156,33 @@ inline ncclResult_t loop_CommInitRank(ncclComm_t* out, int nranks, ncclUniqueId 
         g = slot;
     }
     if (g->nranks != nranks) return ncclInvalidArgument;
+    int mydev = 0;
+    if (hipGetDevice(&mydev) != hipSuccess) return ncclUnhandledCudaError;
     LoopComm* c = new LoopComm();
     c->g = g;
     c->rank = rank;
     {   // like ncclCommInitRank: returns when every rank has joined
         std::unique_lock<std::mutex> lk(g->mu);
+        g->dev[(size_t)rank] = mydev;
         ++g->seated;
         g->cv.notify_all();
-        g->cv.wait(lk, [&] { return g->seated >= g->nranks; });
+        if (!loop_wait(*g, lk, [&] { return g->seated >= g->nranks; })) { delete c; return ncclSystemError; }
+    }
+    // peer access from this seat's device to every other device of the group (enabled once per device pair and process)
+    for (int r = 0; r < nranks; ++r) {
+        const int pd = g->dev[(size_t)r];
+        if (pd == mydev || pd < 0) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, mydev, pd) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+        if (can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(pd, 0);
+            if (e != hipSuccess) (void)hipGetLastError();        // (hipErrorPeerAccessAlreadyEnabled: another seat of this device was first)
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+        }
+        if (!can) {
+            static std::once_flag once;
+            std::call_once(once, [&] { fprintf(stderr, "bella_hip: no peer access between devices %d and %d: the in-process transport stages their copies through the host\n", mydev, pd); });
+        }
     }
     *out = (ncclComm_t)c;
     return ncclSuccess;
@@ -149,27 +197,41 @@ inline ncclResult_t loop_CommDestroy(ncclComm_t comm) {
     delete c;
     return ncclSuccess;
 }
+// a seat that cannot go on (a failed copy, a deadline): nobody waits for it
+inline ncclResult_t loop_break(LoopGroup& g, ncclResult_t rc) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.broken = true;
+    g.cv.notify_all();
+    return rc;
+}
+inline ncclResult_t loop_CommAbort(ncclComm_t comm) {
+    LoopComm* c = (LoopComm*)comm;
+    (void)loop_break(*c->g, ncclSuccess);
+    return loop_CommDestroy(comm);
+}
 inline ncclResult_t loop_AllGather(const void* send, void* recv, size_t count, ncclDataType_t t, ncclComm_t comm, hipStream_t st) {
     LoopComm* c = (LoopComm*)comm;
     LoopGroup& g = *c->g;
     const size_t bytes = count * loop_type_bytes(t);
-    if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;   // my contribution is complete
+    if (hipStreamSynchronize(st) != hipSuccess) return loop_break(g, ncclUnhandledCudaError);   // my contribution is complete
     {
         std::unique_lock<std::mutex> lk(g.mu);
         g.pub[(size_t)c->rank] = send;
-        loop_barrier(g, lk);
+        if (!loop_barrier(g, lk)) return ncclSystemError;
     }
+    const int mydev = g.dev[(size_t)c->rank];
     for (int r = 0; r < g.nranks; ++r)
-        if (bytes && hipMemcpyAsync((char*)recv + (size_t)r * bytes, g.pub[(size_t)r], bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return ncclUnhandledCudaError;
-    if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
+        if (bytes && loop_copy((char*)recv + (size_t)r * bytes, mydev, g.pub[(size_t)r], g.dev[(size_t)r], bytes, st) != hipSuccess) return loop_break(g, ncclUnhandledCudaError);
+    if (hipStreamSynchronize(st) != hipSuccess) return loop_break(g, ncclUnhandledCudaError);
     std::unique_lock<std::mutex> lk(g.mu);
-    loop_barrier(g, lk);                                         // nobody's send buffer changes before everybody has read it
+    if (!loop_barrier(g, lk)) return ncclSystemError;           // nobody's send buffer changes before everybody has read it
     return ncclSuccess;
 }
 inline ncclResult_t loop_run(std::vector<LoopOp>& ops) {
     if (ops.empty()) return ncclSuccess;
+    struct Clear { std::vector<LoopOp>& v; ~Clear() { v.clear(); } } clear{ops};
     for (auto& o : ops)
-        if (o.send && hipStreamSynchronize(o.st) != hipSuccess) return ncclUnhandledCudaError;
+        if (o.send && hipStreamSynchronize(o.st) != hipSuccess) return loop_break(*o.c->g, ncclUnhandledCudaError);
     for (auto& o : ops) {
         if (!o.send) continue;
         LoopGroup& g = *o.c->g;
@@ -187,15 +249,16 @@ inline ncclResult_t loop_run(std::vector<LoopOp>& ops) {
         {
             std::unique_lock<std::mutex> lk(g.mu);
             const size_t x = (size_t)o.peer * g.nranks + o.c->rank;
-            g.cv.wait(lk, [&] { return !g.mail[x].empty(); });
+            if (!loop_wait(g, lk, [&] { return !g.mail[x].empty(); })) return ncclSystemError;
             m = g.mail[x].front();
             g.mail[x].pop_front();
         }
         if (m.bytes != o.bytes) rc = ncclInvalidArgument;          // sizes of a matched pair must agree
-        else if (m.bytes && hipMemcpyAsync(o.p, m.p, m.bytes, hipMemcpyDeviceToDevice, o.st) != hipSuccess) rc = ncclUnhandledCudaError;
+        else if (m.bytes && loop_copy(o.p, g.dev[(size_t)o.c->rank], m.p, g.dev[(size_t)o.peer], m.bytes, o.st) != hipSuccess) rc = ncclUnhandledCudaError;
     }
     for (auto& o : ops)
         if (!o.send && hipStreamSynchronize(o.st) != hipSuccess) rc = ncclUnhandledCudaError;
+    if (rc != ncclSuccess) return loop_break(*ops[0].c->g, rc);
     for (auto& o : ops) {
         if (o.send) continue;
         LoopGroup& g = *o.c->g;
@@ -208,9 +271,8 @@ inline ncclResult_t loop_run(std::vector<LoopOp>& ops) {
         LoopGroup& g = *o.c->g;
         std::unique_lock<std::mutex> lk(g.mu);
         const size_t x = (size_t)o.c->rank * g.nranks + o.peer;
-        g.cv.wait(lk, [&] { return g.taken[x] >= g.sent[x]; });
+        if (!loop_wait(g, lk, [&] { return g.taken[x] >= g.sent[x]; })) return ncclSystemError;
     }
-    ops.clear();
     return rc;
 }
 inline ncclResult_t loop_GroupStart() { ++loop_group_depth(); return ncclSuccess; }
@@ -226,7 +288,7 @@ inline ncclResult_t loop_Recv(void* p, size_t count, ncclDataType_t t, int peer,
     loop_pending().push_back({false, p, count * loop_type_bytes(t), peer, (LoopComm*)comm, st});
     return loop_group_depth() ? ncclSuccess : loop_run(loop_pending());
 }
-inline const char* loop_GetErrorString(ncclResult_t) { return "in-process transport error"; }
+inline const char* loop_GetErrorString(ncclResult_t r) { return r == ncclSystemError ? "in-process transport: a peer did not arrive in time or left the group" : "in-process transport error"; }
 
 inline const Rccl& loopback() {
     static const Rccl api = [] {
@@ -234,6 +296,7 @@ inline const Rccl& loopback() {
         r.h = (void*)1;
         r.GetUniqueId = loop_GetUniqueId; r.CommInitRank = loop_CommInitRank; r.CommDestroy = loop_CommDestroy; r.AllGather = loop_AllGather;
         r.Send = loop_Send; r.Recv = loop_Recv; r.GroupStart = loop_GroupStart; r.GroupEnd = loop_GroupEnd; r.GetErrorString = loop_GetErrorString;
+        r.CommAbort = loop_CommAbort;
         return r;
     }();
     return api;

@@ -439,11 +439,15 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     // product's exact rank inside its pair's list (global path: list position corrected by the chunk-mates on the wrong side; LDS
     // tiers: checked) and the lists in rank order: L_hv / L_gov. -------------------------------------------------------------
     const uint32_t nm = *s_nm;
-    if (nm > Mcap) return false;                              // more multi-product pairs than the dense list holds: the global path has room for any column
-    for (uint32_t j = tid; j < nm; j += kRowBlock) {
-        const uint32_t s = m.M[j];
+    // More multi-product pairs than the dense list holds (dcap / 2: columns whose pairs mostly have several products -- low-error or
+    // deep-coverage input): the two per-pair passes run over the table's slots instead, as they did before the list existed, and the
+    // pair's first product travels through the cid field of its record (round 5 sent such a column to the global-workspace rerun)
+    const bool dense = nm <= Mcap;
+    for (uint32_t j = tid; j < (dense ? nm : H1); j += kRowBlock) {
+        const uint32_t s = dense ? m.M[j] : j;
         const uint32_t ga = m.Gaux[s];
         const uint32_t mm = ga & 0xFFFFu;
+        if (!dense && (mm < 2u || m.T1key[s] == kEmpty)) continue;
         const uint32_t end = m.T1first[s] >> 16;              // range 3's cursor ran to the end of the list
         uint32_t fp = S_p[end - mm];
         if (!OVERLAY) {                                       // chunk-mates may be swapped here (phase R repairs): the smallest of the first chunk
@@ -454,7 +458,8 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
                 fp = o < fp ? o : fp;
             }
         }
-        m.M[j] = s | (fp << 16);
+        if (dense) m.M[j] = s | (fp << 16);
+        else a.tmp_pairs[obase + (ga >> 16)].cid = fp;
         m.T1first[s] = end | (ga & 0xFFFF0000u);
         m.T1cnt[s] = mm | (mm << 16);
         m.Gaux[s] = 0;
@@ -652,17 +657,19 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     BELLA_BPROF(6)
 
     // ---- E: one record per multi-product pair, at the pair's output index (the single-product pairs left in phase S) -------------
-    for (uint32_t j = tid; j < nm; j += kRowBlock) {
-        const uint32_t mj = m.M[j];
+    for (uint32_t j = tid; j < (dense ? nm : H1); j += kRowBlock) {
+        const uint32_t mj = dense ? m.M[j] : j;
         const uint32_t g = mj & 0xFFFFu;
         const uint32_t cw = m.T1cnt[g];
         const uint32_t mm = cw & 0xFFFFu;
+        // (slot scan: a single-product pair still holds its X-phase counts there -- 0 or 1 in the low half; an empty slot 0)
+        if (!dense && (mm < 2u || m.T1key[g] == kEmpty)) continue;
         const uint32_t aux = m.Gaux[g];
         const uint32_t tf = m.T1first[g];
         const uint32_t r = tf >> 16;                          // output index
         const uint32_t st = (tf & 0xFFFFu) - mm;
         const uint32_t keyw = m.T1key[g];
-        const uint32_t firstp = mj >> 16;
+        const uint32_t firstp = dense ? mj >> 16 : a.tmp_pairs[obase + r].cid;
         // plain chain: one bin, headed by the last product (which phase P skips: it always survives)
         uint32_t win = mm - 1, sup = (aux & 0xFFFFu) + 1, nroots = 1;
         if (keyw >> 31) {

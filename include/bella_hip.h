@@ -389,8 +389,9 @@ int bella_hip_trim(bella_ctx* ctx);
  *                             repairing path a device that fails the lane-order self-test gets)
  *   BELLA_TUNE_CACHE_BYTES    values[0] = size of A' from which on it counts as larger than the last-level cache (default 192 MB: three
  *                             quarters of the 256 MB Infinity Cache of an MI355X; the HIP runtime does not report that cache)
- *   BELLA_TUNE_DIST_LAYOUT    values[0] = 0: bella_hip_allgather_panels forms A' on every rank (each sorts ALL entries by k-mer).  Default 1: the
- *                             formation is SHARED over the ranks of the communicator -- rank g sorts the entries whose k-mer id lies in the
+ *   BELLA_TUNE_DIST_LAYOUT    values[0] = 0: bella_hip_allgather_panels forms A' on every rank (each sorts ALL entries by k-mer).  1: the
+ *                             formation is SHARED over the ranks of the communicator (2 = default: shared on the in-process transport, where
+ *                             it is measured; replicated over RCCL until a run on several devices has shown the win) -- rank g sorts the entries whose k-mer id lies in the
  *                             g-th N-th of the id space, emits its slice of A' and the B' entries of all rows for those k-mers; slices and
  *                             entries travel in one more grouped exchange.  The same layout entry for entry.  Taken when EVERY rank can: the
  *                             partition (first, stride) = (rank, ranks) set by bella_hip_set_partition before the call, at most 64 ranks,

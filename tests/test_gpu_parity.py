@@ -2,6 +2,7 @@
 (tests/_oracle.py -> oracle/bella_oracle.c) on the same inputs and against the reference's golden outputs."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -844,6 +845,16 @@ def test_key_table_overflow_is_retried_on_global_path(eng):
     per_read = [[(j, 30 * j) for j in range(500)]] + [[(j, 5)] for j in range(500)]
     exp = _run_constructed(eng, [16000] + [100] * 500, per_read, 500)
     assert len(exp) == 500 and (exp["count"] == 1).all()
+
+
+def test_more_multi_product_pairs_than_the_dense_list_holds_stay_in_lds(eng):
+    """a column whose 750 pairs ALL have two products: the dense list of multi-product pairs (dcap / 2 = 400 entries in its tier) overflows
+    while the key table (800) does not -- the per-pair passes fall back to the slot scan inside the kernel; round 5 abandoned such a
+    column to the global-workspace rerun after its single-product records were written (a silent performance cliff)"""
+    per_read = [[(j, 30 * j) for j in range(1500)]] + [[(2 * j, 5), (2 * j + 1, 40)] for j in range(750)]
+    exp = _run_constructed(eng, [46000] + [100] * 750, per_read, 1500)
+    assert len(exp) == 750 and (exp["count"] >= 2).all()
+    assert eng.timings().retry_columns == 0
 
 
 def test_many_bins_overflow_path_and_std_sort_order(eng):
@@ -1747,6 +1758,87 @@ def _run_ranks(nranks, body, timeout=300):
         t.join(timeout)
     assert not any(t.is_alive() for t in th), "a rank is still inside a collective call: the ranks did not leave it together"
     return out, err
+
+
+def test_in_process_transport_waits_have_a_deadline(monkeypatch):
+    """a rank that never joins (init) or never enters the exchange: its peers leave with an error after BELLA_HIP_COMM_TIMEOUT_S instead
+    of waiting forever (comm.hpp: every rendezvous wait of the in-process transport has the deadline comm_sync gives the stream waits)"""
+    import time
+    monkeypatch.setenv("BELLA_HIP_COMM_TIMEOUT_S", "2")
+    e0 = Engine(0)
+    cid = e0.comm_id(local=True)
+    engines = [Engine(0) for _ in range(2)]
+    t0 = time.time()
+    with pytest.raises(Exception):
+        engines[0].comm_init(2, 0, cid, local=True)             # rank 1 never comes
+    assert 1.5 < time.time() - t0 < 30
+    # a group whose second rank joins but never calls the collective
+    rs = synth.make_reads(40, read_len=1500, coverage=10.0, err=0.15, seed=3)
+    cid = e0.comm_id(local=True)
+
+    def body(r):
+        e = engines[r]
+        e.set_reads(rs)
+        e.comm_init(2, r, cid, local=True)
+        if r == 1:
+            return "stayed out"
+        t1 = time.time()
+        try:
+            e.count_kmers_dist(0, 20, 17, 2, 8)
+        except Exception as ex:  # noqa: BLE001
+            return ("error", time.time() - t1, str(ex))
+        return ("no error", time.time() - t1, "")
+    out, err = _run_ranks(2, body, timeout=60)
+    assert not err, err
+    assert out[0][0] == "error" and 1.5 < out[0][1] < 30, out[0]
+    for e in engines:
+        e.comm_destroy()
+        e.close()
+    e0.close()
+
+
+def test_two_devices_without_oversubscription(tmp_path):
+    """the first run with the contexts of one call on DIFFERENT devices: bella-hip -g 2 with no BELLA_HIP_OVERSUBSCRIBE -- peer access is
+    enabled between the two devices, the panel exchange and the shared formation of A' copy across them (hipMemcpyPeerAsync), the output is
+    the single-GPU one.  Skipped (not passed) on a box with one device."""
+    from bella_amd import _lib
+    if _lib.load().bella_hip_device_count() < 2:
+        pytest.skip("needs two devices")
+    rs = synth.make_reads(2200, read_len=4000, err=0.15, seed=77)
+    fq = str(tmp_path / "a.fastq")
+    synth.write_fastq(fq, rs)
+    for extra, key in ((["--skip-alignment"], "skip"), ([], "align")):
+        bnums, base, _ = _run_native([fq], extra, str(tmp_path / ("one_" + key)))
+        nums, data, err = _run_native([fq], extra + ["-g", "2"], str(tmp_path / ("two_" + key)))
+        assert data == base and nums[:3] == bnums[:3]
+        assert "GPUs = 2" in err
+
+
+def test_rccl_script_with_one_rank():
+    """tools/rccl_two_ranks.py with ONE process: what a one-device box can run of it -- torch.distributed rendezvous, the library's RCCL
+    communicator with its self-test, the distributed counting and the panel exchange with a single rank, the comparison on rank 0"""
+    import subprocess
+    env = dict(os.environ, BELLA_DIST_LAYOUT="0", HSA_ENABLE_IPC_MODE_LEGACY="0", GRAFT_REPO_ROOT=ROOT, BELLA_RCCL_READS="800")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+                        "29531", os.path.join(ROOT, "tools", "rccl_two_ranks.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0 and "RCCL-1 OK" in out, (p.returncode, out[-1500:], p.stderr.decode(errors="replace")[-1500:])
+
+
+@pytest.mark.parametrize("shared", [0, 1])
+def test_two_ranks_over_real_rccl(shared):
+    """two PROCESSES, one device each, the library's own RCCL communicator (tools/rccl_two_ranks.py): distributed counting, the panel
+    exchange, the replicated and the shared formation of A', the pass -- merged records identical to a single-context run.  Skipped (not
+    passed) on a box with one device: the first box with two runs it."""
+    import subprocess
+    from bella_amd import _lib
+    if _lib.load().bella_hip_device_count() < 2:
+        pytest.skip("needs two devices")
+    env = dict(os.environ, BELLA_DIST_LAYOUT=str(shared), HSA_ENABLE_IPC_MODE_LEGACY="0", GRAFT_REPO_ROOT=ROOT)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                        str(29533 + shared), os.path.join(ROOT, "tools", "rccl_two_ranks.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0 and "RCCL-2 OK" in out, (p.returncode, out[-1500:], p.stderr.decode(errors="replace")[-1500:])
 
 
 @pytest.mark.parametrize("shared", [False, True])
