@@ -550,15 +550,21 @@ __global__ void k_layout_own_lengths(const uint32_t* Bptr, uint32_t nreads, uint
 // pass streamed them, decoded them and scanned their zero counts.  They are dropped here, once: one wavefront per row counts its live
 // entries, a scan gives the new row pointers, a second pass moves the live entries -- in their order, so the product order of a column
 // (entry by entry, then down the list) is what it was.  BELLA_TUNE_COMPACT_B 1 keeps every entry (tests, A/B).
-__global__ __launch_bounds__(kBlock) void k_layout_live(const uint32_t* Bloc, const uint2* Bent, uint32_t nreads, uint32_t inl, uint32_t* len) {
+__global__ __launch_bounds__(kBlock) void k_layout_live(const uint32_t* Bloc, const uint2* Bent, uint32_t nreads, uint32_t inl, uint32_t* len,
+                                                        uint32_t* rowF) {
     const uint32_t i = blockIdx.x * kWaves + wave_id();
     if (i > nreads) return;
-    uint32_t n = 0;
+    uint32_t n = 0, f = 0;
     if (i < nreads)
-        for (uint32_t e = Bloc[i] + lane_id(); e < Bloc[i + 1]; e += 64) n += bent_count(Bent[e], inl) ? 1u : 0u;
+        for (uint32_t e = Bloc[i] + lane_id(); e < Bloc[i + 1]; e += 64) { const uint32_t cnt = bent_count(Bent[e], inl); n += cnt ? 1u : 0u; f += cnt; }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) n += __shfl_xor(n, d, 64);
-    if (lane_id() == 0) len[i] = n;                                   // (len[nreads] = 0: the scan's last element)
+    for (int d = 32; d > 0; d >>= 1) { n += __shfl_xor(n, d, 64); f += __shfl_xor(f, d, 64); }
+    if (lane_id() == 0) {
+        if (len) len[i] = n;                                          // (len[nreads] = 0: the scan's last element)
+        // the row's PRODUCTS (estimateFLOP, overlap.hpp:157-202: the sum of the entries' later-read counts) -- a property of the operands
+        // like a row pointer: the passes read four bytes per column instead of streaming a count per entry (round 5: 2 B per nonzero per pass)
+        rowF[i] = f;
+    }
 }
 __global__ __launch_bounds__(kBlock) void k_layout_compact(const uint32_t* Bloc, const uint32_t* Bnew, const uint2* Bent, uint32_t nreads, uint32_t inl,
                                                            uint2* out) {
@@ -577,13 +583,6 @@ __global__ __launch_bounds__(kBlock) void k_layout_compact(const uint32_t* Bloc,
     }
 }
 
-// the products of every entry once more, compact: estimateFLOP streams 2 B per nonzero.  (Its own pass, 0.43 ms at 100k reads: written
-// from k_layout_place next to the entry -- a scattered 2-byte store per entry -- that kernel goes from 2.8 to 7.5 ms.)
-__global__ void k_layout_bcnt(const uint2* Bent, uint64_t nnz, uint16_t* Bcnt, uint32_t inl) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < nnz) Bcnt[e] = (uint16_t)bent_count(Bent[e], inl);
-}
-
 // ---- row lists: the products of every column, ready-made, in product order -----------------------------------------------------
 // The SpGEMM of column i reads, for each entry of row i, the tail of that k-mer's list in A' (the later reads): with A' alone that is
 // one random 8..56-byte read per entry and pass, plus the expansion of the entries into products and the overlap estimate of every
@@ -592,16 +591,6 @@ __global__ void k_layout_bcnt(const uint2* Bent, uint64_t nnz, uint16_t* Bcnt, u
 // posH | posV << 16}, Aov[...] = the partner's read length -- the two operand entries of the product side by side; the multiply of
 // the semiring (the overlap estimate, chain.hpp:47-71) stays in the pass.  The numeric phase streams them -- coalesced, no index per
 // product, no B' entries, no expansion.  10 bytes per product of the whole SpGEMM (1.8 GB at 100k reads); needs read ids < 2^30.
-// products per row (sum of the suffix counts), all rows
-__global__ __launch_bounds__(kBlock) void k_layout_rowflops(const uint32_t* Bptr, const uint16_t* Bcnt, uint32_t nreads, uint32_t* rowflops) {
-    const uint32_t i = blockIdx.x * kWaves + wave_id();
-    if (i > nreads) return;
-    uint32_t s = 0;
-    if (i < nreads) for (uint32_t e = Bptr[i] + lane_id(); e < Bptr[i + 1]; e += 64) s += Bcnt[e];
-#pragma unroll
-    for (int dlt = 32; dlt > 0; dlt >>= 1) s += __shfl_xor(s, dlt, 64);
-    if (lane_id() == 0) rowflops[i] = s;                            // (rowflops[nreads] = 0: the scan's last element)
-}
 // one workgroup per row (grid-stride), its entries in rounds of 1024: block scan of the counts, then groups of L lanes copy the tail
 // of one entry's list each (L = 1, 4 or 16 by the round's products per entry: short lists -- PacBio-like input, less than one later
 // read per entry -- one lane per entry, four independent loads in flight; long lists -- HiFi-like input, tens of later reads -- a

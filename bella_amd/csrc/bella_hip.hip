@@ -150,7 +150,7 @@ struct bella_ctx {
     uint32_t kc_bfirst = 0, kc_brows = 0; // the read block the device-resident tuples cover (all reads unless counted distributed)
     Buf kc_nk, kc_koff, kc_hist, kc_keys, kc_alt, kc_runlen, kc_flag, kc_slot, kc_nruns, kc_dcode, kc_dcount, kc_hkey, kc_hval, kc_found,
         kc_tstart, kc_cursor, kc_sel, kc_ringo, kc_ringp, kc_opos, kc_oid, kc_opos2, kc_oid2;
-    Buf Bptr, Bk, Bpos, Bent, Bcnt, Aent, Aent2, Aov, Arow, Bloc;
+    Buf Bptr, Bk, Bpos, Bent, rowF, Aent, Aent2, Aov, Arow, Bloc;
     bool have_rowlists = false;          // Aent2 / Arow hold the row lists of the current layout
     bool want_rowlists = false;          // BELLA_TUNE_ROW_LISTS: build them with the next layouts (when they fit)
     uint32_t part_first = 0, part_stride = 1;
@@ -433,7 +433,6 @@ int build_layout(bella_ctx* c, bool collective = false) {
     const uint32_t* Bloc = ptr<uint32_t>(c->Bloc);                 // the rows of the owned columns
     // (buffers only ever grow; a context that goes from a whole layout to a partition's gives the difference back)
     if (c->Bent.cap > 16 * nown_nnz + (1u << 20)) release(c->Bent);
-    if (c->Bcnt.cap > 4 * nown_nnz + (1u << 20)) release(c->Bcnt);
     ENSURE(c, c->Bent, 8 * nown_nnz);
     const bool first_app = c->tune_layout_order == 1 || (c->debug & 1024u);
     c->layout_dist = dist;
@@ -524,34 +523,35 @@ int build_layout(bella_ctx* c, bool collective = false) {
         }
         c->owned_nnz = nown_nnz;
         c->live_nnz = nown_nnz;
-        if (nown_nnz && !c->tune_compact_b) {
-            // B' without the entries that have no later read (assemble.hpp: k_layout_live / k_layout_compact): new row pointers by a scan
-            // of the rows' live counts, the live entries moved in their order; from here on Bloc indexes the compacted B'
+        ENSURE(c, c->rowF, 4 * ((size_t)c->nreads + 2));
+        if (!nown_nnz) HIPCHK(c, hipMemsetAsync(c->rowF.p, 0, 4 * ((size_t)c->nreads + 2), c->stream));
+        if (nown_nnz) {
+            // one pass over the rows of B': the rows' products (rowF: what estimateFLOP returns, kept like a row pointer) and their live
+            // entries; then B' without the entries that have no later read (assemble.hpp: k_layout_live / k_layout_compact): new row
+            // pointers by a scan of the live counts, the live entries moved in their order; from here on Bloc indexes the compacted B'
+            const bool compact = !c->tune_compact_b;
             uint32_t* len = ptr<uint32_t>(c->w);
             uint32_t* bnew = ptr<uint32_t>(c->wscan);
-            k_layout_live<<<nblk((uint64_t)c->nreads + 1, kWaves), kBlock, 0, c->stream>>>(Bloc, ptr<uint2>(c->Bent), c->nreads, inl, len);
+            k_layout_live<<<nblk((uint64_t)c->nreads + 1, kWaves), kBlock, 0, c->stream>>>(Bloc, ptr<uint2>(c->Bent), c->nreads, inl, compact ? len : nullptr,
+                                                                                         ptr<uint32_t>(c->rowF));
             KCHK(c);
-            int rc = scan_u32(c, len, bnew, (uint64_t)c->nreads + 1);
-            if (rc) return rc;
-            uint32_t live = 0;
-            HIPCHK(c, hipMemcpyAsync(&live, bnew + c->nreads, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            Buf out;
-            rc = ensure_bytes(c, out, 8 * (size_t)live);
-            if (rc) return rc;
-            k_layout_compact<<<nblk(c->nreads, kWaves), kBlock, 0, c->stream>>>(Bloc, bnew, ptr<uint2>(c->Bent), c->nreads, inl, ptr<uint2>(out));
-            if (hipGetLastError() != hipSuccess) { release(out); return fail(c, BELLA_ERR_HIP, "k_layout_compact failed to launch"); }
-            HIPCHK(c, hipMemcpyAsync(c->Bloc.p, bnew, 4 * ((size_t)c->nreads + 1), hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            std::swap(c->Bent, out);
-            release(out);
-            c->live_nnz = live;
-        }
-        if (c->live_nnz) {
-            int rc = ensure_bytes(c, c->Bcnt, 2 * c->live_nnz);
-            if (rc) return rc;
-            k_layout_bcnt<<<nblk(c->live_nnz), 256, 0, c->stream>>>(ptr<uint2>(c->Bent), c->live_nnz, ptr<uint16_t>(c->Bcnt), inl);
-            KCHK(c);
+            if (compact) {
+                int rc = scan_u32(c, len, bnew, (uint64_t)c->nreads + 1);
+                if (rc) return rc;
+                uint32_t live = 0;
+                HIPCHK(c, hipMemcpyAsync(&live, bnew + c->nreads, 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                Buf out;
+                rc = ensure_bytes(c, out, 8 * (size_t)live);
+                if (rc) return rc;
+                k_layout_compact<<<nblk(c->nreads, kWaves), kBlock, 0, c->stream>>>(Bloc, bnew, ptr<uint2>(c->Bent), c->nreads, inl, ptr<uint2>(out));
+                if (hipGetLastError() != hipSuccess) { release(out); return fail(c, BELLA_ERR_HIP, "k_layout_compact failed to launch"); }
+                HIPCHK(c, hipMemcpyAsync(c->Bloc.p, bnew, 4 * ((size_t)c->nreads + 1), hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                std::swap(c->Bent, out);
+                release(out);
+                c->live_nnz = live;
+            }
         }
         // pairs/products on a sample of (owned) columns -> key-table budget of the LDS tiers (see k_sample_pair_ratio), and: is this a
         // long-list input (HiFi-like: at most one pair in 64 products)?
@@ -580,10 +580,7 @@ int build_layout(bella_ctx* c, bool collective = false) {
             int rc = ensure_bytes(c, c->Arow, 8 * ((size_t)c->nreads + 2));
             uint64_t F = 0;
             if (!rc) {
-                uint32_t* rf = ptr<uint32_t>(c->w);                 // (w is free: k_layout_heads did not run)
-                k_layout_rowflops<<<nblk((uint64_t)c->nreads + 1, kWaves), kBlock, 0, c->stream>>>(Bloc, ptr<uint16_t>(c->Bcnt), c->nreads, rf);
-                KCHK(c);
-                rc = scan_u32_to_u64(c, rf, ptr<uint64_t>(c->Arow), (uint64_t)c->nreads + 1);
+                rc = scan_u32_to_u64(c, ptr<uint32_t>(c->rowF), ptr<uint64_t>(c->Arow), (uint64_t)c->nreads + 1);   // (rowF[nreads] = 0)
                 if (rc) return rc;
                 HIPCHK(c, hipMemcpyAsync(&F, ptr<uint64_t>(c->Arow) + c->nreads, 8, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -613,7 +610,11 @@ int build_layout(bella_ctx* c, bool collective = false) {
         }
     }
     if (!c->have_rowlists) { release(c->Aent2); release(c->Aov); release(c->Arow); }
-    if (!nnz) HIPCHK(c, hipMemsetAsync(c->Bloc.p, 0, 4 * ((size_t)c->nreads + 2), c->stream));
+    if (!nnz) {
+        HIPCHK(c, hipMemsetAsync(c->Bloc.p, 0, 4 * ((size_t)c->nreads + 2), c->stream));
+        ENSURE(c, c->rowF, 4 * ((size_t)c->nreads + 2));
+        HIPCHK(c, hipMemsetAsync(c->rowF.p, 0, 4 * ((size_t)c->nreads + 2), c->stream));
+    }
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     uint32_t st = 0;
     int rc = read_status(c, &st);
@@ -724,7 +725,7 @@ void bella_hip_destroy(bella_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && c->api) { (void)c->api->CommDestroy(c->comm); c->comm = nullptr; }
     release(c->comm_meta);
-    Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->Bcnt, &c->Aent, &c->Aent2, &c->Aov, &c->Arow, &c->Bloc, &c->t_kmer, &c->t_read, &c->t_pos,
+    Buf* all[] = {&c->packed, &c->roff, &c->Bptr, &c->Bk, &c->Bpos, &c->Bent, &c->rowF, &c->Aent, &c->Aent2, &c->Aov, &c->Arow, &c->Bloc, &c->t_kmer, &c->t_read, &c->t_pos,
                   &c->tstart, &c->Bk_tmp, &c->Bpos_tmp, &c->rowcnt, &c->asm_ws, &c->asm_cls, &c->lk_key, &c->lk_key2, &c->lk_val, &c->lk_val2, &c->lk_rinfo,
                   &c->w, &c->wscan, &c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC,
                   &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
@@ -2548,8 +2549,8 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         k_row_flops_rl<<<nblk(nown), kBlock, 0, c->stream>>>(ptr<uint64_t>(c->Arow), i0, c->part_stride, nown, ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC), d_ctl);
         KCHK(c);
     } else if (nown) {
-        k_row_flops<<<nblk(nown, kWaves), kBlock, 0, c->stream>>>(layout_bptr(c), ptr<uint16_t>(c->Bcnt), i0, c->part_stride, nown,
-                                                                  ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC), d_ctl);
+        k_row_flops<<<nblk(nown), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->rowF), i0, c->part_stride, nown,
+                                                          ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC), d_ctl);
         KCHK(c);
     } else {
         HIPCHK(c, hipMemsetAsync(d_ctl, 0, 4 * kCtlWords, c->stream));
@@ -2981,13 +2982,13 @@ int bella_hip_count_pairs(bella_ctx* c, const bella_params* p, uint64_t* colptrC
     uint32_t i0 = 0;
     const uint32_t nown = owned_columns(c, &i0);
     if (!colptrC && !npairs) {
-        // estimateFLOP alone (overlap.hpp:157-202): the products per column are sums over the count stream, no gather at all
+        // estimateFLOP alone (overlap.hpp:157-202): the products per column were summed when the operands were laid out (rowF), no gather at all
         if (nown && c->have_rowlists) {
             k_row_flops_rl<<<nblk(nown), kBlock, 0, c->stream>>>(ptr<uint64_t>(c->Arow), i0, c->part_stride, nown, ptr<uint32_t>(c->flopsr), ptr<uint32_t>(c->nnzC), ptr<uint32_t>(c->ctl));
             KCHK(c);
         } else if (nown) {
-            k_row_flops<<<nblk(nown, kWaves), kBlock, 0, c->stream>>>(layout_bptr(c), ptr<uint16_t>(c->Bcnt), i0, c->part_stride, nown, ptr<uint32_t>(c->flopsr),
-                                                                      ptr<uint32_t>(c->nnzC), ptr<uint32_t>(c->ctl));
+            k_row_flops<<<nblk(nown), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->rowF), i0, c->part_stride, nown, ptr<uint32_t>(c->flopsr),
+                                                              ptr<uint32_t>(c->nnzC), ptr<uint32_t>(c->ctl));
             KCHK(c);
         }
         hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> it(ptr<uint32_t>(c->flopsr), CastU64());
@@ -3055,7 +3056,7 @@ int bella_hip_get_memory(bella_ctx* c, bella_memory* m) {
     m->reads_bytes = sum({&c->packed, &c->roff});
     m->matrix_bytes = sum({&c->Bptr, &c->Bk, &c->Bpos});
     m->layout_A_bytes = sum({&c->Aent});
-    m->layout_B_bytes = sum({&c->Bent, &c->Bcnt, &c->Bloc});
+    m->layout_B_bytes = sum({&c->Bent, &c->rowF, &c->Bloc});
     m->rowlist_bytes = sum({&c->Aent2, &c->Aov, &c->Arow});
     m->pass_bytes = sum({&c->flopsr, &c->flopptr, &c->nnzC, &c->colptrC, &c->rowlists, &c->tiercaps, &c->tmp_pairs, &c->tmp_ext, &c->pairs, &c->ext, &c->sortscr, &c->ws,
                          &c->cubtmp, &c->plist_hv, &c->overflow, &c->ctl, &c->retry, &c->orderlist, &c->order_ws, &c->w_f, &c->w_off, &c->w_key, &c->w_key2, &c->w_idx,

@@ -27,7 +27,7 @@
 //
 // Data layout in HBM (built by assemble.hpp):
 //   Bent[e] = { a_ptr, posV | cnt << 16 (14 bit) | pal << 30 | ori << 31 }  e in B' order (MergeDuplicates slot order)
-//   Bcnt[e] = cnt once more as u16 (the estimateFLOP pass streams 2 B per nonzero)
+//   rowF[i] = products of column i (the sum of its entries' counts: estimateFLOP, written once at layout time)
 //   Aent[x] = { read | ori << 31, posH | readlen << 16 }  k-mer lists, ascending read id, stored in order of first
 //                                                          appearance in B' (streaming for the owner row)
 #pragma once
@@ -939,32 +939,15 @@ __global__ __launch_bounds__(kBlock) void k_row_flops_rl(const uint64_t* Arow, u
     nnzC[i] = 0;
     flops[i] = (uint32_t)(Arow[i + 1] - Arow[i]);
 }
-__global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* Bptr, const uint16_t* Bcnt, uint32_t i0, uint32_t stride, uint32_t nown,
-                                                      uint32_t* flops, uint32_t* nnzC, uint32_t* ctl) {
+// The default layout keeps the products of every row (rowF, written once at layout time: assemble.hpp k_layout_live): one thread per column.
+__global__ __launch_bounds__(kBlock) void k_row_flops(const uint32_t* rowF, uint32_t i0, uint32_t stride, uint32_t nown, uint32_t* flops,
+                                                      uint32_t* nnzC, uint32_t* ctl) {
     if (blockIdx.x == 0 && threadIdx.x < kCtlWords) ctl[threadIdx.x] = 0;   // the pass's control block (first kernel of the pass)
-    const uint32_t j = blockIdx.x * kWaves + wave_id();       // the j-th column of this context: i0 + j * stride
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nown) return;
     const uint32_t i = i0 + j * stride;
-    if (lane_id() == 0) nnzC[i] = 0;                          // this pass's pair counts start from zero
-    uint32_t s = 0;
-    const uint32_t b0 = Bptr[i], b1 = Bptr[i + 1];
-    // head up to an 8-byte boundary, body four counts per lane and load (two loads in flight), tail
-    const uint32_t head0 = (4u - (b0 & 3u)) & 3u, head = head0 < b1 - b0 ? head0 : b1 - b0;
-    if (lane_id() < head) s += Bcnt[b0 + lane_id()];
-    const uint32_t e0 = b0 + head;
-    const uint2* B4 = (const uint2*)(Bcnt + e0);
-    const uint32_t ng = (b1 - e0) >> 2;
-    uint32_t g = lane_id();
-    for (; g + 64 < ng; g += 128) {
-        const uint2 v = B4[g], v2 = B4[g + 64];
-        s += (v.x & 0xFFFFu) + (v.x >> 16) + (v.y & 0xFFFFu) + (v.y >> 16) + (v2.x & 0xFFFFu) + (v2.x >> 16) + (v2.y & 0xFFFFu) + (v2.y >> 16);
-    }
-    for (; g < ng; g += 64) { const uint2 v = B4[g]; s += (v.x & 0xFFFFu) + (v.x >> 16) + (v.y & 0xFFFFu) + (v.y >> 16); }
-    const uint32_t e1 = e0 + (ng << 2);
-    if (e1 + lane_id() < b1) s += Bcnt[e1 + lane_id()];
-#pragma unroll
-    for (int dlt = 32; dlt > 0; dlt >>= 1) s += __shfl_xor(s, dlt, 64);
-    if (lane_id() == 0) flops[i] = s;
+    nnzC[i] = 0;                                               // this pass's pair counts start from zero
+    flops[i] = rowF[i];
 }
 
 // tier lists: column i with f products goes to the first tier whose cap >= f (caps ascending; last tier = global path).
