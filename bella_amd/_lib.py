@@ -46,7 +46,7 @@ class Timings(C.Structure):
 class Memory(C.Structure):
     _fields_ = [("reads_bytes", C.c_uint64), ("matrix_bytes", C.c_uint64), ("layout_A_bytes", C.c_uint64), ("layout_B_bytes", C.c_uint64),
                 ("rowlist_bytes", C.c_uint64), ("pass_bytes", C.c_uint64), ("other_bytes", C.c_uint64), ("owned_nnz", C.c_uint64),
-                ("layout_shared", C.c_uint64)]
+                ("layout_shared", C.c_uint64), ("live_nnz", C.c_uint64)]
 
 
 # every symbol include/bella_hip.h declares: (name, restype, argtypes)
@@ -105,6 +105,7 @@ SIGNATURES = [
                                          C.POINTER(WriteStats)]),
     ("bella_hip_get_timings", C.c_int, [vp, C.POINTER(Timings)]),
     ("bella_hip_get_memory", C.c_int, [vp, C.POINTER(Memory)]),
+    ("bella_hip_get_memory_sized", C.c_int, [vp, vp, C.c_uint64]),
     ("bella_hip_set_debug", C.c_int, [vp, C.c_uint32]),
     ("bella_hip_reserve", C.c_int, [vp, C.c_uint64, C.POINTER(C.c_double)]),
     ("bella_hip_trim", C.c_int, [vp]),

@@ -3050,7 +3050,19 @@ int bella_hip_count_pairs(bella_ctx* c, const bella_params* p, uint64_t* colptrC
     return 0;
 }
 
-int bella_hip_get_memory(bella_ctx* c, bella_memory* m) {
+static int get_memory_impl(bella_ctx* c, bella_memory* m);
+// (the struct grew from 64 to 72 bytes between ABI versions 4 and 5 with no size handshake.)  The sized form writes at most
+// struct_size bytes: a caller built against an older, shorter bella_memory gets the fields it knows and nothing behind its struct.
+int bella_hip_get_memory_sized(bella_ctx* c, void* out, uint64_t struct_size) {
+    if (!c || !out || struct_size < 8) return BELLA_ERR_BAD_ARG;
+    bella_memory m{};
+    const int rc = get_memory_impl(c, &m);
+    if (rc) return rc;
+    std::memcpy(out, &m, (size_t)std::min<uint64_t>(struct_size, sizeof(m)));
+    return 0;
+}
+int bella_hip_get_memory(bella_ctx* c, bella_memory* m) { return get_memory_impl(c, m); }
+static int get_memory_impl(bella_ctx* c, bella_memory* m) {
     if (!c || !m) return BELLA_ERR_BAD_ARG;
     auto sum = [](std::initializer_list<const Buf*> l) { uint64_t t = 0; for (const Buf* b : l) t += b->cap; return t; };
     m->reads_bytes = sum({&c->packed, &c->roff});
@@ -3069,6 +3081,7 @@ int bella_hip_get_memory(bella_ctx* c, bella_memory* m) {
     m->other_bytes += c->pool.bytes;                               // (released buffers waiting for the next request they fit)
     m->owned_nnz = c->have_matrix ? c->owned_nnz : 0;
     m->layout_shared = c->have_matrix && c->layout_dist ? 1 : 0;
+    m->live_nnz = c->have_matrix ? c->live_nnz : 0;
     return 0;
 }
 

@@ -133,7 +133,7 @@ def roofline_of(acc, nnz_share, copy_gbps, traffic_key, expand_ms=0.0, layout="d
     # HBM traffic of the same kernels from the PMC counters (tools/collect_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes,
     # gfx950 FETCH_SIZE x2 correction calibrated on our own stream): a separate profiling run, read from the committed summary and
     # accepted only if it was taken on the same workload AND layout
-    for tag in ("r05", "r04"):
+    for tag in ("r06", "r05"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag)))[traffic_key]
             if abs(tr["algorithmic_bytes"] - alg_bytes) < 1e-3 * alg_bytes and tr.get("layout", "default") == layout:
@@ -141,9 +141,12 @@ def roofline_of(acc, nnz_share, copy_gbps, traffic_key, expand_ms=0.0, layout="d
                 r["traffic_uncorrected"] = tr["FETCH_SIZE_raw_bytes"] + tr["WRITE_SIZE_raw_bytes"]
                 r["traffic_source"] = ("profiles/%s_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes per step; a separate "
                                        "profiled run).  traffic = 2 x FETCH_SIZE + WRITE_SIZE: the gfx950 correction of the guide, calibrated on our own "
-                                       "coalesced stream (0.500).  profiles/%s_mem_counters_100k.txt shows every L2 miss of these kernels leaving as a 128-byte "
+                                       "coalesced stream (0.500).  profiles/r04_mem_counters_100k.txt shows every L2 miss of these kernels leaving as a 128-byte "
                                        "fabric request (TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ), so the correction holds for the random gathers of A' too: "
-                                       "the traffic above the algorithmic bytes is whole lines fetched for 8 ... 24-byte list tails" % (tag, tag))
+                                       "the traffic above the algorithmic bytes is whole lines fetched for 8 ... 24-byte list tails" % tag)
+                # what the pass could reach at this traffic if it moved it at the copy ceiling measured in this run
+                if copy_gbps and r["traffic"]:
+                    r["ceiling_frac"] = copy_gbps / (r["traffic"] / alg_bytes) / HBM_PEAK_GBPS
                 break
         except Exception:
             pass
@@ -582,8 +585,9 @@ def main():
                       not a.no_cpu_baseline, True)
         out = {
             "metric": "candidate overlap pairs/sec", "value": big["value"], "unit": "pairs/s", "n_gpus": 1,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": big["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": big["ms_per_step"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u16/u32 integer", "data": "synthetic",
+            "headline_set": "configs[3]'s 100k-read set on one GPU since round 5 (rounds 1-4 quoted the 10k set: it travels as config_10k)",
             "config": {"workload": ("configs[3]'s read set on one GPU (the set the roofline target is quoted on): " if nreads == BIG_READS else "") + big["workload"],
                        "reads": nreads, "nkmers": big["nkmers"], "nnzA": big["nnzA"], "flops": big["flops"], "pairs": big["pairs"],
                        "partition": "all columns on one GPU"},
@@ -647,6 +651,24 @@ def main():
     # bella_hip_count_kmers_dist, bella_hip_allgather_panels -- every wait has a deadline); any step that fails on any rank sends ALL
     # ranks to the torch.distributed path for that step (prepare: all_ok), and the line says which path ran.
     use_lib = (backend == "nccl" or bool(os.environ.get("BELLA_BENCH_FORCE_LIB_PROBE"))) and not os.environ.get("BELLA_BENCH_NO_LIBCOMM")
+    # Process-level watchdog over set-up + measurement: the library's waits have deadlines, ncclCommInitRank / a torch
+    # collective whose peer never arrives do not.  A rank that is still here after BELLA_BENCH_WATCHDOG_S (default 900 s) says so on
+    # stderr, rank 0 prints a line the driver can parse ("value": null, "error"), and the process leaves.
+    import threading
+    wd_done = threading.Event()
+
+    def watchdog():
+        limit = float(os.environ.get("BELLA_BENCH_WATCHDOG_S", "900"))
+        if wd_done.wait(limit):
+            return
+        log("[bench] rank %d: no result after %.0f s (a peer did not arrive?); giving up" % (rank, limit))
+        if rank == 0:
+            print(json.dumps({"metric": "candidate overlap pairs/sec", "value": None, "unit": "pairs/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+                              "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16/u32 integer",
+                              "data": "synthetic", "config": {"workload": "configs[3]'s read set over %d GPUs" % n_gpus},
+                              "error": "watchdog: the ranks did not finish within %.0f s" % limit}), flush=True)
+        os._exit(3)
+    threading.Thread(target=watchdog, daemon=True).start()
     eng, info = prepare(nreads, False, use_lib=use_lib)
     mA = measure(eng, info)
     xd = None
@@ -731,6 +753,7 @@ def main():
     else:
         out["library_rccl_path"] = {"status": "ok: this line"}
     if rank == 0:
+        wd_done.set()
         print(json.dumps(out), flush=True)
     eng.close()
     dist.destroy_process_group()

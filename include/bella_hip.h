@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define BELLA_HIP_ABI_VERSION 5
+#define BELLA_HIP_ABI_VERSION 6
 
 enum {
     BELLA_OK = 0,
@@ -327,14 +327,18 @@ typedef struct {
     uint64_t reads_bytes;      /* packed reads + offsets: replicated                                                     */
     uint64_t matrix_bytes;     /* B in the reference's layout (colptr / rowids / values): what the all-gather delivers     */
     uint64_t layout_A_bytes;   /* A' (k-mer -> reads lists): whole on every context                                        */
-    uint64_t layout_B_bytes;   /* B' entries + their count stream: owned columns only                                      */
+    uint64_t layout_B_bytes;   /* B' entries + the rows' product counts + row pointers: owned columns only                 */
     uint64_t rowlist_bytes;    /* row lists (BELLA_TUNE_ROW_LISTS) + row pointers: owned columns only                      */
     uint64_t pass_bytes;       /* buffers of the passes (records, product lists, workspaces): follow the pass's products   */
     uint64_t other_bytes;      /* counting / assembly / alignment buffers still held, and released ones kept for reuse      */
     uint64_t owned_nnz;        /* nnz of the owned columns (B' keeps those of them that have a later read: BELLA_TUNE_COMPACT_B) */
     uint64_t layout_shared;    /* 1: the current layout was formed shared over the ranks (BELLA_TUNE_DIST_LAYOUT), else 0  */
+    uint64_t live_nnz;         /* B' entries the layout holds: those of the owned columns that have a later read (ABI 6)  */
 } bella_memory;
 int bella_hip_get_memory(bella_ctx* ctx, bella_memory* m);
+/* the same, writing at most struct_size bytes (pass sizeof(bella_memory) of the header the caller was built against: the struct has
+ * grown between ABI versions -- 64 bytes in version 4, 72 in 5, 80 in 6 -- and will again) */
+int bella_hip_get_memory_sized(bella_ctx* ctx, void* m, uint64_t struct_size);
 /* 0 = default; bit0 = force the global-memory row path (tests); bit1 = no pair_ext output; bit2 = tests: treat every fifth
  * column as if its product lists had come out of order (the LDS tiers verify the order and fall back to the repairing path);
  * bit3 = tests: 512-thread workgroups in every LDS class (default: 1024 threads where a CU holds one or two columns);

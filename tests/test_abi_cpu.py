@@ -21,14 +21,14 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == {s[0] for s in _lib.SIGNATURES}
-    assert lib.bella_hip_abi_version() == 5
+    assert lib.bella_hip_abi_version() == 6
 
 
 def test_struct_layouts_match_header():
     assert _lib.PAIR_DT.itemsize == 16 and _lib.EXT_DT.itemsize == 8 and _lib.ALN_DT.itemsize == 32 and _lib.SEED_DT.itemsize == 12
     import ctypes
     assert ctypes.sizeof(_lib.Params) == 24 and ctypes.sizeof(_lib.Timings) == 80 and ctypes.sizeof(_lib.WriteStats) == 80 and ctypes.sizeof(_lib.IngestStats) == 40
-    assert ctypes.sizeof(_lib.Memory) == 72
+    assert ctypes.sizeof(_lib.Memory) == 80
 
 
 def test_ctypes_structs_equal_the_headers_as_a_c_compiler_sees_them(tmp_path):

@@ -30,15 +30,15 @@ def tot(c, pred):
     return sum(v["sum_kb"] for k, v in out.get(c, {}).items() if pred(k)) * 1024 / passes
 sp = lambda k: "k_spgemm_rows" in k or "k_fold" in k or "k_order" in k
 fetch, write = tot("FETCH_SIZE", sp), tot("WRITE_SIZE", sp)
-# calibration of FETCH_SIZE on our own coalesced stream: k_layout_bcnt (assembly; the bench counts twice, assembles once: one dispatch
+# calibration of FETCH_SIZE on our own coalesced stream: k_layout_live (assembly; the bench counts twice, assembles once: one dispatch
 # in the run) reads the 8-byte B' entry of every nonzero once
 nnz = bench["config"]["nnzA"]
-rf = sum(v["sum_kb"] for k, v in out.get("FETCH_SIZE", {}).items() if "k_layout_bcnt" in k) * 1024
+rf = sum(v["sum_kb"] for k, v in out.get("FETCH_SIZE", {}).items() if "k_layout_live" in k) * 1024
 summary = {
  "workload": "%d reads, 1 GPU" % bench["config"]["reads"], "layout": bench["roofline"].get("layout", "default"),
  "kernels": "k_spgemm_rows_lds (all LDS classes) + k_fold_overflow + k_order_wave/_block", "per": "step (= one launch set)",
  "FETCH_SIZE_raw_bytes": fetch, "WRITE_SIZE_raw_bytes": write,
- "fetch_calibration": {"kernel": "k_layout_bcnt", "expected_bytes": 8 * nnz, "ratio_measured_over_expected": rf / (8.0 * nnz),
+ "fetch_calibration": {"kernel": "k_layout_live", "expected_bytes": 8 * nnz, "ratio_measured_over_expected": rf / (8.0 * nnz),
                        "note": "FETCH_SIZE reads 1/2 of the streamed bytes on gfx950 (MI355X_MICROARCH.md, HBM); checked on our own coalesced 8-byte stream"},
  "hbm_bytes_corrected": 2.0 * fetch + write,
  "algorithmic_bytes": bench["roofline"]["algorithmic_bytes_per_step"],
