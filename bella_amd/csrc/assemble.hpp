@@ -449,12 +449,16 @@ __global__ void k_layout_emit(const uint32_t* skey, const uint64_t* sval, uint64
 // one grouped all-to-all).  The compaction of a row's in-range entries is stable (the sort is, too: a list of A' stays in ascending read
 // order).
 __global__ __launch_bounds__(kBlock) void k_range_rowcount(const uint32_t* Bptr, const uint32_t* Bk, uint32_t nreads, uint32_t klo, uint32_t khi,
-                                                           uint32_t* cnt) {
+                                                           uint32_t* cnt, uint32_t nkmers, uint32_t* status) {
     const uint32_t r = blockIdx.x * kWaves + wave_id();
     if (r > nreads) return;
     uint32_t n = 0;
     if (r < nreads)
-        for (uint32_t e = Bptr[r] + lane_id(); e < Bptr[r + 1]; e += 64) { const uint32_t km = Bk[e]; n += km >= klo && km < khi ? 1u : 0u; }
+        for (uint32_t e = Bptr[r] + lane_id(); e < Bptr[r + 1]; e += 64) {
+            const uint32_t km = Bk[e];
+            n += km >= klo && km < khi ? 1u : 0u;
+            if (km >= nkmers) atomicOr(status, 32u);                     // (every rank sees every entry here: the bad input is reported, not a slice mismatch)
+        }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) n += __shfl_xor(n, d, 64);
     if (lane_id() == 0) cnt[r] = n;

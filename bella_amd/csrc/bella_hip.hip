@@ -52,6 +52,8 @@ struct Arena {
     static size_t round(size_t n) { return (n + 4095) & ~(size_t)4095; }
     bool owns(const void* p) const { return base && (const char*)p >= base && (const char*)p < base + size; }
     size_t free_bytes() const { return size - in_use; }
+    // the largest single buffer the slab can still give (first fit over a fragmented free list: the sum of the holes is not it)
+    size_t largest_hole() const { size_t m = 0; for (const auto& h : holes) m = std::max(m, h.second); return m; }
     void* take(size_t n) {
         n = round(n);
         for (auto it = holes.begin(); it != holes.end(); ++it)
@@ -587,7 +589,9 @@ int build_layout(bella_ctx* c, bool collective = false) {
             }
             size_t mfree = 0, mtotal = 0;
             HIPCHK(c, hipMemGetInfo(&mfree, &mtotal));
-            mfree += c->pool.bytes + c->pool.arena.free_bytes();    // (released buffers and the unused part of the reserved slab are free for this purpose)
+            // (released buffers and the reserved slab count as free for this purpose -- the slab by its largest HOLE: the lists are one
+            // buffer, and a fragmented slab that cannot give it would send the request to the driver next to the slab's 55 % of VRAM)
+            mfree += c->pool.bytes + c->pool.arena.largest_hole();
             // 10 bytes per product for the lists; a pass over all owned columns then needs about 60 more per product (records twice,
             // product lists, scratch, diagnostics) -- the lists are only built when both fit (debug bit 11: tests, "no room")
             const bool fits = (double)F * 70.0 + 1e8 <= (double)mfree && !(c->debug & 2048u);
@@ -1857,7 +1861,9 @@ static int comm_sync(bella_ctx* c, const char* what) {
 // that does not move data fails HERE, at init, not inside the first exchange of a run.
 static int comm_selftest(bella_ctx* c) {
     const int N = c->comm_ranks, me = c->comm_rank;
-    ENSURE(c, c->comm_meta, 8 * 4 * ((size_t)N + 1) + 64);
+    // (sized here, once, for every later use -- the status exchanges and the metadata lines of the shared formation of A': no collective
+    // entry point can find itself without the buffer its peers are waiting to hear from it through)
+    ENSURE(c, c->comm_meta, 8 * (((size_t)N + 3) * ((size_t)N + 1) + 4 * ((size_t)N + 1)) + 8 * 4 * ((size_t)N + 1) + 64);
     uint64_t* d = ptr<uint64_t>(c->comm_meta);
     const uint64_t mine[4] = {0xBE11A000ull + (uint64_t)me, ~(uint64_t)me, 0, 0};
     HIPCHK(c, hipMemsetAsync(d, 0, 8 * 4 * ((size_t)N + 1) + 64, c->stream));
@@ -1984,7 +1990,8 @@ int layout_dist(bella_ctx* c, uint64_t nown_nnz, uint32_t rmask, uint32_t inl, i
     uint32_t nsel32 = 0;
     if (!rc) rc = [&]() -> int {
         HIPCHK(c, hipMemsetAsync(hist, 0, 8 * 2 * (size_t)kOwnerMax, c->stream));
-        k_range_rowcount<<<nblk((uint64_t)nr + 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bk), nr, klo, khi, cnt);
+        k_range_rowcount<<<nblk((uint64_t)nr + 1, kWaves), kBlock, 0, c->stream>>>(ptr<uint32_t>(c->Bptr), ptr<uint32_t>(c->Bk), nr, klo, khi, cnt, nk,
+                                                                                   ptr<uint32_t>(c->status));
         KCHK(c);
         k_owner_hist_rows<<<nblk(nr ? nr : 1), 256, 0, c->stream>>>(cnt, nr, (uint32_t)N, hist);
         KCHK(c);
@@ -1992,8 +1999,12 @@ int layout_dist(bella_ctx* c, uint64_t nown_nnz, uint32_t rmask, uint32_t inl, i
         if (sr) return sr;
         HIPCHK(c, hipMemcpyAsync(&nsel32, rowbase + nr, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(line.data() + 3, hist, 8 * (size_t)N, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        return 0;
+        // a k-mer id beyond the dictionary belongs to no rank's range: the slices would not add up and every rank would report a
+        // STATE error; the rank that sees it reports the bad input instead (status bit 32, as the replicated formation does)
+        uint32_t st0 = 0;
+        const int r0 = read_status(c, &st0);
+        if (r0) return r0;
+        return status_to_error(c, st0);
     }();
     const uint64_t nsel = nsel32;
     // (2) buffers for the rank's share: what it sorts (nsel) and what it receives (nown_nnz)
@@ -3223,7 +3234,7 @@ static int run_xdrop(bella_ctx* c, const bella_params* p, const bella_seed* d_se
                 {
                     size_t mfree = 0, mtotal = 0;
                     if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
-                        const uint64_t held = c->xstate.cap + c->xlive.cap + c->pool.bytes + c->pool.arena.free_bytes();
+                        const uint64_t held = c->xstate.cap + c->xlive.cap + c->pool.bytes + c->pool.arena.largest_hole();   // (one buffer: the slab's largest hole, not the sum of its holes)
                         const uint64_t fit = ((uint64_t)mfree + held) / 4 / (4 * (uint64_t)kXStateWords + 8);
                         if (capB > fit) capB = fit;
                     }

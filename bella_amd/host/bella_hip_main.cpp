@@ -197,12 +197,14 @@ int main(int argc, char** argv) {
     uint8_t comm_id[BELLA_HIP_COMM_ID_BYTES];
     if (N > 1) check(nullptr, bella_hip_comm_id_local(comm_id), "bella_hip_comm_id_local");
     std::vector<uint32_t> nk_of((size_t)N, 0), nreads_of((size_t)N, 0);
-    std::vector<double> t_ingest((size_t)N, 0), t_count((size_t)N, 0), t_asm((size_t)N, 0);
+    std::vector<double> t_ingest((size_t)N, 0), t_count((size_t)N, 0), t_asm((size_t)N, 0), t_init((size_t)N, 0);
     on_all(N, [&](int g) {
         Worker& w = W[(size_t)g];
+        double t0 = now_s();
         check(nullptr, bella_hip_init(g % ndev, &w.ctx), "bella_hip_init");
         reserve_for(w.ctx, file_bytes / 2, (N + ndev - 1) / ndev);   // (a FASTQ file is half bases, half qualities)
-        double t0 = now_s();
+        t_init[(size_t)g] = now_s() - t0;
+        t0 = now_s();
         uint32_t nreads = 0;
         uint64_t nbases = 0;
         check(w.ctx, bella_hip_load_fastq_list(w.ctx, cpaths.data(), (uint32_t)cpaths.size(), &nreads, &nbases), "bella_hip_load_fastq_list");
@@ -248,6 +250,8 @@ int main(int argc, char** argv) {
         nk_of[(size_t)g] = nk;
     });
     const uint32_t nreads = nreads_of[0];
+    const std::string ContextAndReservationTime = std::to_string(t_init[0]) + " seconds";
+    BELLA_HIP_LOGT(tag, ContextAndReservationTime);
     const std::string fastqParsingTime = std::to_string(t_ingest[0]) + " seconds";
     BELLA_HIP_LOGT(tag, fastqParsingTime);
     const uint32_t numReads = nreads;
@@ -287,8 +291,23 @@ int main(int argc, char** argv) {
     so.filename = outfile.c_str();
     so.tag = tag;
     so.exact = o.exact ? 1 : 0;
+    const double t_stages = now_s();
     run_stages(W, so, names.data(), lens.data());
+    {
+        const CallStats& cs = last_call_stats();
+        const std::string OverlapTime = std::to_string(cs.overlap_seconds) + " seconds";            // (overlap.hpp:714-727's bracket)
+        BELLA_HIP_LOGT(tag, OverlapTime);
+        const std::string RecordsAndAlignmentTime = std::to_string(cs.align_seconds) + " seconds";    // records to the host (+ X-drop + alignments to the host)
+        BELLA_HIP_LOGT(tag, RecordsAndAlignmentTime);
+        const std::string WriterTime = std::to_string(cs.write_seconds) + " seconds";
+        BELLA_HIP_LOGT(tag, WriterTime);
+        const std::string StagesTime = std::to_string(now_s() - t_stages) + " seconds";
+        BELLA_HIP_LOGT(tag, StagesTime);
+    }
+    const double t_close = now_s();
     for (auto& w : W) bella_hip_destroy(w.ctx);
+    const std::string TeardownTime = std::to_string(now_s() - t_close) + " seconds";
+    BELLA_HIP_LOGT(tag, TeardownTime);
 
     const double totaltime = now_s() - all;
     const std::string TotalRuntime = std::to_string(totaltime) + " seconds";

@@ -287,9 +287,8 @@ def dropin_call_record(rs, Bhost, nk, device):
     return rec
 
 
-def ingest_record(rs, device, with_e2e=False, with_alignment=False):
-    """FASTQ file -> packed reads on the device (bella_hip_load_fastq) on a fresh context, the file in the page cache; and, on the same
-    file, the native command line end to end (e2e_record)"""
+def ingest_record(rs, device):
+    """FASTQ file -> packed reads on the device (bella_hip_load_fastq) on a fresh context, the file in the page cache"""
     import tempfile
     from bella_amd import Engine
     from bella_testkit import synth
@@ -309,8 +308,18 @@ def ingest_record(rs, device, with_e2e=False, with_alignment=False):
         eng.close()
         best["what"] = ("bella_hip_load_fastq, warm: mmap + threaded line index, bases gathered into pinned 64 MB chunks under the previous "
                         "chunk's transfer, 2-bit pack on the device, names and lengths kept; wall clock on the host")
-        e2e = e2e_record(f, tmp, with_alignment) if with_e2e else None
-    return best, e2e
+    return best
+
+
+def e2e_on_set(rs, with_alignment):
+    """the native command line on this read set's FASTQ (written to a temporary directory first; run when nothing else of the bench is
+    using the host cores: the reference's OpenMP baseline takes all of them)"""
+    import tempfile
+    from bella_testkit import synth
+    with tempfile.TemporaryDirectory() as tmp:
+        f = os.path.join(tmp, "reads.fastq")
+        synth.write_fastq(f, rs)
+        return e2e_record(f, tmp, with_alignment)
 
 
 def e2e_record(fastq, tmp, with_alignment):
@@ -566,15 +575,15 @@ def main():
             if not a.no_dropin:
                 rec["dropin_call"] = dropin_call_record(info["rs"], Bhost, info["nk"], local)
                 rec["dropin_call"]["pairs_match_step"] = rec["dropin_call"]["pairs"] == int(acc["npairs"])
-                rec["ingest"], e2e = ingest_record(info["rs"], local, with_e2e=not a.no_e2e, with_alignment=not a.no_xdrop)
-                if e2e is not None:
-                    rec["e2e"] = e2e
+                rec["ingest"] = ingest_record(info["rs"], local)
             if want_cpu:
                 if cpu_thread is not None:
                     cpu_thread.join()
                 cb = cpu_box.get("cb") or {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": "failed", "pairs": None}
                 cb["pairs_match_gpu"] = cb.pop("pairs", None) == int(acc["npairs"])
                 rec["cpu_baseline"] = cb
+            if not a.no_e2e:                                    # (after the CPU baseline: it runs on all host cores)
+                rec["e2e"] = e2e_on_set(info["rs"], not a.no_xdrop)
             del eng, info, Bhost
             return rec
 
