@@ -63,7 +63,9 @@ inline void on_all(int N, const std::function<void(int)>& fn) {             // o
 // allocate for themselves).  BELLA_HIP_NO_RESERVE=1 leaves it out.
 inline void reserve_for(bella_ctx* ctx, uint64_t total_bases, int contexts_per_device) {
     if (std::getenv("BELLA_HIP_NO_RESERVE")) return;
-    uint64_t want = 44ull * total_bases;
+    uint64_t per_base = 44;
+    if (const char* e = std::getenv("BELLA_HIP_RESERVE_BYTES_PER_BASE")) per_base = (uint64_t)std::strtoull(e, nullptr, 10);
+    uint64_t want = per_base * total_bases;
     if (want < (1ull << 30)) want = 1ull << 30;
     if (contexts_per_device > 1) want /= (uint64_t)contexts_per_device;
     double ms = 0.0;

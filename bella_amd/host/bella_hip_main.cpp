@@ -203,6 +203,10 @@ int main(int argc, char** argv) {
         double t0 = now_s();
         check(nullptr, bella_hip_init(g % ndev, &w.ctx), "bella_hip_init");
         reserve_for(w.ctx, file_bytes / 2, (N + ndev - 1) / ndev);   // (a FASTQ file is half bases, half qualities)
+        if (const char* e = std::getenv("BELLA_HIP_KCOUNT_BUDGET")) {
+            const uint64_t v = std::strtoull(e, nullptr, 10);
+            check(w.ctx, bella_hip_set_tuning(w.ctx, BELLA_TUNE_KCOUNT_BUDGET, &v, 1), "bella_hip_set_tuning");
+        }
         t_init[(size_t)g] = now_s() - t0;
         t0 = now_s();
         uint32_t nreads = 0;

@@ -15,6 +15,6 @@ for rep in 1 2; do
   T0=$(date +%s.%N)
   $R/bella_amd/bin/bella-hip -f in.txt -o out "$@" 2> err.txt | tr '\n' ' '; echo
   T1=$(date +%s.%N)
-  echo "wall $(echo "$T1 - $T0" | bc) s"
+  python -c "print(\"wall %.2f s\" % ($T1 - $T0))"
   grep -E "Time" err.txt | sed 's/INFO:\tbella_hip_main.cpp//' | tr '\n' ';'; echo
 done
