@@ -441,13 +441,14 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     const uint32_t nm = *s_nm;
     // More multi-product pairs than the dense list holds (dcap / 2: columns whose pairs mostly have several products -- low-error or
     // deep-coverage input): the two per-pair passes run over the table's slots instead, as they did before the list existed, and the
-    // pair's first product travels through the cid field of its record (round 5 sent such a column to the global-workspace rerun)
+    // list's storage holds the pairs' first products by SLOT (dcap halves of a word: a product index has 16 bits).  Round 5 sent such a
+    // column to the global-workspace rerun.  (The slot-scan loops are loops of their own and touch LDS only: a global load in phase E --
+    // the first version carried the first product through the record's cid field -- costs every column a wait for the record stores
+    // of phase S, 7 % of the pass, whether the loop runs or not.)
     const bool dense = nm <= Mcap;
-    for (uint32_t j = tid; j < (dense ? nm : H1); j += kRowBlock) {
-        const uint32_t s = dense ? m.M[j] : j;
+    auto c2_one = [&](const uint32_t s, const uint32_t j, const bool by_slot) {
         const uint32_t ga = m.Gaux[s];
         const uint32_t mm = ga & 0xFFFFu;
-        if (!dense && (mm < 2u || m.T1key[s] == kEmpty)) continue;
         const uint32_t end = m.T1first[s] >> 16;              // range 3's cursor ran to the end of the list
         uint32_t fp = S_p[end - mm];
         if (!OVERLAY) {                                       // chunk-mates may be swapped here (phase R repairs): the smallest of the first chunk
@@ -458,11 +459,17 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
                 fp = o < fp ? o : fp;
             }
         }
-        if (dense) m.M[j] = s | (fp << 16);
-        else a.tmp_pairs[obase + (ga >> 16)].cid = fp;
+        if (by_slot) ((uint16_t*)m.M)[s] = (uint16_t)fp;
+        else m.M[j] = s | (fp << 16);
         m.T1first[s] = end | (ga & 0xFFFF0000u);
         m.T1cnt[s] = mm | (mm << 16);
         m.Gaux[s] = 0;
+    };
+    if (dense) {
+        for (uint32_t j = tid; j < nm; j += kRowBlock) c2_one(m.M[j], j, false);
+    } else {
+        for (uint32_t s = tid; s < H1; s += kRowBlock)
+            if (m.T1key[s] != kEmpty && (m.Gaux[s] & 0xFFFFu) >= 2u) c2_one(s, 0u, true);
     }
     if (!OVERLAY) __syncthreads();
     // NX = list positions per thread in the LDS tiers (cap <= NX * kRowBlock)
@@ -657,19 +664,14 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     BELLA_BPROF(6)
 
     // ---- E: one record per multi-product pair, at the pair's output index (the single-product pairs left in phase S) -------------
-    for (uint32_t j = tid; j < (dense ? nm : H1); j += kRowBlock) {
-        const uint32_t mj = dense ? m.M[j] : j;
-        const uint32_t g = mj & 0xFFFFu;
+    auto e_one = [&](const uint32_t g, const uint32_t firstp) {
         const uint32_t cw = m.T1cnt[g];
         const uint32_t mm = cw & 0xFFFFu;
-        // (slot scan: a single-product pair still holds its X-phase counts there -- 0 or 1 in the low half; an empty slot 0)
-        if (!dense && (mm < 2u || m.T1key[g] == kEmpty)) continue;
         const uint32_t aux = m.Gaux[g];
         const uint32_t tf = m.T1first[g];
         const uint32_t r = tf >> 16;                          // output index
         const uint32_t st = (tf & 0xFFFFu) - mm;
         const uint32_t keyw = m.T1key[g];
-        const uint32_t firstp = dense ? mj >> 16 : a.tmp_pairs[obase + r].cid;
         // plain chain: one bin, headed by the last product (which phase P skips: it always survives)
         uint32_t win = mm - 1, sup = (aux & 0xFFFFu) + 1, nroots = 1;
         if (keyw >> 31) {
@@ -680,7 +682,7 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
                 for (uint32_t t = 0; t < mm; ++t) a.plist[obase + st + t] = make_uint2(m.L_hv[st + t], m.L_gov[st + t] & 0xFFFFu);
                 a.tmp_pairs[obase + r].cid = firstp;
                 a.overflow[atomicAdd(&a.ctl[kCtlOverflow], 1u)] = make_uint4(i, keyw & 0x7FFFFFFFu, st | (mm << 16), r);
-                continue;
+                return;
             }
             // bins in the reference's order = roots by descending product index; std::sort by support (desc) on <= 16 bins is
             // an insertion sort: the first maximum wins
@@ -703,6 +705,13 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
             ex.nbins = (uint16_t)nroots; ex.support = (uint16_t)sup; ex.binov = (uint16_t)(m.L_gov[st + win] & 0xFFFFu); ex.pad = 0;
             a.tmp_ext[obase + r] = ex;
         }
+    };
+    if (dense) {
+        for (uint32_t j = tid; j < nm; j += kRowBlock) { const uint32_t mj = m.M[j]; e_one(mj & 0xFFFFu, mj >> 16); }
+    } else {
+        // (slot scan: a single-product pair still holds its X-phase counts in T1cnt -- 0 or 1 in the low half; an empty slot 0)
+        for (uint32_t g = tid; g < H1; g += kRowBlock)
+            if (m.T1key[g] != kEmpty && (m.T1cnt[g] & 0xFFFFu) >= 2u) e_one(g, ((const uint16_t*)m.M)[g]);
     }
     if (tid == 0) a.nnzC[i] = d;
     BELLA_BPROF(7)
