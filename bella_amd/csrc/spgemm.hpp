@@ -179,6 +179,9 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
 #define BELLA_BPROF(n)
 #endif
     const uint32_t H1 = m.dcap;
+    // where the column's records go: asked for HERE, as a scalar load (the column is wave-uniform), so that the trip is long over when
+    // phase C first needs it -- issued where it is used (round 5) every wavefront of every column sat out one full memory latency there
+    const uint64_t obase = a.flopptr[__builtin_amdgcn_readfirstlane((int)i)];
     uint32_t* s_chunk = m.scr + 48;
     uint32_t* s_fail = m.scr + 49;
     uint32_t* s_np = m.scr + 50;                              // LDS tiers: some pair of the column is not a plain chain
@@ -324,7 +327,6 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
     if (*s_fail) return false;
 
     // ---- C: every pair gets its output index (table-slot order), the multi-product pairs their list and four scatter cursors ----
-    const uint64_t obase = a.flopptr[i];
     uint32_t Fm, d;                                           // products of the multi-product pairs = total list length; pairs
     {
         const uint32_t c = (H1 + kRowBlock - 1) / kRowBlock;
