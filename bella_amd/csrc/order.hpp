@@ -47,6 +47,7 @@ struct OrderArgs {
 
 __device__ __forceinline__ void order_copy_record(const OrderArgs& a, uint64_t from, uint64_t to, uint32_t cid) {
     uint4 rec = *(const uint4*)(a.tmp_pairs + from);
+    asm volatile("" : "+v"(rec.y));                          // (keeps the load ONE 16-byte load: the compiler splits it around the word that is replaced)
     rec.y = cid;
     *(uint4*)(a.pairs + to) = rec;
     if (a.ext) a.ext[to] = a.tmp_ext[from];
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_wave(OrderArgs a) {
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) rec[u] = *(const uint4*)(a.tmp_pairs + src + ord[r + 64 * u]);
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) { rec[u].y = i; *(uint4*)(a.pairs + dst + r + 64 * u) = rec[u]; }
+            for (uint32_t u = 0; u < 4; ++u) { asm volatile("" : "+v"(rec[u].y)); rec[u].y = i; *(uint4*)(a.pairs + dst + r + 64 * u) = rec[u]; }
             if (a.ext) {
 #pragma unroll
                 for (uint32_t u = 0; u < 4; ++u) a.ext[dst + r + 64 * u] = a.tmp_ext[src + ord[r + 64 * u]];
