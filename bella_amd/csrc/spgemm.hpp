@@ -277,49 +277,58 @@ __device__ __forceinline__ bool process_row(const SpgemmArgs& a, const uint32_t 
                 }
             }
         }
-        // (Measured and not kept, round 5: every product of the batch decoded first and ONE probe loop for all of them -- the
-        // compare-and-swaps of a lane's products in flight together -- with one decode for both forms of a B' entry: bit-exact, row
-        // kernels 3.58 -> 4.82 ms at 100k reads, 0.28 -> 0.33 ms at 10k.)
+        // Decode all products of the batch, then the FIRST probe of every product back to back (two compare-and-swaps in flight per
+        // lane), then the rest of each insertion.  (Round 5 measured ONE probe loop for the whole batch: +35 %, spills.)
+        uint32_t key[XB], hv[XB], ovf[XB], hh[XB], old[XB];
 #pragma unroll
         for (uint32_t u = 0; u < XB; ++u) {
             const uint32_t p = base + u * kRowBlock + tid;
+            key[u] = 0; hv[u] = 0; ovf[u] = 0; hh[u] = 0; old[u] = kEmpty;
             if (p >= F) continue;
-            uint32_t key, hv, ov, pal;
+            uint32_t ov, pal;
             bool oriented;
             if (RL) {                                          // {partner | pal << 30 | oriented << 31, posH | posV << 16}, partner's length
-                key = ae[u].x & 0x3FFFFFFFu; pal = (ae[u].x >> 30) & 1u; oriented = (ae[u].x >> 31) != 0; hv = ae[u].y;
-                ov = (uint32_t)overlap_estimate(hv & 0xFFFFu, hv >> 16, bw[u], lenV, oriented, k) & 0xFFFFu;
+                key[u] = ae[u].x & 0x3FFFFFFFu; pal = (ae[u].x >> 30) & 1u; oriented = (ae[u].x >> 31) != 0; hv[u] = ae[u].y;
+                ov = (uint32_t)overlap_estimate(hv[u] & 0xFFFFu, hv[u] >> 16, bw[u], lenV, oriented, k) & 0xFFFFu;
             } else if (inl[u]) {                               // the entry itself: partner | oriented << 30 | 1 << 31, posV | posH << 16
-                key = ax[u] & 0x3FFFFFFFu;
+                key[u] = ax[u] & 0x3FFFFFFFu;
                 const uint32_t posH = bw[u] >> 16, posV = bw[u] & 0xFFFFu;
                 pal = 0;
                 oriented = ((ax[u] >> 30) & 1u) != 0;
                 ov = (uint32_t)overlap_estimate(posH, posV, ae[u].y - ae[u].x, lenV, oriented, k) & 0xFFFFu;
-                hv = posH | (posV << 16);
+                hv[u] = posH | (posV << 16);
             } else {
-                key = ae[u].x & 0x7FFFFFFFu;
+                key[u] = ae[u].x & 0x7FFFFFFFu;
                 const uint32_t posH = ae[u].y & 0xFFFFu, lenH = ae[u].y >> 16;
                 const uint32_t posV = bw[u] & 0xFFFFu;
                 pal = (bw[u] >> 30) & 1u;
                 oriented = (ae[u].x >> 31) == (bw[u] >> 31);
                 ov = (uint32_t)overlap_estimate(posH, posV, lenH, lenV, oriented, k) & 0xFFFFu;
-                hv = posH | (posV << 16);
+                hv[u] = posH | (posV << 16);
             }
-            uint32_t h = hash_range(key, H1);
-            uint32_t old = 0;
+            ovf[u] = ov | (((oriented ? 1u : 0u) | (pal << 1)) << 30);
+            hh[u] = hash_range(key[u], H1);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < XB; ++u)
+            if (base + u * kRowBlock + tid < F) old[u] = atomicCAS(&m.T1key[hh[u]], kEmpty, key[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < XB; ++u) {
+            const uint32_t p = base + u * kRowBlock + tid;
+            if (p >= F) continue;
+            uint32_t h = hh[u], o = old[u];
             uint32_t probes = 0;
-            for (; probes < H1; ++probes) {
-                old = atomicCAS(&m.T1key[h], kEmpty, key);
-                if (old == kEmpty || old == key) break;
+            while (o != kEmpty && o != key[u]) {
+                if (++probes == H1) break;
                 h = (h + 1 == H1) ? 0 : h + 1;
+                o = atomicCAS(&m.T1key[h], kEmpty, key[u]);
             }
             if (probes == H1) { *s_fail = 1; continue; }     // more pairs than this tier's key table holds
             const uint32_t q = (p >= RB ? 1u : 0u) + (p >= 2u * RB ? 1u : 0u) + (p >= 3u * RB ? 1u : 0u);
             atomicAdd((q & 2u) ? &m.T1first[h] : &m.T1cnt[h], (q & 1u) ? 0x10000u : 1u);
-            m.A_hv[p] = hv;
-            const uint32_t fl = (oriented ? 1u : 0u) | (pal << 1);
-            if (OVERLAY) m.A_gov[p] = (fl << 30) | (h << 16) | ov;
-            else { m.A_gov[p] = (h << 16) | ov; m.A_fl[p] = (uint8_t)fl; }
+            m.A_hv[p] = hv[u];
+            if (OVERLAY) m.A_gov[p] = (ovf[u] & 0xC000FFFFu) | (h << 16);
+            else { m.A_gov[p] = (h << 16) | (ovf[u] & 0xFFFFu); m.A_fl[p] = (uint8_t)(ovf[u] >> 30); }
         }
     }
     __syncthreads();
