@@ -167,7 +167,14 @@ def layout_ab_record(eng, pars, info, copy_gbps, sync, steps, traffic_key):
         acc = timed_passes(eng, pars, steps, 1, sync)
         nnz = int(eng.get_B()[0][-1])
         r = roofline_of(acc, nnz, copy_gbps, traffic_key, expand_ms=exp_ms, layout=name)
-        out[name] = {"layout_ms": lay, "expansion_ms": exp_ms, "rows_ms": rows_ms, "cold_pass_device_ms": cold, "cold_total_ms": lay + cold,
+        if name == "row_lists":                               # (the committed PMC summary of the same workload with the row lists, if there is one)
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", "r06_hbm_traffic.json"))).get(traffic_key + "_rl")
+                if tr and abs(tr["algorithmic_bytes"] - r["algorithmic_bytes_per_step"]) < 1e-3 * tr["algorithmic_bytes"]:
+                    r["traffic"] = tr["hbm_bytes_corrected"]
+            except Exception:
+                pass
+        out[name] = {"layout_ms": lay, "expansion_ms": exp_ms, "rows_ms": rows_ms, "cold_pass_device_ms": cold, "cold_total_ms": lay + cold, "traffic": r.get("traffic"),
                      "warm_ms_per_step": acc["elapsed"] * 1e3 / steps, "numeric_kernel_ms": r["kernel_ms_per_step"], "frac": r["frac"],
                      "frac_incl_expansion": r["frac_incl_expansion"], "rowlist_bytes": int(eng.memory().rowlist_bytes)}
     eng.set_tuning("row_lists")
