@@ -26,12 +26,33 @@ inline void check(bella_ctx* c, int rc, const char* what) {
     std::abort();                                    // (the reference returns void and prints; CSC.cpp:269 aborts the same way)
 }
 
+// a host array the library fills: no value-initialisation (std::vector::resize writes 2.4 GB of zeros in front of the copy that
+// overwrites them: 0.25 s of a 100k-read run with alignment)
+template <class T>
+struct RawBuf {
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf&) = delete;
+    RawBuf& operator=(const RawBuf&) = delete;
+    RawBuf(RawBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    ~RawBuf() { std::free(p); }
+    void resize(size_t m) {
+        if (m > cap) { std::free(p); p = (T*)std::malloc(m * sizeof(T) + 64); if (!p) { std::cerr << "bella_hip: out of host memory" << std::endl; std::abort(); } cap = m; }
+        n = m;
+    }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    const T* begin() const { return p; }
+    size_t size() const { return n; }
+};
+
 // one context = one GPU: operands in, then per stage [lo, hi): overlap (+ alignment) and the records of ITS columns
 struct Worker {
     bella_ctx* ctx = nullptr;
     std::vector<uint64_t> colptr;            // colptrC of the last pass (nreads + 1)
-    std::vector<bella_pair> pairs;
-    std::vector<bella_aln> alns;
+    RawBuf<bella_pair> pairs;
+    RawBuf<bella_aln> alns;
     uint64_t nnzc = 0;
 };
 // what the last call of this process did (tests, logs): every column must be computed by the numeric phase exactly once

@@ -34,6 +34,8 @@ if [ -f "$stamp" ] && [ "$OUT/libbella_ref.so" -nt "$HERE/ref_shim.cpp" ] && [ -
    && [ "$OUT/libbella_dropin.so" -nt "$ROOTDIR/bella_amd/host/bella_hip_shim.hpp" ] && [ -x "$OUT/bella_eval" ] \
    && [ -x "$OUT/bella_dropin" ] && [ "$OUT/bella_dropin" -nt "$ROOTDIR/bella_amd/host/bella_hip_shim.hpp" ] \
    && [ "$OUT/bella_dropin" -nt "$ROOTDIR/include/bella_hip.h" ] \
+   && [ "$OUT/bella_dropin" -nt "$ROOTDIR/bella_amd/host/bella_hip_driver.hpp" ] \
+   && [ "$OUT/libbella_dropin.so" -nt "$ROOTDIR/bella_amd/host/bella_hip_driver.hpp" ] \
    && [ "${1:-}" != "--force" ]; then
   echo "build_ref: up to date"; exit 0
 fi
