@@ -2317,7 +2317,11 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
             a.R_len_w = ptr<uint32_t>(c->w_rlen); a.R_start_w = ptr<uint32_t>(c->w_rstart); a.R_key_w = c->w_key2.p;
             a.R_first = ptr<uint32_t>(c->w_rfirst);
             if (np) {
+                #ifdef BELLA_G2_OLD
                 k_wide_group2<<<nw < 8192u ? nw : 8192u, kWideGroup2Block, 0, c->stream>>>(a);
+#else
+                k_wide_group2_chunks<<<nw < 8192u ? nw : 8192u, kWideGroup2Block, 0, c->stream>>>(a);
+#endif
                 KCHK(c);
             }
             a.R_key = c->w_key2.p; a.R_len = ptr<uint32_t>(c->w_rlen); a.R_start = ptr<uint32_t>(c->w_rstart); a.npairs = np;

@@ -301,6 +301,152 @@ __global__ __launch_bounds__(kWideGroup2Block) void k_wide_group2(WideArgs a) {
     }
 }
 
+// The append pass, second form: the column's products in CHUNKS of 2,048, every chunk counting-sorted by pair in LDS before it leaves,
+// so that a pair's products of the chunk (a HiFi-like column has ~100 partners: ~20 products per pair and chunk) are written as ONE run
+// of consecutive list entries by neighbouring lanes -- k_wide_group2 above sends every product as an 8-byte store into a line of its
+// own (291 M scattered stores at 10k HiFi-like reads: 2.1 ms against 1.1 ms for the same kernel storing sequentially).  Per chunk:
+//   A  wavefront q takes the chunk's q-th quarter, 64 products per step in product order: slot of the product's pair, rank among
+//      the pair's products of (chunk, wavefront) from an LDS atomic on the pair's packed counters (same-address atomics of one
+//      instruction are applied in lane order, successive instructions of a wavefront in program order: rank order = product order);
+//   B  one lane per pair of the column: the chunk's products of the pair per wavefront -> where the pair's run starts in the staged
+//      chunk (an LDS allocator: the order of the runs is irrelevant), the counts summed from each wavefront on, the list cursor moves on;
+//   C  every product to its place in the stage together with its destination (list cursor - products from its wavefront on + rank);
+//   D  the stage leaves in stage order: neighbouring lanes, neighbouring list entries.
+constexpr uint32_t kG2Chunk = 2048, kG2Per = kG2Chunk / kWideGroup2Block, kG2Quarter = kG2Chunk / (kWideGroup2Block / 64);
+static_assert(kWideGroup2Block == 256 && kG2Quarter == 64 * kG2Per, "four wavefronts, a quarter of the chunk each");
+__global__ __launch_bounds__(kWideGroup2Block) void k_wide_group2_chunks(WideArgs a) {
+    __shared__ uint32_t s_key[kWideGroupSlots];
+    __shared__ uint32_t s_cur[kWideGroupSlots + 1];              // the pair's next list entry (inside the column)
+    __shared__ uint2 s_cnt[kWideGroupSlots + 1];                 // products of the chunk per wavefront (4 x u16); [kWideGroupSlots]: beyond the column's end
+    __shared__ uint2 s_suf[kWideGroupSlots + 1];                 // ... summed from each wavefront on (the first = all of them)
+    __shared__ uint16_t s_loc[kWideGroupSlots + 2];              // start of the pair's run in the stage
+    __shared__ uint16_t s_occ[kWideGroupPairs];                  // the occupied slots
+    __shared__ uint2 s_pay[kG2Chunk];
+    __shared__ uint32_t s_dst[kG2Chunk];
+    __shared__ uint32_t scr[kWideGroup2Block / 64];
+    __shared__ uint32_t s_alloc;
+    const uint32_t tid = threadIdx.x, q = wave_id(), lane = lane_id();
+    for (uint32_t s = blockIdx.x; s < a.nw; s += gridDim.x) {
+        const uint32_t i = a.cols[s];
+        const uint64_t wo = a.woff[s], F = a.woff[s + 1] - wo, arow = a.Arow ? a.Arow[i] : wo;
+        const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
+        const uint4* G = a.gtab + (size_t)s * kWideGroupSlots;
+        const uint32_t pbase = a.gbase[s];
+        constexpr uint32_t kPer = kWideGroupSlots / kWideGroup2Block;
+        uint4 g[kPer];
+        uint32_t occ = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) { g[u] = G[tid * kPer + u]; occ += g[u].x != 0xFFFFFFFFu ? 1u : 0u; }
+        uint32_t d;
+        uint32_t o = block_excl_scan<kWideGroup2Block / 64>(occ, scr, &d);
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t h = tid * kPer + u;
+            s_key[h] = g[u].x; s_cur[h] = g[u].y; s_cnt[h] = make_uint2(0u, 0u);
+            if (g[u].x != 0xFFFFFFFFu) {
+                const uint32_t r = pbase + o;
+                if (a.key32) ((uint32_t*)a.R_key_w)[r] = (s << a.rbits) | g[u].x;
+                else ((uint64_t*)a.R_key_w)[r] = ((uint64_t)s << a.rbits) | g[u].x;
+                a.R_len_w[r] = g[u].z;
+                a.R_start_w[r] = (uint32_t)wo + g[u].y;
+                a.R_first[r] = g[u].w;
+                s_occ[o] = (uint16_t)h;
+                ++o;
+            }
+        }
+        if (tid == 0) { s_alloc = 0; s_cnt[kWideGroupSlots] = make_uint2(0u, 0u); s_suf[kWideGroupSlots] = make_uint2(0u, 0u); s_loc[kWideGroupSlots] = 0; s_cur[kWideGroupSlots] = 0; }
+        __syncthreads();
+        if (F) {
+            const uint64_t plast = F - 1;
+            // (the next chunk's products are on their way while a chunk is sorted; loads and stores unconditional, see k_wide_group2)
+            uint2 nx[kG2Per];
+            uint32_t nl[kG2Per];
+#pragma unroll
+            for (uint32_t u = 0; u < kG2Per; ++u) {
+                const uint64_t p = (uint64_t)q * kG2Quarter + 64ull * u + lane, pc = p < plast ? p : plast;
+                nx[u] = a.Aent2[arow + pc]; nl[u] = a.Aov[arow + pc];
+            }
+            for (uint64_t cb = 0; cb < F; cb += kG2Chunk) {
+                // (every phase in batches of the thread's kG2Per products: all LDS reads of a batch, then all atomics, ... -- the
+                // round trips of a batch overlap instead of following one another; a product beyond the column's end counts into a
+                // slot of its own behind the table and is never staged)
+                uint2 pay[kG2Per];
+                uint32_t key[kG2Per], hs[kG2Per], seen[kG2Per], old[kG2Per];
+                bool live[kG2Per];
+#pragma unroll
+                for (uint32_t u = 0; u < kG2Per; ++u) {
+                    const uint64_t p = cb + (uint64_t)q * kG2Quarter + 64ull * u + lane;
+                    const uint2 r2 = nx[u];
+                    const uint32_t lenH = nl[u];
+                    const uint64_t pn = p + kG2Chunk, pc = pn < plast ? pn : plast;
+                    nx[u] = a.Aent2[arow + pc]; nl[u] = a.Aov[arow + pc];
+                    const bool oriented = (r2.x >> 31) != 0;
+                    const uint32_t ov = (uint32_t)overlap_estimate(r2.y & 0xFFFFu, r2.y >> 16, lenH, lenV, oriented, (uint32_t)a.k) & 0xFFFFu;
+                    const uint32_t fl = (oriented ? 1u : 0u) | (((r2.x >> 30) & 1u) << 1);
+                    pay[u] = make_uint2(r2.y, ov | (fl << 16));
+                    live[u] = p < F;
+                    key[u] = r2.x & 0x3FFFFFFFu;
+                    hs[u] = hash_range(key[u], kWideGroupSlots);
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kG2Per; ++u) seen[u] = s_key[hs[u]];
+#pragma unroll
+                for (uint32_t u = 0; u < kG2Per; ++u) {
+                    while (live[u] && seen[u] != key[u]) { hs[u] = hs[u] + 1 == kWideGroupSlots ? 0 : hs[u] + 1; seen[u] = s_key[hs[u]]; }
+                    if (!live[u]) hs[u] = kWideGroupSlots;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kG2Per; ++u) old[u] = atomicAdd(&((uint32_t*)&s_cnt[hs[u]])[q >> 1], 1u << (16u * (q & 1u)));
+                __syncthreads();
+                for (uint32_t t0 = q * 64u; t0 < d; t0 += kWideGroup2Block) {
+                    const uint32_t t = t0 + lane;
+                    uint32_t h = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                    if (t < d) {
+                        h = s_occ[t];
+                        const uint2 c = s_cnt[h];
+                        c0 = c.x & 0xFFFFu; c1 = c.x >> 16; c2 = c.y & 0xFFFFu; c3 = c.y >> 16;
+                    }
+                    const uint32_t tot = c0 + c1 + c2 + c3;
+                    const uint32_t inc = wave_incl_scan(tot);
+                    uint32_t base = 0;
+                    if (lane == 63 && inc) base = atomicAdd(&s_alloc, inc);
+                    base = (uint32_t)__shfl((int)base, 63, 64);
+                    if (tot) {
+                        s_cnt[h] = make_uint2(0u, 0u);
+                        s_loc[h] = (uint16_t)(base + inc - tot);
+                        s_suf[h] = make_uint2(tot | ((c1 + c2 + c3) << 16), (c2 + c3) | (c3 << 16));
+                        s_cur[h] += tot;
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) s_alloc = 0;
+                {
+                    uint2 sf[kG2Per];
+                    uint32_t lc[kG2Per], cu[kG2Per];
+#pragma unroll
+                    for (uint32_t u = 0; u < kG2Per; ++u) { sf[u] = s_suf[hs[u]]; lc[u] = s_loc[hs[u]]; cu[u] = s_cur[hs[u]]; }
+#pragma unroll
+                    for (uint32_t u = 0; u < kG2Per; ++u) {
+                        const uint32_t rank = (old[u] >> (16u * (q & 1u))) & 0xFFFFu;
+                        const uint32_t from = q == 0 ? sf[u].x & 0xFFFFu : q == 1 ? sf[u].x >> 16 : q == 2 ? sf[u].y & 0xFFFFu : sf[u].y >> 16;
+                        const uint32_t pos = lc[u] + (sf[u].x & 0xFFFFu) - from + rank;
+                        if (live[u]) { s_pay[pos] = pay[u]; s_dst[pos] = cu[u] - from + rank; }
+                    }
+                }
+                __syncthreads();
+                const uint32_t n = F - cb < kG2Chunk ? (uint32_t)(F - cb) : kG2Chunk;
+#pragma unroll
+                for (uint32_t u = 0; u < kG2Per; ++u) {
+                    const uint32_t j = tid + u * kWideGroup2Block;
+                    const uint64_t dst = j < n ? wo + s_dst[j] : a.plist_pad + lane;
+                    a.plist[dst] = s_pay[j];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ uint64_t wide_rkey(const WideArgs& a, uint32_t r) {
     return a.key32 ? (uint64_t)((const uint32_t*)a.R_key)[r] : ((const uint64_t*)a.R_key)[r];
 }
