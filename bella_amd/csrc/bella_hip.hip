@@ -2293,7 +2293,7 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
         }
     }
     if (lists && c->lane_order_ok && !(c->debug & 4096u)) {
-        ENSURE(c, c->w_gtab, sizeof(uint4) * 2 * (size_t)nw * kWideGroupSlots);
+        ENSURE(c, c->w_gtab, sizeof(uint4) * (size_t)nw * kWideGroupSlots);
         ENSURE(c, c->w_gcount, 4 * ((size_t)nw + 4));
         ENSURE(c, c->w_gbase, 4 * ((size_t)nw + 4));
         a.gtab = ptr<uint4>(c->w_gtab); a.gcount = ptr<uint32_t>(c->w_gcount); a.gbase = ptr<uint32_t>(c->w_gbase);
@@ -2317,11 +2317,7 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
             a.R_len_w = ptr<uint32_t>(c->w_rlen); a.R_start_w = ptr<uint32_t>(c->w_rstart); a.R_key_w = c->w_key2.p;
             a.R_first = ptr<uint32_t>(c->w_rfirst);
             if (np) {
-                #ifdef BELLA_G2_OLD
-                k_wide_group2<<<nw < 8192u ? nw : 8192u, kWideGroup2Block, 0, c->stream>>>(a);
-#else
                 k_wide_group2_chunks<<<nw < 8192u ? nw : 8192u, kWideGroup2Block, 0, c->stream>>>(a);
-#endif
                 KCHK(c);
             }
             a.R_key = c->w_key2.p; a.R_len = ptr<uint32_t>(c->w_rlen); a.R_start = ptr<uint32_t>(c->w_rstart); a.npairs = np;

@@ -45,7 +45,7 @@ struct WideArgs {
     const void* S_key;
     const uint32_t* S_idx;
     uint2* plist;                // [totalF + 64] {hv, ov} in sorted order = per-pair lists in product order
-    uint64_t plist_pad;          // totalF: 64 entries behind the lists that k_wide_group2's idle lanes write
+    uint64_t plist_pad;          // totalF: 64 entries behind the lists that k_wide_group2_chunks' idle lanes write
     // pairs (runs of S_key)
     const void* R_key;           // [npairs]
     const uint32_t* R_len;
@@ -70,7 +70,7 @@ struct WideArgs {
     uint32_t* gcount;            // [nw + 2]: pairs per column; gcount[nw + 1] = overflow flag
     const uint32_t* gbase;       // [nw + 1] exclusive scan of gcount
     uint32_t* R_first;           // [npairs] first product of the pair inside its column (nullptr: S_idx[R_start[r]] - woff[seg])
-    uint32_t* R_len_w;           // writable views of R_len / R_start / R_key for k_wide_group2
+    uint32_t* R_len_w;           // writable views of R_len / R_start / R_key for k_wide_group2_chunks
     uint32_t* R_start_w;
     void* R_key_w;
     uint32_t* redo;              // [npairs] pairs left to the serial fold (k_wide_fold) by k_wide_fold_wg; redo[npairs] = their number
@@ -144,46 +144,73 @@ __global__ __launch_bounds__(kWideExpandBlock) void k_wide_expand(WideArgs a) {
 // ---- grouping by partner in LDS (row lists only) ---------------------------------------------------------------------------------
 // A wide column has many products but few partners (HiFi reads with a raised -u: 36,000 ... 200,000 products on ~50 ... 500 partners):
 // instead of sorting 16 bytes per product three or four times, the column's products are streamed twice.  k_wide_group1: one
-// workgroup per column inserts the partner of every product into an LDS table (compare-and-swap) and counts the pair's products per
-// RANGE of the column (four ranges of whole 64-product chunks) and its first product; a scan over the slots gives every pair its list
-// inside the column's part of plist.  k_wide_group2: four wavefronts per column, wavefront q appends the products of range q, 64 at a
-// time in product order, at the cursor of (pair, range) -- the same-address LDS atomics of one instruction are applied in lane
-// order (k_lane_order_selftest), so every list ends up in product order.  A column whose partners do not fit the table raises a flag and
-// the batch takes the sort-based path below.
+// workgroup per column inserts the partner of every product into an LDS table (compare-and-swap), counts the pair's products and
+// notes its first product; a scan over the slots gives every pair its list inside the column's part of plist.
+// k_wide_group2_chunks: the products again, appended to their pairs' lists in product order (below).  A column whose partners do not
+// fit the table raises a flag and the batch takes the sort-based path.
 constexpr uint32_t kWideGroupSlots = 2048;                 // table slots per column (at most kWideGroupPairs pairs)
 constexpr uint32_t kWideGroupPairs = 1536;
 constexpr int kWideGroup1Block = 1024, kWideGroup2Block = 256;
-__device__ __forceinline__ uint32_t wide_group_range(uint64_t F) { return (uint32_t)(((F + 255u) >> 8) << 6); }   // products per range
+constexpr uint32_t kG1Per = 8;                             // products per thread and round: their loads, then their insertions, together
 __global__ __launch_bounds__(kWideGroup1Block) void k_wide_group1(WideArgs a) {
-    __shared__ uint32_t s_key[kWideGroupSlots];
-    __shared__ uint32_t s_cnt[kWideGroupSlots][4];
-    __shared__ uint32_t s_first[kWideGroupSlots];
+    __shared__ uint32_t s_key[kWideGroupSlots + 1];        // (the last slot: products beyond the column's end)
+    __shared__ uint32_t s_cnt[kWideGroupSlots + 1];
+    __shared__ uint32_t s_first[kWideGroupSlots + 1];
     __shared__ uint32_t scr[kWideGroup1Block / 64];
     __shared__ uint32_t s_n, s_fail;
     const uint32_t tid = threadIdx.x;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
     for (uint32_t s = blockIdx.x; s < a.nw; s += gridDim.x) {
         const uint32_t i = a.cols[s];
         const uint64_t F = a.woff[s + 1] - a.woff[s], arow = a.Arow ? a.Arow[i] : a.woff[s];
-        const uint32_t RB = wide_group_range(F);
-        for (uint32_t h = tid; h < kWideGroupSlots; h += kWideGroup1Block) {
-            s_key[h] = 0xFFFFFFFFu; s_first[h] = 0xFFFFFFFFu;
-            s_cnt[h][0] = 0; s_cnt[h][1] = 0; s_cnt[h][2] = 0; s_cnt[h][3] = 0;
-        }
+        for (uint32_t h = tid; h <= kWideGroupSlots; h += kWideGroup1Block) { s_key[h] = kNone; s_first[h] = kNone; s_cnt[h] = 0; }
         if (tid == 0) { s_n = 0; s_fail = 0; }
         __syncthreads();
         uint32_t mine = 0;
-        for (uint64_t p = tid; p < F; p += kWideGroup1Block) {
-            const uint32_t key = a.Aent2[arow + p].x & 0x3FFFFFFFu;
-            uint32_t h = hash_range(key, kWideGroupSlots), probes = 0;
-            for (; probes < kWideGroupSlots; ++probes) {
-                const uint32_t old = atomicCAS(&s_key[h], 0xFFFFFFFFu, key);
-                if (old == 0xFFFFFFFFu) { ++mine; break; }
-                if (old == key) break;
-                h = h + 1 == kWideGroupSlots ? 0 : h + 1;
+        bool failed = false;
+        const uint64_t plast = F ? F - 1 : 0;
+        for (uint64_t p0 = 0; p0 < F && !failed; p0 += (uint64_t)kWideGroup1Block * kG1Per) {
+            uint32_t key[kG1Per], h[kG1Per], old[kG1Per];
+#pragma unroll
+            for (uint32_t u = 0; u < kG1Per; ++u) {
+                const uint64_t p = p0 + (uint64_t)u * kWideGroup1Block + tid;
+                key[u] = a.Aent2[arow + (p < plast ? p : plast)].x & 0x3FFFFFFFu;
             }
-            if (probes == kWideGroupSlots) { s_fail = 1; break; }
-            atomicAdd(&s_cnt[h][(uint32_t)(p / RB)], 1u);
-            atomicMin(&s_first[h], (uint32_t)p);
+#pragma unroll
+            for (uint32_t u = 0; u < kG1Per; ++u) {
+                const bool live = p0 + (uint64_t)u * kWideGroup1Block + tid < F;
+                h[u] = live ? hash_range(key[u], kWideGroupSlots) : kWideGroupSlots;
+                if (!live) key[u] = kNone;
+            }
+            // (a plain read first: the lanes that meet the same pair share one read, and after a column's first rounds every pair is in
+            // the table -- a compare-and-swap only into a slot seen empty, a minimum only below the first product seen so far: what is left
+            // per product is the count's atomic)
+#pragma unroll
+            for (uint32_t u = 0; u < kG1Per; ++u) old[u] = s_key[h[u]];
+#pragma unroll
+            for (uint32_t u = 0; u < kG1Per; ++u) {
+                uint32_t probes = 0;
+                for (;;) {
+                    if (old[u] == key[u]) break;
+                    if (old[u] == kNone) {
+                        const uint32_t o = atomicCAS(&s_key[h[u]], kNone, key[u]);
+                        if (o == kNone) { ++mine; break; }
+                        if (o == key[u]) break;
+                    }
+                    if (++probes == kWideGroupSlots) { failed = true; break; }
+                    h[u] = h[u] + 1 == kWideGroupSlots ? 0 : h[u] + 1;
+                    old[u] = s_key[h[u]];
+                }
+            }
+            if (failed) { s_fail = 1; break; }
+#pragma unroll
+            for (uint32_t u = 0; u < kG1Per; ++u) old[u] = s_first[h[u]];
+#pragma unroll
+            for (uint32_t u = 0; u < kG1Per; ++u) {
+                const uint32_t p = (uint32_t)(p0 + (uint64_t)u * kWideGroup1Block + tid);
+                atomicAdd(&s_cnt[h[u]], 1u);
+                if (p < old[u]) atomicMin(&s_first[h[u]], p);
+            }
         }
         {
             const uint32_t mw = wave_incl_scan(mine);
@@ -200,11 +227,7 @@ __global__ __launch_bounds__(kWideGroup1Block) void k_wide_group1(WideArgs a) {
         constexpr uint32_t kPer = kWideGroupSlots / kWideGroup1Block;
         uint32_t m[kPer], sum = 0;
 #pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) {
-            const uint32_t h = tid * kPer + u;
-            m[u] = s_cnt[h][0] + s_cnt[h][1] + s_cnt[h][2] + s_cnt[h][3];
-            sum += m[u];
-        }
+        for (uint32_t u = 0; u < kPer; ++u) { m[u] = s_cnt[tid * kPer + u]; sum += m[u]; }
         uint32_t tot;
         uint32_t ex = block_excl_scan<kWideGroup1Block / 64>(sum, scr, &tot);
         uint4* G = a.gtab + (size_t)s * kWideGroupSlots;
@@ -214,97 +237,16 @@ __global__ __launch_bounds__(kWideGroup1Block) void k_wide_group1(WideArgs a) {
             G[h] = make_uint4(s_key[h], ex, m[u], s_first[h]);       // {key (0xFFFFFFFF: empty), list start inside the column, products, first product}
             ex += m[u];
         }
-        // the per-range counts travel in the table image's second half (4 x u32 per slot)
-        uint4* GC = a.gtab + ((size_t)a.nw + s) * kWideGroupSlots;
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) { const uint32_t h = tid * kPer + u; GC[h] = make_uint4(s_cnt[h][0], s_cnt[h][1], s_cnt[h][2], s_cnt[h][3]); }
         if (tid == 0) a.gcount[s] = d;
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(kWideGroup2Block) void k_wide_group2(WideArgs a) {
-    __shared__ uint32_t s_key[kWideGroupSlots];
-    __shared__ uint32_t s_cur[kWideGroupSlots][4];
-    __shared__ uint32_t scr[kWideGroup2Block / 64];
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t s = blockIdx.x; s < a.nw; s += gridDim.x) {
-        const uint32_t i = a.cols[s];
-        const uint64_t wo = a.woff[s], F = a.woff[s + 1] - wo, arow = a.Arow ? a.Arow[i] : wo;
-        const uint32_t RB = wide_group_range(F);
-        const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
-        const uint4* G = a.gtab + (size_t)s * kWideGroupSlots;
-        const uint4* GC = a.gtab + ((size_t)a.nw + s) * kWideGroupSlots;
-        const uint32_t pbase = a.gbase[s];
-        // pair numbers in slot order (any order does: the output order comes from k_wide_insert / k_wide_ranks), cursors per range
-        constexpr uint32_t kPer = kWideGroupSlots / kWideGroup2Block;
-        uint4 g[kPer];
-        uint32_t occ = 0;
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) { g[u] = G[tid * kPer + u]; occ += g[u].x != 0xFFFFFFFFu ? 1u : 0u; }
-        uint32_t tot;
-        uint32_t r = pbase + block_excl_scan<kWideGroup2Block / 64>(occ, scr, &tot);
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) {
-            const uint32_t h = tid * kPer + u;
-            const uint4 c4 = GC[h];
-            s_key[h] = g[u].x;
-            s_cur[h][0] = g[u].y; s_cur[h][1] = g[u].y + c4.x; s_cur[h][2] = g[u].y + c4.x + c4.y; s_cur[h][3] = g[u].y + c4.x + c4.y + c4.z;
-            if (g[u].x != 0xFFFFFFFFu) {
-                if (a.key32) ((uint32_t*)a.R_key_w)[r] = (s << a.rbits) | g[u].x;
-                else ((uint64_t*)a.R_key_w)[r] = ((uint64_t)s << a.rbits) | g[u].x;
-                a.R_len_w[r] = g[u].z;
-                a.R_start_w[r] = (uint32_t)wo + g[u].y;
-                a.R_first[r] = g[u].w;
-                ++r;
-            }
-        }
-        __syncthreads();
-        // wavefront q owns range q: 64 products at a time in product order
-        const uint32_t q = wave_id(), lane = lane_id();
-        const uint64_t lo = (uint64_t)q * RB, hi = lo + RB < F ? lo + RB : F;
-        // (the products of the next kAhead steps are on their way while a step is appended: a step alone is one trip to HBM)
-        // Loads and stores are unconditional (clamped index / a pad entry behind the lists for the lanes past the range's end): with a
-        // memory operation inside a branch the compiler can no longer count what is in flight and waits for everything at every step.
-        constexpr uint32_t kAhead = 16;
-        uint2 nx[kAhead];
-        uint32_t nl[kAhead];
-        if (lo < hi) {
-            const uint64_t plast = hi - 1;
-#pragma unroll
-            for (uint32_t u = 0; u < kAhead; ++u) {
-                const uint64_t p = lo + 64ull * u + lane, pc = p < plast ? p : plast;
-                nx[u] = a.Aent2[arow + pc]; nl[u] = a.Aov[arow + pc];
-            }
-            for (uint64_t base = lo; base < hi; base += 64ull * kAhead) {
-#pragma unroll
-                for (uint32_t u = 0; u < kAhead; ++u) {
-                    const uint64_t p = base + 64ull * u + lane;
-                    const uint2 r2 = nx[u];
-                    const uint32_t lenH = nl[u];
-                    const uint64_t pn = p + 64ull * kAhead, pc = pn < plast ? pn : plast;
-                    nx[u] = a.Aent2[arow + pc]; nl[u] = a.Aov[arow + pc];
-                    uint64_t dst = a.plist_pad + lane;           // (lanes past the end write here)
-                    const bool oriented = (r2.x >> 31) != 0;
-                    const uint32_t ov = (uint32_t)overlap_estimate(r2.y & 0xFFFFu, r2.y >> 16, lenH, lenV, oriented, (uint32_t)a.k) & 0xFFFFu;
-                    const uint32_t fl = (oriented ? 1u : 0u) | (((r2.x >> 30) & 1u) << 1);
-                    if (p < hi) {
-                        const uint32_t key = r2.x & 0x3FFFFFFFu;
-                        uint32_t h = hash_range(key, kWideGroupSlots);
-                        while (s_key[h] != key) h = h + 1 == kWideGroupSlots ? 0 : h + 1;
-                        dst = wo + atomicAdd(&s_cur[h][q], 1u);  // (same-address atomics of one instruction: lane order)
-                    }
-                    a.plist[dst] = make_uint2(r2.y, ov | (fl << 16));
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
 
-// The append pass, second form: the column's products in CHUNKS of 2,048, every chunk counting-sorted by pair in LDS before it leaves,
-// so that a pair's products of the chunk (a HiFi-like column has ~100 partners: ~20 products per pair and chunk) are written as ONE run
-// of consecutive list entries by neighbouring lanes -- k_wide_group2 above sends every product as an 8-byte store into a line of its
-// own (291 M scattered stores at 10k HiFi-like reads: 2.1 ms against 1.1 ms for the same kernel storing sequentially).  Per chunk:
+// The append pass: the column's products in CHUNKS of 2,048, every chunk counting-sorted by pair in LDS before it leaves, so that a
+// pair's products of the chunk (a HiFi-like column has ~100 partners: ~20 products per pair and chunk) are written as ONE run of
+// consecutive list entries by neighbouring lanes.  (Until round 6 four wavefronts per column appended a quarter of the column each,
+// every product an 8-byte store into a line of its own: 291 M scattered stores at 10k HiFi-like reads, 2.1 .. 2.5 ms against 1.1 ms
+// for the same kernel storing sequentially; this form 1.4 ms.)  Per chunk:
 //   A  wavefront q takes the chunk's q-th quarter, 64 products per step in product order: slot of the product's pair, rank among
 //      the pair's products of (chunk, wavefront) from an LDS atomic on the pair's packed counters (same-address atomics of one
 //      instruction are applied in lane order, successive instructions of a wavefront in program order: rank order = product order);
@@ -358,7 +300,7 @@ __global__ __launch_bounds__(kWideGroup2Block) void k_wide_group2_chunks(WideArg
         __syncthreads();
         if (F) {
             const uint64_t plast = F - 1;
-            // (the next chunk's products are on their way while a chunk is sorted; loads and stores unconditional, see k_wide_group2)
+            // (the next chunk's products are on their way while a chunk is sorted; loads and stores unconditional, a memory operation inside a branch makes the compiler wait for everything in flight)
             uint2 nx[kG2Per];
             uint32_t nl[kG2Per];
 #pragma unroll
