@@ -2246,7 +2246,20 @@ __global__ void k_wide_sizes(const uint32_t* cols, const uint32_t* flops, uint32
 
 // columns with >= 65536 products: expand -> sort by (column, partner) -> pairs -> slot order -> serial fold (wide.hpp)
 // T: the batch's products (run_wide has the columns' sizes on the host: no second trip for their sum)
-static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint32_t* d_cols, uint64_t T) {
+// A batch runs in two parts: wide_batch_begin enqueues everything up to the point where the host must know the batch's pair count (the
+// columns' sizes, the row lists if the layout has none, the first grouping pass and the copy of its totals into pinned memory) and
+// returns without waiting -- run_spgemm enqueues it BEFORE the LDS classes' row kernels, so that the first grouping pass starts with
+// them instead of behind their queue --; wide_batch_finish waits for the totals and enqueues the rest.
+struct WideBatch {
+    WideArgs a{};
+    uint32_t nw = 0;
+    uint64_t T = 0;
+    int rbits = 1, seg_bits = 1;
+    bool tried_group = false;
+};
+constexpr uint32_t kPinWide = 112;                                  // c->pinned[112 ..]: pairs of the batch, overflow flag, runs of the sort-based path
+static int wide_batch_begin(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint32_t* d_cols, uint64_t T, WideBatch& wb) {
+    wb.nw = nw; wb.T = T;
     ENSURE(c, c->w_f, 4 * ((size_t)nw + 2));
     ENSURE(c, c->w_off, 8 * ((size_t)nw + 2));
     ENSURE(c, c->w_nruns, 16);
@@ -2259,22 +2272,17 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
     ENSURE(c, c->w_plist, 8 * (T + 64)); ENSURE(c, c->w_scr, 2 * T);
     ENSURE(c, c->w_segfirst, 4 * ((size_t)nw + 2));
     ENSURE(c, c->w_toff, 8 * ((size_t)nw + 2));
-    WideArgs a{};
+    WideArgs& a = wb.a;
     a.cols = d_cols; a.nw = nw; a.woff = ptr<uint64_t>(c->w_off);
     a.Bptr = sa.Bptr; a.Bent = sa.Bent; a.inl = sa.inl; a.Aent = sa.Aent; a.Aent2 = sa.Aent2; a.Aov = sa.Aov; a.Arow = sa.Arow; a.roff = sa.roff; a.packed = sa.packed; a.flopptr = sa.flopptr;
     a.k = sa.k; a.binSize = sa.binSize;
     a.plist = ptr<uint2>(c->w_plist); a.plist_pad = T; a.sort_scratch = ptr<uint16_t>(c->w_scr);
     a.tmp_pairs = sa.tmp_pairs; a.tmp_ext = sa.tmp_ext; a.nnzC = sa.nnzC; a.status = sa.ctl + kCtlStatus;
-    int rbits = 1;
-    while ((1ull << rbits) < (uint64_t)c->nreads) ++rbits;       // a partner read id fits rbits bits
-    a.rbits = (uint32_t)rbits;
-    int seg_bits = 1;
-    while ((1u << seg_bits) < nw) ++seg_bits;
-    a.key32 = rbits + seg_bits <= 32 && !(c->debug & 64u) ? 1u : 0u;   // debug bit 6: tests, 64-bit keys on any input
+    while ((1ull << wb.rbits) < (uint64_t)c->nreads) ++wb.rbits;   // a partner read id fits rbits bits
+    a.rbits = (uint32_t)wb.rbits;
+    while ((1u << wb.seg_bits) < nw) ++wb.seg_bits;
+    a.key32 = wb.rbits + wb.seg_bits <= 32 && !(c->debug & 64u) ? 1u : 0u;   // debug bit 6: tests, 64-bit keys on any input
     a.R_first = nullptr;
-    uint32_t np = 0;
-    bool grouped = false;
-    std::vector<uint32_t> segf;                                    // first pair of every column (host: sizes of the slot-order tables)
     // wide columns with few partners (HiFi-like input): group in LDS, two streaming passes over the columns' products (wide.hpp) --
     // unless a column's partners do not fit the table, the lane-order self-test failed, or debug bit 12 asks for the sort-based path
     // (tests).  The products are read from the row lists; a layout without them (the default) expands the BATCH's columns into a
@@ -2302,36 +2310,89 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
         KCHK(c);
         rc = scan_u32(c, ptr<uint32_t>(c->w_gcount), ptr<uint32_t>(c->w_gbase), (uint64_t)nw + 1);
         if (rc) return rc;
-        uint32_t fin[2] = {0, 0};
-        // (the columns' first pairs come along: the slot-order tables below are sized from them -- no trip of their own after the append pass)
-        segf.resize((size_t)nw + 1);
-        HIPCHK(c, hipMemcpyAsync(segf.data(), ptr<uint32_t>(c->w_gbase), 4 * ((size_t)nw + 1), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&fin[1], ptr<uint32_t>(c->w_gcount) + nw + 1, 4, hipMemcpyDeviceToHost, c->stream));
+        // (8 bytes into pinned memory: the pairs of the batch and the overflow flag; the slot-order tables are sized on the device)
+        HIPCHK(c, hipMemcpyAsync(c->pinned + kPinWide, ptr<uint32_t>(c->w_gbase) + nw, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->pinned + kPinWide + 1, ptr<uint32_t>(c->w_gcount) + nw + 1, 4, hipMemcpyDeviceToHost, c->stream));
+        wb.tried_group = true;
+    }
+    return 0;
+}
+
+// sync_at_end: another batch follows (its buffers may be reallocated: the kernels of this one must be done)
+static int wide_batch_finish(bella_ctx* c, WideBatch& wb, bool sync_at_end) {
+    WideArgs& a = wb.a;
+    const uint32_t nw = wb.nw;
+    const uint64_t T = wb.T;
+    hipStream_t const s2 = c->side[kNumTiers - 1];
+    uint32_t np = 0;
+    bool grouped = false;
+    int rc = 0;
+    // slot-order tables (pow2 >= max(16, pairs) slots per column: at most 16 nw + 2 np in all), ranks, descriptors by class: small kernels
+    auto tables_and_descriptors = [&](hipStream_t st) -> int {
+        const uint64_t tab_cap = 16ull * nw + 2ull * np;
+        ENSURE(c, c->w_table, 8 * tab_cap);
+        a.table = ptr<uint64_t>(c->w_table); a.toff = ptr<uint64_t>(c->w_toff);
+        k_wide_toff<<<1, 1024, 0, st>>>(a.seg_first, nw, ptr<uint64_t>(c->w_toff));
+        KCHK(c);
+        k_wide_table_fill<<<nblk(tab_cap), 256, 0, st>>>(a.table, tab_cap);
+        KCHK(c);
+        if (np) {
+            k_wide_insert<<<nblk(np), 256, 0, st>>>(a);
+            KCHK(c);
+        }
+        k_wide_ranks<<<nw < 1024u ? nw : 1024u, kBlock, 0, st>>>(a);
+        KCHK(c);
+        if (np) {
+            ENSURE(c, c->w_redo, 4 * ((size_t)np + 4));
+            a.redo = ptr<uint32_t>(c->w_redo);
+            HIPCHK(c, hipMemsetAsync(a.redo + np, 0, 16, st));    // (the redo count and the three class counts of k_wide_desc)
+            ENSURE(c, c->w_desc, 3 * sizeof(WidePairAddr) * (size_t)np);
+            a.desc = (WidePairAddr*)c->w_desc.p;
+            k_wide_desc<<<nblk(np), 256, 0, st>>>(a);
+            KCHK(c);
+        }
+        return 0;
+    };
+    if (wb.tried_group) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        fin[0] = segf[nw];
-        if (fin[1] == 0) {
-            np = fin[0];
+        if (c->pinned[kPinWide + 1] == 0) {
+            np = c->pinned[kPinWide];
             ENSURE(c, c->w_rlen, 4 * ((size_t)np + 1)); ENSURE(c, c->w_rstart, 4 * ((size_t)np + 2)); ENSURE(c, c->w_rrank, 4 * ((size_t)np + 1));
             ENSURE(c, c->w_rfirst, 4 * ((size_t)np + 1));
             ENSURE(c, c->w_key2, 8 * ((size_t)np + 1));
             a.R_len_w = ptr<uint32_t>(c->w_rlen); a.R_start_w = ptr<uint32_t>(c->w_rstart); a.R_key_w = c->w_key2.p;
             a.R_first = ptr<uint32_t>(c->w_rfirst);
-            if (np) {
-                k_wide_group2_chunks<<<nw < 8192u ? nw : 8192u, kWideGroup2Block, 0, c->stream>>>(a);
-                KCHK(c);
-            }
             a.R_key = c->w_key2.p; a.R_len = ptr<uint32_t>(c->w_rlen); a.R_start = ptr<uint32_t>(c->w_rstart); a.npairs = np;
             a.R_rank = ptr<uint32_t>(c->w_rrank);
             a.seg_first = ptr<uint32_t>(c->w_gbase);                 // first pair of every column = the prefix sums of the pair counts
             grouped = true;
+            if (np) {
+                // the pairs' keys / lists / first products (from the table images), then the append pass -- and NEXT to it, on a stream of
+                // their own, the small kernels that only need the pairs: tables, slot-order insertion, ranks, descriptors
+                k_wide_pairs<<<nw < 8192u ? nw : 8192u, kWideGroup2Block, 0, c->stream>>>(a);
+                KCHK(c);
+                HIPCHK(c, hipEventRecord(c->fork, c->stream));
+                k_wide_group2_chunks<<<nw < 8192u ? nw : 8192u, kWideGroup2Block, 0, c->stream>>>(a);
+                KCHK(c);
+                HIPCHK(c, hipStreamWaitEvent(s2, c->fork, 0));
+                rc = tables_and_descriptors(s2);
+                if (rc) return rc;
+                HIPCHK(c, hipEventRecord(c->join[kNumTiers - 2], s2));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->join[kNumTiers - 2], 0));
+            } else {
+                rc = tables_and_descriptors(c->stream);
+                if (rc) return rc;
+            }
         }
     }
     if (!grouped) {
         // the sort-based path: 38 bytes per product of the batch in flight (only allocated when this path runs)
+        const int rbits = wb.rbits, seg_bits = wb.seg_bits;
         ENSURE(c, c->w_key, 8 * T); ENSURE(c, c->w_key2, 8 * T);
         ENSURE(c, c->w_idx, 4 * T); ENSURE(c, c->w_idx2, 4 * T);
         ENSURE(c, c->w_hv, 8 * T);
         ENSURE(c, c->w_rlen, 4 * (T + 1)); ENSURE(c, c->w_rstart, 4 * (T + 2)); ENSURE(c, c->w_rrank, 4 * T);
+        a.R_first = nullptr;
         a.W_key = c->w_key.p; a.W_idx = ptr<uint32_t>(c->w_idx); a.W_rec = ptr<uint2>(c->w_hv);
         k_wide_expand<<<nw < 2048u ? nw : 2048u, kWideExpandBlock, 0, c->stream>>>(a);
         KCHK(c);
@@ -2357,8 +2418,9 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
             const int rc2 = a.key32 ? sort_and_encode(uint32_t{}) : sort_and_encode(uint64_t{});
             if (rc2) return rc2;
         }
-        HIPCHK(c, hipMemcpyAsync(&np, c->w_nruns.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->pinned + kPinWide + 2, c->w_nruns.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        np = c->pinned[kPinWide + 2];
         HIPCHK(c, hipMemsetAsync(ptr<uint32_t>(c->w_rlen) + np, 0, 4, c->stream));
         rc = scan_u32(c, ptr<uint32_t>(c->w_rlen), ptr<uint32_t>(c->w_rstart), (uint64_t)np + 1);
         if (rc) return rc;
@@ -2368,39 +2430,11 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
         KCHK(c);
         k_wide_segments<<<nblk((uint64_t)np + 1), 256, 0, c->stream>>>(a);
         KCHK(c);
+        rc = tables_and_descriptors(c->stream);
+        if (rc) return rc;
     }
-    if (!grouped) {
-        segf.resize((size_t)nw + 1);
-        HIPCHK(c, hipMemcpyAsync(segf.data(), a.seg_first, 4 * ((size_t)nw + 1), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    std::vector<uint64_t> toff((size_t)nw + 1, 0);
-    for (uint32_t s = 0; s < nw; ++s) {
-        const uint64_t d = segf[s + 1] - segf[s];
-        uint64_t ht = 16;
-        while (ht < d) ht <<= 1;                                   // overlap.hpp:291-295
-        toff[s + 1] = toff[s] + ht;
-    }
-    ENSURE(c, c->w_table, 8 * toff[nw]);
-    HIPCHK(c, hipMemcpyAsync(c->w_toff.p, toff.data(), 8 * ((size_t)nw + 1), hipMemcpyHostToDevice, c->stream));
-    a.table = ptr<uint64_t>(c->w_table); a.toff = ptr<uint64_t>(c->w_toff);
-    k_wide_table_fill<<<nblk(toff[nw]), 256, 0, c->stream>>>(a.table, toff[nw]);
-    KCHK(c);
-    if (np) {
-        k_wide_insert<<<nblk(np), 256, 0, c->stream>>>(a);
-        KCHK(c);
-    }
-    k_wide_ranks<<<nw < 1024u ? nw : 1024u, kBlock, 0, c->stream>>>(a);
-    KCHK(c);
     if (np) {
         // one workgroup per pair (closed-form fold); what it leaves over (lists of >= 32768 products, > 16 bins) to the serial fold
-        ENSURE(c, c->w_redo, 4 * ((size_t)np + 4));
-        a.redo = ptr<uint32_t>(c->w_redo);
-        HIPCHK(c, hipMemsetAsync(a.redo + np, 0, 16, c->stream));   // (the redo count and the three class counts of k_wide_desc)
-        ENSURE(c, c->w_desc, 3 * sizeof(WidePairAddr) * (size_t)np);
-        a.desc = (WidePairAddr*)c->w_desc.p;
-        k_wide_desc<<<nblk(np), 256, 0, c->stream>>>(a);
-        KCHK(c);
 #ifdef BELLA_WF_CLOCK
         static unsigned long long* d_clk = nullptr;
         if (!d_clk) (void)hipMalloc(&d_clk, 64);
@@ -2410,7 +2444,6 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
         // (three instances by list length, wide.hpp: the class counts are on the device, workgroups beyond a class's pairs leave at once)
         // The instances run side by side (other pairs, other lists; the redo list and its counter take atomics): the short lists on a
         // stream of their own, so that one instance's last pairs do not hold up the next one's first.
-        hipStream_t const s2 = c->side[kNumTiers - 1];
         HIPCHK(c, hipEventRecord(c->fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(s2, c->fork, 0));
         k_wide_fold_wg<kWideFoldBlockLarge, kWideFoldMid, kGridBucketsLarge, 1, 6><<<np < 16384u ? np : 16384u, kWideFoldBlockLarge, 0, c->stream>>>(a);
@@ -2436,15 +2469,21 @@ static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const
         k_wide_fold<<<nblk(np, 64), 64, 0, c->stream>>>(a);
         KCHK(c);
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));                    // toff / segf are host vectors
+    if (sync_at_end) HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
+}
+static int run_wide_batch(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint32_t* d_cols, uint64_t T, bool sync_at_end) {
+    WideBatch wb;
+    int rc = wide_batch_begin(c, sa, nw, d_cols, T, wb);
+    if (rc) return rc;
+    return wide_batch_finish(c, wb, sync_at_end);
 }
 
 // batches of wide columns holding at most `budget` products each (38 bytes of HBM per product in flight)
 // Tall: the products of all nw columns (known from the symbolic kernels' control block): when they fit one batch -- the usual case -- the
 // columns' sizes need not come to the host at all
 static int run_wide(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint32_t* d_cols, uint64_t Tall) {
-    if (Tall && Tall <= c->wide_budget) return run_wide_batch(c, sa, nw, d_cols, Tall);
+    if (Tall && Tall <= c->wide_budget) return run_wide_batch(c, sa, nw, d_cols, Tall, false);
     ENSURE(c, c->w_f, 4 * ((size_t)nw + 2));
     k_wide_sizes<<<nblk((uint64_t)nw + 1), 256, 0, c->stream>>>(d_cols, ptr<uint32_t>(c->flopsr), nw, ptr<uint32_t>(c->w_f));
     KCHK(c);
@@ -2456,7 +2495,7 @@ static int run_wide(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, const uint3
         uint64_t t = wf[b];
         uint32_t e = b + 1;
         while (e < nw && t + wf[e] <= budget) t += wf[e++];
-        int rc = run_wide_batch(c, sa, e - b, d_cols + b, t);
+        int rc = run_wide_batch(c, sa, e - b, d_cols + b, t, e < nw);
         if (rc) return rc;
         b = e;
     }
@@ -2743,6 +2782,32 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
         launches++;
         return 0;
     };
+    // The wide path's first part goes BEFORE the row kernels when it is a large part of the pass (long-list inputs: HiFi-like reads with
+    // a raised -u): its small kernels and the first grouping pass start at once instead of behind the classes' queues (five streams on
+    // four hardware queues: every small kernel waited ~40 us for its turn, 0.3 ms before the first grouping pass began), the rest
+    // follows when the classes are enqueued.  Otherwise (a few wide columns in a pass of LDS columns) the classes go first as before.
+    c->n_wide = tcnt[g_ntiers] + (mid_to_wide ? n_mid : 0);
+    uint32_t* const widelist = (uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr);
+    const uint64_t wide_products = c->pass_wide_products[1] + (mid_to_wide ? c->pass_wide_products[0] : 0);
+    auto wide_columns = [&]() -> int {                             // (the columns above the LDS tiers join the wide columns' list)
+        if (mid_to_wide) {
+            k_desc_cols<<<nblk(n_mid), 256, 0, c->stream>>>(ptr<uint4>(c->rowlists) + (size_t)(g_ntiers - 1) * nr, n_mid, widelist + tcnt[g_ntiers]);
+            if (hipGetLastError() != hipSuccess) return fail(c, BELLA_ERR_HIP, "k_desc_cols launch failed");
+        }
+        return 0;
+    };
+    WideBatch wide_batch;
+    bool wide_begun = false;
+    if (c->n_wide && wide_products && wide_products <= c->wide_budget && wide_products * 4 >= c->pass_products) {
+        hipStream_t const main_stream = c->stream, wst = c->side[kNumTiers];
+        HIPCHK(c, hipStreamWaitEvent(wst, c->ev[3], 0));
+        c->stream = wst;
+        int rw = wide_columns();
+        if (!rw) rw = wide_batch_begin(c, a, c->n_wide, widelist, wide_products, wide_batch);
+        c->stream = main_stream;
+        if (rw) { (void)hipStreamSynchronize(wst); return rw; }
+        wide_begun = true;
+    }
     auto whole_cu = [&](int l) { return 2 * ln[l].lds > kClassLds[kNumClasses - 1]; };
     // the whole-CU class (few columns, if any) goes FIRST, on a side stream of its own: its workgroups take their CUs before the other
     // classes' workgroups arrive, and those fill the rest of the chip next to it instead of waiting behind it
@@ -2779,18 +2844,16 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     // The columns of the sort-based path (wide.hpp) are other columns than the LDS classes': the path -- host-driven, several
     // synchronisations -- runs on a stream of its own NEXT to the class launches above instead of after them (HiFi-like input with a
     // raised -u, 10k reads: the classes take 1.35 ms of a pass whose wide path takes 8.7)
-    c->n_wide = tcnt[g_ntiers] + (mid_to_wide ? n_mid : 0);
     if (c->n_wide) {
-        uint32_t* const widelist = (uint32_t*)(ptr<uint4>(c->rowlists) + (size_t)kNumTiers * nr);
         hipStream_t const main_stream = c->stream, wst = c->side[kNumTiers];
-        HIPCHK(c, hipStreamWaitEvent(wst, c->ev[3], 0));
         c->stream = wst;                                           // (everything run_wide enqueues, allocates for and waits on)
         int rw = 0;
-        if (mid_to_wide) {
-            k_desc_cols<<<nblk(n_mid), 256, 0, c->stream>>>(ptr<uint4>(c->rowlists) + (size_t)(g_ntiers - 1) * nr, n_mid, widelist + tcnt[g_ntiers]);
-            if (hipGetLastError() != hipSuccess) rw = fail(c, BELLA_ERR_HIP, "k_desc_cols launch failed");
+        if (wide_begun) rw = wide_batch_finish(c, wide_batch, false);
+        else {
+            HIPCHK(c, hipStreamWaitEvent(wst, c->ev[3], 0));
+            rw = wide_columns();
+            if (!rw) rw = run_wide(c, a, c->n_wide, widelist, wide_products);
         }
-        if (!rw) rw = run_wide(c, a, c->n_wide, widelist, c->pass_wide_products[1] + (mid_to_wide ? c->pass_wide_products[0] : 0));
         c->stream = main_stream;
         if (rw) { (void)hipStreamSynchronize(wst); return rw; }
         HIPCHK(c, hipEventRecord(c->join[kNumTiers], wst));

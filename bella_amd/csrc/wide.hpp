@@ -242,6 +242,36 @@ __global__ __launch_bounds__(kWideGroup1Block) void k_wide_group1(WideArgs a) {
     }
 }
 
+// the pairs of the grouped columns, numbered column by column in slot order (any order does: the output order comes from
+// k_wide_insert / k_wide_ranks): key, list, first product -- all that the slot-order tables, ranks and descriptors need, so that those
+// run next to the append pass instead of behind it
+__global__ __launch_bounds__(kWideGroup2Block) void k_wide_pairs(WideArgs a) {
+    __shared__ uint32_t scr[kWideGroup2Block / 64];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t s = blockIdx.x; s < a.nw; s += gridDim.x) {
+        const uint64_t wo = a.woff[s];
+        const uint4* G = a.gtab + (size_t)s * kWideGroupSlots;
+        constexpr uint32_t kPer = kWideGroupSlots / kWideGroup2Block;
+        uint4 g[kPer];
+        uint32_t occ = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) { g[u] = G[tid * kPer + u]; occ += g[u].x != 0xFFFFFFFFu ? 1u : 0u; }
+        uint32_t d;
+        uint32_t r = a.gbase[s] + block_excl_scan<kWideGroup2Block / 64>(occ, scr, &d);
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            if (g[u].x == 0xFFFFFFFFu) continue;
+            if (a.key32) ((uint32_t*)a.R_key_w)[r] = (s << a.rbits) | g[u].x;
+            else ((uint64_t*)a.R_key_w)[r] = ((uint64_t)s << a.rbits) | g[u].x;
+            a.R_len_w[r] = g[u].z;
+            a.R_start_w[r] = (uint32_t)wo + g[u].y;
+            a.R_first[r] = g[u].w;
+            ++r;
+        }
+        __syncthreads();
+    }
+}
+
 // The append pass: the column's products in CHUNKS of 2,048, every chunk counting-sorted by pair in LDS before it leaves, so that a
 // pair's products of the chunk (a HiFi-like column has ~100 partners: ~20 products per pair and chunk) are written as ONE run of
 // consecutive list entries by neighbouring lanes.  (Until round 6 four wavefronts per column appended a quarter of the column each,
@@ -273,7 +303,6 @@ __global__ __launch_bounds__(kWideGroup2Block) void k_wide_group2_chunks(WideArg
         const uint64_t wo = a.woff[s], F = a.woff[s + 1] - wo, arow = a.Arow ? a.Arow[i] : wo;
         const uint32_t lenV = (uint32_t)(a.roff[i + 1] - a.roff[i]);
         const uint4* G = a.gtab + (size_t)s * kWideGroupSlots;
-        const uint32_t pbase = a.gbase[s];
         constexpr uint32_t kPer = kWideGroupSlots / kWideGroup2Block;
         uint4 g[kPer];
         uint32_t occ = 0;
@@ -285,16 +314,7 @@ __global__ __launch_bounds__(kWideGroup2Block) void k_wide_group2_chunks(WideArg
         for (uint32_t u = 0; u < kPer; ++u) {
             const uint32_t h = tid * kPer + u;
             s_key[h] = g[u].x; s_cur[h] = g[u].y; s_cnt[h] = make_uint2(0u, 0u);
-            if (g[u].x != 0xFFFFFFFFu) {
-                const uint32_t r = pbase + o;
-                if (a.key32) ((uint32_t*)a.R_key_w)[r] = (s << a.rbits) | g[u].x;
-                else ((uint64_t*)a.R_key_w)[r] = ((uint64_t)s << a.rbits) | g[u].x;
-                a.R_len_w[r] = g[u].z;
-                a.R_start_w[r] = (uint32_t)wo + g[u].y;
-                a.R_first[r] = g[u].w;
-                s_occ[o] = (uint16_t)h;
-                ++o;
-            }
+            if (g[u].x != 0xFFFFFFFFu) { s_occ[o] = (uint16_t)h; ++o; }
         }
         if (tid == 0) { s_alloc = 0; s_cnt[kWideGroupSlots] = make_uint2(0u, 0u); s_suf[kWideGroupSlots] = make_uint2(0u, 0u); s_loc[kWideGroupSlots] = 0; s_cur[kWideGroupSlots] = 0; }
         __syncthreads();
@@ -411,6 +431,29 @@ __global__ void k_wide_segments(WideArgs a) {
 
 // the reference's slot order (overlap.hpp:289-361): keys enter a table of pow2 >= max(16, pairs) slots at (key*107) & mask in
 // order of their first product; parallel form: atomicMin on (first product << 32 | pair), the displaced entry probes on
+// sizes and starts of the columns' tables on the device (one workgroup; the host only knows the bound 16 nw + 2 npairs)
+__global__ __launch_bounds__(1024) void k_wide_toff(const uint32_t* seg_first, uint32_t nw, uint64_t* toff) {
+    __shared__ uint32_t scr[16];
+    __shared__ uint64_t s_run;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (uint32_t b = 0; b <= nw; b += 1024) {
+        const uint32_t s = b + threadIdx.x;
+        uint32_t ht = 0;
+        if (s < nw) {
+            const uint32_t d = seg_first[s + 1] - seg_first[s];
+            ht = 16;
+            while (ht < d) ht <<= 1;                                  // overlap.hpp:291-295
+        }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<16>(ht, scr, &tot);       // (a round's sum < 16 * 1024 + 2 * pairs < 2^32)
+        const uint64_t run = s_run;
+        if (s <= nw) toff[s] = run + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) s_run = run + tot;
+        __syncthreads();
+    }
+}
 __global__ void k_wide_table_fill(uint64_t* table, uint64_t n) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x < n) table[x] = ~0ull;
