@@ -866,10 +866,6 @@ __global__ __launch_bounds__(kWideFoldBlock, kMinWaves) void k_wide_fold_wg(Wide
             const uint32_t cw = wave_incl_scan(contrib), sw = wave_incl_scan(surv);
             if (lane_id() == 63) { if (cw) atomicAdd(&s_contrib, cw); if (sw) atomicAdd(&s_surv, sw); }
         }
-        // a plain chain's winner is its last product: read here, before the barrier, so that the other wavefronts may go on to the
-        // next pair's staging (which overwrites s_hv / s_ov) while thread 0 finishes this pair's result -- no barrier at the loop's end
-        uint32_t last_hv = 0, last_ov = 0;
-        if (tid == 0 && plain && staged) { last_hv = s_hv[mm - 1]; last_ov = s_ov[mm - 1]; }
         __syncthreads();
         WFCLK(5);
         FoldResult fr;
@@ -902,8 +898,7 @@ __global__ __launch_bounds__(kWideFoldBlock, kMinWaves) void k_wide_fold_wg(Wide
         // would wait for (and the store would hold up wavefront 0 at its next wait for loads); up to kPend results collect in LDS and
         // wavefront 0 writes them lane-parallel
         if (tid == 0) {
-            if (plain && staged) { fr.seed = last_hv; fr.binov = (uint16_t)last_ov; }
-            else if (staged) { fr.seed = s_hv[win]; fr.binov = s_ov[win]; }
+            if (staged) { fr.seed = s_hv[win]; fr.binov = s_ov[win]; }
             else { const uint2 e = w[win]; fr.seed = e.x; fr.binov = (uint16_t)(e.y & 0xFFFFu); }
             s_pfr[npend] = fr; s_pr[npend] = r;
         }
@@ -913,9 +908,7 @@ __global__ __launch_bounds__(kWideFoldBlock, kMinWaves) void k_wide_fold_wg(Wide
             npend = 0;
         }
         WFCLK(6);
-        // (thread 0 resets the pair's scalars at the top of the loop, after it has read them here; the next pair's first use of them by
-        // the other threads lies behind that pair's first barrier)
-        if (!(plain && staged)) __syncthreads();
+        __syncthreads();
         WFCLK(7);
     }
     if (tid < npend) wide_write_pair(a, desc[s_pr[tid]], s_pfr[tid]);
