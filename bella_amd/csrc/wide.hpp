@@ -594,7 +594,7 @@ __device__ __forceinline__ void wide_write_pair(const WideArgs& a, const WidePai
 #define BELLA_WIDE_FOLD_LDS 4096
 #endif
 #ifndef BELLA_WIDE_VISIT
-#define BELLA_WIDE_VISIT 8
+#define BELLA_WIDE_VISIT 6
 #endif
 #ifndef BELLA_WIDE_GRID_BUCKETS
 #define BELLA_WIDE_GRID_BUCKETS 4096
