@@ -171,6 +171,7 @@ struct bella_ctx {
     // overlap
     uint64_t flops = 0, npairs = 0;
     uint32_t pair_ratio1024 = 1024;   // max over sampled columns of 1024 * pairs/products
+    bool long_list_sample = false;    // the sampled columns TOGETHER hold >= 64 products per pair
 #ifdef BELLA_DEV_PROF
     Buf prof;
 #endif
@@ -432,6 +433,7 @@ int build_layout(bella_ctx* c, bool collective = false) {
     }
     c->owned_nnz = 0;
     uint32_t ratio1024 = 1024;
+    c->long_list_sample = false;
     const uint32_t* Bloc = ptr<uint32_t>(c->Bloc);                 // the rows of the owned columns
     // (buffers only ever grow; a context that goes from a whole layout to a partition's gives the difference back)
     if (c->Bent.cap > 16 * nown_nnz + (1u << 20)) release(c->Bent);
@@ -575,7 +577,8 @@ int build_layout(bella_ctx* c, bool collective = false) {
         // Long-list inputs send most of their columns to the path above the LDS tiers, which groups a column's products in LDS from a
         // product list -- expanded per batch and per pass when the layout has none.  The same expansion once, here, costs a one-shot
         // call nothing and every further pass less: such inputs get the row lists whenever they fit.
-        const bool auto_lists = samp[1] > 0 && samp[0] <= samp[1] && !(c->debug & 1u) && c->tune_row_path != 1 && c->lane_order_ok;   // >= 64 products per pair on the sample
+        c->long_list_sample = samp[1] > 0 && samp[0] <= samp[1];     // >= 64 products per pair on the sample
+        const bool auto_lists = c->long_list_sample && !(c->debug & 1u) && c->tune_row_path != 1 && c->lane_order_ok;
         if (by_kmer && (c->want_rowlists || auto_lists) && c->nreads <= (1u << 30)) {
             // row lists (BELLA_TUNE_ROW_LISTS): products per owned row -> row starts -> the tails of the lists copied in product order.
             // Optional in every respect: if they do not fit next to what a pass needs, or an allocation fails, the layout stands without them.
@@ -2550,7 +2553,9 @@ static int run_spgemm(bella_ctx* c, const bella_params* p, uint32_t* status_out,
     // Long-list inputs (at most one pair in 64 products on the assembly-time sample: HiFi-like sets): the fold of a pair is
     // quadratic in its list inside the row kernels and has a position grid on the sort-based path, so the larger LDS tiers are
     // closed and their columns take that path with the columns above the tiers.
-    const bool long_lists = !force_global && !c->tiers_from_env && c->pair_ratio1024 < 16;
+    // (either every sampled column is like that, or the sample as a whole: since round 6 the path above the tiers is the faster one for
+    // such columns even when a few short-list columns stand among them -- HiFi-like 10k reads, -u 40: 6.35 -> 5.9 ms per pass)
+    const bool long_lists = !force_global && !c->tiers_from_env && (c->pair_ratio1024 < 16 || c->long_list_sample);
     for (uint32_t t = 0; t < g_ntiers; ++t)
         caps[t] = (force_global || (long_lists && tier_caps[t] > kLongListMaxCap)) && t + 1 < g_ntiers ? 0 : tier_caps[t];
     const int want_state = (force_global ? 2 : 1) + (half_tables ? 2 : 0) + (long_lists ? 4 : 0);
