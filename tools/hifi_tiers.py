@@ -13,7 +13,7 @@ eng.count_kmers(17, 2, upper, syncmer=True)
 eng.assemble_counted()
 eng.set_debug(2)
 base = [384, 689, 1000, 1394, 2048, 2752, 3712, 4600, 5568, 8192, 11008]
-for top in (None, 11008, 8192, 5568, 3712, 2752, 1394, None):
+for top in (None, 2752, 2048, 1394, 1000, 689, 384, None):
     if top is None: eng.set_tuning("lds_tiers")
     else: eng.set_tuning("lds_tiers", *[c for c in base if c <= top])
     ts = []
