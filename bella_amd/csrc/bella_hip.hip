@@ -2372,12 +2372,13 @@ static int wide_batch_finish(bella_ctx* c, WideBatch& wb, bool sync_at_end) {
             if (np) {
                 // the pairs' keys / lists / first products (from the table images), then the append pass -- and NEXT to it, on a stream of
                 // their own, the small kernels that only need the pairs: tables, slot-order insertion, ranks, descriptors
-                k_wide_pairs<<<nw < 8192u ? nw : 8192u, kWideGroup2Block, 0, c->stream>>>(a);
-                KCHK(c);
+                // (the append pass needs the table images only: the pair numbering goes to the second stream with what builds on it)
                 HIPCHK(c, hipEventRecord(c->fork, c->stream));
                 k_wide_group2_chunks<<<nw < 8192u ? nw : 8192u, kWideGroup2Block, 0, c->stream>>>(a);
                 KCHK(c);
                 HIPCHK(c, hipStreamWaitEvent(s2, c->fork, 0));
+                k_wide_pairs<<<nw < 8192u ? nw : 8192u, kWideGroup2Block, 0, s2>>>(a);
+                KCHK(c);
                 rc = tables_and_descriptors(s2);
                 if (rc) return rc;
                 HIPCHK(c, hipEventRecord(c->join[kNumTiers - 2], s2));
