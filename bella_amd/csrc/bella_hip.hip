@@ -2316,6 +2316,12 @@ static int wide_batch_begin(bella_ctx* c, const SpgemmArgs& sa, uint32_t nw, con
         // (8 bytes into pinned memory: the pairs of the batch and the overflow flag; the slot-order tables are sized on the device)
         HIPCHK(c, hipMemcpyAsync(c->pinned + kPinWide, ptr<uint32_t>(c->w_gbase) + nw, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->pinned + kPinWide + 1, ptr<uint32_t>(c->w_gcount) + nw + 1, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->join[kNumTiers - 3], c->stream));
+        // The append pass needs nothing from the host (the table images and the batch's product count): it follows at once and leaves by
+        // itself if a column's partners did not fit the table (the flag); the host meanwhile waits for the totals and prepares the
+        // kernels that need the pair count on a second stream.
+        k_wide_group2_chunks<<<nw < 8192u ? nw : 8192u, kWideGroup2Block, 0, c->stream>>>(a);
+        KCHK(c);
         wb.tried_group = true;
     }
     return 0;
@@ -2357,7 +2363,7 @@ static int wide_batch_finish(bella_ctx* c, WideBatch& wb, bool sync_at_end) {
         return 0;
     };
     if (wb.tried_group) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipEventSynchronize(c->join[kNumTiers - 3]));      // (the totals are there; the append pass is running)
         if (c->pinned[kPinWide + 1] == 0) {
             np = c->pinned[kPinWide];
             ENSURE(c, c->w_rlen, 4 * ((size_t)np + 1)); ENSURE(c, c->w_rstart, 4 * ((size_t)np + 2)); ENSURE(c, c->w_rrank, 4 * ((size_t)np + 1));
@@ -2370,13 +2376,10 @@ static int wide_batch_finish(bella_ctx* c, WideBatch& wb, bool sync_at_end) {
             a.seg_first = ptr<uint32_t>(c->w_gbase);                 // first pair of every column = the prefix sums of the pair counts
             grouped = true;
             if (np) {
-                // the pairs' keys / lists / first products (from the table images), then the append pass -- and NEXT to it, on a stream of
-                // their own, the small kernels that only need the pairs: tables, slot-order insertion, ranks, descriptors
-                // (the append pass needs the table images only: the pair numbering goes to the second stream with what builds on it)
-                HIPCHK(c, hipEventRecord(c->fork, c->stream));
-                k_wide_group2_chunks<<<nw < 8192u ? nw : 8192u, kWideGroup2Block, 0, c->stream>>>(a);
-                KCHK(c);
-                HIPCHK(c, hipStreamWaitEvent(s2, c->fork, 0));
+                // NEXT to the append pass (which wide_batch_begin enqueued), on a stream of their own: the pairs' keys / lists / first
+                // products (from the table images) and the small kernels that only need those -- tables, slot-order insertion, ranks,
+                // descriptors
+                HIPCHK(c, hipStreamWaitEvent(s2, c->join[kNumTiers - 3], 0));
                 k_wide_pairs<<<nw < 8192u ? nw : 8192u, kWideGroup2Block, 0, s2>>>(a);
                 KCHK(c);
                 rc = tables_and_descriptors(s2);

@@ -298,6 +298,7 @@ __global__ __launch_bounds__(kWideGroup2Block) void k_wide_group2_chunks(WideArg
     __shared__ uint32_t scr[kWideGroup2Block / 64];
     __shared__ uint32_t s_alloc;
     const uint32_t tid = threadIdx.x, q = wave_id(), lane = lane_id();
+    if (a.gcount[a.nw + 1]) return;                                // a column's partners did not fit the table: the batch takes the sort-based path
     for (uint32_t s = blockIdx.x; s < a.nw; s += gridDim.x) {
         const uint32_t i = a.cols[s];
         const uint64_t wo = a.woff[s], F = a.woff[s + 1] - wo, arow = a.Arow ? a.Arow[i] : wo;
