@@ -1317,6 +1317,31 @@ def test_wide_columns_bit_exact(eng, budget, layout, passdbg, rowlists):
     assert (ext["nbins"] > 1).any()
 
 
+def test_wide_columns_with_more_partners_than_the_grouping_table_holds(eng):
+    """1,700 copies of one 26-base read (strands mixed), -u 2000: ten k-mers shared by all reads, column i has 10 * (1699 - i) products
+    on 1699 - i partners -- ~600 columns above the LDS tiers, the first ~160 of them with more than the 1,536 partners the LDS grouping
+    table of the wide path holds: the first grouping pass raises its flag, the append pass (already enqueued behind it) leaves by
+    itself and the batch takes the sort-based path"""
+    rng = np.random.default_rng(23)
+    base = rng.integers(0, 4, size=26, dtype=np.uint8)
+    comp = (3 - base)[::-1]
+    seqs = [synth.BASES[base if i % 3 else comp].tobytes() for i in range(1700)]
+    rs = synth.ReadSet.from_strings(seqs)
+    eng.set_tuning("row_lists", 1)
+    eng.set_reads(rs)
+    nk, nt, _ = eng.count_kmers(17, 2, 2000)
+    tk, tr, tp = eng.get_tuples()
+    eng.assemble_counted()
+    n, flops = eng.overlap(BellaPars(skipAlignment=True))
+    eng.set_tuning("row_lists")
+    pairs, ext, colptrC = eng.get_pairs()
+    _, flop, ecol, exp = oracle_pairs(rs, rs.seqs(), nk, tk, tr, tp, 17)
+    assert int(flop.max()) >= 11009 and int(np.diff(ecol.astype(np.int64)).max()) > 1536
+    assert flops == int(flop.sum()) and n == len(exp)
+    assert np.array_equal(colptrC, ecol.astype(np.uint64))
+    check_pairs(pairs, ext, exp, rs.lengths, 17)
+
+
 def test_hifi_syncmer_medium_set_parity(eng):
     """BASELINE configs[4]'s regime at medium size: 1,200 HiFi-like reads (15 kb, 0.5 % error, 30x), syncmer selection (-s) with
     -u 40: ~30,000 products per column (the columns of the 11k-65k global-workspace path and of the >= 65,536 wide path), pairs
